@@ -1,0 +1,150 @@
+"""ctypes binding of ``libfgnn_hip.so`` (C ABI declared in ``include/fgnn_hip.h``).
+
+The product path has no CPU fallback: if the library is missing, or an entry
+point reports an error, a ``RuntimeError`` is raised.  PyTorch is used only for
+device memory and the stream handle; tensors cross the boundary as raw device
+pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
+
+FGNN_H = 32
+FGNN_TILE = 32
+FGNN_MAX_DEPTH = 3
+
+c_float_p = C.c_void_p   # device pointers travel as integers
+
+
+class Slab(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('gstride', C.c_longlong), ('ldp', C.c_longlong), ('C', C.c_int),
+                ('nrm', C.c_void_p), ('beta', C.c_void_p)]
+
+
+class MlpFwdArgs(C.Structure):
+    _fields_ = [('G', C.c_int), ('N', C.c_int), ('depth', C.c_int), ('nmlp', C.c_int),
+                ('nvalid', C.c_void_p),
+                ('a', Slab), ('b', Slab),
+                ('W', (C.c_void_p * FGNN_MAX_DEPTH) * 2),
+                ('bias', (C.c_void_p * FGNN_MAX_DEPTH) * 2),
+                ('z', C.c_void_p * 2),
+                ('ldz', C.c_longlong),
+                ('part', C.c_void_p * 2),
+                ('cnt', C.c_void_p)]
+
+
+class MlpBwdArgs(C.Structure):
+    _fields_ = [('G', C.c_int), ('N', C.c_int), ('depth', C.c_int),
+                ('nvalid', C.c_void_p),
+                ('a', Slab), ('b', Slab),
+                ('W', C.c_void_p * FGNN_MAX_DEPTH),
+                ('bias', C.c_void_p * FGNN_MAX_DEPTH),
+                ('dy', C.c_void_p), ('dgstride', C.c_longlong), ('ldd', C.c_longlong),
+                ('z', C.c_void_p), ('zgstride', C.c_longlong), ('ldz', C.c_longlong),
+                ('coef', C.c_void_p),
+                ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
+                ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
+                ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
+                ('wpart', C.c_void_p)]
+
+
+_VP, _LL, _I, _F = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    'fgnn_last_error': [],
+    'fgnn_version': [],
+    'fgnn_tiles_per_graph': [_I],
+    'fgnn_mlp_bwd_num_workgroups': [],
+    'fgnn_mlp_fwd': [C.POINTER(MlpFwdArgs), _VP],
+    'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
+    'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
+    'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_chan_matmul_fwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_colmax_fwd': [C.POINTER(Slab), _VP, _I, _I, _VP, _VP, _VP],
+    'fgnn_score_ce_fwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
+    'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_score_bwd': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_ce_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP],
+    'fgnn_ce_bwd': [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP],
+    'fgnn_colmax_bwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_gn_bwd_stats': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _VP],
+    'fgnn_gn_bwd_coef': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
+    'fgnn_gn_bwd_apply': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_mlp_bwd': [C.POINTER(MlpBwdArgs), _VP],
+    'fgnn_mlp_param_count': [_I, _I],
+    'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
+    'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP],
+    'fgnn_sum_scale': [_VP, _I, _I, _F, _VP, _VP],
+}
+_RESTYPES = {'fgnn_last_error': C.c_char_p}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'graph_neural_net_amd: %s is missing. Build it with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `make -C graph_neural_net_amd/csrc`. '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().fgnn_last_error().decode('utf-8', 'replace')
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, last_error()))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('graph_neural_net_amd: expected a CUDA/HIP tensor, got device %s '
+                           '(there is no CPU path)' % (t.device,))
+    return C.c_void_p(t.data_ptr())
+
+
+def make_slab(t, gstride, ldp, channels, nrm=None, beta=None):
+    s = Slab()
+    s.ptr = t.data_ptr() if t is not None else None
+    s.gstride = gstride
+    s.ldp = ldp
+    s.C = channels
+    s.nrm = nrm.data_ptr() if nrm is not None else None
+    s.beta = beta.data_ptr() if beta is not None else None
+    return s
+
+
+def tiles_per_graph(n):
+    return (n * n + FGNN_TILE - 1) // FGNN_TILE
+
+
+def mlp_param_count(cin, depth):
+    return 32 * cin + 32 + (depth - 1) * (32 * 32 + 32)

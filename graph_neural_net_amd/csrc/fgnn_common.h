@@ -1,0 +1,71 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) FGNN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fgnn_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DEVI __device__ __forceinline__
+#define WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D(32x32) = A(32x2) * B(2x32) + C, exact fp32 fma chain.
+//   lane l supplies a = A[l&31][l>>5], b = B[l>>5][l&31];
+//   D[row][col]: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+DEVI f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Row (channel) held by accumulator register r in the half-wave h = lane>>5.
+// Using these 16 registers as the next layer's B operand makes k-step r contract
+// channels {ch_of(r,0), ch_of(r,1)} -- the conv chain never leaves the register file.
+DEVI constexpr int ch_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int CTRL>
+DEVI float dpp_mov(float v) {
+    return __builtin_bit_cast(float,
+        __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the 32 lanes that share h = lane>>5; every lane of the half gets the total.
+DEVI float half_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    // xor 16 inside each 32-lane group: ds_swizzle bit-mode and=0x1f, or=0, xor=0x10
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+    return v;
+}
+
+// Sum / max over all 64 lanes (result in every lane).
+DEVI float wave_sum(float v) {
+    v = half_sum(v);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+DEVI float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
+
+// error plumbing shared by the launchers
+void fgnn_set_error(const char *fmt, ...);
+#define FGNN_CHECK(cond, ...)                       \
+    do {                                            \
+        if (!(cond)) {                              \
+            fgnn_set_error(__VA_ARGS__);            \
+            return 1;                               \
+        }                                           \
+    } while (0)
+#define FGNN_LAUNCH_CHECK()                                                        \
+    do {                                                                           \
+        hipError_t e_ = hipGetLastError();                                         \
+        if (e_ != hipSuccess) {                                                    \
+            fgnn_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,          \
+                           hipGetErrorString(e_));                                 \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)

@@ -1,0 +1,208 @@
+// Per-channel N x N matrix products (Matmul, models/layers.py:161-162) and their
+// backward for gfx950.  One workgroup (4 waves) owns one 64x64 output tile of one (g,c)
+// matrix: operands are normalised on load ((z-mean)*a+beta, padding -> 0), staged in LDS
+// with a 65-float row stride (conflict-free column reads), and multiplied with
+// v_mfma_f32_32x32x2_f32, one 32x32 quadrant per wave.
+//
+//   forward : M  = Ya @ Yb
+//   backward: dA = dM @ Yb^T,   dB = Ya^T @ dM
+#include "fgnn_common.h"
+
+namespace {
+
+constexpr int TM = 64;        // output tile edge
+constexpr int LDS_LD = 65;    // LDS row stride (floats)
+
+struct NormRec {
+    float mean, a, beta;
+    bool on;
+};
+
+DEVI NormRec norm_of(const fgnn_slab &s, int g, int c) {
+    NormRec r;
+    r.on = s.nrm != nullptr;
+    if (r.on) {
+        const float4 n = reinterpret_cast<const float4 *>(s.nrm)[(long long)g * s.C + c];
+        r.mean = n.x;
+        r.a = n.y;
+        r.beta = s.beta ? s.beta[c] : 0.f;
+    } else {
+        r.mean = 0.f;
+        r.a = 1.f;
+        r.beta = 0.f;
+    }
+    return r;
+}
+
+// Stage the [row0,row0+64) x [col0,col0+64) window of an N x N matrix into LDS (zero fill
+// outside the valid nv x nv region), optionally normalising.
+DEVI void stage_tile(float *lds, const float *mat, int N, int nv, int row0, int col0, const NormRec &nr, int tid) {
+    if (row0 == 0 && col0 == 0 && N <= TM) {
+        // whole matrix is one tile: walk it linearly (fully coalesced)
+        for (int e = tid; e < TM * TM; e += 256) lds[(e >> 6) * LDS_LD + (e & 63)] = 0.f;
+        __syncthreads();
+        const int P = N * N;
+        for (int e = tid; e < P; e += 256) {
+            const int r = e / N, c = e - r * N;
+            float v = mat[e];
+            const bool ok = r < nv && c < nv;
+            v = ok ? (nr.on ? (v - nr.mean) * nr.a + nr.beta : v) : 0.f;
+            lds[r * LDS_LD + c] = v;
+        }
+    } else {
+        for (int e = tid; e < TM * TM; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const int gr = row0 + r, gc = col0 + c;
+            float v = 0.f;
+            if (gr < nv && gc < nv) {
+                v = mat[(long long)gr * N + gc];
+                if (nr.on) v = (v - nr.mean) * nr.a + nr.beta;
+            }
+            lds[r * LDS_LD + c] = v;
+        }
+    }
+}
+
+// D-fragment store of one 32x32 quadrant.
+DEVI void store_quadrant(float *out, int N, int row0, int col0, const f32x16 &acc, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const int col = col0 + j;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + ch_of(r, h);
+        if (row < N && col < N) out[(long long)row * N + col] = acc[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward: grid (tiles_n, tiles_m, G*C)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_matmul_fwd_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                              const int *nvalid, int N, float *out,
+                                                              long long ogstride, long long ldo) {
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];
+    const int C = ya.C;
+    const int gc = blockIdx.z;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
+    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
+    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+    float *O = out + (long long)g * ogstride + (long long)c * ldo;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const bool live = (row0 + 32 * qi < N) && (col0 + 32 * qj < N);
+
+    for (int k0 = 0; k0 < N; k0 += TM) {
+        if (k0) __syncthreads();
+        stage_tile(As, A, N, nv, row0, k0, na, tid);
+        stage_tile(Bs, B, N, nv, k0, col0, nb, tid);
+        __syncthreads();
+        if (live) {
+            const int kmax = (N - k0 < TM ? N - k0 : TM);
+            const float *ap = As + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Bs + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < kmax; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
+        }
+    }
+    if (live) store_quadrant(O, N, row0 + 32 * qi, col0 + 32 * qj, acc, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward: grid (tiles, tiles, G*C); each workgroup produces the (ti,tj) tile of dA and of dB.
+//   dA[i][k] = sum_j dM[i][j] Yb[k][j]      dB[k][j] = sum_i Ya[i][k] dM[i][j]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                              const float *dm, long long dmg, long long ldm,
+                                                              const int *nvalid, int N, float *da, float *db,
+                                                              long long ogstride, long long ldo) {
+    __shared__ float Xs[TM * LDS_LD];
+    __shared__ float Ds[TM * LDS_LD];
+    const int C = ya.C;
+    const int gc = blockIdx.z;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
+    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
+    const float *D = dm + (long long)g * dmg + (long long)c * ldm;
+    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+    NormRec none;
+    none.on = false; none.mean = 0.f; none.a = 1.f; none.beta = 0.f;
+    float *OA = da + (long long)g * ogstride + (long long)c * ldo;
+    float *OB = db + (long long)g * ogstride + (long long)c * ldo;
+    const bool live = (row0 + 32 * qi < N) && (col0 + 32 * qj < N);
+
+    // ---- dA tile (rows row0.., cols col0..): A-operand = dM[row0+i][j0+..], B-operand = Yb[col0+k][j0+..]
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int j0 = 0; j0 < N; j0 += TM) {
+        if (j0) __syncthreads();
+        stage_tile(Ds, D, N, nv, row0, j0, none, tid);
+        stage_tile(Xs, B, N, nv, col0, j0, nb, tid);
+        __syncthreads();
+        if (live) {
+            const int kmax = (N - j0 < TM ? N - j0 : TM);
+            const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Xs + (32 * qj + j) * LDS_LD + h;
+            for (int k = 0; k < kmax; k += 2) acc = mfma32(ap[k], bp[k], acc);
+        }
+    }
+    if (live) store_quadrant(OA, N, row0 + 32 * qi, col0 + 32 * qj, acc, lane);
+
+    // ---- dB tile (rows row0.., cols col0..): A-operand = Ya^T[row0+k'][i0+..] = Ya[i0+..][row0+k'],
+    //      B-operand = dM[i0+..][col0+j]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i0 = 0; i0 < N; i0 += TM) {
+        __syncthreads();
+        stage_tile(Xs, A, N, nv, i0, row0, na, tid);
+        stage_tile(Ds, D, N, nv, i0, col0, none, tid);
+        __syncthreads();
+        if (live) {
+            const int kmax = (N - i0 < TM ? N - i0 : TM);
+            const float *ap = Xs + h * LDS_LD + 32 * qi + j;
+            const float *bp = Ds + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < kmax; k += 2) acc = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], acc);
+        }
+    }
+    if (live) store_quadrant(OB, N, row0 + 32 * qi, col0 + 32 * qj, acc, lane);
+}
+
+}  // namespace
+
+extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
+                                    float *out, long long ogstride, long long ldo, void *stream) {
+    FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr, "fgnn_chan_matmul_fwd: null argument");
+    FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_fwd: bad shapes");
+    FGNN_CHECK((long long)G * ya->C <= 65535 * 1024ll, "fgnn_chan_matmul_fwd: G*C too large");
+    const int t = (N + TM - 1) / TM;
+    FGNN_CHECK(G * ya->C <= 0x7fffffff / 1, "fgnn_chan_matmul_fwd: grid overflow");
+    hipLaunchKernelGGL(chan_matmul_fwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb,
+                       nvalid, N, out, ogstride, ldo);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride,
+                                    long long ldm, const int *nvalid, int G, int N, float *da, float *db,
+                                    long long ogstride, long long ldo, void *stream) {
+    FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd: null argument");
+    FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_bwd: bad shapes");
+    const int t = (N + TM - 1) / TM;
+    hipLaunchKernelGGL(chan_matmul_bwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
+                       dmgstride, ldm, nvalid, N, da, db, ogstride, ldo);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

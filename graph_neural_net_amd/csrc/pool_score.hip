@@ -1,0 +1,262 @@
+// ColumnMaxPooling (models/layers.py:194-203, masked variant maskedtensor.py:213-228),
+// siamese scoring (models/trainers.py:67) and triplet_loss (toolbox/losses.py:20-34)
+// forward/backward for gfx950.  These are small (O(B*C*N^2)) next to the blocks.
+#include <float.h>
+#include "fgnn_common.h"
+
+namespace {
+
+// one thread per (g,c,i) row; consecutive lanes read consecutive rows (stride N), the
+// row segments stay L1-resident across the j loop.
+__global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, int N, float *e, int *idx) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = y.C;
+    if (t >= (long long)G * C * N) return;
+    const int i = (int)(t % N);
+    const int gc = (int)(t / N);
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    float best = 0.f;
+    int bi = 0;
+    if (i < nv) {
+        const float *row = y.ptr + (long long)g * y.gstride + (long long)c * y.ldp + (long long)i * N;
+        float mean = 0.f, a = 1.f, be = 0.f;
+        if (y.nrm) {
+            const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
+            mean = n.x;
+            a = n.y;
+            be = y.beta ? y.beta[c] : 0.f;
+        }
+        best = -FLT_MAX;
+        for (int j = 0; j < nv; ++j) {
+            float v = row[j];
+            if (y.nrm) v = (v - mean) * a + be;
+            if (v > best) {
+                best = v;
+                bi = j;
+            }
+        }
+    }
+    e[t] = best;
+    idx[t] = bi;
+}
+
+// thread per (g,c,i): writes the whole row of dy (zeros + one scattered value)
+__global__ void colmax_bwd_kernel(const float *de, const int *idx, const int *nvalid, int G, int C, int N,
+                                  float *dy, long long gstride, long long ldp) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)G * C * N) return;
+    const int i = (int)(t % N);
+    const int gc = (int)(t / N);
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    float *row = dy + (long long)g * gstride + (long long)c * ldp + (long long)i * N;
+    const int bi = idx[t];
+    const float d = i < nv ? de[t] : 0.f;
+    for (int j = 0; j < N; ++j) row[j] = (j == bi) ? d : 0.f;
+}
+
+// one workgroup per pair b.  e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j].
+__global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, const float *e2, const int *nvalid,
+                                                           int C, int N, float *scores, float *lse,
+                                                           float *pair_loss) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *s1 = sm, *s2 = sm + (size_t)C * N;
+    float *red = s2 + (size_t)C * N;     // 4 floats
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = nvalid_of(nvalid, b, N);
+    const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
+    for (int e = tid; e < C * N; e += 256) {
+        s1[e] = p1[e];
+        s2[e] = p2[e];
+    }
+    __syncthreads();
+    float *S = scores + (long long)b * N * N;
+    for (int e = tid; e < N * N; e += 256) {
+        const int i = e / N, j = e - i * N;
+        float acc = 0.f;
+        if (i < nv && j < nv)
+            for (int c = 0; c < C; ++c) acc = fmaf(s1[c * N + i], s2[c * N + j], acc);
+        S[e] = acc;
+    }
+    __syncthreads();   // workgroup-scope visibility of S for the row pass below
+    float wl = 0.f;
+    for (int i = wave; i < N; i += 4) {
+        float l = 0.f;
+        if (i < nv) {
+            float mx = -FLT_MAX;
+            for (int j = lane; j < nv; j += WAVE) mx = fmaxf(mx, S[(long long)i * N + j]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int j = lane; j < nv; j += WAVE) se += expf(S[(long long)i * N + j] - mx);
+            se = wave_sum(se);
+            l = mx + logf(se);
+            wl += l - S[(long long)i * N + i];
+        }
+        if (lane == 0 && lse) lse[(long long)b * N + i] = l;
+    }
+    if (lane == 0) red[wave] = wl;
+    __syncthreads();
+    if (tid == 0 && pair_loss) pair_loss[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
+// de1[c][i] = sum_j e2[c][j] dS[i][j];  de2[c][j] = sum_i e1[c][i] dS[i][j].
+template <bool CE>
+__global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const float *e2, const float *scores,
+                                                        const float *lse, const float *dscores, const int *nvalid,
+                                                        const float *gscale, int C, int N, float *de1, float *de2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *s1 = sm, *s2 = sm + (size_t)C * N;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nv = nvalid_of(nvalid, b, N);
+    const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
+    for (int e = tid; e < C * N; e += 256) {
+        s1[e] = p1[e];
+        s2[e] = p2[e];
+    }
+    __syncthreads();
+    const float gs = CE ? *gscale : 1.f;
+    const float *S = (CE ? scores : dscores) + (long long)b * N * N;
+    const float *L = CE ? lse + (long long)b * N : nullptr;
+    for (int e = tid; e < C * N; e += 256) {
+        const int c = e / N, i = e - c * N;
+        float a1 = 0.f, a2 = 0.f;
+        if (i < nv) {
+            const float li = CE ? L[i] : 0.f;
+            for (int j = 0; j < nv; ++j) {
+                // dS[i][j] for de1
+                float d = S[(long long)i * N + j];
+                if (CE) d = (expf(d - li) - (i == j ? 1.f : 0.f)) * gs;
+                a1 = fmaf(s2[c * N + j], d, a1);
+                // dS[j][i] for de2 (index i plays the role of the column)
+                float dt = S[(long long)j * N + i];
+                if (CE) dt = (expf(dt - L[j]) - (i == j ? 1.f : 0.f)) * gs;
+                a2 = fmaf(s1[c * N + j], dt, a2);
+            }
+        }
+        de1[(long long)b * C * N + e] = a1;
+        de2[(long long)b * C * N + e] = a2;
+    }
+}
+
+// triplet_loss pieces on a given score tensor (module-level API): one workgroup per pair.
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float *scores, const int *nvalid, int N, float *lse,
+                                                     float *pair_loss) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = nvalid_of(nvalid, b, N);
+    const float *S = scores + (long long)b * N * N;
+    float wl = 0.f;
+    for (int i = wave; i < N; i += 4) {
+        float l = 0.f;
+        if (i < nv) {
+            float mx = -FLT_MAX;
+            for (int j = lane; j < nv; j += WAVE) mx = fmaxf(mx, S[(long long)i * N + j]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int j = lane; j < nv; j += WAVE) se += expf(S[(long long)i * N + j] - mx);
+            se = wave_sum(se);
+            l = mx + logf(se);
+            wl += l - S[(long long)i * N + i];
+        }
+        if (lane == 0 && lse) lse[(long long)b * N + i] = l;
+    }
+    if (lane == 0) red[wave] = wl;
+    __syncthreads();
+    if (tid == 0 && pair_loss) pair_loss[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void ce_bwd_kernel(const float *scores, const float *lse, const int *nvalid, const float *gscale, int N,
+                              float *dscores) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * N) return;
+    const int nv = nvalid_of(nvalid, b, N);
+    const int i = e / N, j = e - i * N;
+    float d = 0.f;
+    if (i < nv && j < nv)
+        d = (expf(scores[(long long)b * N * N + e] - lse[(long long)b * N + i]) - (i == j ? 1.f : 0.f)) * (*gscale);
+    dscores[(long long)b * N * N + e] = d;
+}
+
+}  // namespace
+
+extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *e, int *idx, void *stream) {
+    FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && y->C > 0, "fgnn_colmax_fwd: bad arguments");
+    const long long tot = (long long)G * y->C * N;
+    hipLaunchKernelGGL(colmax_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *y,
+                       nvalid, G, N, e, idx);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvalid, int G, int C, int N, float *dy,
+                               long long gstride, long long ldp, void *stream) {
+    FGNN_CHECK(de && idx && dy && G > 0 && C > 0 && N > 0, "fgnn_colmax_bwd: bad arguments");
+    const long long tot = (long long)G * C * N;
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, de,
+                       idx, nvalid, G, C, N, dy, gstride, ldp);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int score_lds_bytes(int C, int N) { return (2 * C * N + 4) * (int)sizeof(float); }
+
+extern "C" int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
+                                 float *scores, float *lse, float *pair_loss, void *stream) {
+    FGNN_CHECK(e1 && e2 && scores && B > 0 && C > 0 && N > 0, "fgnn_score_ce_fwd: bad arguments");
+    const int lds = score_lds_bytes(C, N);
+    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_fwd: C*N=%d too large for LDS staging", C * N);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)score_ce_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, C, N, scores,
+                       lse, pair_loss);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
+                                 const int *nvalid, const float *gscale, int B, int C, int N, float *de1, float *de2,
+                                 void *stream) {
+    FGNN_CHECK(e1 && e2 && scores && lse && gscale && de1 && de2 && B > 0, "fgnn_score_ce_bwd: bad arguments");
+    const int lds = score_lds_bytes(C, N);
+    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_bwd: C*N=%d too large for LDS staging", C * N);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)score_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(score_bwd_kernel<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2, scores, lse,
+                       (const float *)nullptr, nvalid, gscale, C, N, de1, de2);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_score_bwd(const float *e1, const float *e2, const float *dscores, const int *nvalid, int B, int C,
+                              int N, float *de1, float *de2, void *stream) {
+    FGNN_CHECK(e1 && e2 && dscores && de1 && de2 && B > 0, "fgnn_score_bwd: bad arguments");
+    const int lds = score_lds_bytes(C, N);
+    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_bwd: C*N=%d too large for LDS staging", C * N);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)score_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(score_bwd_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2,
+                       (const float *)nullptr, (const float *)nullptr, dscores, nvalid, (const float *)nullptr, C, N,
+                       de1, de2);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_ce_fwd(const float *scores, const int *nvalid, int B, int N, float *lse, float *pair_loss,
+                           void *stream) {
+    FGNN_CHECK(scores && lse && pair_loss && B > 0 && N > 0, "fgnn_ce_fwd: bad arguments");
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, nvalid, N, lse, pair_loss);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_ce_bwd(const float *scores, const float *lse, const int *nvalid, const float *gscale, int B, int N,
+                           float *dscores, void *stream) {
+    FGNN_CHECK(scores && lse && gscale && dscores && B > 0 && N > 0, "fgnn_ce_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((N * N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scores, lse,
+                       nvalid, gscale, N, dscores);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,317 @@
+"""Fused execution of the 2-FGNN hot path on one MI355X.
+
+``FgnnEngine`` runs what ``Siamese_Node_Exp.forward`` + ``triplet_loss`` +
+autograd do in the reference (models/trainers.py:60-68, models/blocks_emb.py:16-43,
+toolbox/losses.py:20-34) as a fixed sequence of HIP kernels from
+``libfgnn_hip.so``.  Both branches of the siamese pair share weights, so they are
+stacked into one batch of G = 2B graphs.  Activations live in HBM as
+(G, 32, ldp) slabs of *pre-norm* values plus a small GraphNorm record per (g, c);
+every consumer normalises on load, ``cat`` is never materialised, and the hidden
+MLP activations never leave the register file (they are recomputed in backward).
+
+Parameters and their gradients are flat fp32 buffers laid out in the reference's
+``state_dict`` order (models/utils.py:57-58), so data-parallel training needs a
+single all-reduce of ``grads``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+EPS = 1e-05
+
+
+class ParamLayout:
+    """Offsets of every tensor of the node embedder inside one flat buffer, in the
+    reference's ``named_parameters`` order."""
+
+    def __init__(self, original_features_num=2, num_blocks=4, in_features=32, out_features=32, depth_of_mlp=3):
+        if in_features != _lib.FGNN_H or out_features != _lib.FGNN_H:
+            raise RuntimeError('the HIP kernels are built for in_features = out_features = 32 (got %d, %d)'
+                               % (in_features, out_features))
+        if not 1 <= depth_of_mlp <= _lib.FGNN_MAX_DEPTH:
+            raise RuntimeError('depth_of_mlp must be in 1..%d' % _lib.FGNN_MAX_DEPTH)
+        if original_features_num % 2:
+            raise RuntimeError('original_features_num must be even')
+        self.c0 = original_features_num
+        self.num_blocks = num_blocks
+        self.depth = depth_of_mlp
+        self.entries = []        # (name, offset, shape)
+        self.mlp = {}            # (blk, j) -> dict(off=..., cin=..., conv_off=[...], gn_w=..., gn_b=...)
+        off = 0
+        last = original_features_num
+        for blk in range(1, num_blocks + 1):
+            for j, cin in ((1, last), (2, last), (3, last + 32)):
+                pfx = 'ne_bm_block%d_mlp%d.' % (blk, j)
+                rec = {'off': off, 'cin': cin, 'w': [], 'b': []}
+                c = cin
+                for i in range(depth_of_mlp):
+                    self.entries.append((pfx + 'convs.%d.weight' % i, off, (32, c, 1, 1)))
+                    rec['w'].append(off)
+                    off += 32 * c
+                    self.entries.append((pfx + 'convs.%d.bias' % i, off, (32,)))
+                    rec['b'].append(off)
+                    off += 32
+                    c = 32
+                self.entries.append((pfx + 'gn.weight', off, (1, 32, 1, 1)))
+                rec['gn_w'] = off
+                off += 32
+                self.entries.append((pfx + 'gn.bias', off, (1, 32, 1, 1)))
+                rec['gn_b'] = off
+                off += 32
+                rec['count'] = _lib.mlp_param_count(cin, depth_of_mlp)
+                self.mlp[(blk, j)] = rec
+            last = 32
+        self.total = off
+
+    def flatten(self, state_dict, device):
+        flat = torch.empty(self.total, dtype=torch.float32, device=device)
+        for name, off, shape in self.entries:
+            key = name if name in state_dict else 'node_embedder.' + name
+            t = state_dict[key]
+            n = t.numel()
+            flat[off:off + n].copy_(t.reshape(-1).to(torch.float32))
+        return flat
+
+    def unflatten(self, flat):
+        return {name: flat[off:off + _numel(shape)].view(shape) for name, off, shape in self.entries}
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class FgnnEngine:
+    """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
+
+    def __init__(self, layout, G, N, device, ragged=False):
+        _lib.load()
+        self.layout = layout
+        self.G, self.N = G, N
+        self.P = N * N
+        self.ldp = _round_up(self.P, 32)
+        self.tpg = _lib.tiles_per_graph(N)
+        self.device = device
+        K = layout.num_blocks
+        f32 = dict(dtype=torch.float32, device=device)
+        act = lambda: torch.empty(G * 32 * self.ldp, **f32)
+        self.z = {(k, j): act() for k in range(1, K + 1) for j in (1, 2, 3)}
+        self.mult = {k: act() for k in range(1, K + 1)}
+        self.nrm = {(k, j): torch.empty(G * 32 * 4, **f32) for k in range(1, K + 1) for j in (1, 2, 3)}
+        self.part = [torch.empty(G * self.tpg * 32 * 2, **f32) for _ in range(2)]
+        self.cnt = torch.empty(G * self.tpg, **f32)
+        self.E = torch.empty(G, 32, N, **f32)
+        self.idx = torch.empty(G, 32, N, dtype=torch.int32, device=device)
+        self.B = G // 2
+        self.scores = torch.empty(self.B, N, N, **f32)
+        self.lse = torch.empty(self.B, N, **f32)
+        self.pair_loss = torch.empty(self.B, **f32)
+        self.loss = torch.empty(1, **f32)
+        self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
+        # backward workspace (allocated lazily)
+        self._bwd = None
+        self.x = None
+
+    # ------------------------------------------------------------------ helpers
+    def _nv(self):
+        return _lib.ptr(self.nvalid) if self.nvalid is not None else None
+
+    def _w(self, params, off):
+        return params.data_ptr() + 4 * off
+
+    def _slab_in(self, k, params):
+        """Input slab of block k: raw x for k == 1, else block k-1's mlp3 output (normalise on load)."""
+        if k == 1:
+            return _lib.make_slab(self.x, self.layout.c0 * self.P, self.P, self.layout.c0)
+        rec = self.layout.mlp[(k - 1, 3)]
+        s = _lib.make_slab(self.z[(k - 1, 3)], 32 * self.ldp, self.ldp, 32, nrm=self.nrm[(k - 1, 3)])
+        s.beta = self._w(params, rec['gn_b'])
+        return s
+
+    def _slab_z(self, k, j, params):
+        rec = self.layout.mlp[(k, j)]
+        s = _lib.make_slab(self.z[(k, j)], 32 * self.ldp, self.ldp, 32, nrm=self.nrm[(k, j)])
+        s.beta = self._w(params, rec['gn_b'])
+        return s
+
+    def _slab_raw(self, t):
+        return _lib.make_slab(t, 32 * self.ldp, self.ldp, 32)
+
+    def _mlp_fwd(self, params, k, js, a, b):
+        L = self.layout
+        args = _lib.MlpFwdArgs()
+        args.G, args.N, args.depth, args.nmlp = self.G, self.N, L.depth, len(js)
+        args.nvalid = self.nvalid.data_ptr() if self.nvalid is not None else None
+        args.a = a
+        if b is not None:
+            args.b = b
+        for m, j in enumerate(js):
+            rec = L.mlp[(k, j)]
+            for l in range(L.depth):
+                args.W[m][l] = self._w(params, rec['w'][l])
+                args.bias[m][l] = self._w(params, rec['b'][l])
+            args.z[m] = self.z[(k, j)].data_ptr()
+            args.part[m] = self.part[m].data_ptr()
+        args.ldz = self.ldp
+        args.cnt = self.cnt.data_ptr()
+        st = _lib.stream_ptr()
+        _lib.call('fgnn_mlp_fwd', C.byref(args), st)
+        for m, j in enumerate(js):
+            rec = L.mlp[(k, j)]
+            _lib.call('fgnn_gn_finalize', _lib.ptr(self.part[m]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, EPS,
+                      _lib.ptr(self.nrm[(k, j)]), st)
+
+    # ------------------------------------------------------------------ forward
+    def embed(self, params, x, nvalid=None):
+        """x: (G, c0, N, N) contiguous device tensor.  Fills self.E / self.idx."""
+        L = self.layout
+        if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
+            raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
+                               % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
+        if (nvalid is None) != (self.nvalid is None):
+            raise RuntimeError('FgnnEngine: ragged flag and nvalid argument disagree')
+        if nvalid is not None:
+            self.nvalid.copy_(nvalid.to(torch.int32))
+        self.x = x
+        st = _lib.stream_ptr()
+        for k in range(1, L.num_blocks + 1):
+            sin = self._slab_in(k, params)
+            self._mlp_fwd(params, k, (1, 2), sin, None)
+            ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
+            _lib.call('fgnn_chan_matmul_fwd', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
+                      _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st)
+            self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
+        out = self._slab_z(L.num_blocks, 3, params)
+        _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
+        return self.E
+
+    def forward(self, params, x, nvalid=None, total_nodes=None):
+        """Siamese forward on the stacked batch x = cat(x1, x2): returns (scores, loss)."""
+        self.embed(params, x, nvalid)
+        B, N = self.B, self.N
+        st = _lib.stream_ptr()
+        e1, e2 = self.E[:B], self.E[B:]
+        _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N,
+                  _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), st)
+        if total_nodes is None:
+            total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
+        self.total_nodes = float(total_nodes)
+        _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B, 1, 1.0 / self.total_nodes, _lib.ptr(self.loss), st)
+        return self.scores, self.loss
+
+    # ------------------------------------------------------------------ backward
+    def _alloc_bwd(self):
+        if self._bwd is not None:
+            return self._bwd
+        f32 = dict(dtype=torch.float32, device=self.device)
+        act = lambda: torch.empty(self.G * 32 * self.ldp, **f32)
+        nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
+        maxp = _lib.mlp_param_count(64, self.layout.depth)
+        self._bwd = {
+            'dE': torch.empty(self.G, 32, self.N, **f32),
+            'dy': [act(), act()],
+            'dmult': act(), 'dy1': act(), 'dy2': act(),
+            's12': torch.empty(self.G * 32 * 2, **f32),
+            'coef': torch.empty(self.G * 32 * 4, **f32),
+            'wpart': torch.empty(nwg * maxp, **f32),
+            'nwg': nwg,
+            'gscale': torch.empty(1, **f32),
+        }
+        return self._bwd
+
+    def _mlp_bwd(self, params, grads, k, j, a, b, dy, dxa, dxb, acc_a, acc_b):
+        L = self.layout
+        W = self._bwd
+        rec = L.mlp[(k, j)]
+        st = _lib.stream_ptr()
+        gs = 32 * self.ldp
+        _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, self.ldp, _lib.ptr(self.z[(k, j)]), gs, self.ldp,
+                  _lib.ptr(self.nrm[(k, j)]), self._nv(), self.G, 32, self.N, _lib.ptr(W['s12']), st)
+        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12']), _lib.ptr(self.nrm[(k, j)]), self._nv(), self.G, 32, self.N,
+                  _lib.ptr(W['coef']), C.c_void_p(grads.data_ptr() + 4 * rec['gn_w']),
+                  C.c_void_p(grads.data_ptr() + 4 * rec['gn_b']), st)
+        args = _lib.MlpBwdArgs()
+        args.G, args.N, args.depth = self.G, self.N, L.depth
+        args.nvalid = self.nvalid.data_ptr() if self.nvalid is not None else None
+        args.a = a
+        if b is not None:
+            args.b = b
+        for l in range(L.depth):
+            args.W[l] = self._w(params, rec['w'][l])
+            args.bias[l] = self._w(params, rec['b'][l])
+        args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
+        args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
+        args.coef = W['coef'].data_ptr()
+        if dxa is not None:
+            args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), gs, self.ldp
+        if dxb is not None:
+            args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
+        args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
+        args.wpart = W['wpart'].data_ptr()
+        _lib.call('fgnn_mlp_bwd', C.byref(args), st)
+        _lib.call('fgnn_reduce_partials', _lib.ptr(W['wpart']), W['nwg'], rec['count'],
+                  C.c_void_p(grads.data_ptr() + 4 * rec['off']), st)
+
+    def backward(self, params, grads, grad_scale=1.0):
+        """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer."""
+        L = self.layout
+        W = self._alloc_bwd()
+        B, N = self.B, self.N
+        st = _lib.stream_ptr()
+        W['gscale'].fill_(grad_scale / self.total_nodes)
+        e1, e2 = self.E[:B], self.E[B:]
+        _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
+                  self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
+        return self.backward_from_dE(params, grads, W['dE'])
+
+    def backward_from_dE(self, params, grads, dE):
+        """Backward of the node embedder given d loss / d E  (G, 32, N)."""
+        L = self.layout
+        W = self._alloc_bwd()
+        st = _lib.stream_ptr()
+        gs = 32 * self.ldp
+        dy = W['dy'][0]
+        _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
+                  _lib.ptr(dy), gs, self.ldp, st)
+        for k in range(L.num_blocks, 0, -1):
+            sin = self._slab_in(k, params)
+            first = (k == 1)
+            din = None if first else W['dy'][(L.num_blocks - k + 1) % 2]
+            # mlp3: inputs [mult ; in]
+            self._mlp_bwd(params, grads, k, 3, self._slab_raw(self.mult[k]), sin, dy, W['dmult'], din, False, False)
+            ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
+            _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
+                      self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp, st)
+            self._mlp_bwd(params, grads, k, 1, sin, None, W['dy1'], din, None, True, False)
+            self._mlp_bwd(params, grads, k, 2, sin, None, W['dy2'], din, None, True, False)
+            dy = din
+        return grads
+
+    def step(self, params, grads, x, nvalid=None, total_nodes=None):
+        """One training step's model work: forward + loss + backward."""
+        scores, loss = self.forward(params, x, nvalid, total_nodes)
+        self.backward(params, grads)
+        return scores, loss
+
+    # ------------------------------------------------------------------ inspection (tests / module API)
+    def normalized(self, k, j, params):
+        """Materialise the normalised output of MLP (k, j) as a (G, 32, N, N) tensor."""
+        rec = self.layout.mlp[(k, j)]
+        y = torch.empty(self.G, 32, self.N, self.N, dtype=torch.float32, device=self.device)
+        _lib.call('fgnn_gn_apply', _lib.ptr(self.z[(k, j)]), 32 * self.ldp, self.ldp, _lib.ptr(self.nrm[(k, j)]),
+                  C.c_void_p(self._w(params, rec['gn_b'])), self._nv(), self.G, 32, self.N,
+                  _lib.ptr(y), 32 * self.P, self.P, _lib.stream_ptr())
+        return y
+
+    def unpadded(self, buf):
+        """View a (G*32*ldp) workspace slab as (G, 32, N, N) (copy)."""
+        return buf.view(self.G, 32, self.ldp)[:, :, :self.P].reshape(self.G, 32, self.N, self.N).clone()

@@ -1,0 +1,172 @@
+/*
+ * fgnn_hip.h -- C ABI of libfgnn_hip.so, the MI355X (gfx950) implementation of the
+ * 2-FGNN hot path of mlelarge/graph_neural_net.
+ *
+ * The reference has no FFI: its boundary is the Python nn.Module surface
+ * (models/layers.py, models/blocks_emb.py, maskedtensors/maskedtensor.py).  Each entry
+ * point below names the reference code (file:line under /root/reference) whose
+ * arithmetic it replaces; graph_neural_net_amd/ (Python) binds them with ctypes and
+ * re-exposes the reference's module names on top.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), fp32 unless stated, owned by the caller;
+ *   - activations are channel-first: element (g, c, i, j) of a (G, C, N, N) tensor lives at
+ *     ptr[g*gstride + c*ldp + i*N + j]; ldp >= N*N is the channel stride (the Python host
+ *     uses ldp = N*N for user-visible tensors and a 32-float-aligned ldp internally);
+ *   - `nvalid` (optional, int32[G]) is the per-graph vertex count of a ragged batch
+ *     (MaskedTensor masks, maskedtensor.py:8-48); NULL means every graph has N vertices.
+ *     Entries with i >= nvalid[g] or j >= nvalid[g] are padding: read as 0, written as 0,
+ *     excluded from every statistic (maskedtensor.py:87-112, 310-335);
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it;
+ *   - return value 0 = success; non-zero = error, message via fgnn_last_error().
+ *     Unsupported shapes are errors, never a silent fallback.
+ *   - hidden/output width of the MLP kernels is FGNN_H = 32 channels (the reference's
+ *     in_features = out_features = 32, default_config.yaml:47-57).
+ */
+#ifndef FGNN_HIP_H
+#define FGNN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FGNN_H 32            /* hidden / output channels of every MLP kernel          */
+#define FGNN_TILE 32         /* pixels per statistics tile                             */
+#define FGNN_MAX_DEPTH 3     /* convs per MlpBlock_Real handled by the fused kernels  */
+
+/* One input slab of an MLP: C channels, optionally the *pre-norm* output `z` of an
+ * earlier MLP kernel together with that MLP's GraphNorm record, in which case the
+ * consumer applies y = (z - mean) * a + beta on load (models/layers.py:68-80). */
+typedef struct {
+    const float *ptr;        /* (G, C, ldp)                                            */
+    long long gstride;       /* floats between graphs                                  */
+    long long ldp;           /* floats between channels                                */
+    int C;                   /* channels (even; 0 = slab unused)                       */
+    const float *nrm;        /* optional (G*C*4): {mean, a, q, r2} per (g,c)           */
+    const float *beta;       /* optional (C): GraphNorm bias                           */
+} fgnn_slab;
+
+/* ---- library ---------------------------------------------------------------------- */
+const char *fgnn_last_error(void);
+int fgnn_version(void);
+/* number of statistics tiles per graph for N vertices: ceil(N*N / FGNN_TILE) */
+int fgnn_tiles_per_graph(int N);
+/* workgroups the persistent MLP kernels launch (partials buffers are sized by it) */
+int fgnn_mlp_bwd_num_workgroups(void);
+
+/* ---- MlpBlock_Real.forward minus the final normalisation ---------------------------
+ * replaces models/layers.py:126-131 (conv1x1+ReLU chain, last conv without ReLU) and the
+ * reductions of normalize (:72-73).  Computes, for nmlp (1 or 2) MLPs sharing one input
+ *   z_m = W_m[d-1] relu(... relu(W_m[0] x + b_m[0]) ...) + b_m[d-1]      (G, 32, ldz)
+ * with x = [slab a ; slab b] on channels (Concat, layers.py:145-146, never materialised),
+ * and per (graph, tile, channel) partial statistics {mean, M2} of z over valid pixels.  */
+typedef struct {
+    int G, N, depth, nmlp;
+    const int *nvalid;
+    fgnn_slab a, b;
+    const float *W[2][FGNN_MAX_DEPTH];      /* conv weights (32, Cin_l) row-major       */
+    const float *bias[2][FGNN_MAX_DEPTH];   /* conv biases (32)                          */
+    float *z[2];                            /* out (G, 32, ldz)                          */
+    long long ldz;
+    float *part[2];                         /* out (G, tpg, 32, 2) {mean, M2}            */
+    float *cnt;                             /* out (G, tpg) valid pixels per tile        */
+} fgnn_mlp_fwd_args;
+int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
+
+/* ---- GraphNorm statistics ------------------------------------------------------------
+ * replaces torch.mean / torch.var(unbiased=False) over (N,N) and the scale of normalize
+ * (models/layers.py:71-80) incl. the ragged n = sum(mask) (:79).  Combines the tile
+ * partials (Chan's parallel update, fixed order) into nrm[g,c] = {mean, a, q, r2} with
+ *   var = M2/m, r2 = 1/(var+eps), q = 1/(2 sqrt(n (var+eps))), a = gn_weight[c] * q.     */
+int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight /* (C) or NULL=1 */,
+                     const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
+/* same record computed directly from a dense (G, C, ldp) tensor (two-pass), any C */
+int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float *gn_weight,
+                  const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
+/* y = (z - mean) * a + beta on valid entries, 0 on padding (GraphNorm.forward, :68-69) */
+int fgnn_gn_apply(const float *z, long long zgstride, long long ldz, const float *nrm, const float *beta /* (C) or NULL=0 */,
+                  const int *nvalid, int G, int C, int N, float *y, long long ygstride, long long ldy, void *stream);
+
+/* ---- Matmul.forward: per (g,c) N x N product (models/layers.py:161-162) --------------
+ * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
+int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
+                         float *out, long long ogstride, long long ldo, void *stream);
+
+/* ---- ColumnMaxPooling.forward (models/layers.py:202-203; masked: maskedtensor.py:213-228)
+ * e[g,c,i] = max_j y[g,c,i,j] (first index on ties), idx int32; rows i >= nvalid -> 0.   */
+int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *e /* (G,C,N) */,
+                    int *idx /* (G,C,N) */, void *stream);
+
+/* ---- Siamese scoring + triplet_loss (models/trainers.py:67, toolbox/losses.py:20-34) ---
+ * e1,e2: (B, C, N).  scores[b] = e1[b]^T e2[b] (B,N,N); lse (B,N) row log-sum-exp;
+ * pair_loss[b] = sum_i (lse_i - scores[b,i,i]) over valid rows.                          */
+int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
+                      float *scores, float *lse, float *pair_loss, void *stream);
+/* d e1, d e2 of loss = sum_b pair_loss[b] * (*gscale)   (gscale: device scalar = grad / sum n) */
+int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
+                      const int *nvalid, const float *gscale, int B, int C, int N,
+                      float *de1, float *de2, void *stream);
+/* triplet_loss on a given score tensor: lse (B,N), pair_loss (B) (toolbox/losses.py:27-34) */
+int fgnn_ce_fwd(const float *scores, const int *nvalid, int B, int N, float *lse, float *pair_loss, void *stream);
+/* dscores = (softmax_row(scores) - I) * (*gscale) on valid entries, 0 on padding */
+int fgnn_ce_bwd(const float *scores, const float *lse, const int *nvalid, const float *gscale, int B, int N,
+                float *dscores, void *stream);
+/* d scores given (B,N,N) -> d e1, d e2 (plain bmm backward, for the module-level API) */
+int fgnn_score_bwd(const float *e1, const float *e2, const float *dscores, const int *nvalid,
+                   int B, int C, int N, float *de1, float *de2, void *stream);
+
+/* ---- backward ---------------------------------------------------------------------- */
+/* ColumnMaxPooling backward: dy[g,c,i,idx] = de[g,c,i], 0 elsewhere (dense write).       */
+int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvalid, int G, int C, int N,
+                    float *dy, long long gstride, long long ldp, void *stream);
+
+/* GraphNorm backward reductions per (g,c): S1 = sum dy, S2 = sum dy * (z - mean).         */
+int fgnn_gn_bwd_stats(const float *dy, long long dgstride, long long ldd,
+                      const float *z, long long zgstride, long long ldz, const float *nrm,
+                      const int *nvalid, int G, int C, int N, float *s12 /* (G*C*2) */, void *stream);
+/* coefficients of dz = ca*dy + cb*(z-mean) + cc : coef[g,c] = {mean, ca, cb, cc};
+ * plus d gn_weight[c] = sum_g q*S2, d gn_bias[c] = sum_g S1 (fixed order over g).         */
+int fgnn_gn_bwd_coef(const float *s12, const float *nrm, const int *nvalid, int G, int C, int N,
+                     float *coef /* (G*C*4) */, float *dgn_w /* (C) or NULL */, float *dgn_b /* (C) or NULL */,
+                     void *stream);
+/* dense dz = ca*dy + cb*(z-mean) + cc on valid entries (module-level GraphNorm backward) */
+int fgnn_gn_bwd_apply(const float *dy, long long dgstride, long long ldd,
+                      const float *z, long long zgstride, long long ldz, const float *coef,
+                      const int *nvalid, int G, int C, int N, float *dz, long long ogstride, long long ldo, void *stream);
+
+/* MlpBlock_Real backward (autograd of models/layers.py:126-131): recomputes the hidden
+ * activations from the input slabs, forms dz from (dy, z, coef), back-propagates through
+ * the convs and accumulates per-workgroup partial weight/bias gradients.                 */
+typedef struct {
+    int G, N, depth;
+    const int *nvalid;
+    fgnn_slab a, b;                          /* forward inputs (recompute)                */
+    const float *W[FGNN_MAX_DEPTH];
+    const float *bias[FGNN_MAX_DEPTH];
+    const float *dy;  long long dgstride, ldd;   /* grad of the normalised output (G,32,ldd) */
+    const float *z;   long long zgstride, ldz;   /* saved pre-norm output                    */
+    const float *coef;                       /* (G*32*4) from fgnn_gn_bwd_coef           */
+    float *dxa; long long dxa_gstride, dxa_ld;   /* out: grad wrt slab a (NULL = not needed) */
+    float *dxb; long long dxb_gstride, dxb_ld;   /* out: grad wrt slab b (NULL = not needed) */
+    int accumulate_a, accumulate_b;          /* 1: dx += (read-modify-write)             */
+    float *wpart;                            /* out (num_wg, fgnn_mlp_param_count) partial dW/db */
+} fgnn_mlp_bwd_args;
+int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
+/* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
+ * layout [W0 (32*Cin) | b0 (32) | W1 (32*32) | b1 (32) | ...]                           */
+int fgnn_mlp_param_count(int Cin, int depth);
+/* deterministic reduction of the per-workgroup partials: out[i] = sum_w wpart[w][i]      */
+int fgnn_reduce_partials(const float *wpart, int num_wg, int count, float *out, void *stream);
+
+/* Matmul backward: da = dm @ Yb^T, db = Ya^T @ dm per (g,c) (autograd of layers.py:161-162) */
+int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride, long long ldm,
+                         const int *nvalid, int G, int N,
+                         float *da, float *db, long long ogstride, long long ldo, void *stream);
+
+/* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
+int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGNN_HIP_H */
