@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the 2-FGNN hot path: graph-pairs/sec, forward + loss + backward.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = forward of both siamese branches + scoring + triplet loss + full backward to
+all 96 parameter-gradient tensors on one batch of synthetic N=50 random-regular graph
+pairs (BASELINE.json configs[1]: batch 32 per GPU, 4 blocks x 32 features, depth 3, fp32),
+inputs resident in HBM.  With N > 1 ranks (torchrun, one process per GPU) every rank owns
+its own 32-pair shard (weak scaling) and the step ends with ONE RCCL all-reduce of the flat
+gradient buffer.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from graph_neural_net_amd import _lib, dp, synthetic            # noqa: E402
+from graph_neural_net_amd.engine import FgnnEngine, ParamLayout  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA
+
+
+def kernel_model(tag, G, N):
+    """Algorithmic (bytes, flops) of one launch of `tag` (interface reads + writes, fp32)."""
+    P = N * N
+    if tag.startswith('mlp_fwd['):
+        cin, nmlp = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
+        return 4.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
+    if tag.startswith('mlp_bwd['):
+        cin, dx = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
+        return 4.0 * G * P * (cin + 64 + dx), 4.0 * G * P * (cin * 32 + 2 * 1024)
+    if tag == 'fgnn_chan_matmul_fwd':
+        return 4.0 * G * 32 * P * 3, 2.0 * G * 32 * N ** 3
+    if tag == 'fgnn_chan_matmul_bwd':
+        return 4.0 * G * 32 * P * 5, 4.0 * G * 32 * N ** 3
+    if tag == 'fgnn_gn_bwd_stats':
+        return 4.0 * G * 32 * P * 2, 4.0 * G * 32 * P
+    if tag == 'fgnn_colmax_bwd' or tag == 'fgnn_colmax_fwd':
+        return 4.0 * G * 32 * P, 1.0 * G * 32 * P
+    return 0.0, 0.0
+
+
+def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2):
+    """(flops fwd+bwd, bytes fwd+bwd) per pair."""
+    fg, by, cin = 0, 0, c0
+    for _ in range(num_blocks):
+        fg += 2 * N * N * (3 * cin * C + 7 * C * C) + 2 * N ** 3 * C
+        by += 9 * cin + 17 * C
+        cin = C
+    return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * 4 * N * N * by
+
+
+def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=8):
+    """The oracle (pure PyTorch CPU, same ATen op sequence as the reference) on the host cores."""
+    from oracle import fgnn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.clone() for k, v in layout.unflatten(params.cpu()).items()}
+    O.step_fwd_bwd(x1, x2, sd)   # warm-up
+    t0 = time.time()
+    n = 0
+    while n < max_steps and (n == 0 or time.time() - t0 < min_seconds):
+        O.step_fwd_bwd(x1, x2, sd)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': x1.shape[0] / dt, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full steps of the same workload (batch %d, N=%d), %.2f s/step, torch %s CPU, %d threads'
+                      % (n, x1.shape[0], x1.shape[-1], dt, torch.__version__, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
+    ap.add_argument('--n', type=int, default=50, help='vertices per graph')
+    ap.add_argument('--blocks', type=int, default=4)
+    ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
+    args = ap.parse_args()
+
+    rank, local_rank, world = dp.init_process_group()
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU; there is no CPU fallback for the product path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    B, N = args.batch, args.n
+    layout = ParamLayout(2, args.blocks, 32, 32, 3)
+    params = layout.init_flat(0, dev)
+    grads = torch.zeros_like(params)
+    x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
+    x = torch.cat([x1, x2]).contiguous().to(dev)
+    eng = FgnnEngine(layout, 2 * B, N, dev)
+    total_nodes = float(B * N * world)            # loss normaliser of the concatenated global batch
+
+    def model_work():
+        eng.step(params, grads, x, total_nodes=total_nodes)
+
+    graph = None
+    model_work()                                  # allocates the backward workspace, sets kernel attributes
+    torch.cuda.synchronize()
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model_work()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                model_work()
+        except Exception as exc:                  # capture unsupported -> eager launches (still the HIP path)
+            graph = None
+            if rank == 0:
+                print('bench.py: HIP graph capture failed (%s); running eager' % (exc,), file=sys.stderr)
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            model_work()
+        dp.allreduce_sum_(grads)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
+
+    # ---- roofline leg: per-kernel durations from events on the launch stream (eager launches) ----
+    roofline = None
+    kernels = {}
+    if rank == 0 and args.profile_steps > 0:
+        _lib.PROFILE = []
+        for _ in range(args.profile_steps):
+            model_work()
+        torch.cuda.synchronize()
+        rec, _lib.PROFILE = _lib.PROFILE, None
+        for tag, e0, e1 in rec:
+            k = kernels.setdefault(tag, [0, 0.0])
+            k[0] += 1
+            k[1] += e0.elapsed_time(e1)
+        tot = sum(v[1] for v in kernels.values())
+        summary = {t: {'launches_per_step': v[0] / args.profile_steps, 'avg_ms': v[1] / v[0],
+                       'share': v[1] / tot} for t, v in kernels.items()}
+        dom = max(kernels, key=lambda t: kernels[t][1])
+        by, fl = kernel_model(dom, 2 * B, N)
+        dur = summary[dom]['avg_ms'] * 1e-3
+        if fl / (MFMA_F32_PEAK_TF * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
+            ach = fl / dur / 1e12
+            roofline = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                        'frac': ach / MFMA_F32_PEAK_TF, 'traffic': None}
+        else:
+            ach = by / dur / 1e9
+            roofline = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': ach / HBM_PEAK_GBS, 'traffic': None}
+        roofline.update({'kernel': dom, 'avg_launch_ms': summary[dom]['avg_ms'],
+                         'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
+                         'alt_hbm_gbs': by / dur / 1e9, 'alt_mfma_tflops': fl / dur / 1e12})
+        kernels = summary
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        fl_pair, by_pair = algorithmic_per_pair(N, args.blocks)
+        out = {
+            'metric': 'graph-pairs/sec FGNN fwd+bwd, N=%d regular pairs' % N,
+            'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'cfg2: N=%d random-regular pairs (d=%d, ER edge noise 0.1), %d pairs per GPU, '
+                                   '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd'
+                                   % (N, synthetic.regular_degree(N, 0.2), B, args.blocks),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
+                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
+                       'grad_allreduce': 'rccl sum of %d fp32 per step' % layout.total if world > 1 else 'none'},
+            'roofline': roofline,
+            'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,
+                           'hbm_frac_of_8TBs': value / world * by_pair / (HBM_PEAK_GBS * 1e9),
+                           'mfma_frac_of_157TF': value / world * fl_pair / (MFMA_F32_PEAK_TF * 1e12)},
+            'kernels': kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(layout, params, x1, x2)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -110,9 +110,23 @@ def last_error():
     return load().fgnn_last_error().decode('utf-8', 'replace')
 
 
-def call(name, *args):
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every
+# call is bracketed by two events on torch's current stream -- the stream the kernels are
+# launched on -- and (tag, start, stop) is appended.
+PROFILE = None
+
+
+def call(name, *args, tag=None):
     """Call an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
+    if PROFILE is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(load(), name)(*args)
+        e1.record()
+        PROFILE.append((tag or name, e0, e1))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, last_error()))
 

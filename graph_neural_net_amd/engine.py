@@ -74,6 +74,21 @@ class ParamLayout:
             flat[off:off + n].copy_(t.reshape(-1).to(torch.float32))
         return flat
 
+    def init_flat(self, seed, device):
+        """Random initial weights in the reference's scheme (models/layers.py:134-142, 63-66):
+        xavier-uniform conv weights, zero conv biases, GraphNorm weight 1 / bias 0."""
+        gen = torch.Generator().manual_seed(seed)
+        flat = torch.zeros(self.total, dtype=torch.float32)
+        for name, off, shape in self.entries:
+            n = _numel(shape)
+            if name.endswith('.weight') and '.convs.' in name:
+                fan_out, fan_in = shape[0], shape[1]
+                bound = (6.0 / (fan_in + fan_out)) ** 0.5
+                flat[off:off + n] = (torch.rand(n, generator=gen) * 2 - 1) * bound
+            elif name.endswith('gn.weight'):
+                flat[off:off + n] = 1.0
+        return flat.to(device)
+
     def unflatten(self, flat):
         return {name: flat[off:off + _numel(shape)].view(shape) for name, off, shape in self.entries}
 
@@ -163,7 +178,7 @@ class FgnnEngine:
         args.ldz = self.ldp
         args.cnt = self.cnt.data_ptr()
         st = _lib.stream_ptr()
-        _lib.call('fgnn_mlp_fwd', C.byref(args), st)
+        _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         for m, j in enumerate(js):
             rec = L.mlp[(k, j)]
             _lib.call('fgnn_gn_finalize', _lib.ptr(self.part[m]), _lib.ptr(self.cnt),
@@ -257,7 +272,7 @@ class FgnnEngine:
             args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'].data_ptr()
-        _lib.call('fgnn_mlp_bwd', C.byref(args), st)
+        _lib.call('fgnn_mlp_bwd', C.byref(args), st, tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0), (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
         _lib.call('fgnn_reduce_partials', _lib.ptr(W['wpart']), W['nwg'], rec['count'],
                   C.c_void_p(grads.data_ptr() + 4 * rec['off']), st)
 

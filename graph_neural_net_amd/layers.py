@@ -1,0 +1,365 @@
+"""Host-side mirror of the reference's layer surface (models/layers.py) on top of
+``libfgnn_hip.so``.
+
+Same class names, constructor signatures, attribute names (``.convs``, ``.gn``) and
+parameter shapes as the reference, so ``state_dict``s are interchangeable
+(``MlpBlock_Real`` :109-131, ``GraphNorm`` :47-69, ``normalize`` :71-80, ``Matmul``
+:161-162, ``Concat`` :145-146, ``ColumnMaxPooling`` :194-203, ``Identity`` :151-152).
+Each forward/backward is a HIP kernel sequence behind a ``torch.autograd.Function``;
+inputs must live on the GPU -- there is no CPU path in this package.
+A ``MaskedTensor`` input (ragged batch) is handled by passing its per-graph vertex
+counts to the kernels; the result is again a ``MaskedTensor`` with exact zeros in the
+padding.
+"""
+import ctypes as C
+import math
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parameter import Parameter
+
+from . import _lib
+from .masked import MaskedTensor
+
+FGNN_H = _lib.FGNN_H
+
+
+def _split(x):
+    """(tensor | MaskedTensor) -> (dense tensor, nvalid or None)."""
+    if isinstance(x, MaskedTensor):
+        return x.tensor, x.nvalid
+    return x, None
+
+
+def _wrap(y, like, masked_dims=None):
+    if isinstance(like, MaskedTensor):
+        return MaskedTensor(y, like.nvalid, masked_dims or like.masked_dims, like.base_name)
+    return y
+
+
+def _check(x, name):
+    if not x.is_cuda:
+        raise RuntimeError('%s: tensor is on %s; graph_neural_net_amd only runs on the GPU (no CPU fallback)'
+                           % (name, x.device))
+    if x.dtype != torch.float32:
+        raise RuntimeError('%s: only float32 is supported (got %s)' % (name, x.dtype))
+
+
+def _nv(nvalid):
+    return _lib.ptr(nvalid) if nvalid is not None else None
+
+
+def _off(t, floats):
+    return C.c_void_p(t.data_ptr() + 4 * floats)
+
+
+def _input_slabs(x, cin, P):
+    """Describe a (G, cin, N, N) tensor as one or two <=32-channel slabs."""
+    a = _lib.make_slab(x, cin * P, P, min(cin, 32))
+    b = None
+    if cin > 32:
+        b = _lib.make_slab(x, cin * P, P, cin - 32)
+        b.ptr = x.data_ptr() + 4 * 32 * P
+    return a, b
+
+
+# --------------------------------------------------------------------------------------
+# MlpBlock_Real = conv1x1/ReLU chain + GraphNorm, one fused forward and one fused backward
+# --------------------------------------------------------------------------------------
+class _MlpGnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nvalid, eps, gn_w, gn_b, *wb):
+        _check(x, 'MlpBlock_Real')
+        x = x.contiguous()
+        G, cin, N, _ = x.shape
+        P = N * N
+        depth = len(wb) // 2
+        dev = x.device
+        tpg = _lib.tiles_per_graph(N)
+        z = torch.empty(G, FGNN_H, N, N, dtype=torch.float32, device=dev)
+        y = torch.empty_like(z)
+        part = torch.empty(G * tpg * FGNN_H * 2, dtype=torch.float32, device=dev)
+        cnt = torch.empty(G * tpg, dtype=torch.float32, device=dev)
+        nrm = torch.empty(G * FGNN_H * 4, dtype=torch.float32, device=dev)
+        wb = [t.contiguous() for t in wb]
+        args = _lib.MlpFwdArgs()
+        args.G, args.N, args.depth, args.nmlp = G, N, depth, 1
+        args.nvalid = nvalid.data_ptr() if nvalid is not None else None
+        a, b = _input_slabs(x, cin, P)
+        args.a = a
+        if b is not None:
+            args.b = b
+        for l in range(depth):
+            if wb[2 * l].shape[0] != FGNN_H:
+                raise RuntimeError('MlpBlock_Real: the HIP kernels are built for out_features = 32')
+            args.W[0][l] = wb[2 * l].data_ptr()
+            args.bias[0][l] = wb[2 * l + 1].data_ptr()
+        args.z[0] = z.data_ptr()
+        args.part[0] = part.data_ptr()
+        args.ldz = P
+        args.cnt = cnt.data_ptr()
+        st = _lib.stream_ptr()
+        _lib.call('fgnn_mlp_fwd', C.byref(args), st)
+        _lib.call('fgnn_gn_finalize', _lib.ptr(part), _lib.ptr(cnt), _lib.ptr(gn_w), _nv(nvalid), G, FGNN_H, N,
+                  float(eps), _lib.ptr(nrm), st)
+        _lib.call('fgnn_gn_apply', _lib.ptr(z), FGNN_H * P, P, _lib.ptr(nrm), _lib.ptr(gn_b), _nv(nvalid), G, FGNN_H, N,
+                  _lib.ptr(y), FGNN_H * P, P, st)
+        ctx.save_for_backward(x, z, nrm, nvalid, gn_w, gn_b, *wb)
+        ctx.depth = depth
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, nrm, nvalid, gn_w, gn_b = ctx.saved_tensors[:6]
+        wb = ctx.saved_tensors[6:]
+        depth = ctx.depth
+        dy = dy.contiguous()
+        G, cin, N, _ = x.shape
+        P = N * N
+        dev = x.device
+        st = _lib.stream_ptr()
+        f32 = dict(dtype=torch.float32, device=dev)
+        s12 = torch.empty(G * FGNN_H * 2, **f32)
+        coef = torch.empty(G * FGNN_H * 4, **f32)
+        dgw = torch.empty(FGNN_H, **f32) if gn_w is not None else None
+        dgb = torch.empty(FGNN_H, **f32) if gn_b is not None else None
+        gs = FGNN_H * P
+        _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, P, _lib.ptr(z), gs, P, _lib.ptr(nrm), _nv(nvalid), G, FGNN_H, N,
+                  _lib.ptr(s12), st)
+        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(s12), _lib.ptr(nrm), _nv(nvalid), G, FGNN_H, N, _lib.ptr(coef),
+                  _lib.ptr(dgw), _lib.ptr(dgb), st)
+        need_dx = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_dx else None
+        nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
+        pcount = _lib.mlp_param_count(cin, depth)
+        wpart = torch.empty(nwg * pcount, **f32)
+        flat = torch.empty(pcount, **f32)
+        args = _lib.MlpBwdArgs()
+        args.G, args.N, args.depth = G, N, depth
+        args.nvalid = nvalid.data_ptr() if nvalid is not None else None
+        a, b = _input_slabs(x, cin, P)
+        args.a = a
+        if b is not None:
+            args.b = b
+        for l in range(depth):
+            args.W[l] = wb[2 * l].data_ptr()
+            args.bias[l] = wb[2 * l + 1].data_ptr()
+        args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, P
+        args.z, args.zgstride, args.ldz = z.data_ptr(), gs, P
+        args.coef = coef.data_ptr()
+        if need_dx:
+            args.dxa, args.dxa_gstride, args.dxa_ld = dx.data_ptr(), cin * P, P
+            if cin > 32:
+                args.dxb, args.dxb_gstride, args.dxb_ld = dx.data_ptr() + 4 * 32 * P, cin * P, P
+        args.wpart = wpart.data_ptr()
+        _lib.call('fgnn_mlp_bwd', C.byref(args), st)
+        _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), nwg, pcount, _lib.ptr(flat), st)
+        grads = []
+        off = 0
+        c = cin
+        for l in range(depth):
+            grads.append(flat[off:off + 32 * c].view(32, c, 1, 1))
+            off += 32 * c
+            grads.append(flat[off:off + 32])
+            off += 32
+            c = 32
+        return (dx, None, None,
+                dgw.view(1, FGNN_H, 1, 1) if dgw is not None else None,
+                dgb.view(1, FGNN_H, 1, 1) if dgb is not None else None, *grads)
+
+
+# --------------------------------------------------------------------------------------
+# GraphNorm / normalize on an arbitrary (G, C, N, N) tensor
+# --------------------------------------------------------------------------------------
+class _GraphNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nvalid, eps, gn_w, gn_b):
+        _check(x, 'GraphNorm')
+        x = x.contiguous()
+        G, Cc, N, _ = x.shape
+        P = N * N
+        nrm = torch.empty(G * Cc * 4, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        st = _lib.stream_ptr()
+        _lib.call('fgnn_gn_stats', _lib.ptr(x), Cc * P, P, _lib.ptr(gn_w), _nv(nvalid), G, Cc, N, float(eps),
+                  _lib.ptr(nrm), st)
+        _lib.call('fgnn_gn_apply', _lib.ptr(x), Cc * P, P, _lib.ptr(nrm), _lib.ptr(gn_b), _nv(nvalid), G, Cc, N,
+                  _lib.ptr(y), Cc * P, P, st)
+        ctx.save_for_backward(x, nrm, nvalid, gn_w, gn_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, nrm, nvalid, gn_w, gn_b = ctx.saved_tensors
+        dy = dy.contiguous()
+        G, Cc, N, _ = x.shape
+        P = N * N
+        f32 = dict(dtype=torch.float32, device=x.device)
+        s12 = torch.empty(G * Cc * 2, **f32)
+        coef = torch.empty(G * Cc * 4, **f32)
+        dgw = torch.empty(Cc, **f32) if gn_w is not None else None
+        dgb = torch.empty(Cc, **f32) if gn_b is not None else None
+        dx = torch.empty_like(x)
+        st = _lib.stream_ptr()
+        gs = Cc * P
+        _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(nrm), _nv(nvalid), G, Cc, N,
+                  _lib.ptr(s12), st)
+        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(s12), _lib.ptr(nrm), _nv(nvalid), G, Cc, N, _lib.ptr(coef),
+                  _lib.ptr(dgw), _lib.ptr(dgb), st)
+        _lib.call('fgnn_gn_bwd_apply', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(coef), _nv(nvalid), G, Cc, N,
+                  _lib.ptr(dx), gs, P, st)
+        return (dx, None, None, dgw.view(1, Cc, 1, 1) if dgw is not None else None,
+                dgb.view(1, Cc, 1, 1) if dgb is not None else None)
+
+
+def normalize(b, constant_n_vertices=True, eps=1e-05):
+    """(b - mean) / (2 sqrt(n (var + eps))) per (graph, channel)  (models/layers.py:71-80)."""
+    x, nvalid = _split(b)
+    if not constant_n_vertices and nvalid is None:
+        raise RuntimeError('normalize(constant_n_vertices=False) expects a MaskedTensor')
+    return _wrap(_GraphNormFn.apply(x, nvalid, eps, None, None), b)
+
+
+class GraphNorm(nn.Module):
+    def __init__(self, features, constant_n_vertices=True, elementwise_affine=True, eps=1e-05, device=None, dtype=None):
+        super().__init__()
+        factory_kwargs = {'device': device, 'dtype': dtype}
+        self.constant_n_vertices = constant_n_vertices
+        self.eps = eps
+        self.elementwise_affine = elementwise_affine
+        self.features = (1, features, 1, 1)
+        if elementwise_affine:
+            self.weight = Parameter(torch.ones(self.features, **factory_kwargs))
+            self.bias = Parameter(torch.zeros(self.features, **factory_kwargs))
+        else:
+            self.register_parameter('weight', None)
+            self.register_parameter('bias', None)
+
+    def reset_parameters(self):
+        if self.elementwise_affine:
+            nn.init.ones_(self.weight)
+            nn.init.zeros_(self.bias)
+
+    def forward(self, b):
+        x, nvalid = _split(b)
+        return _wrap(_GraphNormFn.apply(x, nvalid, self.eps, self.weight, self.bias), b)
+
+
+def _init_weights(layer):
+    nn.init.xavier_uniform_(layer.weight)
+    if layer.bias is not None:
+        nn.init.zeros_(layer.bias)
+
+
+class MlpBlock_Real(nn.Module):
+    """depth_of_mlp 1x1 convs with ReLU after all but the last, then GraphNorm."""
+
+    def __init__(self, in_features, out_features, depth_of_mlp, activation_fn=F.relu, constant_n_vertices=True):
+        super().__init__()
+        if activation_fn is not F.relu:
+            raise RuntimeError('MlpBlock_Real: the fused HIP kernels implement ReLU only')
+        self.activation = activation_fn
+        self.depth_mlp = depth_of_mlp
+        self.cst_vertices = constant_n_vertices
+        self.convs = nn.ModuleList()
+        for _ in range(depth_of_mlp):
+            self.convs.append(nn.Conv2d(in_features, out_features, kernel_size=1, padding=0, bias=True))
+            _init_weights(self.convs[-1])
+            in_features = out_features
+        self.gn = GraphNorm(out_features, constant_n_vertices=constant_n_vertices)
+
+    def forward(self, inputs):
+        x, nvalid = _split(inputs)
+        wb = []
+        for conv in self.convs:
+            wb += [conv.weight, conv.bias]
+        y = _MlpGnFn.apply(x, nvalid, self.gn.eps, self.gn.weight, self.gn.bias, *wb)
+        return _wrap(y, inputs)
+
+
+# --------------------------------------------------------------------------------------
+# Matmul / Concat / ColumnMaxPooling / Identity
+# --------------------------------------------------------------------------------------
+class _MatmulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, nvalid):
+        _check(a, 'Matmul')
+        _check(b, 'Matmul')
+        a, b = a.contiguous(), b.contiguous()
+        G, Cc, N, _ = a.shape
+        P = N * N
+        out = torch.empty_like(a)
+        sa, sb = _lib.make_slab(a, Cc * P, P, Cc), _lib.make_slab(b, Cc * P, P, Cc)
+        _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), _nv(nvalid), G, N, _lib.ptr(out), Cc * P, P,
+                  _lib.stream_ptr())
+        ctx.save_for_backward(a, b, nvalid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dm):
+        a, b, nvalid = ctx.saved_tensors
+        dm = dm.contiguous()
+        G, Cc, N, _ = a.shape
+        P = N * N
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        sa, sb = _lib.make_slab(a, Cc * P, P, Cc), _lib.make_slab(b, Cc * P, P, Cc)
+        _lib.call('fgnn_chan_matmul_bwd', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * P, P, _nv(nvalid), G, N,
+                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.stream_ptr())
+        return da, db, None
+
+
+class Matmul(nn.Module):
+    def forward(self, xs1, xs2):
+        a, nvalid = _split(xs1)
+        b, _ = _split(xs2)
+        return _wrap(_MatmulFn.apply(a, b, nvalid), xs1)
+
+
+class Concat(nn.Module):
+    """torch.cat on channels (padding stays zero, so no re-mask is needed)."""
+
+    def forward(self, *xs):
+        ts = [_split(x)[0] for x in xs]
+        return _wrap(torch.cat(ts, dim=1), xs[0])
+
+
+class _ColMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nvalid):
+        _check(x, 'ColumnMaxPooling')
+        x = x.contiguous()
+        G, Cc, N, _ = x.shape
+        P = N * N
+        e = torch.empty(G, Cc, N, dtype=torch.float32, device=x.device)
+        idx = torch.empty(G, Cc, N, dtype=torch.int32, device=x.device)
+        s = _lib.make_slab(x, Cc * P, P, Cc)
+        _lib.call('fgnn_colmax_fwd', C.byref(s), _nv(nvalid), G, N, _lib.ptr(e), _lib.ptr(idx), _lib.stream_ptr())
+        ctx.save_for_backward(idx, nvalid)
+        ctx.n = N
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        idx, nvalid = ctx.saved_tensors
+        de = de.contiguous()
+        G, Cc, N = de.shape
+        P = N * N
+        dx = torch.empty(G, Cc, N, N, dtype=torch.float32, device=de.device)
+        _lib.call('fgnn_colmax_bwd', _lib.ptr(de), _lib.ptr(idx), _nv(nvalid), G, Cc, N, _lib.ptr(dx), Cc * P, P,
+                  _lib.stream_ptr())
+        return dx, None
+
+
+class ColumnMaxPooling(nn.Module):
+    """(bs, features, n, n) -> (bs, features, n): max over the last index."""
+
+    def forward(self, x):
+        t, nvalid = _split(x)
+        return _wrap(_ColMaxFn.apply(t, nvalid), x, masked_dims=(2,))
+
+
+class Identity(namedtuple('Identity', [])):
+    def __call__(self, x):
+        return x

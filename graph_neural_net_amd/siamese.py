@@ -1,0 +1,97 @@
+"""``Siamese_Node_Exp`` (models/trainers.py:20-68) without the Lightning shell: shared node
+embedder on both graphs of a pair, scores[b,i,j] = <E1[b,:,i], E2[b,:,j]>.
+
+The two branches share weights, so they are embedded as ONE stacked batch of 2B graphs
+through the fused engine; the outer-product scoring and its backward are HIP kernels too.
+Inputs arrive as the reference's loaders produce them: ``{'input': T}`` dicts
+(loaders/loaders.py:12-15) or bare tensors / MaskedTensors.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .blocks import block, block_emb, node_embedding
+from .losses import triplet_loss
+from .masked import MaskedTensor
+from .network import Network
+
+get_node_emb = {'node_embedding': node_embedding}
+get_block_init = {'block_emb': block_emb}
+get_block_inside = {'block': block}
+
+
+class _ScoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e1, e2, nvalid):
+        e1, e2 = e1.contiguous(), e2.contiguous()
+        B, Cc, N = e1.shape
+        scores = torch.empty(B, N, N, dtype=torch.float32, device=e1.device)
+        _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(nvalid) if nvalid is not None else None,
+                  B, Cc, N, _lib.ptr(scores), None, None, _lib.stream_ptr())
+        ctx.save_for_backward(e1, e2, nvalid)
+        return scores
+
+    @staticmethod
+    def backward(ctx, ds):
+        e1, e2, nvalid = ctx.saved_tensors
+        B, Cc, N = e1.shape
+        d1, d2 = torch.empty_like(e1), torch.empty_like(e2)
+        _lib.call('fgnn_score_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(ds.contiguous()),
+                  _lib.ptr(nvalid) if nvalid is not None else None, B, Cc, N, _lib.ptr(d1), _lib.ptr(d2),
+                  _lib.stream_ptr())
+        return d1, d2, None
+
+
+def _unwrap_input(x):
+    return x['input'] if isinstance(x, dict) else x
+
+
+class Siamese_Node_Exp(nn.Module):
+    def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5):
+        super().__init__()
+        node_emb = dict(node_emb)
+        try:
+            node_emb_type = get_node_emb[node_emb['type']]
+        except KeyError:
+            raise NotImplementedError(f"node embedding {node_emb['type']} is not implemented")
+        try:
+            node_emb['block_inside'] = get_block_inside[node_emb['block_inside']]
+        except KeyError:
+            raise NotImplementedError(f"block inside {node_emb['block_inside']} is not implemented")
+        try:
+            node_emb['block_init'] = get_block_init[node_emb['block_init']]
+        except KeyError:
+            raise NotImplementedError(f"block init {node_emb['block_init']} is not implemented")
+        self.out_features = node_emb['out_features']
+        self.node_embedder_dic = {'input': (None, []), 'ne': node_emb_type(original_features_num, **node_emb)}
+        self.node_embedder = Network(self.node_embedder_dic)
+        self.loss = triplet_loss()
+        self.lr, self.scheduler_decay, self.scheduler_step, self.lr_stop = lr, scheduler_decay, scheduler_step, lr_stop
+
+    def forward(self, x1, x2):
+        """x1, x2: (bs, features, n, n) (or MaskedTensors of ragged graphs, both sides sharing the
+        per-pair vertex counts) -> raw scores (bs, n, n)."""
+        x1, x2 = _unwrap_input(x1), _unwrap_input(x2)
+        ragged = isinstance(x1, MaskedTensor)
+        if ragged:
+            t = torch.cat([x1.tensor, x2.tensor])
+            stacked = MaskedTensor(t, torch.cat([x1.nvalid, x2.nvalid]), x1.masked_dims, x1.base_name)
+            nvalid = x1.nvalid
+        else:
+            stacked = torch.cat([x1, x2])
+            nvalid = None
+        e = self.node_embedder.fused_embedding(stacked)
+        et = e.tensor if ragged else e
+        B = et.shape[0] // 2
+        scores = _ScoreFn.apply(et[:B], et[B:], nvalid)
+        if ragged:
+            return MaskedTensor(scores, nvalid, (1, 2), x1.base_name)
+        return scores
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, amsgrad=False)
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=self.scheduler_decay,
+                                                               patience=self.scheduler_step, min_lr=self.lr_stop)
+        return {'optimizer': optimizer, 'lr_scheduler': {'scheduler': scheduler, 'monitor': 'val_loss', 'frequency': 1}}

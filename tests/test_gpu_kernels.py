@@ -1,0 +1,120 @@
+"""GPU: individual entry points of the C ABI against plain PyTorch fp32/fp64 references."""
+import ctypes as C
+
+import pytest
+import torch
+
+from graph_neural_net_amd import _lib
+from util import rel
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _slab(t, nrm=None, beta=None):
+    G, Cc, N, _ = t.shape
+    return _lib.make_slab(t, Cc * N * N, N * N, Cc, nrm=nrm, beta=beta)
+
+
+@pytest.mark.parametrize('G,Cc,N', [(3, 4, 50), (2, 2, 7), (1, 3, 64), (2, 2, 65), (1, 2, 130)])
+def test_chan_matmul_fwd_bwd(G, Cc, N):
+    g = torch.Generator().manual_seed(N)
+    a = torch.randn(G, Cc, N, N, generator=g)
+    b = torch.randn(G, Cc, N, N, generator=g)     # asymmetric operands: catches transposed fragments
+    dm = torch.randn(G, Cc, N, N, generator=g)
+    ad, bd, dmd = a.to(DEV), b.to(DEV), dm.to(DEV)
+    out = torch.empty_like(ad)
+    P = N * N
+    sa, sb = _slab(ad), _slab(bd)
+    _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), None, G, N, _lib.ptr(out), Cc * P, P, _lib.stream_ptr())
+    ref = torch.matmul(a.double(), b.double())
+    assert rel(out.cpu(), ref) < 2e-6
+    da, db = torch.empty_like(ad), torch.empty_like(ad)
+    _lib.call('fgnn_chan_matmul_bwd', C.byref(sa), C.byref(sb), _lib.ptr(dmd), Cc * P, P, None, G, N,
+              _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.stream_ptr())
+    assert rel(da.cpu(), torch.matmul(dm.double(), b.double().transpose(-1, -2))) < 2e-6
+    assert rel(db.cpu(), torch.matmul(a.double().transpose(-1, -2), dm.double())) < 2e-6
+
+
+def test_chan_matmul_ragged_padding_is_zero():
+    G, Cc, N = 3, 2, 20
+    nv = torch.tensor([20, 13, 5], dtype=torch.int32)
+    a = torch.randn(G, Cc, N, N)
+    b = torch.randn(G, Cc, N, N)                  # garbage in the padding on purpose
+    out = torch.full((G, Cc, N, N), 7.0, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    sa, sb = _slab(ad), _slab(bd)
+    P = N * N
+    _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), _lib.ptr(nv.to(DEV)), G, N, _lib.ptr(out), Cc * P, P,
+              _lib.stream_ptr())
+    out = out.cpu()
+    for g, n in enumerate(nv.tolist()):
+        ref = a[g, :, :n, :n].double() @ b[g, :, :n, :n].double()
+        assert rel(out[g, :, :n, :n], ref) < 2e-6
+        assert out[g, :, n:, :].abs().sum() == 0 and out[g, :, :, n:].abs().sum() == 0
+
+
+def test_colmax_first_index_on_ties_bit_exact():
+    G, Cc, N = 2, 3, 11
+    x = torch.randint(-3, 4, (G, Cc, N, N)).float()      # many exact ties
+    xd = x.to(DEV)
+    e = torch.empty(G, Cc, N, device=DEV)
+    idx = torch.empty(G, Cc, N, dtype=torch.int32, device=DEV)
+    s = _slab(xd)
+    _lib.call('fgnn_colmax_fwd', C.byref(s), None, G, N, _lib.ptr(e), _lib.ptr(idx), _lib.stream_ptr())
+    # first-max index (what torch.max on CPU returns for the reference) = N-1 - argmax of the reversed row
+    val = x.max(-1)[0]
+    first = (x == val.unsqueeze(-1)).float().argmax(-1)
+    assert torch.equal(e.cpu(), val)
+    assert torch.equal(idx.cpu().long(), first)
+    de = torch.randn(G, Cc, N)
+    dy = torch.empty(G, Cc, N, N, device=DEV)
+    _lib.call('fgnn_colmax_bwd', _lib.ptr(de.to(DEV)), _lib.ptr(idx), None, G, Cc, N, _lib.ptr(dy), Cc * N * N, N * N,
+              _lib.stream_ptr())
+    ref = torch.zeros(G, Cc, N, N).scatter_(-1, first.unsqueeze(-1), de.unsqueeze(-1))
+    assert torch.equal(dy.cpu(), ref)
+
+
+@pytest.mark.parametrize('B,Cc,N', [(3, 32, 50), (2, 8, 9)])
+def test_score_and_ce(B, Cc, N):
+    e1 = torch.randn(B, Cc, N)
+    e2 = torch.randn(B, Cc, N)
+    e1d, e2d = e1.to(DEV), e2.to(DEV)
+    scores = torch.empty(B, N, N, device=DEV)
+    lse = torch.empty(B, N, device=DEV)
+    pl = torch.empty(B, device=DEV)
+    _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1d), _lib.ptr(e2d), None, B, Cc, N, _lib.ptr(scores), _lib.ptr(lse),
+              _lib.ptr(pl), _lib.stream_ptr())
+    a, b = e1.double().requires_grad_(True), e2.double().requires_grad_(True)
+    sref = torch.matmul(a.transpose(1, 2), b)
+    lref = sum(torch.nn.functional.cross_entropy(s, torch.arange(N), reduction='sum') for s in sref)
+    assert rel(scores.cpu(), sref) < 2e-6
+    assert rel(pl.sum().cpu(), lref) < 2e-6
+    gscale = torch.tensor([0.37], device=DEV)
+    d1, d2 = torch.empty_like(e1d), torch.empty_like(e2d)
+    _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1d), _lib.ptr(e2d), _lib.ptr(scores), _lib.ptr(lse), None,
+              _lib.ptr(gscale), B, Cc, N, _lib.ptr(d1), _lib.ptr(d2), _lib.stream_ptr())
+    (lref * 0.37).backward()
+    assert rel(d1.cpu(), a.grad) < 5e-6 and rel(d2.cpu(), b.grad) < 5e-6
+
+
+def test_gn_stats_two_pass_is_shift_robust():
+    """Large mean / small variance: the tile-wise Chan combination must not cancel."""
+    G, Cc, N = 2, 4, 50
+    x = (1000.0 + 0.01 * torch.randn(G, Cc, N, N)).float()
+    xd = x.to(DEV)
+    nrm = torch.empty(G * Cc * 4, device=DEV)
+    P = N * N
+    _lib.call('fgnn_gn_stats', _lib.ptr(xd), Cc * P, P, None, None, G, Cc, N, 1e-5, _lib.ptr(nrm), _lib.stream_ptr())
+    nrm = nrm.cpu().view(G, Cc, 4)
+    mean = x.double().mean((-1, -2))
+    var = x.double().var((-1, -2), unbiased=False)
+    assert rel(nrm[..., 0], mean) < 1e-6
+    assert rel(nrm[..., 3], 1.0 / (var + 1e-5)) < 1e-3
+
+
+def test_unsupported_shapes_fail_loudly():
+    args = _lib.MlpFwdArgs()
+    args.G, args.N, args.depth, args.nmlp = 1, 4, 3, 1
+    with pytest.raises(RuntimeError, match='fgnn_mlp_fwd'):
+        _lib.call('fgnn_mlp_fwd', C.byref(args), _lib.stream_ptr())

@@ -1,0 +1,157 @@
+"""GPU: the reference's module surface on top of the HIP kernels.  These read like the
+reference's own tests (maskedtensors/test_maskedtensor.py): masked batch == list of
+per-graph dense results, atol 1e-5; expected values come from the oracle / golden vectors."""
+import pytest
+import torch
+
+from graph_neural_net_amd import synthetic
+from graph_neural_net_amd.layers import ColumnMaxPooling, Concat, GraphNorm, Matmul, MlpBlock_Real, normalize
+from graph_neural_net_amd.losses import triplet_loss
+from graph_neural_net_amd.masked import from_list
+from graph_neural_net_amd.siamese import Siamese_Node_Exp
+from oracle import fgnn_oracle as O
+from util import is_zero_grad, load_golden, rel, sub
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ATOL = 1e-5
+N_FEATURES = 16
+N_VERTICES_RANGE = range(40, 50)
+
+
+def apply_list_tensors(lst, func):
+    return [func(t.unsqueeze(0)).squeeze(0) for t in lst]
+
+
+@pytest.fixture
+def tensor_list():
+    g = torch.Generator().manual_seed(0)
+    return [torch.empty((N_FEATURES, n, n)).normal_(generator=g).to(DEV) for n in N_VERTICES_RANGE]
+
+
+def _mlp_pair():
+    torch.manual_seed(1)
+    mlp_mt = MlpBlock_Real(N_FEATURES, 2 * N_FEATURES, 2, constant_n_vertices=False).to(DEV)
+    mlp = MlpBlock_Real(N_FEATURES, 2 * N_FEATURES, 2).to(DEV)
+    mlp.convs = mlp_mt.convs
+    return mlp_mt, mlp
+
+
+def test_layers_masked_equals_per_graph_dense(tensor_list):
+    mlp_mt, mlp = _mlp_pair()
+    gn_mt, gn = GraphNorm(N_FEATURES, constant_n_vertices=False).to(DEV), GraphNorm(N_FEATURES).to(DEV)
+    for func_mt, func in ((mlp_mt, mlp), (gn_mt, gn),
+                          (lambda t: normalize(t, constant_n_vertices=False), normalize)):
+        mt = from_list(tensor_list, dims=(1, 2))
+        res_mt = list(func_mt(mt))
+        res_lst = apply_list_tensors(tensor_list, func)
+        for a, b in zip(res_mt, res_lst):
+            assert a.size() == b.size()
+            assert torch.allclose(a, b, atol=ATOL), torch.norm(a - b, p=float('inf'))
+
+
+def test_binary_masked_equals_per_graph_dense(tensor_list):
+    g = torch.Generator().manual_seed(5)
+    other = [torch.empty((N_FEATURES, n, n)).normal_(generator=g).to(DEV) for n in N_VERTICES_RANGE]
+    for func in (Matmul(), Concat()):
+        mt, ot = from_list(tensor_list, dims=(1, 2)), from_list(other, dims=(1, 2))
+        res_mt = list(func(mt, ot))
+        res_lst = [func(a.unsqueeze(0), b.unsqueeze(0)).squeeze(0) for a, b in zip(tensor_list, other)]
+        for a, b in zip(res_mt, res_lst):
+            assert a.size() == b.size() and torch.allclose(a, b, atol=1e-4)
+    mt = from_list(tensor_list, dims=(1, 2))
+    res_mt = list(ColumnMaxPooling()(mt))
+    for a, t in zip(res_mt, tensor_list):
+        assert torch.equal(a, t.max(-1)[0])
+
+
+def test_layers_against_reference_golden():
+    d = load_golden('layers_16to32_depth2.npz')
+    mlp = MlpBlock_Real(16, 32, 2).to(DEV)
+    mlp.load_state_dict({k: v for k, v in sub(d, 'mlp_sd/').items()})
+    gn = GraphNorm(16).to(DEV)
+    gn.load_state_dict(sub(d, 'gn_sd/'))
+    for i in range(3):
+        x = d['x/%d' % i].unsqueeze(0).to(DEV)
+        assert rel(mlp(x).squeeze(0).cpu(), d['mlp/%d' % i]) < ATOL
+        assert rel(gn(x).squeeze(0).cpu(), d['gn/%d' % i]) < ATOL
+        assert rel(normalize(x).squeeze(0).cpu(), d['normalize/%d' % i]) < ATOL
+
+
+def test_module_autograd_against_oracle():
+    """Unfused module graph (Network.forward) fwd+bwd == oracle autograd."""
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=1,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    x1, x2 = d['x1'].to(DEV), d['x2'].to(DEV)
+    out = model.node_embedder({'input': x1})
+    for k in ('mlp1', 'mlp2', 'mult', 'mlp3'):
+        assert rel(out['ne/bm/block1/' + k].cpu(), d['inter/ne/bm/block1/' + k]) < ATOL
+    e1 = out['ne/suffix']
+    e2 = model.node_embedder({'input': x2})['ne/suffix']
+    scores = torch.matmul(e1.transpose(1, 2), e2)
+    loss = model.loss(scores)
+    loss.backward()
+    assert rel(scores.detach().cpu(), d['scores']) < ATOL
+    assert abs(loss.item() - d['loss'].item()) < 1e-5
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if not is_zero_grad(k):
+            assert rel(p.grad.cpu(), d['grad/' + k]) < 5e-5, k
+
+
+def test_siamese_fused_module_path():
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=4,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    scores = model({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+    loss = model.loss(scores)
+    loss.backward()
+    assert rel(scores.detach().cpu(), d['scores']) < 3e-5
+    assert abs(loss.item() - d['loss'].item()) < 1e-5 * d['loss'].item()
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if not is_zero_grad(k):
+            yard = rel(d['grad/' + k], d['grad64/' + k])
+            assert rel(p.grad.cpu(), d['grad64/' + k]) < 2 * yard + 1e-5, k
+
+
+def test_siamese_ragged_module_path():
+    """Variable-N pairs through MaskedTensors: the path that is broken in the reference;
+    expected values = per-graph dense oracle runs."""
+    torch.manual_seed(2)
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2,
+              in_features=32, out_features=32, depth_of_mlp=3, constant_n_vertices=False)
+    model = Siamese_Node_Exp(2, ne).to(DEV)
+    sd = {k[len('node_embedder.'):]: v.detach().cpu() for k, v in model.state_dict().items()}
+    xs, ys = synthetic.make_ragged_batch(4, 5, 30, 44)
+    s_ref, l_ref, g_ref = O.step_fwd_bwd_ragged(xs, ys, sd)
+    m1 = from_list([x.to(DEV) for x in xs], dims=(1, 2), base_name='N')
+    m2 = from_list([y.to(DEV) for y in ys], dims=(1, 2), base_name='M')
+    scores = model(m1, m2)
+    loss = model.loss(scores)
+    loss.backward()
+    for a, b in zip(list(scores), s_ref):
+        assert a.shape == b.shape and rel(a.detach().cpu(), b) < 2e-5
+    assert abs(loss.item() - l_ref.item()) < 1e-5 * l_ref.item()
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if not is_zero_grad(k):
+            assert rel(p.grad.cpu(), g_ref[k]) < 2e-4, (k, rel(p.grad.cpu(), g_ref[k]))
+
+
+def test_loss_masked_equals_stacked():
+    g = torch.Generator().manual_seed(0)
+    lst = [torch.empty((50, 50)).normal_(generator=g).to(DEV) for _ in range(6)]
+    for red in ('mean', 'mean_of_mean'):
+        f = triplet_loss(loss_reduction=red)
+        a = f(from_list(lst, dims=(0, 1)))
+        b = f(torch.stack(lst))
+        assert torch.allclose(a, b, atol=ATOL)
+    stacked = torch.stack(lst).cpu()
+    ref = O.triplet_loss_mean(stacked)
+    assert abs(triplet_loss()(torch.stack(lst)).item() - ref.item()) < 1e-5

@@ -1,0 +1,162 @@
+"""GPU: the fused HIP path (through the C ABI) against the golden vectors of the reference
+and against the oracle on the same seeded inputs.
+
+Tolerances (max-norm relative error): the reference's own fp32
+result differs from its fp64 result by ~1e-5 on scores and up to ~2e-3 on early-layer
+gradients, so gradients are gated against the fp64 golden with the reference's own
+fp32-vs-fp64 error as the yard-stick (we must be no worse than 2x that + 1e-5).
+"""
+import numpy as np
+import pytest
+import torch
+
+from graph_neural_net_amd import synthetic
+from graph_neural_net_amd.engine import FgnnEngine, ParamLayout
+from oracle import fgnn_oracle as O
+from util import is_zero_grad, load_golden, rel, sub
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+OP_TOL = 1e-5          # per-block forward / scores at small depth
+E2E_FWD_TOL = 3e-5     # block-4 activations / scores after 4 blocks (reference fp32-vs-fp64: 1.6e-5 / 1.4e-5)
+
+
+def _run_engine(sd, x1, x2, nblk, nvalid=None):
+    lay = ParamLayout(2, nblk, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    grads = torch.zeros_like(params)
+    B = x1.shape[0]
+    eng = FgnnEngine(lay, 2 * B, x1.shape[-1], DEV, ragged=nvalid is not None)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nv = None if nvalid is None else torch.cat([nvalid, nvalid]).to(DEV)
+    scores, loss = eng.step(params, grads, x, nvalid=nv)
+    torch.cuda.synchronize()
+    return eng, params, lay, scores.cpu(), loss.item(), lay.unflatten(grads.cpu())
+
+
+def _check_grads(got, d):
+    for k, ref in sub(d, 'grad/').items():
+        if is_zero_grad(k):
+            assert got[k].abs().max() < 1e-4, k
+            continue
+        ref64 = d['grad64/' + k]
+        yard = rel(ref, ref64)                    # the reference's own fp32 error
+        assert rel(got[k], ref64) < 2 * yard + 1e-5, (k, rel(got[k], ref64), yard)
+
+
+def test_cfg1_against_golden():
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    eng, params, lay, scores, loss, grads = _run_engine(sub(d, 'sd/'), d['x1'], d['x2'], 1)
+    B = d['x1'].shape[0]
+    for j in (1, 2, 3):
+        y = eng.normalized(1, j, params).cpu()[:B]
+        assert rel(y, d['inter/ne/bm/block1/mlp%d' % j]) < OP_TOL
+    assert rel(eng.unpadded(eng.mult[1]).cpu()[:B], d['inter/ne/bm/block1/mult']) < OP_TOL
+    assert rel(eng.E.cpu()[:B], d['inter/ne/suffix']) < OP_TOL
+    assert rel(scores, d['scores']) < OP_TOL
+    assert abs(loss - d['loss'].item()) < 1e-5 * abs(d['loss'].item())
+    _check_grads(grads, d)
+    for k, ref in sub(d, 'grad/').items():      # 1 block: also tight against the fp32 golden
+        if not is_zero_grad(k):
+            assert rel(grads[k], ref) < 2e-5, k
+
+
+def test_cfg2_against_golden():
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    eng, params, lay, scores, loss, grads = _run_engine(sub(d, 'sd/'), d['x1'], d['x2'], 4)
+    assert rel(eng.normalized(1, 3, params).cpu()[:1], d['inter/ne/bm/block1/mlp3']) < OP_TOL
+    assert rel(eng.normalized(4, 3, params).cpu()[:1], d['inter/ne/bm/block4/mlp3']) < E2E_FWD_TOL
+    assert rel(eng.E.cpu()[:1], d['inter/ne/suffix']) < E2E_FWD_TOL
+    assert rel(scores, d['scores']) < E2E_FWD_TOL
+    assert rel(scores, d['scores64']) < E2E_FWD_TOL
+    assert abs(loss - d['loss'].item()) < 1e-5 * abs(d['loss'].item())
+    _check_grads(grads, d)
+
+
+def test_ragged_against_golden():
+    d = load_golden('ragged_er_b4_2blk.npz')
+    ns = [int(v) for v in d['ns']]
+    nmax = max(ns)
+    xs = [d['x1/%d' % i] for i in range(len(ns))]
+    ys = [d['x2/%d' % i] for i in range(len(ns))]
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    eng, params, lay, scores, loss, grads = _run_engine(sub(d, 'sd/'), x1, x2, 2, nvalid=nv)
+    E = eng.E.cpu()
+    for i, n in enumerate(ns):
+        assert rel(E[i, :, :n], d['e1/%d' % i]) < OP_TOL
+        assert rel(E[len(ns) + i, :, :n], d['e2/%d' % i]) < OP_TOL
+        assert rel(scores[i, :n, :n], d['scores/%d' % i]) < OP_TOL
+        # padding is exactly zero (MaskedTensor invariant), bit-exact
+        assert E[i, :, n:].abs().sum() == 0 and scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
+    y = eng.normalized(2, 3, params).cpu()
+    for i, n in enumerate(ns):
+        assert y[i, :, n:, :].abs().sum() == 0 and y[i, :, :, n:].abs().sum() == 0
+    assert abs(loss - d['loss'].item()) < 1e-5 * abs(d['loss'].item())
+    for k, ref in sub(d, 'grad/').items():
+        if is_zero_grad(k):
+            assert grads[k].abs().max() < 1e-4
+        else:
+            assert rel(grads[k], ref) < 1e-4, (k, rel(grads[k], ref))
+
+
+def test_seeded_random_against_oracle():
+    """ER pairs, N=23 (odd N, N*N not a multiple of the tile), 2 blocks, perturbed affine."""
+    torch.manual_seed(3)
+    sd = O.init_state_dict(num_blocks=2)
+    g = torch.Generator().manual_seed(9)
+    for k in sd:
+        if k.endswith('.bias') and sd[k].dim() == 1:
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith('gn.weight'):
+            sd[k] = sd[k] * (1 + 0.3 * torch.randn(sd[k].shape, generator=g))
+        elif k.endswith('gn.bias'):
+            sd[k] = 0.05 * torch.randn(sd[k].shape, generator=g)
+    x1, x2 = synthetic.make_batch(5, 3, 23, 'ErdosRenyi', 0.3, 0.1)
+    s_ref, l_ref, g_ref = O.step_fwd_bwd(x1, x2, sd)
+    _, _, _, scores, loss, grads = _run_engine(sd, x1, x2, 2)
+    assert rel(scores, s_ref) < OP_TOL
+    assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    for k, v in g_ref.items():
+        if not is_zero_grad(k):
+            assert rel(grads[k], v) < 1e-4, (k, rel(grads[k], v))
+
+
+def test_full_size_properties():
+    """BASELINE config 1 at full size (B=32, N=50, 4 blocks): size-independent properties."""
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.init_flat(0, DEV)
+    x1, x2 = synthetic.make_batch(2000, 32, 50, 'Regular', 0.2, 0.1)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    eng = FgnnEngine(lay, 64, 50, DEV)
+    g1 = torch.zeros_like(params)
+    s1, l1 = eng.step(params, g1, x)
+    s1, l1 = s1.clone(), l1.clone()
+    E1 = eng.E.clone()
+    # (1) run-to-run determinism: bit-exact (fixed-order reductions, no atomics)
+    g2 = torch.zeros_like(params)
+    s2, l2 = eng.step(params, g2, x)
+    assert torch.equal(s1, s2) and torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and torch.isfinite(s1).all()
+    # (2) graphs are independent: a sub-batch gives bit-identical embeddings
+    eng8 = FgnnEngine(lay, 16, 50, DEV)
+    xs = torch.cat([x1[:8], x2[:8]]).contiguous().to(DEV)
+    eng8.embed(params, xs)
+    assert torch.equal(eng8.E[:8], E1[:8]) and torch.equal(eng8.E[8:], E1[32:40])
+    # (3) vertex-permutation equivariance of the embedder (per-graph relabelling permutes columns)
+    perm = torch.randperm(50, generator=torch.Generator().manual_seed(1))
+    xp = x1[:8][:, :, perm][:, :, :, perm]
+    eng8.embed(params, torch.cat([xp, x2[:8]]).contiguous().to(DEV))
+    assert rel(eng8.E[:8].cpu(), E1[:8].cpu()[:, :, perm]) < 1e-4
+    # (4) data-parallel decomposition: sum of shard gradients (global normaliser) == full gradient
+    acc = torch.zeros_like(params)
+    for lo in range(0, 32, 8):
+        xs = torch.cat([x1[lo:lo + 8], x2[lo:lo + 8]]).contiguous().to(DEV)
+        gs = torch.zeros_like(params)
+        eng8.step(params, gs, xs, total_nodes=32 * 50)
+        acc += gs
+    assert rel(acc.cpu(), g1.cpu()) < 1e-5
+    # (5) oracle spot check on 2 pairs of the same batch
+    sd = {k: v.clone() for k, v in lay.unflatten(params.cpu()).items()}
+    s_ref = O.siamese_scores(x1[:2], x2[:2], sd)
+    assert rel(s1[:2].cpu(), s_ref) < E2E_FWD_TOL
