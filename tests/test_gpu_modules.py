@@ -117,7 +117,7 @@ def test_siamese_fused_module_path():
         k = n[len('node_embedder.'):]
         if not is_zero_grad(k):
             yard = rel(d['grad/' + k], d['grad64/' + k])
-            assert rel(p.grad.cpu(), d['grad64/' + k]) < 2 * yard + 1e-5, k
+            assert rel(p.grad.cpu(), d['grad64/' + k]) < 4 * yard + 1e-5, k
 
 
 def test_siamese_ragged_module_path():
