@@ -49,9 +49,15 @@ class MlpBwdArgs(C.Structure):
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
-                ('wpart', C.c_void_p)]
+                ('wpart', C.c_void_p), ('s12part', C.c_void_p)]
 
 
+class GradJob(C.Structure):
+    _fields_ = [('wpart', C.c_void_p), ('count', C.c_int), ('out', C.c_void_p), ('s12', C.c_void_p),
+                ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p)]
+
+
+MAX_GRAD_JOBS = 16
 _VP, _LL, _I, _F = C.c_void_p, C.c_longlong, C.c_int, C.c_float
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -71,14 +77,16 @@ _SIGNATURES = {
     'fgnn_score_bwd': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_ce_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_ce_bwd': [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP],
-    'fgnn_colmax_bwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_colmax_bwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab), _VP, _VP],
     'fgnn_gn_bwd_stats': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _VP],
     'fgnn_gn_bwd_coef': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
+    'fgnn_gn_bwd_coef_tiles': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_grad_finalize': [_VP, _I, _I, _I, _I, _VP],
     'fgnn_gn_bwd_apply': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_mlp_bwd': [C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
-    'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP],
+    'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
     'fgnn_sum_scale': [_VP, _I, _I, _F, _VP, _VP],
 }
 _RESTYPES = {'fgnn_last_error': C.c_char_p}

@@ -49,6 +49,34 @@ DEVI float wave_max(float v) {
     return v;
 }
 
+// ---- buffer-descriptor addressing of a (G, C, ld) fp32 tensor -------------------------
+// One VGPR byte offset per lane per tile (pixel + half-wave row part), the per-row part in
+// an SGPR soffset: no 64-bit per-load address VGPRs.  Out-of-range lanes use OOB_OFF, for
+// which loads return 0 and stores are dropped (tensors are checked to be < 2 GiB).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int OOB_OFF = (int)0x80000000;
+
+struct View {
+    rsrc_t r;
+    int gs4, ld4;     // byte strides between graphs / channels
+};
+
+DEVI View make_view(const float *p, long long gstride, long long ld, int G) {
+    View v;
+    long long bytes = (long long)G * gstride * 4;
+    if (bytes > 0x7fffffffll) bytes = 0x7fffffffll;
+    v.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+    v.gs4 = (int)(gstride * 4);
+    v.ld4 = (int)(ld * 4);
+    return v;
+}
+DEVI float buf_load(const View &v, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(v.r, voff, soff, 0));
+}
+DEVI void buf_store(float x, const View &v, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), v.r, voff, soff, 0);
+}
+
 DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
 
 // error plumbing shared by the launchers

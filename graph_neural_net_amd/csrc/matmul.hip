@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void chan_matmul_fwd_kernel(const fgnn_slab ya
 __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                               const float *dm, long long dmg, long long ldm,
                                                               const int *nvalid, int N, float *da, float *db,
-                                                              long long ogstride, long long ldo) {
+                                                              long long ogstride, long long ldo, float *s12a,
+                                                              float *s12b) {
     __shared__ float Xs[TM * LDS_LD];
     __shared__ float Ds[TM * LDS_LD];
+    __shared__ float red[4][4];
     const int C = ya.C;
     const int gc = blockIdx.z;
     const int g = gc / C, c = gc - g * C;
@@ -160,6 +162,19 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya
         }
     }
     if (live) store_quadrant(OA, N, row0 + 32 * qi, col0 + 32 * qj, acc, lane);
+    // GraphNorm-backward sums of the producer of Ya: S1 = sum dA, S2 = sum dA * (z_a - mean_a)
+    float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+    if (s12a && live) {
+        const int col = col0 + 32 * qj + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * qi + ch_of(r, h);
+            if (row < nv && col < nv) {
+                sa1 += acc[r];
+                sa2 += acc[r] * (A[(long long)row * N + col] - na.mean);
+            }
+        }
+    }
 
     // ---- dB tile (rows row0.., cols col0..): A-operand = Ya^T[row0+k'][i0+..] = Ya[i0+..][row0+k'],
     //      B-operand = dM[i0+..][col0+j]
@@ -178,6 +193,35 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya
         }
     }
     if (live) store_quadrant(OB, N, row0 + 32 * qi, col0 + 32 * qj, acc, lane);
+    if (s12a) {     // only launched with a 1x1 tile grid (whole matrix in this workgroup)
+        if (live) {
+            const int col = col0 + 32 * qj + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 32 * qi + ch_of(r, h);
+                if (row < nv && col < nv) {
+                    sb1 += acc[r];
+                    sb2 += acc[r] * (B[(long long)row * N + col] - nb.mean);
+                }
+            }
+        }
+        sa1 = wave_sum(sa1);
+        sa2 = wave_sum(sa2);
+        sb1 = wave_sum(sb1);
+        sb2 = wave_sum(sb2);
+        if (lane == 0) {
+            red[wave][0] = sa1;
+            red[wave][1] = sa2;
+            red[wave][2] = sb1;
+            red[wave][3] = sb2;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
+            *dst = v;
+        }
+    }
 }
 
 }  // namespace
@@ -197,12 +241,21 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
 
 extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride,
                                     long long ldm, const int *nvalid, int G, int N, float *da, float *db,
-                                    long long ogstride, long long ldo, void *stream) {
+                                    long long ogstride, long long ldo, float *s12a, float *s12b, void *stream) {
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_bwd: bad shapes");
+    FGNN_CHECK((s12a == nullptr) == (s12b == nullptr), "fgnn_chan_matmul_bwd: s12a and s12b come together");
+    FGNN_CHECK(!s12a || (ya->nrm && yb->nrm), "fgnn_chan_matmul_bwd: s12 outputs need normalised slabs");
     const int t = (N + TM - 1) / TM;
+    const bool fused = s12a && t == 1;
     hipLaunchKernelGGL(chan_matmul_bwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
-                       dmgstride, ldm, nvalid, N, da, db, ogstride, ldo);
+                       dmgstride, ldm, nvalid, N, da, db, ogstride, ldo, fused ? s12a : nullptr, fused ? s12b : nullptr);
     FGNN_LAUNCH_CHECK();
+    if (s12a && !fused) {   // matrices span several workgroups: separate reduction passes
+        int rc = fgnn_gn_bwd_stats(da, ogstride, ldo, ya->ptr, ya->gstride, ya->ldp, ya->nrm, nvalid, G, ya->C, N, s12a, stream);
+        if (rc) return rc;
+        rc = fgnn_gn_bwd_stats(db, ogstride, ldo, yb->ptr, yb->gstride, yb->ldp, yb->nrm, nvalid, G, yb->C, N, s12b, stream);
+        if (rc) return rc;
+    }
     return 0;
 }

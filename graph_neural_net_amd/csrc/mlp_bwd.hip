@@ -11,7 +11,9 @@
 //        db_l += dpre_l
 //        d in_l = W_l^T dpre_l          in-register chain again (D fragment -> B operand)
 //        dpre_{l-1} = d in_l * [h_{l-1} > 0]
-//   4. dx written (or accumulated) per input slab.
+//   4. dx written (or accumulated) per input slab; optionally the per-tile sums
+//      S1 = sum dx, S2 = sum dx*(z_in - mean_in) that the GraphNorm backward of the MLP
+//      which PRODUCED slab a needs (saves a separate reduction pass over dx and z).
 // dW/db accumulate in registers over the wave's whole tile range; at the end the four
 // waves of a workgroup are summed through LDS and one partial per workgroup is written,
 // to be reduced in fixed order by fgnn_reduce_partials (deterministic).
@@ -30,7 +32,7 @@ struct TileCtx {
 
 DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, const int *nvalid, int j) {
     TileCtx c;
-    c.g = active ? tile / tpg : 0;
+    c.g = __builtin_amdgcn_readfirstlane(active ? tile / tpg : 0);
     c.tt = active ? tile - c.g * tpg : 0;
     c.p = c.tt * FGNN_TILE + j;
     c.inb = active && c.p < P;
@@ -41,32 +43,53 @@ DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, const int
     return c;
 }
 
+// channel contracted by k-step k in half-wave h (same convention as mlp_fwd.hip)
 template <int S>
-DEVI void load_raw(float (&x)[S > 0 ? S : 1], const fgnn_slab &s, const TileCtx &c, int h) {
+DEVI constexpr int slab_ch(int k, int h) { return S == 16 ? ch_of(k, h) : 2 * k + h; }
+
+// h-independent part of slab_ch, and the row multiplier of the h part
+template <int S>
+DEVI constexpr int slab_kbase(int k) { return S == 16 ? (k & 3) + 8 * (k >> 2) : 2 * k; }
+template <int S>
+DEVI constexpr int slab_hmul() { return S == 16 ? 4 : 1; }
+
+// per-lane byte offset of pixel c.p in the half-wave's first row (OOB_OFF when out of range)
+template <int HMUL>
+DEVI int lane_off(const View &v, const TileCtx &c, int h) {
+    return c.inb ? HMUL * h * v.ld4 + 4 * c.p : OOB_OFF;
+}
+
+template <int S>
+DEVI void load_raw(float (&x)[S > 0 ? S : 1], const View &v, const TileCtx &c, int h) {
     if constexpr (S > 0) {
-        const float *base = s.ptr + (long long)c.g * s.gstride + (long long)h * s.ldp + c.p;
+        const int voff = lane_off<slab_hmul<S>()>(v, c, h);
+        const int s0 = c.g * v.gs4;
 #pragma unroll
-        for (int k = 0; k < S; ++k) x[k] = c.inb ? base[(long long)(2 * k) * s.ldp] : 0.f;
+        for (int k = 0; k < S; ++k) x[k] = buf_load(v, voff, s0 + slab_kbase<S>(k) * v.ld4);
     }
 }
 
 // rows ch_of(r,h) of a (G,32,ld) tensor
-DEVI void load_rows16(float (&x)[16], const float *ptr, long long gstride, long long ld, const TileCtx &c, int h) {
-    const float *base = ptr + (long long)c.g * gstride + (long long)(4 * h) * ld + c.p;
+DEVI void load_rows16(float (&x)[16], const View &v, const TileCtx &c, int h) {
+    const int voff = lane_off<4>(v, c, h);
+    const int s0 = c.g * v.gs4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = c.inb ? base[(long long)((r & 3) + 8 * (r >> 2)) * ld] : 0.f;
+    for (int r = 0; r < 16; ++r) x[r] = buf_load(v, voff, s0 + ((r & 3) + 8 * (r >> 2)) * v.ld4);
 }
 
+// y = (x - mean) * a + beta with the per-graph records {mean, a, beta, -} read from LDS
 template <int S>
-DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const fgnn_slab &s, const TileCtx &c, int h) {
+DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 1], const float *rec, bool on,
+                        bool valid, int h) {
     if constexpr (S > 0) {
-        if (s.nrm) {
-            const float4 *nr = reinterpret_cast<const float4 *>(s.nrm) + (long long)c.g * s.C + h;
+        const float4 *r4 = reinterpret_cast<const float4 *>(rec);
 #pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const float4 n = nr[2 * k];
-                const float be = s.beta ? s.beta[2 * k + h] : 0.f;
-                x[k] = c.valid ? (x[k] - n.x) * n.y + be : 0.f;
+        for (int k = 0; k < S; ++k) {
+            if (on) {
+                const float4 n = r4[slab_ch<S>(k, h)];
+                y[k] = valid ? (x[k] - n.x) * n.y + n.z : 0.f;
+            } else {
+                y[k] = x[k];
             }
         }
     }
@@ -109,11 +132,12 @@ struct BwdLayout {
     static constexpr int OFF_WT0B = OFF_WT0A + 16;                        // 16: W_0^T slab b
     static constexpr int NSTEPS = OFF_WT0B + (CB > 0 ? 16 : 0);
     static constexpr int WEIGHT_F = NSTEPS * 64;                          // floats
+    static constexpr int REC_F = 4 * 3 * 32 * 4;                          // per wave: nrm a, nrm b, coef (32 x float4 each)
     static constexpr int NTILES = 1 + (CB > 0 ? 1 : 0) + (DEPTH - 1) + 1;
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int TILE_F_ALL = 4 * NTILES * TILE_F;
     static constexpr int RED_F = 4 * PCOUNT;
-    static constexpr int LDS_F = WEIGHT_F + (TILE_F_ALL > RED_F ? TILE_F_ALL : RED_F);
+    static constexpr int LDS_F = WEIGHT_F + REC_F + (TILE_F_ALL > RED_F ? TILE_F_ALL : RED_F);
 };
 
 template <int OFF, int CNT>
@@ -137,14 +161,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
     using L = BwdLayout<CA, CB, DEPTH>;
     constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
     constexpr int NTILES = L::NTILES;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int wave = blockIdx.x * 4 + wv;
     const int nwaves = gridDim.x * 4;
     const int P = A.N * A.N;
+    const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
+    const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
+    const View vdy = make_view(A.dy, A.dgstride, A.ldd, A.G);
+    const View vz = make_view(A.z, A.zgstride, A.ldz, A.G);
+    const View vdxa = make_view(A.dxa, A.dxa_gstride, A.dxa_ld, A.G);
+    const View vdxb = make_view(A.dxb, A.dxb_gstride, A.dxb_ld, A.G);
 
     float *wl = smem;                                   // shared operand sets
-    float *tiles = smem + L::WEIGHT_F;
+    float *rec = smem + L::WEIGHT_F + wv * (3 * 32 * 4);      // wave-private per-graph records
+    float *recA = rec, *recB = rec + 128, *recK = rec + 256;
+    float *tiles = smem + L::WEIGHT_F + L::REC_F;
     float *my = tiles + wv * (NTILES * TILE_F);
     float *XA = my;
     float *XB = my + TILE_F;                                  // only if CB > 0
@@ -158,9 +190,9 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
         if ((((t_) >> 2) & 3) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
     } while (0)
 #pragma unroll
-    for (int s = 0; s < SA; ++s) FGNN_PUT(L::OFF_W1A + s, A.W[0][j * CIN + 2 * s + h]);
+    for (int s = 0; s < SA; ++s) FGNN_PUT(L::OFF_W1A + s, A.W[0][j * CIN + slab_ch<SA>(s, h)]);
 #pragma unroll
-    for (int s = 0; s < SB; ++s) FGNN_PUT(L::OFF_W1B + s, A.W[0][j * CIN + CA + 2 * s + h]);
+    for (int s = 0; s < SB; ++s) FGNN_PUT(L::OFF_W1B + s, A.W[0][j * CIN + CA + slab_ch<SB>(s, h)]);
 #pragma unroll
     for (int l = 1; l + 1 < DEPTH; ++l)
 #pragma unroll
@@ -197,37 +229,61 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
     const int q = total_tiles / nwaves, rem = total_tiles % nwaves;
     const int t0 = wave * q + (wave < rem ? wave : rem);
     const int t1 = t0 + q + (wave < rem ? 1 : 0);
+    const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
+    const bool emit = (CA == 32) && normA && A.dxa != nullptr && A.s12part != nullptr;
 
-    float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1], dyr[16], zr[16];
+    float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     {
         const TileCtx c = decode_tile(t0, t0 < t1, tpg, A.N, P, A.nvalid, j);
-        load_raw<SA>(xa, A.a, c, h);
-        load_raw<SB>(xb, A.b, c, h);
-        load_rows16(dyr, A.dy, A.dgstride, A.ldd, c, h);
-        load_rows16(zr, A.z, A.zgstride, A.ldz, c, h);
+        load_raw<SA>(xa, va, c, h);
+        load_raw<SB>(xb, vb, c, h);
     }
+    int cached_g = -1;
 
     for (int tile = t0; tile < t1; ++tile) {
-        // prefetch the next tile's raw operands
-        float nxa[SA > 0 ? SA : 1], nxb[SB > 0 ? SB : 1], ndy[16], nz[16];
-        {
-            const TileCtx c = decode_tile(tile + 1, tile + 1 < t1, tpg, A.N, P, A.nvalid, j);
-            load_raw<SA>(nxa, A.a, c, h);
-            load_raw<SB>(nxb, A.b, c, h);
-            load_rows16(ndy, A.dy, A.dgstride, A.ldd, c, h);
-            load_rows16(nz, A.z, A.zgstride, A.ldz, c, h);
+        const int g = __builtin_amdgcn_readfirstlane(tile / tpg);
+        if (g != cached_g) {
+            // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the prefetch
+            // below so that the in-order vmcnt wait does not drain the prefetch.
+            if (lane < 32) {
+                float4 k4 = reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + lane];
+                reinterpret_cast<float4 *>(recK)[lane] = k4;
+                if (normA && lane < CA) {
+                    float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)g * A.a.C + lane];
+                    n.z = A.a.beta ? A.a.beta[lane] : 0.f;
+                    reinterpret_cast<float4 *>(recA)[lane] = n;
+                }
+                if (normB && lane < CB) {
+                    float4 n = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)g * A.b.C + lane];
+                    n.z = A.b.beta ? A.b.beta[lane] : 0.f;
+                    reinterpret_cast<float4 *>(recB)[lane] = n;
+                }
+            }
+            cached_g = g;
         }
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
-        apply_norm<SA>(xa, A.a, c, h);
-        apply_norm<SB>(xb, A.b, c, h);
+        // this tile's dy / z: consumed only after the forward recompute, which hides their latency
+        float dyr[16], zr[16];
+        load_rows16(dyr, vdy, c, h);
+        load_rows16(zr, vz, c, h);
+        // prefetch the next tile's input slabs (needed at the very start of the next iteration)
+        float nxa[SA > 0 ? SA : 1], nxb[SB > 0 ? SB : 1];
+        {
+            const TileCtx cn = decode_tile(tile + 1, tile + 1 < t1, tpg, A.N, P, A.nvalid, j);
+            load_raw<SA>(nxa, va, cn, h);
+            load_raw<SB>(nxb, vb, cn, h);
+        }
+        float ya[SA > 0 ? SA : 1], yb[SB > 0 ? SB : 1];
+        norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
+        norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
 #pragma unroll
-        for (int s = 0; s < SA; ++s) XA[(2 * s + h) * TLD + j] = xa[s];
+        for (int s = 0; s < SA; ++s) XA[slab_ch<SA>(s, h) * TLD + j] = ya[s];
 #pragma unroll
-        for (int s = 0; s < SB; ++s) XB[(2 * s + h) * TLD + j] = xb[s];
+        for (int s = 0; s < SB; ++s) XB[slab_ch<SB>(s, h) * TLD + j] = yb[s];
 
         // ---- forward recompute of the hidden activations ----
-        float hid[DEPTH > 1 ? DEPTH - 1 : 1][16];
         if constexpr (DEPTH > 1) {
+            float hid[16];
             f32x16 acc;
             {
                 float b0[16];
@@ -237,20 +293,20 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
                 float w1a[SA > 0 ? SA : 1];
                 load_ops<L::OFF_W1A, SA>(w1a, wl, lane);
 #pragma unroll
-                for (int s = 0; s < SA; ++s) acc = mfma32(w1a[s], xa[s], acc);
+                for (int s = 0; s < SA; ++s) acc = mfma32(w1a[s], ya[s], acc);
                 if constexpr (SB > 0) {
                     float w1b[SB > 0 ? SB : 1];
                     load_ops<L::OFF_W1B, SB>(w1b, wl, lane);
 #pragma unroll
-                    for (int s = 0; s < SB; ++s) acc = mfma32(w1b[s], xb[s], acc);
+                    for (int s = 0; s < SB; ++s) acc = mfma32(w1b[s], yb[s], acc);
                 }
             }
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    hid[l - 1][r] = fmaxf(acc[r], 0.f);
-                    HT[(l - 1) * TILE_F + ch_of(r, h) * TLD + j] = hid[l - 1][r];
+                    hid[r] = fmaxf(acc[r], 0.f);
+                    HT[(l - 1) * TILE_F + ch_of(r, h) * TLD + j] = hid[r];
                 }
                 if (l + 1 < DEPTH) {
                     float bl[16], wl_[16];
@@ -258,15 +314,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = bl[r];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc = mfma32(wl_[r], hid[l - 1][r], acc);
+                    for (int r = 0; r < 16; ++r) acc = mfma32(wl_[r], hid[r], acc);
                 }
             }
         }
 
+        __builtin_amdgcn_sched_barrier(0);
         // ---- dz from (dy, z, coef) ----
         float dpre[16];
         {
-            const float4 *kp = reinterpret_cast<const float4 *>(A.coef) + (long long)c.g * FGNN_H + 4 * h;
+            const float4 *kp = reinterpret_cast<const float4 *>(recK) + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float4 k = kp[(r & 3) + 8 * (r >> 2)];
@@ -277,6 +334,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
         // ---- backward through the layers ----
 #pragma unroll
         for (int l = DEPTH - 1; l >= 0; --l) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 DT[ch_of(r, h) * TLD + j] = dpre[r];
@@ -292,7 +350,8 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dpre[r] = hid[l - 1][r] > 0.f ? acc[r] : 0.f;
+                for (int r = 0; r < 16; ++r)
+                    dpre[r] = HT[(l - 1) * TILE_F + ch_of(r, h) * TLD + j] > 0.f ? acc[r] : 0.f;   // ReLU mask from the saved tile
             } else {
                 dW0a = wgrad_tile(DT, XA, dW0a, lane);
                 if constexpr (CB > 0) dW0b = wgrad_tile(DT, XB, dW0b, lane);
@@ -303,13 +362,29 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
                     zero16(acc);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-                    float *op = A.dxa + (long long)c.g * A.dxa_gstride + c.p;
+                    float *sp = A.s12part + (((long long)c.g * tpg + c.tt) * FGNN_H) * 2;
+                    const int voff = lane_off<4>(vdxa, c, h);
+                    const int s0 = c.g * vdxa.gs4;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ch = ch_of(r, h);
-                        if (ch < CA && c.inb) {
-                            float *o = op + (long long)ch * A.dxa_ld;
-                            *o = A.accumulate_a ? *o + acc[r] : acc[r];
+                        const int vo = ch < CA ? voff : OOB_OFF;
+                        const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4;
+                        float v = acc[r];
+                        if (A.accumulate_a) v += buf_load(vdxa, vo, so);
+                        buf_store(v, vdxa, vo, so);
+                        if constexpr (CA == 32) {
+                            if (emit) {
+                                // GraphNorm-backward sums of the producer of slab a: S1 += v, S2 += v * (z - mean)
+                                const float mean = reinterpret_cast<const float4 *>(recA)[ch].x;
+                                const float u = c.valid ? xa[r] - mean : 0.f;
+                                const float s1 = half_sum(c.valid ? v : 0.f);
+                                const float s2 = half_sum(c.valid ? v * u : 0.f);
+                                if (j == 0) {
+                                    sp[ch * 2 + 0] = s1;
+                                    sp[ch * 2 + 1] = s2;
+                                }
+                            }
                         }
                     }
                 }
@@ -321,14 +396,16 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
                         zero16(acc);
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-                        float *op = A.dxb + (long long)c.g * A.dxb_gstride + c.p;
+                        const int voff = lane_off<4>(vdxb, c, h);
+                        const int s0 = c.g * vdxb.gs4;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ch = ch_of(r, h);
-                            if (ch < CB && c.inb) {
-                                float *o = op + (long long)ch * A.dxb_ld;
-                                *o = A.accumulate_b ? *o + acc[r] : acc[r];
-                            }
+                            const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4;
+                            const int vo = ch < CB ? voff : OOB_OFF;
+                            float v = acc[r];
+                            if (A.accumulate_b) v += buf_load(vdxb, vo, so);
+                            buf_store(v, vdxb, vo, so);
                         }
                     }
                 }
@@ -339,11 +416,6 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
         for (int s = 0; s < SA; ++s) xa[s] = nxa[s];
 #pragma unroll
         for (int s = 0; s < SB; ++s) xb[s] = nxb[s];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dyr[r] = ndy[r];
-            zr[r] = nz[r];
-        }
     }
 
     // ---- workgroup reduction of the parameter gradients ----
@@ -422,6 +494,12 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a->a.ptr && a->a.C > 0, "fgnn_mlp_bwd: slab a missing");
     FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_bwd: slab b has channels but no pointer");
     FGNN_CHECK(a->dy && a->z && a->coef && a->wpart, "fgnn_mlp_bwd: missing dy/z/coef/wpart");
+    {
+        const long long lim = 0x7fffffffll / 4, G = a->G;
+        FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&
+                   G * a->dxa_gstride < lim && G * a->dxb_gstride < lim,
+                   "fgnn_mlp_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
+    }
     for (int l = 0; l < a->depth; ++l) FGNN_CHECK(a->W[l] && a->bias[l], "fgnn_mlp_bwd: missing weights layer %d", l);
     const int tpg = fgnn_tiles_per_graph(a->N);
     const long long total = (long long)a->G * tpg;

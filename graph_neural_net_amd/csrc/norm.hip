@@ -31,25 +31,37 @@ DEVI void write_nrm(float *nrm, long long idx, float mean, float m2, float m, fl
     reinterpret_cast<float4 *>(nrm)[idx] = o;
 }
 
-// one thread per (g,c): Chan's pairwise update over the tiles, fixed order.
+// Chan's pairwise combination of (n, mean, M2) records.
+DEVI void chan_combine(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
+    const float nn = n + nb;
+    if (nb > 0.f) {
+        const float delta = mb - mean;
+        const float f = nb / nn;
+        mean += delta * f;
+        m2 += m2b + delta * delta * (n * f);
+        n = nn;
+    }
+}
+
+// one wave per (g,c): lanes take tiles lane, lane+64, ... then a fixed shuffle tree.
 __global__ void gn_finalize_kernel(const float *part, const float *cnt, const float *gw, const int *nvalid,
                                    int G, int C, int N, int tpg, float eps, float *nrm) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (idx >= G * C) return;
+    const int lane = threadIdx.x & 63;
     const int g = idx / C, c = idx - g * C;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int t = 0; t < tpg; ++t) {
+    for (int t = lane; t < tpg; t += WAVE) {
         const float nb = cnt[(long long)g * tpg + t];
-        if (nb > 0.f) {
-            const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
-            const float delta = pm.x - mean;
-            const float nn = n + nb;
-            mean += delta * (nb / nn);
-            m2 += pm.y + delta * delta * (n * nb / nn);
-            n = nn;
-        }
+        const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
+        chan_combine(n, mean, m2, nb, pm.x, pm.y);
     }
-    write_nrm(nrm, idx, mean, m2, n, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float nb = __shfl_down(n, off), mb = __shfl_down(mean, off), m2b = __shfl_down(m2, off);
+        chan_combine(n, mean, m2, nb, mb, m2b);
+    }
+    if (lane == 0) write_nrm(nrm, idx, mean, m2, n, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
 }
 
 // one wave per (g,c): two-pass mean / M2 over the valid n x n region.
@@ -141,18 +153,70 @@ __global__ void gn_bwd_coef_kernel(const float *s12, const float *nrm, const int
     reinterpret_cast<float4 *>(coef)[idx] = o;
 }
 
-// d gn_weight[c] = sum_g q[g,c]*S2[g,c], d gn_bias[c] = sum_g S1[g,c]; fixed order over g.
-__global__ void gn_bwd_affine_kernel(const float *s12, const float *nrm, int G, int C, float *dgw, float *dgb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float aw = 0.f, ab = 0.f;
-    for (int g = 0; g < G; ++g) {
-        const long long idx = (long long)g * C + c;
-        aw += nrm[idx * 4 + 2] * s12[idx * 2 + 1];
-        ab += s12[idx * 2];
+// d gn_weight[c] = sum_g q[g,c]*S2[g,c], d gn_bias[c] = sum_g S1[g,c]; fixed order.
+// one block of 256 threads: thread (c = tid % 32 within a 32-channel chunk, gg = tid / 32) strides g.
+DEVI void affine_reduce(const float *s12, const float *nrm, int G, int C, float *dgw, float *dgb, float *sm) {
+    const int tid = threadIdx.x, cl = tid & 31, gg = tid >> 5;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cl;
+        float aw = 0.f, ab = 0.f;
+        if (c < C)
+            for (int g = gg; g < G; g += 8) {
+                const long long idx = (long long)g * C + c;
+                aw += nrm[idx * 4 + 2] * s12[idx * 2 + 1];
+                ab += s12[idx * 2];
+            }
+        sm[tid] = aw;
+        sm[256 + tid] = ab;
+        __syncthreads();
+        if (tid < 32 && c < C) {
+            float w = 0.f, b = 0.f;
+            for (int k = 0; k < 8; ++k) {
+                w += sm[k * 32 + tid];
+                b += sm[256 + k * 32 + tid];
+            }
+            if (dgw) dgw[c] = w;
+            if (dgb) dgb[c] = b;
+        }
+        __syncthreads();
     }
-    if (dgw) dgw[c] = aw;
-    if (dgb) dgb[c] = ab;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float *s12, const float *nrm, int G, int C, float *dgw,
+                                                            float *dgb) {
+    __shared__ float sm[512];
+    affine_reduce(s12, nrm, G, C, dgw, dgb, sm);
+}
+
+// sums per-tile {S1,S2} partials (G,tpg,C,2) over the tiles (one wave per (g,c), fixed tree),
+// writes s12 (G*C*2) and the dz coefficients.
+__global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                         int tpg, float *s12, float *coef) {
+    const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (idx >= G * C) return;
+    const int lane = threadIdx.x & 63;
+    const int g = idx / C, c = idx - g * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int t = lane; t < tpg; t += WAVE) {
+        const float2 p = reinterpret_cast<const float2 *>(s12part)[((long long)g * tpg + t) * C + c];
+        s1 += p.x;
+        s2 += p.y;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        const float nv = (float)nvalid_of(nvalid, g, N);
+        const float m = nv * nv;
+        const float4 n = reinterpret_cast<const float4 *>(nrm)[idx];
+        s12[(long long)idx * 2] = s1;
+        s12[(long long)idx * 2 + 1] = s2;
+        float4 o;
+        o.x = n.x;
+        o.y = n.y;
+        o.z = m > 0.f ? -n.y * s2 * n.w / m : 0.f;
+        o.w = m > 0.f ? -n.y * s1 / m : 0.f;
+        reinterpret_cast<float4 *>(coef)[idx] = o;
+    }
 }
 
 __global__ void gn_bwd_apply_kernel(const float *dy, long long dg, long long ldd, const float *z, long long zg,
@@ -170,12 +234,38 @@ __global__ void gn_bwd_apply_kernel(const float *dy, long long dg, long long ldd
     dz[(long long)g * og + (long long)c * ldo + p] = (i < nv && j < nv) ? k.y * d + k.z * u + k.w : 0.f;
 }
 
-__global__ void reduce_rows_kernel(const float *in, int rows, int cols, float scale, float *out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cols) return;
+// out[i] = scale * sum_r in[r][i]; block = 4 row groups x 64 columns, fixed order.
+DEVI void reduce_cols(const float *in, int rows, int cols, float scale, float *out, int cblock, float *sm) {
+    const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
+    const int i = cblock * 64 + cl;
     float a = 0.f;
-    for (int r = 0; r < rows; ++r) a += in[(long long)r * cols + i];
-    out[i] = a * scale;
+    if (i < cols)
+        for (int r = rg; r < rows; r += 4) a += in[(long long)r * cols + i];
+    sm[tid] = a;
+    __syncthreads();
+    if (tid < 64 && i < cols) out[i] = ((sm[tid] + sm[64 + tid]) + (sm[128 + tid] + sm[192 + tid])) * scale;
+}
+
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float *in, int rows, int cols, float scale, float *out) {
+    __shared__ float sm[256];
+    reduce_cols(in, rows, cols, scale, out, blockIdx.x, sm);
+}
+
+struct GradJobs {
+    fgnn_grad_job job[FGNN_MAX_GRAD_JOBS];
+};
+
+// grid (max column blocks + 1, njobs): column blocks reduce the workgroup partials of one MLP,
+// the extra block reduces its GraphNorm affine gradients over the graphs.
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J, int num_wg, int G, int C) {
+    __shared__ float sm[512];
+    const fgnn_grad_job &jb = J.job[blockIdx.y];
+    const int nblk = (jb.count + 63) / 64;
+    if ((int)blockIdx.x < nblk) {
+        reduce_cols(jb.wpart, num_wg, jb.count, 1.f, jb.out, blockIdx.x, sm);
+    } else if ((int)blockIdx.x == gridDim.x - 1 && jb.s12) {
+        affine_reduce(jb.s12, jb.nrm, G, C, jb.dgn_w, jb.dgn_b, sm);
+    }
 }
 
 }  // namespace
@@ -184,7 +274,7 @@ extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float
                                 int G, int C, int N, float eps, float *nrm, void *stream) {
     FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, cnt,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, cnt,
                        gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -230,7 +320,7 @@ extern "C" int fgnn_gn_bwd_coef(const float *s12, const float *nrm, const int *n
                        nvalid, G, C, N, coef);
     FGNN_LAUNCH_CHECK();
     if (dgn_w || dgn_b) {
-        hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, s12, nrm, G, C,
+        hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s12, nrm, G, C,
                            dgn_w, dgn_b);
         FGNN_LAUNCH_CHECK();
     }
@@ -249,7 +339,7 @@ extern "C" int fgnn_gn_bwd_apply(const float *dy, long long dgstride, long long 
 
 extern "C" int fgnn_reduce_partials(const float *wpart, int num_wg, int count, float *out, void *stream) {
     FGNN_CHECK(wpart && out && num_wg > 0 && count > 0, "fgnn_reduce_partials: bad arguments");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, wpart, num_wg,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((count + 63) / 64), dim3(256), 0, (hipStream_t)stream, wpart, num_wg,
                        count, 1.0f, out);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -257,8 +347,34 @@ extern "C" int fgnn_reduce_partials(const float *wpart, int num_wg, int count, f
 
 extern "C" int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream) {
     FGNN_CHECK(in && out && rows > 0 && cols > 0, "fgnn_sum_scale: bad arguments");
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, in, rows, cols,
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, in, rows, cols,
                        scale, out);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                      float *s12, float *coef, void *stream) {
+    FGNN_CHECK(s12part && nrm && s12 && coef && G > 0 && C > 0 && N > 0, "fgnn_gn_bwd_coef_tiles: bad arguments");
+    const int tot = G * C;
+    hipLaunchKernelGGL(gn_bwd_coef_tiles_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, s12part, nrm,
+                       nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream) {
+    FGNN_CHECK(jobs && njobs > 0 && njobs <= FGNN_MAX_GRAD_JOBS && num_wg > 0, "fgnn_grad_finalize: bad arguments (njobs=%d)", njobs);
+    GradJobs J;
+    int maxc = 0;
+    for (int i = 0; i < njobs; ++i) {
+        FGNN_CHECK(jobs[i].wpart && jobs[i].out && jobs[i].count > 0, "fgnn_grad_finalize: job %d incomplete", i);
+        FGNN_CHECK(!jobs[i].s12 || jobs[i].nrm, "fgnn_grad_finalize: job %d has s12 but no nrm", i);
+        J.job[i] = jobs[i];
+        if (jobs[i].count > maxc) maxc = jobs[i].count;
+    }
+    hipLaunchKernelGGL(grad_finalize_kernel, dim3((maxc + 63) / 64 + 1, njobs), dim3(256), 0, (hipStream_t)stream, J,
+                       num_wg, G, C);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

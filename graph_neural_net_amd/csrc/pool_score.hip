@@ -41,19 +41,38 @@ __global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, i
     idx[t] = bi;
 }
 
-// thread per (g,c,i): writes the whole row of dy (zeros + one scattered value)
+// one wave per (g,c): each lane writes whole rows of dy (zeros + one scattered value) and the
+// wave accumulates the GraphNorm-backward sums S1 = sum de, S2 = sum de * (z[i, idx] - mean).
 __global__ void colmax_bwd_kernel(const float *de, const int *idx, const int *nvalid, int G, int C, int N,
-                                  float *dy, long long gstride, long long ldp) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)G * C * N) return;
-    const int i = (int)(t % N);
-    const int gc = (int)(t / N);
+                                  float *dy, long long gstride, long long ldp, const fgnn_slab y, float *s12) {
+    const int gc = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (gc >= G * C) return;
+    const int lane = threadIdx.x & 63;
     const int g = gc / C, c = gc - g * C;
     const int nv = nvalid_of(nvalid, g, N);
-    float *row = dy + (long long)g * gstride + (long long)c * ldp + (long long)i * N;
-    const int bi = idx[t];
-    const float d = i < nv ? de[t] : 0.f;
-    for (int j = 0; j < N; ++j) row[j] = (j == bi) ? d : 0.f;
+    float *mat = dy + (long long)g * gstride + (long long)c * ldp;
+    const float *zm = s12 ? y.ptr + (long long)g * y.gstride + (long long)c * y.ldp : nullptr;
+    const float mean = s12 ? y.nrm[(long long)gc * 4] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < N; i += WAVE) {
+        const long long t = (long long)gc * N + i;
+        const int bi = idx[t];
+        const float d = i < nv ? de[t] : 0.f;
+        float *row = mat + (long long)i * N;
+        for (int j = 0; j < N; ++j) row[j] = (j == bi) ? d : 0.f;
+        if (s12 && i < nv) {
+            s1 += d;
+            s2 += d * (zm[(long long)i * N + bi] - mean);
+        }
+    }
+    if (s12) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            s12[(long long)gc * 2] = s1;
+            s12[(long long)gc * 2 + 1] = s2;
+        }
+    }
 }
 
 // one workgroup per pair b.  e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j].
@@ -192,11 +211,14 @@ extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int
 }
 
 extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvalid, int G, int C, int N, float *dy,
-                               long long gstride, long long ldp, void *stream) {
+                               long long gstride, long long ldp, const fgnn_slab *y, float *s12, void *stream) {
     FGNN_CHECK(de && idx && dy && G > 0 && C > 0 && N > 0, "fgnn_colmax_bwd: bad arguments");
-    const long long tot = (long long)G * C * N;
-    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, de,
-                       idx, nvalid, G, C, N, dy, gstride, ldp);
+    FGNN_CHECK(!s12 || (y && y->ptr && y->nrm && y->C == C), "fgnn_colmax_bwd: s12 needs the normalised input slab");
+    fgnn_slab ys = {};
+    if (s12) ys = *y;
+    const int tot = G * C;
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream, de,
+                       idx, nvalid, G, C, N, dy, gstride, ldp, ys, s12);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -230,30 +230,34 @@ class FgnnEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         act = lambda: torch.empty(self.G * 32 * self.ldp, **f32)
         nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
-        maxp = _lib.mlp_param_count(64, self.layout.depth)
+        L = self.layout
+        keys = [(k, j) for k in range(1, L.num_blocks + 1) for j in (1, 2, 3)]
         self._bwd = {
             'dE': torch.empty(self.G, 32, self.N, **f32),
             'dy': [act(), act()],
             'dmult': act(), 'dy1': act(), 'dy2': act(),
-            's12': torch.empty(self.G * 32 * 2, **f32),
-            'coef': torch.empty(self.G * 32 * 4, **f32),
-            'wpart': torch.empty(nwg * maxp, **f32),
+            # per-MLP GraphNorm-backward sums and workgroup partials live until the final
+            # fgnn_grad_finalize launch
+            's12': {kj: torch.empty(self.G * 32 * 2, **f32) for kj in keys},
+            'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32) for kj in keys},
+            's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
+            'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
             'nwg': nwg,
             'gscale': torch.empty(1, **f32),
         }
         return self._bwd
 
-    def _mlp_bwd(self, params, grads, k, j, a, b, dy, dxa, dxb, acc_a, acc_b):
+    def _coef(self, kj, slot):
+        """coef[slot] <- dz coefficients of MLP kj from its summed s12."""
+        W = self._bwd
+        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12'][kj]), _lib.ptr(self.nrm[kj]), self._nv(), self.G, 32, self.N,
+                  _lib.ptr(W['coef'][slot]), None, None, _lib.stream_ptr())
+
+    def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
-        st = _lib.stream_ptr()
         gs = 32 * self.ldp
-        _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, self.ldp, _lib.ptr(self.z[(k, j)]), gs, self.ldp,
-                  _lib.ptr(self.nrm[(k, j)]), self._nv(), self.G, 32, self.N, _lib.ptr(W['s12']), st)
-        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12']), _lib.ptr(self.nrm[(k, j)]), self._nv(), self.G, 32, self.N,
-                  _lib.ptr(W['coef']), C.c_void_p(grads.data_ptr() + 4 * rec['gn_w']),
-                  C.c_void_p(grads.data_ptr() + 4 * rec['gn_b']), st)
         args = _lib.MlpBwdArgs()
         args.G, args.N, args.depth = self.G, self.N, L.depth
         args.nvalid = self.nvalid.data_ptr() if self.nvalid is not None else None
@@ -265,20 +269,21 @@ class FgnnEngine:
             args.bias[l] = self._w(params, rec['b'][l])
         args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
-        args.coef = W['coef'].data_ptr()
+        args.coef = coef.data_ptr()
         if dxa is not None:
             args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), gs, self.ldp
         if dxb is not None:
             args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
-        args.wpart = W['wpart'].data_ptr()
-        _lib.call('fgnn_mlp_bwd', C.byref(args), st, tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0), (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
-        _lib.call('fgnn_reduce_partials', _lib.ptr(W['wpart']), W['nwg'], rec['count'],
-                  C.c_void_p(grads.data_ptr() + 4 * rec['off']), st)
+        args.wpart = W['wpart'][(k, j)].data_ptr()
+        if emit:
+            args.s12part = W['s12part'].data_ptr()
+        _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
+                  tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
+                                                (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 
     def backward(self, params, grads, grad_scale=1.0):
         """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer."""
-        L = self.layout
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
@@ -289,26 +294,55 @@ class FgnnEngine:
         return self.backward_from_dE(params, grads, W['dE'])
 
     def backward_from_dE(self, params, grads, dE):
-        """Backward of the node embedder given d loss / d E  (G, 32, N)."""
+        """Backward of the node embedder given d loss / d E  (G, 32, N).
+
+        Per block (last to first):  mlp3 bwd -> matmul bwd (+ S1/S2 of mlp1, mlp2) -> mlp1 bwd ->
+        mlp2 bwd (accumulates d_in and emits the S1/S2 tile partials of the previous block's
+        mlp3).  No separate reduction pass over the activations is needed; all parameter
+        gradients are finished by ONE fgnn_grad_finalize launch at the end."""
         L = self.layout
         W = self._alloc_bwd()
         st = _lib.stream_ptr()
         gs = 32 * self.ldp
+        K = L.num_blocks
         dy = W['dy'][0]
+        out = self._slab_z(K, 3, params)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
-                  _lib.ptr(dy), gs, self.ldp, st)
-        for k in range(L.num_blocks, 0, -1):
+                  _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
+        self._coef((K, 3), 2)
+        for k in range(K, 0, -1):
             sin = self._slab_in(k, params)
             first = (k == 1)
-            din = None if first else W['dy'][(L.num_blocks - k + 1) % 2]
+            din = None if first else W['dy'][(K - k + 1) % 2]
             # mlp3: inputs [mult ; in]
-            self._mlp_bwd(params, grads, k, 3, self._slab_raw(self.mult[k]), sin, dy, W['dmult'], din, False, False)
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, W['coef'][2], W['dmult'], din, False, False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
-                      self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp, st)
-            self._mlp_bwd(params, grads, k, 1, sin, None, W['dy1'], din, None, True, False)
-            self._mlp_bwd(params, grads, k, 2, sin, None, W['dy2'], din, None, True, False)
+                      self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
+                      _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
+            self._coef((k, 1), 0)
+            self._coef((k, 2), 1)
+            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
+            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
+            if not first:
+                _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
+                          self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
             dy = din
+        # ---- one launch: reduce the workgroup partials + GraphNorm affine gradients of all MLPs ----
+        keys = [(k, j) for k in range(1, K + 1) for j in (1, 2, 3)]
+        for lo in range(0, len(keys), _lib.MAX_GRAD_JOBS):
+            chunk = keys[lo:lo + _lib.MAX_GRAD_JOBS]
+            jobs = (_lib.GradJob * len(chunk))()
+            for i, kj in enumerate(chunk):
+                rec = L.mlp[kj]
+                jobs[i].wpart = W['wpart'][kj].data_ptr()
+                jobs[i].count = rec['count']
+                jobs[i].out = grads.data_ptr() + 4 * rec['off']
+                jobs[i].s12 = W['s12'][kj].data_ptr()
+                jobs[i].nrm = self.nrm[kj].data_ptr()
+                jobs[i].dgn_w = grads.data_ptr() + 4 * rec['gn_w']
+                jobs[i].dgn_b = grads.data_ptr() + 4 * rec['gn_b']
+            _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
         return grads
 
     def step(self, params, grads, x, nvalid=None, total_nodes=None):

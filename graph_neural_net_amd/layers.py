@@ -306,7 +306,7 @@ class _MatmulFn(torch.autograd.Function):
         da, db = torch.empty_like(a), torch.empty_like(b)
         sa, sb = _lib.make_slab(a, Cc * P, P, Cc), _lib.make_slab(b, Cc * P, P, Cc)
         _lib.call('fgnn_chan_matmul_bwd', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * P, P, _nv(nvalid), G, N,
-                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.stream_ptr())
+                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, None, None, _lib.stream_ptr())
         return da, db, None
 
 
@@ -348,7 +348,7 @@ class _ColMaxFn(torch.autograd.Function):
         P = N * N
         dx = torch.empty(G, Cc, N, N, dtype=torch.float32, device=de.device)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(de), _lib.ptr(idx), _nv(nvalid), G, Cc, N, _lib.ptr(dx), Cc * P, P,
-                  _lib.stream_ptr())
+                  None, None, _lib.stream_ptr())
         return dx, None
 
 

@@ -116,9 +116,11 @@ int fgnn_score_bwd(const float *e1, const float *e2, const float *dscores, const
                    int B, int C, int N, float *de1, float *de2, void *stream);
 
 /* ---- backward ---------------------------------------------------------------------- */
-/* ColumnMaxPooling backward: dy[g,c,i,idx] = de[g,c,i], 0 elsewhere (dense write).       */
+/* ColumnMaxPooling backward: dy[g,c,i,idx] = de[g,c,i], 0 elsewhere (dense write).
+ * Optional: y (the normalised-on-load input slab of the pooling) and s12 (G*C*2) -> also emits
+ * the GraphNorm-backward sums {sum dy, sum dy*(z-mean)} of the MLP that produced y.         */
 int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvalid, int G, int C, int N,
-                    float *dy, long long gstride, long long ldp, void *stream);
+                    float *dy, long long gstride, long long ldp, const fgnn_slab *y, float *s12, void *stream);
 
 /* GraphNorm backward reductions per (g,c): S1 = sum dy, S2 = sum dy * (z - mean).         */
 int fgnn_gn_bwd_stats(const float *dy, long long dgstride, long long ldd,
@@ -129,6 +131,10 @@ int fgnn_gn_bwd_stats(const float *dy, long long dgstride, long long ldd,
 int fgnn_gn_bwd_coef(const float *s12, const float *nrm, const int *nvalid, int G, int C, int N,
                      float *coef /* (G*C*4) */, float *dgn_w /* (C) or NULL */, float *dgn_b /* (C) or NULL */,
                      void *stream);
+/* same coefficients from per-tile partial sums (G, tpg, C, 2) as emitted by fgnn_mlp_bwd
+ * (s12part); also writes the summed s12 (G*C*2) for the affine gradients.                  */
+int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                           float *s12, float *coef, void *stream);
 /* dense dz = ca*dy + cb*(z-mean) + cc on valid entries (module-level GraphNorm backward) */
 int fgnn_gn_bwd_apply(const float *dy, long long dgstride, long long ldd,
                       const float *z, long long zgstride, long long ldz, const float *coef,
@@ -150,6 +156,9 @@ typedef struct {
     float *dxb; long long dxb_gstride, dxb_ld;   /* out: grad wrt slab b (NULL = not needed) */
     int accumulate_a, accumulate_b;          /* 1: dx += (read-modify-write)             */
     float *wpart;                            /* out (num_wg, fgnn_mlp_param_count) partial dW/db */
+    float *s12part;                          /* optional out (G, tpg, 32, 2): per-tile {sum dxa, sum dxa*(z_a-mean_a)} of
+                                                the FINAL dxa values (needs a.C == 32, a.nrm and dxa) -- the GraphNorm
+                                                backward sums of the MLP that produced slab a */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
@@ -158,10 +167,22 @@ int fgnn_mlp_param_count(int Cin, int depth);
 /* deterministic reduction of the per-workgroup partials: out[i] = sum_w wpart[w][i]      */
 int fgnn_reduce_partials(const float *wpart, int num_wg, int count, float *out, void *stream);
 
+/* One launch that finishes the parameter gradients of up to FGNN_MAX_GRAD_JOBS MLPs:
+ * out[i] = sum_w wpart[w][i] (fixed order) and, when s12 is given, the GraphNorm affine
+ * gradients dgn_w[c] = sum_g q[g,c]*S2[g,c], dgn_b[c] = sum_g S1[g,c].                      */
+#define FGNN_MAX_GRAD_JOBS 16
+typedef struct {
+    const float *wpart; int count; float *out;
+    const float *s12; const float *nrm; float *dgn_w; float *dgn_b;
+} fgnn_grad_job;
+int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream);
+
 /* Matmul backward: da = dm @ Yb^T, db = Ya^T @ dm per (g,c) (autograd of layers.py:161-162) */
 int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride, long long ldm,
                          const int *nvalid, int G, int N,
-                         float *da, float *db, long long ogstride, long long ldo, void *stream);
+                         float *da, float *db, long long ogstride, long long ldo,
+                         float *s12a /* optional (G*C*2): {sum da, sum da*(z_a-mean_a)} */,
+                         float *s12b /* optional (G*C*2) */, void *stream);
 
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);

@@ -31,7 +31,7 @@ def test_chan_matmul_fwd_bwd(G, Cc, N):
     assert rel(out.cpu(), ref) < 2e-6
     da, db = torch.empty_like(ad), torch.empty_like(ad)
     _lib.call('fgnn_chan_matmul_bwd', C.byref(sa), C.byref(sb), _lib.ptr(dmd), Cc * P, P, None, G, N,
-              _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.stream_ptr())
+              _lib.ptr(da), _lib.ptr(db), Cc * P, P, None, None, _lib.stream_ptr())
     assert rel(da.cpu(), torch.matmul(dm.double(), b.double().transpose(-1, -2))) < 2e-6
     assert rel(db.cpu(), torch.matmul(a.double().transpose(-1, -2), dm.double())) < 2e-6
 
@@ -70,7 +70,7 @@ def test_colmax_first_index_on_ties_bit_exact():
     de = torch.randn(G, Cc, N)
     dy = torch.empty(G, Cc, N, N, device=DEV)
     _lib.call('fgnn_colmax_bwd', _lib.ptr(de.to(DEV)), _lib.ptr(idx), None, G, Cc, N, _lib.ptr(dy), Cc * N * N, N * N,
-              _lib.stream_ptr())
+              None, None, _lib.stream_ptr())
     ref = torch.zeros(G, Cc, N, N).scatter_(-1, first.unsqueeze(-1), de.unsqueeze(-1))
     assert torch.equal(dy.cpu(), ref)
 
