@@ -14,9 +14,12 @@
 //   4. dx written (or accumulated) per input slab; optionally the per-tile sums
 //      S1 = sum dx, S2 = sum dx*(z_in - mean_in) that the GraphNorm backward of the MLP
 //      which PRODUCED slab a needs (saves a separate reduction pass over dx and z).
-// dW/db accumulate in registers over the wave's whole tile range; at the end the four
-// waves of a workgroup are summed through LDS and one partial per workgroup is written,
-// to be reduced in fixed order by fgnn_reduce_partials (deterministic).
+// dW/db accumulate in registers over the wave's (statically assigned) tiles; at the end
+// the eight waves of a workgroup are summed through LDS in a fixed order and one partial
+// per workgroup is written, to be reduced in fixed order by fgnn_grad_finalize: results
+// are bit-reproducible run to run.
+// Execution shape: one 512-thread workgroup per CU (2 waves per SIMD, <= 256 VGPRs), all
+// MFMA A-operands in workgroup-shared LDS, three aliased 32x36 LDS tiles per wave.
 #include "fgnn_common.h"
 
 namespace {
@@ -95,8 +98,11 @@ DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 
     }
 }
 
-// dW += Dt (rows = out channel) x In (rows = in channel), contraction over the 32 pixels
-DEVI f32x16 wgrad_tile(const float *Dt, const float *In, f32x16 acc, int lane) {
+// dW += Dt (rows = out channel) x In (rows = in channel), contraction over the 32 pixels.
+// The Dt fragments of lane (o, h) are 16 pixels of channel o, so the bias gradient
+// db[o] = sum_px Dt[o][px] falls out of the same LDS reads (WITH_DB).
+template <bool WITH_DB>
+DEVI f32x16 wgrad_tile(const float *Dt, const float *In, f32x16 acc, float &db, int lane) {
     const int i = lane & 31, h = lane >> 5;
     const float4 *dp = reinterpret_cast<const float4 *>(Dt + i * TLD + 4 * h);
     const float4 *ip = reinterpret_cast<const float4 *>(In + i * TLD + 4 * h);
@@ -104,6 +110,7 @@ DEVI f32x16 wgrad_tile(const float *Dt, const float *In, f32x16 acc, int lane) {
     for (int q = 0; q < 4; ++q) {
         const float4 a = dp[2 * q];
         const float4 b = ip[2 * q];
+        if (WITH_DB) db += (a.x + a.y) + (a.z + a.w);
         acc = mfma32(a.x, b.x, acc);
         acc = mfma32(a.y, b.y, acc);
         acc = mfma32(a.z, b.z, acc);
@@ -117,8 +124,13 @@ DEVI void zero16(f32x16 &a) {
     for (int r = 0; r < 16; ++r) a[r] = 0.f;
 }
 
+constexpr int NW = 8;                // waves per workgroup (2 per SIMD)
+
 // Operand sets kept in workgroup-shared LDS (one float per lane per k-step, stored as
-// [step/4][lane][4] so a ds_read_b128 returns four consecutive k-steps of a lane).
+// [step/4][lane][4] so a ds_read_b128 returns four consecutive k-steps of a lane), the
+// wave-private per-graph records and the wave-private 32x36 transposition tiles.
+// Tile slots per wave: S0 = h1 / later x_a, S1 = h2 / dpre_1 / later x_b, S2 = dz / dpre_0
+// (a slab with fewer than 32 channels zero-fills its slot before staging its rows).
 template <int CA, int CB, int DEPTH>
 struct BwdLayout {
     static constexpr int SA = CA / 2, SB = CB / 2;
@@ -132,12 +144,12 @@ struct BwdLayout {
     static constexpr int OFF_WT0B = OFF_WT0A + 16;                        // 16: W_0^T slab b
     static constexpr int NSTEPS = OFF_WT0B + (CB > 0 ? 16 : 0);
     static constexpr int WEIGHT_F = NSTEPS * 64;                          // floats
-    static constexpr int REC_F = 4 * 3 * 32 * 4;                          // per wave: nrm a, nrm b, coef (32 x float4 each)
-    static constexpr int NTILES = 1 + (CB > 0 ? 1 : 0) + (DEPTH - 1) + 1;
+    static constexpr int REC_F = 3 * 32 * 4;                              // per wave: nrm a, nrm b, coef
+    static constexpr int SLOT_XA = 0, SLOT_XB = 1, NSLOT = 3;             // x tiles alias the dead h1 / dpre_1 slots
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
-    static constexpr int TILE_F_ALL = 4 * NTILES * TILE_F;
-    static constexpr int RED_F = 4 * PCOUNT;
-    static constexpr int LDS_F = WEIGHT_F + REC_F + (TILE_F_ALL > RED_F ? TILE_F_ALL : RED_F);
+    static constexpr int TILE_F_ALL = NW * NSLOT * TILE_F;
+    static constexpr int RED_F = 4 * PCOUNT;                              // reduction runs in two rounds of 4 waves
+    static constexpr int LDS_F = WEIGHT_F + NW * REC_F + (TILE_F_ALL > RED_F ? TILE_F_ALL : RED_F);
 };
 
 template <int OFF, int CNT>
@@ -155,16 +167,14 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int lane) {
 }
 
 template <int CA, int CB, int DEPTH>
-__global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
-                                                         const int total_tiles) {
+__global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
+                                                              const int total_tiles) {
+    static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BwdLayout<CA, CB, DEPTH>;
     constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
-    constexpr int NTILES = L::NTILES;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int wave = blockIdx.x * 4 + wv;
-    const int nwaves = gridDim.x * 4;
     const int P = A.N * A.N;
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
@@ -174,20 +184,19 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
     const View vdxb = make_view(A.dxb, A.dxb_gstride, A.dxb_ld, A.G);
 
     float *wl = smem;                                   // shared operand sets
-    float *rec = smem + L::WEIGHT_F + wv * (3 * 32 * 4);      // wave-private per-graph records
+    float *rec = smem + L::WEIGHT_F + wv * L::REC_F;    // wave-private per-graph records
     float *recA = rec, *recB = rec + 128, *recK = rec + 256;
-    float *tiles = smem + L::WEIGHT_F + L::REC_F;
-    float *my = tiles + wv * (NTILES * TILE_F);
-    float *XA = my;
-    float *XB = my + TILE_F;                                  // only if CB > 0
-    float *HT = my + (1 + (CB > 0 ? 1 : 0)) * TILE_F;         // DEPTH-1 tiles
-    float *DT = HT + (DEPTH - 1) * TILE_F;
-    for (int e = lane; e < NTILES * TILE_F; e += WAVE) my[e] = 0.f;
+    float *tiles = smem + L::WEIGHT_F + NW * L::REC_F;
+    float *my = tiles + wv * (L::NSLOT * TILE_F);
+    float *S0 = my, *S1 = my + TILE_F, *S2 = my + 2 * TILE_F;
+    float *XA = my + L::SLOT_XA * TILE_F;
+    float *XB = my + L::SLOT_XB * TILE_F;
+    for (int e = lane; e < L::NSLOT * TILE_F; e += WAVE) my[e] = 0.f;
 
-    // ---- fill the operand sets (float4 groups round-robin over the 4 waves) ----
+    // ---- fill the operand sets (float4 groups round-robin over the waves) ----
 #define FGNN_PUT(t_, expr_)                                                        \
     do {                                                                           \
-        if ((((t_) >> 2) & 3) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
+        if ((((t_) >> 2) % NW) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
     } while (0)
 #pragma unroll
     for (int s = 0; s < SA; ++s) FGNN_PUT(L::OFF_W1A + s, A.W[0][j * CIN + slab_ch<SA>(s, h)]);
@@ -216,76 +225,67 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
 
     // ---- persistent accumulators ----
     f32x16 dW0a, dW0b, dWh[DEPTH > 1 ? DEPTH - 1 : 1];
-    float dbacc[DEPTH][16];
+    float db[DEPTH];
     zero16(dW0a);
     zero16(dW0b);
 #pragma unroll
     for (int l = 0; l + 1 < DEPTH; ++l) zero16(dWh[l]);
 #pragma unroll
-    for (int l = 0; l < DEPTH; ++l)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dbacc[l][r] = 0.f;
+    for (int l = 0; l < DEPTH; ++l) db[l] = 0.f;
 
-    const int q = total_tiles / nwaves, rem = total_tiles % nwaves;
-    const int t0 = wave * q + (wave < rem ? wave : rem);
-    const int t1 = t0 + q + (wave < rem ? 1 : 0);
+    // static, strided tile assignment inside the workgroup's contiguous range: the order in
+    // which a wave accumulates its weight gradients is fixed -> bit-reproducible results
+    const int nwg = gridDim.x;
+    const int q = total_tiles / nwg, rem = total_tiles % nwg;
+    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
-    const bool emit = (CA == 32) && normA && A.dxa != nullptr && A.s12part != nullptr;
+    const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
 
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     {
-        const TileCtx c = decode_tile(t0, t0 < t1, tpg, A.N, P, A.nvalid, j);
+        const int t = T0 + wv;
+        const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, A.nvalid, j);
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
     }
     int cached_g = -1;
 
-    for (int tile = t0; tile < t1; ++tile) {
-        const int g = __builtin_amdgcn_readfirstlane(tile / tpg);
-        if (g != cached_g) {
-            // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the prefetch
-            // below so that the in-order vmcnt wait does not drain the prefetch.
+    for (int tile = T0 + wv; tile < T1; tile += NW) {
+        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
+        if (c.g != cached_g) {
+            // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the loads
+            // below so that the in-order vmcnt wait does not drain them.
             if (lane < 32) {
-                float4 k4 = reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + lane];
+                float4 k4 = reinterpret_cast<const float4 *>(A.coef)[(long long)c.g * FGNN_H + lane];
                 reinterpret_cast<float4 *>(recK)[lane] = k4;
                 if (normA && lane < CA) {
-                    float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)g * A.a.C + lane];
+                    float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
                     n.z = A.a.beta ? A.a.beta[lane] : 0.f;
                     reinterpret_cast<float4 *>(recA)[lane] = n;
                 }
                 if (normB && lane < CB) {
-                    float4 n = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)g * A.b.C + lane];
+                    float4 n = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)c.g * A.b.C + lane];
                     n.z = A.b.beta ? A.b.beta[lane] : 0.f;
                     reinterpret_cast<float4 *>(recB)[lane] = n;
                 }
             }
-            cached_g = g;
+            cached_g = c.g;
         }
-        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
-        // this tile's dy / z: consumed only after the forward recompute, which hides their latency
-        float dyr[16], zr[16];
-        load_rows16(dyr, vdy, c, h);
-        load_rows16(zr, vz, c, h);
-        // prefetch the next tile's input slabs (needed at the very start of the next iteration)
-        float nxa[SA > 0 ? SA : 1], nxb[SB > 0 ? SB : 1];
-        {
-            const TileCtx cn = decode_tile(tile + 1, tile + 1 < t1, tpg, A.N, P, A.nvalid, j);
-            load_raw<SA>(nxa, va, cn, h);
-            load_raw<SB>(nxb, vb, cn, h);
-        }
-        float ya[SA > 0 ? SA : 1], yb[SB > 0 ? SB : 1];
-        norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
-        norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
-#pragma unroll
-        for (int s = 0; s < SA; ++s) XA[slab_ch<SA>(s, h) * TLD + j] = ya[s];
-#pragma unroll
-        for (int s = 0; s < SB; ++s) XB[slab_ch<SB>(s, h) * TLD + j] = yb[s];
+        // early read-modify-write prefetch of dx only exists in the single-slab variants
+        // (mlp1 / mlp2 accumulating into d_in); two-slab kernels re-read at the store
+        constexpr bool EARLY_RMW = (CB == 0);
+        float dyr[16], zr[16], old[EARLY_RMW ? 16 : 1];
+        const bool rmw = EARLY_RMW && A.dxa != nullptr && A.accumulate_a;
 
-        // ---- forward recompute of the hidden activations ----
+        // ---- forward recompute of the hidden activations (ReLU masks kept as bitmasks) ----
+        unsigned hmask[DEPTH > 1 ? DEPTH - 1 : 1];
         if constexpr (DEPTH > 1) {
-            float hid[16];
             f32x16 acc;
             {
+                float ya[SA > 0 ? SA : 1], yb[SB > 0 ? SB : 1];
+                norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
+                norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
                 float b0[16];
                 load_ops<L::OFF_BV, 16>(b0, wl, lane);
 #pragma unroll
@@ -301,25 +301,44 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
                     for (int s = 0; s < SB; ++s) acc = mfma32(w1b[s], yb[s], acc);
                 }
             }
+            // this tile's dy / z (consumed after the recompute) and, when accumulating, the
+            // current dx values (consumed at the very end) fly behind the recompute MFMAs
+            load_rows16(dyr, vdy, c, h);
+            load_rows16(zr, vz, c, h);
+            if constexpr (EARLY_RMW) {
+                if (rmw) load_rows16(old, vdxa, c, h);
+            }
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
+                float hid[16];
+                float *Hs = (l == 1) ? S0 : S1;
+                unsigned m = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     hid[r] = fmaxf(acc[r], 0.f);
-                    HT[(l - 1) * TILE_F + ch_of(r, h) * TLD + j] = hid[r];
+                    m |= (hid[r] > 0.f ? 1u : 0u) << r;
+                    Hs[ch_of(r, h) * TLD + j] = hid[r];
                 }
+                hmask[l - 1] = m;
                 if (l + 1 < DEPTH) {
-                    float bl[16], wl_[16];
-                    if (l == 1) { load_ops<L::OFF_BV + 16, 16>(bl, wl, lane); load_ops<L::OFF_WH, 16>(wl_, wl, lane); }
+                    float bl[16], wf[16];
+                    load_ops<L::OFF_BV + 16, 16>(bl, wl, lane);
+                    load_ops<L::OFF_WH, 16>(wf, wl, lane);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = bl[r];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc = mfma32(wl_[r], hid[r], acc);
+                    for (int r = 0; r < 16; ++r) acc = mfma32(wf[r], hid[r], acc);
                 }
             }
         }
 
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DEPTH == 1) {
+            load_rows16(dyr, vdy, c, h);
+            load_rows16(zr, vz, c, h);
+            if constexpr (EARLY_RMW) {
+                if (rmw) load_rows16(old, vdxa, c, h);
+            }
+        }
         // ---- dz from (dy, z, coef) ----
         float dpre[16];
         {
@@ -331,99 +350,165 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
             }
         }
 
-        // ---- backward through the layers ----
+        // ---- backward through the hidden layers: l = DEPTH-1 .. 1 ----
+        //   l == DEPTH-1 : D tile = S2, input tile = (DEPTH == 3 ? S1 : S0)
+        //   l == 1 (DEPTH == 3): D tile = S1 (h2 is dead), input tile = S0
 #pragma unroll
-        for (int l = DEPTH - 1; l >= 0; --l) {
-            __builtin_amdgcn_sched_barrier(0);
+        for (int l = DEPTH - 1; l >= 1; --l) {
+            float *Dt = (l == DEPTH - 1) ? S2 : S1;
+            const float *In = (l == 2) ? S1 : S0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                DT[ch_of(r, h) * TLD + j] = dpre[r];
-                dbacc[l][r] += dpre[r];
-            }
-            if (l > 0) {
-                dWh[l - 1] = wgrad_tile(DT, HT + (l - 1) * TILE_F, dWh[l - 1], lane);
-                float wt[16];
-                if (l == 1) load_ops<L::OFF_WT, 16>(wt, wl, lane);
-                if (l == 2) load_ops<L::OFF_WT + (DEPTH > 2 ? 16 : 0), 16>(wt, wl, lane);
-                f32x16 acc;
-                zero16(acc);
+            for (int r = 0; r < 16; ++r) Dt[ch_of(r, h) * TLD + j] = dpre[r];
+            float wt[16];
+            if (l == 1) load_ops<L::OFF_WT, 16>(wt, wl, lane);
+            if (l == 2) load_ops<L::OFF_WT + (DEPTH > 2 ? 16 : 0), 16>(wt, wl, lane);
+            f32x16 acc;
+            zero16(acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
+            for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
+            dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
+            const unsigned m = hmask[l - 1];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dpre[r] = HT[(l - 1) * TILE_F + ch_of(r, h) * TLD + j] > 0.f ? acc[r] : 0.f;   // ReLU mask from the saved tile
-            } else {
-                dW0a = wgrad_tile(DT, XA, dW0a, lane);
-                if constexpr (CB > 0) dW0b = wgrad_tile(DT, XB, dW0b, lane);
-                if (A.dxa) {
-                    float wt[16];
-                    load_ops<L::OFF_WT0A, 16>(wt, wl, lane);
-                    f32x16 acc;
-                    zero16(acc);
+            for (int r = 0; r < 16; ++r) dpre[r] = ((m >> r) & 1u) ? acc[r] : 0.f;
+        }
+
+        // ---- layer 0: D tile = (DEPTH == 1 ? S2 : (DEPTH == 2 ? S1 : S2)); x tiles re-staged now ----
+        {
+            float *Dt = (DEPTH == 2) ? S1 : S2;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-                    float *sp = A.s12part + (((long long)c.g * tpg + c.tt) * FGNN_H) * 2;
-                    const int voff = lane_off<4>(vdxa, c, h);
-                    const int s0 = c.g * vdxa.gs4;
+            for (int r = 0; r < 16; ++r) Dt[ch_of(r, h) * TLD + j] = dpre[r];
+            {
+                float ya[SA > 0 ? SA : 1];
+                norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
+                if constexpr (CA < 32) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = ch_of(r, h);
-                        const int vo = ch < CA ? voff : OOB_OFF;
-                        const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4;
-                        float v = acc[r];
-                        if (A.accumulate_a) v += buf_load(vdxa, vo, so);
-                        buf_store(v, vdxa, vo, so);
-                        if constexpr (CA == 32) {
-                            if (emit) {
-                                // GraphNorm-backward sums of the producer of slab a: S1 += v, S2 += v * (z - mean)
-                                const float mean = reinterpret_cast<const float4 *>(recA)[ch].x;
-                                const float u = c.valid ? xa[r] - mean : 0.f;
-                                const float s1 = half_sum(c.valid ? v : 0.f);
-                                const float s2 = half_sum(c.valid ? v * u : 0.f);
-                                if (j == 0) {
-                                    sp[ch * 2 + 0] = s1;
-                                    sp[ch * 2 + 1] = s2;
-                                }
-                            }
-                        }
-                    }
+                    for (int r = 0; r < 16; ++r) XA[ch_of(r, h) * TLD + j] = 0.f;
                 }
-                if constexpr (CB > 0) {
-                    if (A.dxb) {
-                        float wt[16];
-                        load_ops<L::OFF_WT0B, 16>(wt, wl, lane);
-                        f32x16 acc;
-                        zero16(acc);
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-                        const int voff = lane_off<4>(vdxb, c, h);
-                        const int s0 = c.g * vdxb.gs4;
+                for (int s = 0; s < SA; ++s) XA[slab_ch<SA>(s, h) * TLD + j] = ya[s];
+            }
+            if constexpr (CB > 0) {
+                float yb[SB > 0 ? SB : 1];
+                norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
+                if constexpr (CB < 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) XB[ch_of(r, h) * TLD + j] = 0.f;
+                }
+#pragma unroll
+                for (int s = 0; s < SB; ++s) XB[slab_ch<SB>(s, h) * TLD + j] = yb[s];
+            }
+            // x of this tile is staged; prefetch the next tile's input slabs now (register pressure
+            // is lowest here).  The S1/S2-emitting variant still needs xa for (z - mean).
+            float nxa[(CA == 32 && CB == 0) ? 16 : 1];
+            {
+                const int tn = tile + NW;
+                const TileCtx cn = decode_tile(tn, tn < T1, tpg, A.N, P, A.nvalid, j);
+                if constexpr (CA == 32 && CB == 0) {
+                    load_raw<SA>(nxa, va, cn, h);
+                } else {
+                    load_raw<SA>(xa, va, cn, h);
+                    load_raw<SB>(xb, vb, cn, h);
+                }
+            }
+            f32x16 dxa_acc, dxb_acc;
+            if (A.dxa) {
+                float wt[16];
+                load_ops<L::OFF_WT0A, 16>(wt, wl, lane);
+                zero16(dxa_acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dxa_acc = mfma32(wt[r], dpre[r], dxa_acc);
+            }
+            if constexpr (CB > 0) {
+                if (A.dxb) {
+                    float wt[16];
+                    load_ops<L::OFF_WT0B, 16>(wt, wl, lane);
+                    zero16(dxb_acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dxb_acc = mfma32(wt[r], dpre[r], dxb_acc);
+                }
+            }
+            dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
+            if constexpr (CB > 0) {
+                float dummy = 0.f;
+                dW0b = wgrad_tile<false>(Dt, XB, dW0b, dummy, lane);
+            }
+            if (A.dxa) {
+                const int voff = lane_off<4>(vdxa, c, h);
+                const int s0 = c.g * vdxa.gs4;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = ch_of(r, h);
+                    const int vo = ch < CA ? voff : OOB_OFF;
+                    const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4;
+                    v[r] = dxa_acc[r];
+                    if constexpr (EARLY_RMW) {
+                        if (rmw) v[r] += old[r];
+                    } else {
+                        if (A.accumulate_a) v[r] += buf_load(vdxa, vo, so);
+                    }
+                    buf_store(v[r], vdxa, vo, so);
+                }
+                if constexpr (CA == 32 && CB == 0) {
+                    if (emit) {
+                        // GraphNorm-backward sums of the producer of slab a over this tile:
+                        // S1 = sum v, S2 = sum v * (z_a - mean_a); transposed through S1 / S2 so that
+                        // lane (ch, h) sums 16 pixels of its channel.  v is 0 on invalid pixels.
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ch = ch_of(r, h);
-                            const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4;
-                            const int vo = ch < CB ? voff : OOB_OFF;
-                            float v = acc[r];
-                            if (A.accumulate_b) v += buf_load(vdxb, vo, so);
-                            buf_store(v, vdxb, vo, so);
+                            const float mean = reinterpret_cast<const float4 *>(recA)[ch].x;
+                            S1[ch * TLD + j] = c.valid ? v[r] : 0.f;
+                            S2[ch * TLD + j] = xa[r] - mean;
+                        }
+                        const float4 *vp = reinterpret_cast<const float4 *>(S1 + j * TLD + 16 * h);
+                        const float4 *up = reinterpret_cast<const float4 *>(S2 + j * TLD + 16 * h);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float4 a = vp[k], b = up[k];
+                            s1 += (a.x + a.y) + (a.z + a.w);
+                            s2 += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+                        }
+                        s1 += __shfl_xor(s1, 32);
+                        s2 += __shfl_xor(s2, 32);
+                        if (h == 0) {
+                            float2 o;
+                            o.x = s1;
+                            o.y = s2;
+                            reinterpret_cast<float2 *>(A.s12part)[((long long)c.g * tpg + c.tt) * FGNN_H + j] = o;
                         }
                     }
                 }
             }
+            if constexpr (CB > 0) {
+                if (A.dxb) {
+                    const int voff = lane_off<4>(vdxb, c, h);
+                    const int s0 = c.g * vdxb.gs4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = ch_of(r, h);
+                        const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4;
+                        const int vo = ch < CB ? voff : OOB_OFF;
+                        float v = dxb_acc[r];
+                        if (A.accumulate_b) v += buf_load(vdxb, vo, so);
+                        buf_store(v, vdxb, vo, so);
+                    }
+                }
+            }
+            if constexpr (CA == 32 && CB == 0) {
+#pragma unroll
+                for (int s = 0; s < SA; ++s) xa[s] = nxa[s];
+            }
         }
-
-#pragma unroll
-        for (int s = 0; s < SA; ++s) xa[s] = nxa[s];
-#pragma unroll
-        for (int s = 0; s < SB; ++s) xb[s] = nxb[s];
     }
 
-    // ---- workgroup reduction of the parameter gradients ----
+    // ---- workgroup reduction of the parameter gradients (fixed order: waves 4-7 fold into 0-3) ----
     // layout: [W0 (32*CIN) | b0 (32) | W1 (1024) | b1 (32) | ...]
     constexpr int PCOUNT = L::PCOUNT;
-    __syncthreads();                       // everyone done with the tile buffers
-    float *red = tiles + wv * PCOUNT;      // aliases the tile region
-    {
+#pragma unroll
+    for (int l = 0; l < DEPTH; ++l) db[l] += __shfl_xor(db[l], 32);
+    auto put_partials = [&](float *red) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = ch_of(r, h);
@@ -438,17 +523,39 @@ __global__ __launch_bounds__(256, 1) void mlp_bwd_kernel(const fgnn_mlp_bwd_args
                 for (int r = 0; r < 16; ++r) red[off + ch_of(r, h) * 32 + j] = dWh[l - 1][r];
                 off += 1024;
             }
+            if (h == 0) red[off + j] = db[l];
+            off += 32;
+        }
+    };
+    __syncthreads();                       // everyone done with the tile buffers
+    if (wv >= 4) put_partials(tiles + (wv - 4) * PCOUNT);
+    __syncthreads();
+    if (wv < 4) {
+        // fold the partner wave (wv + 4) into the registers, same element mapping as put_partials
+        const float *red = tiles + wv * PCOUNT;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s = half_sum(dbacc[l][r]);
-                if (j == 0) red[off + ch_of(r, h)] = s;
+        for (int r = 0; r < 16; ++r) {
+            const int o = ch_of(r, h);
+            if (j < CA) dW0a[r] += red[o * CIN + j];
+            if (CB > 0 && j < CB) dW0b[r] += red[o * CIN + CA + j];
+        }
+        int off = 32 * CIN;
+#pragma unroll
+        for (int l = 0; l < DEPTH; ++l) {
+            if (l > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dWh[l - 1][r] += red[off + ch_of(r, h) * 32 + j];
+                off += 1024;
             }
+            if (h == 0) db[l] += red[off + j];
             off += 32;
         }
     }
     __syncthreads();
+    if (wv < 4) put_partials(tiles + wv * PCOUNT);
+    __syncthreads();
     float *out = A.wpart + (long long)blockIdx.x * PCOUNT;
-    for (int e = threadIdx.x; e < PCOUNT; e += 256)
+    for (int e = threadIdx.x; e < PCOUNT; e += 64 * NW)
         out[e] = (tiles[e] + tiles[PCOUNT + e]) + (tiles[2 * PCOUNT + e] + tiles[3 * PCOUNT + e]);
 }
 
@@ -461,7 +568,7 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(256), LDS, st, *a, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

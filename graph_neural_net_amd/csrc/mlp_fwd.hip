@@ -8,21 +8,26 @@
 // B operand of the next layer, so the whole conv/ReLU chain stays in registers; HBM sees
 // one read of the input slabs and one write of z per MLP.
 //
-// Work decomposition: a tile = 32 consecutive pixels of one graph (all channels).  Waves
-// are persistent (one per SIMD, 256 workgroups x 4 waves), each takes a contiguous tile
-// range and processes two tiles of one graph at a time (two independent MFMA chains hide
-// the MFMA->VALU->MFMA gaps); raw inputs of the next tiles are prefetched into registers
-// while the current ones compute.  The per-graph GraphNorm records of the input slabs are
-// cached in registers and (re)loaded BEFORE the prefetch is issued, so that the in-order
-// vmcnt wait for them does not drain the prefetch.
-// Tile statistics: the z tile is transposed through a wave-private LDS tile so that every
-// lane owns one channel and sums its 16 pixels in registers (two-pass mean / M2).
+// Execution shape (from the PMC profile of the first version: one wave per SIMD left the
+// MFMA pipe idle >60 % of the time behind exposed VALU/LDS/VMEM latency):
+//   * one 512-thread workgroup per CU = 2 waves per SIMD, so one wave's epilogue / waits
+//     overlap the other's MFMA chain;
+//   * all MFMA A-operands (weights, biases) live in workgroup-shared LDS, laid out
+//     [k-step/4][lane][4] so a ds_read_b128 returns four k-steps of a lane;
+//   * a tile = 32 consecutive pixels of one graph; every workgroup owns a contiguous tile
+//     range and its waves pull tiles from an LDS counter (dynamic balance inside the CU);
+//     the raw inputs of a wave's next tile are prefetched while the current one computes;
+//   * per-graph GraphNorm records of the input slabs are cached in registers and reloaded
+//     BEFORE the prefetch is issued (vmcnt is in-order);
+//   * tile statistics: the z tile is transposed through a wave-private LDS tile so that a
+//     lane owns one channel and sums its 16 pixels in registers (two-pass mean / M2).
 #include "fgnn_common.h"
 
 namespace {
 
 constexpr int TLD = 36;              // LDS tile row stride (floats)
 constexpr int TILE_F = 32 * TLD;
+constexpr int NW = 8;                // waves per workgroup
 
 struct TileCtx {
     int g, tt, p;
@@ -46,7 +51,6 @@ DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, const int
 // slabs use the accumulator-fragment pairing (same as the hidden layers), narrower ones (2k, 2k+1)
 template <int S>
 DEVI constexpr int slab_ch(int k, int h) { return S == 16 ? ch_of(k, h) : 2 * k + h; }
-
 template <int S>
 DEVI constexpr int slab_kbase(int k) { return S == 16 ? (k & 3) + 8 * (k >> 2) : 2 * k; }
 template <int S>
@@ -99,93 +103,178 @@ DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const NormCache<S> &nc, bool on,
     }
 }
 
+// LDS operand sets of one MLP (units: k-steps; one float per lane per step)
 template <int CA, int CB, int NMLP, int DEPTH>
-struct FwdWeights {
+struct FwdLayout {
     static constexpr int SA = CA / 2, SB = CB / 2;
-    float w1a[NMLP][SA > 0 ? SA : 1];
-    float w1b[NMLP][SB > 0 ? SB : 1];
-    float wh[NMLP][DEPTH > 1 ? DEPTH - 1 : 1][16];
-    float bv[NMLP][DEPTH][16];
+    static constexpr int pad4(int x) { return (x + 3) & ~3; }
+    static constexpr int OFF_W1A = 0;
+    static constexpr int OFF_W1B = OFF_W1A + pad4(SA);
+    static constexpr int OFF_WH = OFF_W1B + pad4(SB);              // 16*(DEPTH-1)
+    static constexpr int OFF_BV = OFF_WH + 16 * (DEPTH - 1);       // 16*DEPTH
+    static constexpr int MLP_STEPS = OFF_BV + 16 * DEPTH;
+    static constexpr int WEIGHT_F = NMLP * MLP_STEPS * 64;
+    static constexpr int LDS_F = WEIGHT_F + NW * TILE_F + 4;
 };
 
-template <int CA, int CB, int NMLP, int DEPTH, int NT>
-DEVI void fwd_compute(const fgnn_mlp_fwd_args &A, const FwdWeights<CA, CB, NMLP, DEPTH> &w,
-                      const NormCache<CA / 2> &nca, const NormCache<CB / 2> &ncb, const int tile0,
-                      float (&xa)[2][CA / 2 > 0 ? CA / 2 : 1], float (&xb)[2][CB / 2 > 0 ? CB / 2 : 1],
-                      const View (&vz)[NMLP], float *lds, int tpg, int P, int lane) {
-    constexpr int SA = CA / 2, SB = CB / 2;
-    const int j = lane & 31, h = lane >> 5;
-    TileCtx c[NT];
+template <int CNT>
+DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int off_steps, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(wl) + (off_steps / 4) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        c[t] = decode_tile(tile0 + t, true, tpg, A.N, P, A.nvalid, j);
-        apply_norm<SA>(xa[t], nca, A.a.nrm != nullptr, c[t].valid);
-        apply_norm<SB>(xb[t], ncb, A.b.nrm != nullptr, c[t].valid);
+    for (int q = 0; q < (CNT + 3) / 4; ++q) {
+        const float4 v = p[q * 64];
+        if (4 * q + 0 < CNT) dst[4 * q + 0] = v.x;
+        if (4 * q + 1 < CNT) dst[4 * q + 1] = v.y;
+        if (4 * q + 2 < CNT) dst[4 * q + 2] = v.z;
+        if (4 * q + 3 < CNT) dst[4 * q + 3] = v.w;
     }
+}
+
+template <int CA, int CB, int NMLP, int DEPTH>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_args A, const int tpg,
+                                                              const int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using L = FwdLayout<CA, CB, NMLP, DEPTH>;
+    constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int P = A.N * A.N;
+    float *wl = smem;
+    float *tl = smem + L::WEIGHT_F + wv * TILE_F;
+    int *ctr = reinterpret_cast<int *>(smem + L::WEIGHT_F + NW * TILE_F);
+    const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
+    const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
+    View vz[NMLP];
+#pragma unroll
+    for (int m = 0; m < NMLP; ++m) vz[m] = make_view(A.z[m], FGNN_H * A.ldz, A.ldz, A.G);
+
+    // contiguous tile range of this workgroup; waves pull tiles from the LDS counter
+    const int nwg = gridDim.x;
+    const int q = total_tiles / nwg, rem = total_tiles % nwg;
+    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    if (threadIdx.x == 0) *ctr = T0 + NW;     // the first NW tiles are assigned statically
+
+    // ---- fill the operand sets (float4 groups round-robin over the waves) ----
+#define FGNN_PUT(t_, expr_)                                                        \
+    do {                                                                           \
+        if ((((t_) >> 2) % NW) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
+    } while (0)
 #pragma unroll
     for (int m = 0; m < NMLP; ++m) {
-        f32x16 acc[NT];
+        const int base = m * L::MLP_STEPS;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int s = 0; s < SA; ++s) FGNN_PUT(base + L::OFF_W1A + s, A.W[m][0][j * CIN + slab_ch<SA>(s, h)]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = w.bv[m][0][r];
+        for (int s = 0; s < SB; ++s) FGNN_PUT(base + L::OFF_W1B + s, A.W[m][0][j * CIN + CA + slab_ch<SB>(s, h)]);
 #pragma unroll
-        for (int s = 0; s < SA; ++s)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma32(w.w1a[m][s], xa[t][s], acc[t]);
-#pragma unroll
-        for (int s = 0; s < SB; ++s)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma32(w.w1b[m][s], xb[t][s], acc[t]);
-#pragma unroll
-        for (int l = 1; l < DEPTH; ++l) {
-            float hid[NT][16];
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    hid[t][r] = fmaxf(acc[t][r], 0.f);
-                    acc[t][r] = w.bv[m][l][r];
-                }
+        for (int l = 1; l < DEPTH; ++l)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
+                FGNN_PUT(base + L::OFF_WH + 16 * (l - 1) + r, A.W[m][l][j * FGNN_H + ch_of(r, h)]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma32(w.wh[m][l - 1][r], hid[t][r], acc[t]);
+        for (int l = 0; l < DEPTH; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) FGNN_PUT(base + L::OFF_BV + 16 * l + r, A.bias[m][l][ch_of(r, h)]);
+    }
+#undef FGNN_PUT
+    __syncthreads();
+
+    NormCache<SA> nca;
+    NormCache<SB> ncb;
+    int cached_g = -1;
+
+    int tile = T0 + wv;
+    float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
+    {
+        const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, A.nvalid, j);
+        load_raw<SA>(xa, va, c, h);
+        load_raw<SB>(xb, vb, c, h);
+    }
+    while (tile < T1) {
+        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
+        if (c.g != cached_g) {        // wave-uniform; issued before the prefetch (vmcnt is in-order)
+            load_norm<SA>(nca, A.a, c.g, h);
+            load_norm<SB>(ncb, A.b, c.g, h);
+            cached_g = c.g;
         }
-        // epilogue: mask, store z, transpose through LDS, per-tile {mean, M2} with lane = channel
+        // grab and prefetch this wave's next tile
+        int next = 0;
+        if (lane == 0) next = atomicAdd(ctr, 1);
+        next = __builtin_amdgcn_readfirstlane(next);
+        float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
+        {
+            const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, A.nvalid, j);
+            load_raw<SA>(na, va, cn, h);
+            load_raw<SB>(nb, vb, cn, h);
+        }
+        apply_norm<SA>(xa, nca, A.a.nrm != nullptr, c.valid);
+        apply_norm<SB>(xb, ncb, A.b.nrm != nullptr, c.valid);
+
+        const unsigned vmask = (unsigned)__ballot(c.valid);      // bit px = pixel valid (low half-wave)
+        const float cnt = (float)__popc(vmask);
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const unsigned vmask = (unsigned)__ballot(c[t].valid);      // bit px = pixel valid (low half-wave)
-            const float cnt = (float)__popc(vmask);
-            const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-            const int zoff = lane_off<4>(vz[m], c[t], h);
-            const int zs0 = c[t].g * vz[m].gs4;
-            float *tl = lds + t * TILE_F;
+        for (int m = 0; m < NMLP; ++m) {
+            const float *wm = wl + m * (L::MLP_STEPS * 64);
+            f32x16 acc;
+            {
+                float b0[16];
+                load_ops<16>(b0, wm, L::OFF_BV, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = b0[r];
+                float w1a[SA > 0 ? SA : 1];
+                load_ops<SA>(w1a, wm, L::OFF_W1A, lane);
+#pragma unroll
+                for (int s = 0; s < SA; ++s) acc = mfma32(w1a[s], xa[s], acc);
+                if constexpr (SB > 0) {
+                    float w1b[SB > 0 ? SB : 1];
+                    load_ops<SB>(w1b, wm, L::OFF_W1B, lane);
+#pragma unroll
+                    for (int s = 0; s < SB; ++s) acc = mfma32(w1b[s], xb[s], acc);
+                }
+            }
+#pragma unroll
+            for (int l = 1; l < DEPTH; ++l) {
+                float hid[16], bl[16], wh[16];
+                load_ops<16>(bl, wm, L::OFF_BV + 16 * l, lane);
+                load_ops<16>(wh, wm, L::OFF_WH + 16 * (l - 1), lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    hid[r] = fmaxf(acc[r], 0.f);
+                    acc[r] = bl[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc = mfma32(wh[r], hid[r], acc);
+            }
+            // epilogue: mask, store z, transpose through LDS, per-tile {mean, M2} with lane = channel
+            const int zoff = lane_off<4>(vz[m], c, h);
+            const int zs0 = c.g * vz[m].gs4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int chl = (r & 3) + 8 * (r >> 2);   // channel minus 4*h
-                const float v = c[t].valid ? acc[t][r] : 0.f;
+                const float v = c.valid ? acc[r] : 0.f;
                 buf_store(v, vz[m], zoff, zs0 + chl * vz[m].ld4);
                 tl[(chl + 4 * h) * TLD + j] = v;
             }
             // lane (ch = j, h) owns pixels 16h .. 16h+15 of channel ch
             const float4 *rp = reinterpret_cast<const float4 *>(tl + j * TLD + 16 * h);
-            float4 q[4];
+            float4 qv[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = rp[k];
+            for (int k = 0; k < 4; ++k) qv[k] = rp[k];
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s += (q[k].x + q[k].y) + (q[k].z + q[k].w);
+            for (int k = 0; k < 4; ++k) s += (qv[k].x + qv[k].y) + (qv[k].z + qv[k].w);
             s += __shfl_xor(s, 32);
             const float mean = s * inv;
             const unsigned mh = vmask >> (16 * h);
             float m2 = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float d0 = ((mh >> (4 * k + 0)) & 1u) ? q[k].x - mean : 0.f;
-                const float d1 = ((mh >> (4 * k + 1)) & 1u) ? q[k].y - mean : 0.f;
-                const float d2 = ((mh >> (4 * k + 2)) & 1u) ? q[k].z - mean : 0.f;
-                const float d3 = ((mh >> (4 * k + 3)) & 1u) ? q[k].w - mean : 0.f;
+                const float d0 = ((mh >> (4 * k + 0)) & 1u) ? qv[k].x - mean : 0.f;
+                const float d1 = ((mh >> (4 * k + 1)) & 1u) ? qv[k].y - mean : 0.f;
+                const float d2 = ((mh >> (4 * k + 2)) & 1u) ? qv[k].z - mean : 0.f;
+                const float d3 = ((mh >> (4 * k + 3)) & 1u) ? qv[k].w - mean : 0.f;
                 m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
             m2 += __shfl_xor(m2, 32);
@@ -193,100 +282,33 @@ DEVI void fwd_compute(const fgnn_mlp_fwd_args &A, const FwdWeights<CA, CB, NMLP,
                 float2 o;
                 o.x = mean;
                 o.y = m2;
-                reinterpret_cast<float2 *>(A.part[m])[((long long)c[t].g * tpg + c[t].tt) * FGNN_H + j] = o;
+                reinterpret_cast<float2 *>(A.part[m])[((long long)c.g * tpg + c.tt) * FGNN_H + j] = o;
             }
-            if (m == 0 && lane == 0) A.cnt[(long long)c[t].g * tpg + c[t].tt] = cnt;
         }
-    }
-}
+        if (lane == 0) A.cnt[(long long)c.g * tpg + c.tt] = cnt;
 
-template <int CA, int CB, int NMLP, int DEPTH>
-__global__ __launch_bounds__(256, 1) void mlp_fwd_kernel(const fgnn_mlp_fwd_args A, const int tpg,
-                                                         const int total_tiles) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * TILE_F];
-    constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int o = lane & 31, h = lane >> 5;
-    const int wave = blockIdx.x * 4 + wv;
-    const int nwaves = gridDim.x * 4;
-    const int P = A.N * A.N;
-    float *lds = smem + wv * (2 * TILE_F);
-    const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
-    const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
-    View vz[NMLP];
 #pragma unroll
-    for (int m = 0; m < NMLP; ++m) vz[m] = make_view(A.z[m], FGNN_H * A.ldz, A.ldz, A.G);
-
-    FwdWeights<CA, CB, NMLP, DEPTH> w;
+        for (int s = 0; s < SA; ++s) xa[s] = na[s];
 #pragma unroll
-    for (int m = 0; m < NMLP; ++m) {
-#pragma unroll
-        for (int s = 0; s < SA; ++s) w.w1a[m][s] = A.W[m][0][o * CIN + slab_ch<SA>(s, h)];
-#pragma unroll
-        for (int s = 0; s < SB; ++s) w.w1b[m][s] = A.W[m][0][o * CIN + CA + slab_ch<SB>(s, h)];
-#pragma unroll
-        for (int l = 1; l < DEPTH; ++l)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w.wh[m][l - 1][r] = A.W[m][l][o * FGNN_H + ch_of(r, h)];
-#pragma unroll
-        for (int l = 0; l < DEPTH; ++l)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) w.bv[m][l][r] = A.bias[m][l][ch_of(r, h)];
-    }
-
-    const int q = total_tiles / nwaves, rem = total_tiles % nwaves;
-    const int t0 = wave * q + (wave < rem ? wave : rem);
-    const int t1 = t0 + q + (wave < rem ? 1 : 0);
-
-    NormCache<SA> nca;
-    NormCache<SB> ncb;
-    int cached_g = -1;
-
-    float xa[2][SA > 0 ? SA : 1], xb[2][SB > 0 ? SB : 1];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const TileCtx c = decode_tile(t0 + t, t0 + t < t1, tpg, A.N, P, A.nvalid, o);
-        load_raw<SA>(xa[t], va, c, h);
-        load_raw<SB>(xb[t], vb, c, h);
-    }
-    int tile = t0;
-    while (tile < t1) {
-        const int g = __builtin_amdgcn_readfirstlane(tile / tpg);
-        const bool pair = (tile + 1 < t1) && ((tile + 1) / tpg == g);
-        const int step = pair ? 2 : 1;
-        if (g != cached_g) {          // wave-uniform; issued before the prefetch (vmcnt is in-order)
-            load_norm<SA>(nca, A.a, g, h);
-            load_norm<SB>(ncb, A.b, g, h);
-            cached_g = g;
-        }
-        float na[2][SA > 0 ? SA : 1], nb[2][SB > 0 ? SB : 1];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int nt = tile + step + t;
-            const TileCtx c = decode_tile(nt, nt < t1, tpg, A.N, P, A.nvalid, o);
-            load_raw<SA>(na[t], va, c, h);
-            load_raw<SB>(nb[t], vb, c, h);
-        }
-        if (pair)
-            fwd_compute<CA, CB, NMLP, DEPTH, 2>(A, w, nca, ncb, tile, xa, xb, vz, lds, tpg, P, lane);
-        else
-            fwd_compute<CA, CB, NMLP, DEPTH, 1>(A, w, nca, ncb, tile, xa, xb, vz, lds, tpg, P, lane);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int s = 0; s < SA; ++s) xa[t][s] = na[t][s];
-#pragma unroll
-            for (int s = 0; s < SB; ++s) xb[t][s] = nb[t][s];
-        }
-        tile += step;
+        for (int s = 0; s < SB; ++s) xb[s] = nb[s];
+        tile = next;
     }
 }
 
 template <int CA, int CB, int NMLP, int DEPTH>
 int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
-    int nwaves = total < 1024 ? total : 1024;
-    int grid = (nwaves + 3) / 4;
-    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH>), dim3(grid), dim3(256), 0, st, *a, tpg, total);
+    using L = FwdLayout<CA, CB, NMLP, DEPTH>;
+    constexpr int LDS = L::LDS_F * 4;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set && LDS > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    int grid = (total + NW - 1) / NW;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
