@@ -224,6 +224,166 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Single-tile fast path (N <= 64, i.e. the whole matrix is one 64x64 tile): every operand is
+// staged exactly once -- all global loads of the workgroup are issued back to back into
+// registers, written to LDS, ONE barrier -- and the four waves then run their MFMA chains
+// and epilogues independently.
+// ---------------------------------------------------------------------------------------
+DEVI void load_tile_regs(float (&v)[16], const float *mat, int N, int nv, const NormRec &nr, int tid) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + 256 * k;
+        const int r = e >> 6, c = e & 63;
+        float x = 0.f;
+        if (r < nv && c < nv) {
+            x = mat[r * N + c];
+            if (nr.on) x = (x - nr.mean) * nr.a + nr.beta;
+        }
+        v[k] = x;
+    }
+}
+DEVI void store_tile_lds(float *lds, const float (&v)[16], int tid) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + 256 * k;
+        lds[(e >> 6) * LDS_LD + (e & 63)] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void chan_matmul_fwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                               const int *nvalid, int N, float *out,
+                                                               long long ogstride, long long ldo) {
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];
+    const int C = ya.C;
+    const int gc = blockIdx.x;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
+    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
+    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+    float *O = out + (long long)g * ogstride + (long long)c * ldo;
+    {
+        float va[16], vb[16];
+        load_tile_regs(va, A, N, nv, na, tid);
+        load_tile_regs(vb, B, N, nv, nb, tid);
+        store_tile_lds(As, va, tid);
+        store_tile_lds(Bs, vb, tid);
+    }
+    __syncthreads();
+    if (32 * qi < N && 32 * qj < N) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *ap = As + (32 * qi + j) * LDS_LD + h;
+        const float *bp = Bs + h * LDS_LD + 32 * qj + j;
+        for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
+        store_quadrant(O, N, 32 * qi, 32 * qj, acc, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                               const float *dm, long long dmg, long long ldm,
+                                                               const int *nvalid, int N, float *da, float *db,
+                                                               long long ogstride, long long ldo, float *s12a,
+                                                               float *s12b) {
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];
+    __shared__ float Ds[TM * LDS_LD];
+    __shared__ float red[4][4];
+    const int C = ya.C;
+    const int gc = blockIdx.x;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave >> 1, qj = wave & 1;
+    const int j = lane & 31, h = lane >> 5;
+    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
+    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
+    const float *D = dm + (long long)g * dmg + (long long)c * ldm;
+    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+    NormRec none;
+    none.on = false; none.mean = 0.f; none.a = 1.f; none.beta = 0.f;
+    float *OA = da + (long long)g * ogstride + (long long)c * ldo;
+    float *OB = db + (long long)g * ogstride + (long long)c * ldo;
+    {
+        float va[16], vb[16], vd[16];
+        load_tile_regs(va, A, N, nv, na, tid);
+        load_tile_regs(vb, B, N, nv, nb, tid);
+        load_tile_regs(vd, D, N, nv, none, tid);
+        store_tile_lds(As, va, tid);
+        store_tile_lds(Bs, vb, tid);
+        store_tile_lds(Ds, vd, tid);
+    }
+    __syncthreads();
+    const bool live = 32 * qi < N && 32 * qj < N;
+    float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+    if (live) {
+        const int col = 32 * qj + j;
+        // dA[i][k] = sum_j dM[i][j] Yb[k][j]
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
+            for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k], acc);
+        }
+        store_quadrant(OA, N, 32 * qi, 32 * qj, acc, lane);
+        if (s12a) {   // u = z - mean = (y - beta) / a is avoided: re-read the raw z (L2-hot, coalesced rows)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * qi + ch_of(r, h);
+                if (row < nv && col < nv) {
+                    sa1 += acc[r];
+                    sa2 += acc[r] * (A[row * N + col] - na.mean);
+                }
+            }
+        }
+        // dB[k][j] = sum_i Ya[i][k] dM[i][j]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const float *ap = As + h * LDS_LD + 32 * qi + j;
+            const float *bp = Ds + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < N; k += 2) acc = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], acc);
+        }
+        store_quadrant(OB, N, 32 * qi, 32 * qj, acc, lane);
+        if (s12a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * qi + ch_of(r, h);
+                if (row < nv && col < nv) {
+                    sb1 += acc[r];
+                    sb2 += acc[r] * (B[row * N + col] - nb.mean);
+                }
+            }
+        }
+    }
+    if (s12a) {
+        sa1 = wave_sum(sa1);
+        sa2 = wave_sum(sa2);
+        sb1 = wave_sum(sb1);
+        sb2 = wave_sum(sb2);
+        if (lane == 0) {
+            red[wave][0] = sa1;
+            red[wave][1] = sa2;
+            red[wave][2] = sb1;
+            red[wave][3] = sb2;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
+            *dst = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
@@ -232,7 +392,12 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_fwd: bad shapes");
     FGNN_CHECK((long long)G * ya->C <= 65535 * 1024ll, "fgnn_chan_matmul_fwd: G*C too large");
     const int t = (N + TM - 1) / TM;
-    FGNN_CHECK(G * ya->C <= 0x7fffffff / 1, "fgnn_chan_matmul_fwd: grid overflow");
+    if (t == 1) {
+        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
+                           N, out, ogstride, ldo);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(chan_matmul_fwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb,
                        nvalid, N, out, ogstride, ldo);
     FGNN_LAUNCH_CHECK();
@@ -248,6 +413,12 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     FGNN_CHECK(!s12a || (ya->nrm && yb->nrm), "fgnn_chan_matmul_bwd: s12 outputs need normalised slabs");
     const int t = (N + TM - 1) / TM;
     const bool fused = s12a && t == 1;
+    if (t == 1) {
+        hipLaunchKernelGGL(chan_matmul_bwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
+                           dmgstride, ldm, nvalid, N, da, db, ogstride, ldo, s12a, s12b);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(chan_matmul_bwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
                        dmgstride, ldm, nvalid, N, da, db, ogstride, ldo, fused ? s12a : nullptr, fused ? s12b : nullptr);
     FGNN_LAUNCH_CHECK();

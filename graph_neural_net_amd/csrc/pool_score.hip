@@ -6,8 +6,7 @@
 
 namespace {
 
-// one thread per (g,c,i) row; consecutive lanes read consecutive rows (stride N), the
-// row segments stay L1-resident across the j loop.
+// generic: one thread per (g,c,i) row (used when a matrix does not fit the LDS staging below)
 __global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, int N, float *e, int *idx) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int C = y.C;
@@ -39,6 +38,55 @@ __global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, i
     }
     e[t] = best;
     idx[t] = bi;
+}
+
+// N <= 64: one wave per (g,c); the matrix is read with coalesced loads, normalised and staged in a
+// wave-private LDS tile (row stride N+1: conflict-free row scans), then lane i scans row i.
+__global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, const int *nvalid, int G, int N,
+                                                             float *e, int *idx) {
+    __shared__ float sm[4][64 * 65];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gc = blockIdx.x * 4 + wave;
+    const int C = y.C;
+    if (gc >= G * C) return;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const float *mat = y.ptr + (long long)g * y.gstride + (long long)c * y.ldp;
+    float mean = 0.f, a = 1.f, be = 0.f;
+    if (y.nrm) {
+        const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
+        mean = n.x;
+        a = n.y;
+        be = y.beta ? y.beta[c] : 0.f;
+    }
+    float *t = sm[wave];
+    const int ld = N + 1;
+    const float invN = 1.f / (float)N;
+    for (int p = lane; p < N * N; p += WAVE) {
+        const int i = (int)(((float)p + 0.5f) * invN);
+        const int jj = p - i * N;
+        float v = mat[p];
+        if (y.nrm) v = (v - mean) * a + be;
+        t[i * ld + jj] = v;
+    }
+    // same wave wrote and reads: LDS operations of a wave execute in order
+    float best = 0.f;
+    int bi = 0;
+    if (lane < nv) {
+        best = -FLT_MAX;
+        const float *row = t + lane * ld;
+        for (int jj = 0; jj < nv; ++jj) {
+            const float v = row[jj];
+            if (v > best) {
+                best = v;
+                bi = jj;
+            }
+        }
+    }
+    if (lane < N) {
+        e[(long long)gc * N + lane] = best;
+        idx[(long long)gc * N + lane] = bi;
+    }
 }
 
 // one wave per (g,c): each lane writes whole rows of dy (zeros + one scattered value) and the
@@ -121,41 +169,55 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
 
 // dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
 // de1[c][i] = sum_j e2[c][j] dS[i][j];  de2[c][j] = sum_i e1[c][i] dS[i][j].
-template <bool CE>
+// grid (B, CSPLIT): every workgroup stages dS (N x N) once in LDS and handles C/CSPLIT channels.
+constexpr int CSPLIT = 4;
+template <bool CE, bool STAGE>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const float *e2, const float *scores,
                                                         const float *lse, const float *dscores, const int *nvalid,
                                                         const float *gscale, int C, int N, float *de1, float *de2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *s1 = sm, *s2 = sm + (size_t)C * N;
+    const int cper = (C + CSPLIT - 1) / CSPLIT;
+    const int c0 = blockIdx.y * cper;
+    const int cn = (c0 + cper <= C ? cper : (C > c0 ? C - c0 : 0));
+    float *s1 = sm, *s2 = sm + (size_t)cper * N;
+    float *dS = s2 + (size_t)cper * N;         // [i][j], row stride N + 1
+    const int ld = N + 1;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nv = nvalid_of(nvalid, b, N);
-    const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
-    for (int e = tid; e < C * N; e += 256) {
+    const float *p1 = e1 + ((long long)b * C + c0) * N, *p2 = e2 + ((long long)b * C + c0) * N;
+    for (int e = tid; e < cn * N; e += 256) {
         s1[e] = p1[e];
         s2[e] = p2[e];
     }
-    __syncthreads();
     const float gs = CE ? *gscale : 1.f;
     const float *S = (CE ? scores : dscores) + (long long)b * N * N;
-    const float *L = CE ? lse + (long long)b * N : nullptr;
-    for (int e = tid; e < C * N; e += 256) {
+    const float *Lr = CE ? lse + (long long)b * N : nullptr;
+    const float invN = 1.f / (float)N;
+    auto ds_at = [&](int i, int jj) -> float {     // valid i, jj only
+        float d = S[(long long)i * N + jj];
+        if (CE) d = (expf(d - Lr[i]) - (i == jj ? 1.f : 0.f)) * gs;
+        return d;
+    };
+    if (STAGE) {
+        for (int e = tid; e < N * N; e += 256) {
+            const int i = (int)(((float)e + 0.5f) * invN);
+            const int jj = e - i * N;
+            dS[i * ld + jj] = (i < nv && jj < nv) ? ds_at(i, jj) : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < cn * N; e += 256) {
         const int c = e / N, i = e - c * N;
         float a1 = 0.f, a2 = 0.f;
         if (i < nv) {
-            const float li = CE ? L[i] : 0.f;
-            for (int j = 0; j < nv; ++j) {
-                // dS[i][j] for de1
-                float d = S[(long long)i * N + j];
-                if (CE) d = (expf(d - li) - (i == j ? 1.f : 0.f)) * gs;
-                a1 = fmaf(s2[c * N + j], d, a1);
-                // dS[j][i] for de2 (index i plays the role of the column)
-                float dt = S[(long long)j * N + i];
-                if (CE) dt = (expf(dt - L[j]) - (i == j ? 1.f : 0.f)) * gs;
-                a2 = fmaf(s1[c * N + j], dt, a2);
+            const float *r2 = s2 + c * N, *r1 = s1 + c * N;
+            for (int jj = 0; jj < nv; ++jj) {
+                a1 = fmaf(r2[jj], STAGE ? dS[i * ld + jj] : ds_at(i, jj), a1);
+                a2 = fmaf(r1[jj], STAGE ? dS[jj * ld + i] : ds_at(jj, i), a2);
             }
         }
-        de1[(long long)b * C * N + e] = a1;
-        de2[(long long)b * C * N + e] = a2;
+        de1[((long long)b * C + c0) * N + e] = a1;
+        de2[((long long)b * C + c0) * N + e] = a2;
     }
 }
 
@@ -204,6 +266,12 @@ __global__ void ce_bwd_kernel(const float *scores, const float *lse, const int *
 extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *e, int *idx, void *stream) {
     FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && y->C > 0, "fgnn_colmax_fwd: bad arguments");
     const long long tot = (long long)G * y->C * N;
+    if (N <= 64) {
+        hipLaunchKernelGGL(colmax_fwd_lds_kernel, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           *y, nvalid, G, N, e, idx);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(colmax_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *y,
                        nvalid, G, N, e, idx);
     FGNN_LAUNCH_CHECK();
@@ -224,6 +292,31 @@ extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvali
 }
 
 static int score_lds_bytes(int C, int N) { return (2 * C * N + 4) * (int)sizeof(float); }
+static int score_bwd_lds_bytes(int C, int N, bool stage) {
+    const int cper = (C + CSPLIT - 1) / CSPLIT;
+    return (2 * cper * N + (stage ? N * (N + 1) : 0)) * (int)sizeof(float);
+}
+template <bool CE>
+static int launch_score_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
+                            const float *dscores, const int *nvalid, const float *gscale, int B, int C, int N,
+                            float *de1, float *de2, hipStream_t st) {
+    const bool stage = score_bwd_lds_bytes(C, N, true) <= 160 * 1024;
+    const int lds = score_bwd_lds_bytes(C, N, stage);
+    FGNN_CHECK(lds <= 160 * 1024, "score backward: C*N=%d too large for LDS staging", C * N);
+    if (stage) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)score_bwd_kernel<CE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((score_bwd_kernel<CE, true>), dim3(B, CSPLIT), dim3(256), lds, st, e1, e2, scores, lse, dscores,
+                           nvalid, gscale, C, N, de1, de2);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)score_bwd_kernel<CE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((score_bwd_kernel<CE, false>), dim3(B, CSPLIT), dim3(256), lds, st, e1, e2, scores, lse, dscores,
+                           nvalid, gscale, C, N, de1, de2);
+    }
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
                                  float *scores, float *lse, float *pair_loss, void *stream) {
@@ -242,28 +335,13 @@ extern "C" int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *
                                  const int *nvalid, const float *gscale, int B, int C, int N, float *de1, float *de2,
                                  void *stream) {
     FGNN_CHECK(e1 && e2 && scores && lse && gscale && de1 && de2 && B > 0, "fgnn_score_ce_bwd: bad arguments");
-    const int lds = score_lds_bytes(C, N);
-    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_bwd: C*N=%d too large for LDS staging", C * N);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)score_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(score_bwd_kernel<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2, scores, lse,
-                       (const float *)nullptr, nvalid, gscale, C, N, de1, de2);
-    FGNN_LAUNCH_CHECK();
-    return 0;
+    return launch_score_bwd<true>(e1, e2, scores, lse, nullptr, nvalid, gscale, B, C, N, de1, de2, (hipStream_t)stream);
 }
 
 extern "C" int fgnn_score_bwd(const float *e1, const float *e2, const float *dscores, const int *nvalid, int B, int C,
                               int N, float *de1, float *de2, void *stream) {
     FGNN_CHECK(e1 && e2 && dscores && de1 && de2 && B > 0, "fgnn_score_bwd: bad arguments");
-    const int lds = score_lds_bytes(C, N);
-    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_bwd: C*N=%d too large for LDS staging", C * N);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)score_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(score_bwd_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2,
-                       (const float *)nullptr, (const float *)nullptr, dscores, nvalid, (const float *)nullptr, C, N,
-                       de1, de2);
-    FGNN_LAUNCH_CHECK();
-    return 0;
+    return launch_score_bwd<false>(e1, e2, nullptr, nullptr, dscores, nvalid, nullptr, B, C, N, de1, de2, (hipStream_t)stream);
 }
 
 extern "C" int fgnn_ce_fwd(const float *scores, const int *nvalid, int B, int N, float *lse, float *pair_loss,
