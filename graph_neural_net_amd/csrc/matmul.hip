@@ -230,17 +230,20 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya
 // registers, written to LDS, ONE barrier -- and the four waves then run their MFMA chains
 // and epilogues independently.
 // ---------------------------------------------------------------------------------------
-DEVI void load_tile_regs(float (&v)[16], const float *mat, int N, int nv, const NormRec &nr, int tid) {
+// Unconditional (address-clamped) loads + selects: a predicated load would become one branch
+// region per element, each waiting for its own round trip.
+// v = operand value (normalised, 0 in padding); u = z - mean (0 in padding) when WANT_U.
+template <bool WANT_U>
+DEVI void load_tile_regs(float (&v)[16], float (&u)[16], const float *mat, int N, int nv, const NormRec &nr, int tid) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int e = tid + 256 * k;
         const int r = e >> 6, c = e & 63;
-        float x = 0.f;
-        if (r < nv && c < nv) {
-            x = mat[r * N + c];
-            if (nr.on) x = (x - nr.mean) * nr.a + nr.beta;
-        }
-        v[k] = x;
+        const bool ok = r < nv && c < nv;
+        const float x = mat[ok ? r * N + c : 0];
+        const float d = x - nr.mean;
+        v[k] = ok ? (nr.on ? d * nr.a + nr.beta : x) : 0.f;
+        if (WANT_U) u[k] = ok ? d : 0.f;
     }
 }
 DEVI void store_tile_lds(float *lds, const float (&v)[16], int tid) {
@@ -248,6 +251,27 @@ DEVI void store_tile_lds(float *lds, const float (&v)[16], int tid) {
     for (int k = 0; k < 16; ++k) {
         const int e = tid + 256 * k;
         lds[(e >> 6) * LDS_LD + (e & 63)] = v[k];
+    }
+}
+// D fragment of one quadrant -> LDS tile (row stride LDS_LD)
+DEVI void frag_to_lds(float *lds, int row0, int col0, const f32x16 &acc, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[(row0 + ch_of(r, h)) * LDS_LD + col0 + j] = acc[r];
+}
+// LDS tile -> global (coalesced rows), optionally accumulating S1 = sum t, S2 = sum t * u
+template <bool WANT_S>
+DEVI void tile_to_global(float *out, const float *lds, int N, const float (&u)[16], float &s1, float &s2, int tid) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + 256 * k;
+        const int r = e >> 6, c = e & 63;
+        const float t = lds[r * LDS_LD + c];
+        if (r < N && c < N) out[r * N + c] = t;
+        if (WANT_S) {
+            s1 += t;
+            s2 += t * u[k];
+        }
     }
 }
 
@@ -267,23 +291,28 @@ __global__ __launch_bounds__(256) void chan_matmul_fwd1_kernel(const fgnn_slab y
     const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
     const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
     float *O = out + (long long)g * ogstride + (long long)c * ldo;
+    float dummy[16];
     {
         float va[16], vb[16];
-        load_tile_regs(va, A, N, nv, na, tid);
-        load_tile_regs(vb, B, N, nv, nb, tid);
+        load_tile_regs<false>(va, dummy, A, N, nv, na, tid);
+        load_tile_regs<false>(vb, dummy, B, N, nv, nb, tid);
         store_tile_lds(As, va, tid);
         store_tile_lds(Bs, vb, tid);
     }
     __syncthreads();
-    if (32 * qi < N && 32 * qj < N) {
-        f32x16 acc;
+    f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (32 * qi < N && 32 * qj < N) {
         const float *ap = As + (32 * qi + j) * LDS_LD + h;
         const float *bp = Bs + h * LDS_LD + 32 * qj + j;
         for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
-        store_quadrant(O, N, 32 * qi, 32 * qj, acc, lane);
     }
+    __syncthreads();                                   // all waves done reading As
+    frag_to_lds(As, 32 * qi, 32 * qj, acc, lane);
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    tile_to_global<false>(O, As, N, dummy, s1, s2, tid);
 }
 
 __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
@@ -310,61 +339,46 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
     none.on = false; none.mean = 0.f; none.a = 1.f; none.beta = 0.f;
     float *OA = da + (long long)g * ogstride + (long long)c * ldo;
     float *OB = db + (long long)g * ogstride + (long long)c * ldo;
+    float ua[16], ub[16], dummy[16];
     {
         float va[16], vb[16], vd[16];
-        load_tile_regs(va, A, N, nv, na, tid);
-        load_tile_regs(vb, B, N, nv, nb, tid);
-        load_tile_regs(vd, D, N, nv, none, tid);
+        load_tile_regs<true>(va, ua, A, N, nv, na, tid);
+        load_tile_regs<true>(vb, ub, B, N, nv, nb, tid);
+        load_tile_regs<false>(vd, dummy, D, N, nv, none, tid);
         store_tile_lds(As, va, tid);
         store_tile_lds(Bs, vb, tid);
         store_tile_lds(Ds, vd, tid);
     }
     __syncthreads();
     const bool live = 32 * qi < N && 32 * qj < N;
-    float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
-    if (live) {
-        const int col = 32 * qj + j;
-        // dA[i][k] = sum_j dM[i][j] Yb[k][j]
-        f32x16 acc;
+    f32x16 accA, accB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+        accA[r] = 0.f;
+        accB[r] = 0.f;
+    }
+    if (live) {
+        // dA[i][k] = sum_j dM[i][j] Yb[k][j]
         {
             const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
             const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
-            for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k], acc);
-        }
-        store_quadrant(OA, N, 32 * qi, 32 * qj, acc, lane);
-        if (s12a) {   // u = z - mean = (y - beta) / a is avoided: re-read the raw z (L2-hot, coalesced rows)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * qi + ch_of(r, h);
-                if (row < nv && col < nv) {
-                    sa1 += acc[r];
-                    sa2 += acc[r] * (A[row * N + col] - na.mean);
-                }
-            }
+            for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
         }
         // dB[k][j] = sum_i Ya[i][k] dM[i][j]
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         {
             const float *ap = As + h * LDS_LD + 32 * qi + j;
             const float *bp = Ds + h * LDS_LD + 32 * qj + j;
-            for (int k = 0; k < N; k += 2) acc = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], acc);
-        }
-        store_quadrant(OB, N, 32 * qi, 32 * qj, acc, lane);
-        if (s12a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * qi + ch_of(r, h);
-                if (row < nv && col < nv) {
-                    sb1 += acc[r];
-                    sb2 += acc[r] * (B[row * N + col] - nb.mean);
-                }
-            }
+            for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
         }
     }
+    __syncthreads();                                   // all products done: As / Bs are free
+    frag_to_lds(Bs, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
+    frag_to_lds(As, 32 * qi, 32 * qj, accB, lane);     // dB -> As
+    __syncthreads();
+    float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     if (s12a) {
+        tile_to_global<true>(OA, Bs, N, ua, sa1, sa2, tid);
+        tile_to_global<true>(OB, As, N, ub, sb1, sb2, tid);
         sa1 = wave_sum(sa1);
         sa2 = wave_sum(sa2);
         sb1 = wave_sum(sb1);
@@ -381,6 +395,9 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
             float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
             *dst = v;
         }
+    } else {
+        tile_to_global<false>(OA, Bs, N, dummy, sa1, sa2, tid);
+        tile_to_global<false>(OB, As, N, dummy, sb1, sb2, tid);
     }
 }
 
