@@ -148,8 +148,9 @@ struct BwdLayout {
     static constexpr int SLOT_XA = 0, SLOT_XB = 1, NSLOT = 3;             // x tiles alias the dead h1 / dpre_1 slots
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int TILE_F_ALL = NW * NSLOT * TILE_F;
-    static constexpr int RED_F = 4 * PCOUNT;                              // reduction runs in two rounds of 4 waves
-    static constexpr int LDS_F = WEIGHT_F + NW * REC_F + (TILE_F_ALL > RED_F ? TILE_F_ALL : RED_F);
+    static constexpr int RED_F = NW * PCOUNT;                             // final reduction reuses the whole allocation
+    static constexpr int MAIN_F = WEIGHT_F + NW * REC_F + TILE_F_ALL;
+    static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
 };
 
 template <int OFF, int CNT>
@@ -191,36 +192,60 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     float *S0 = my, *S1 = my + TILE_F, *S2 = my + 2 * TILE_F;
     float *XA = my + L::SLOT_XA * TILE_F;
     float *XB = my + L::SLOT_XB * TILE_F;
-    for (int e = lane; e < L::NSLOT * TILE_F; e += WAVE) my[e] = 0.f;
 
-    // ---- fill the operand sets (float4 groups round-robin over the waves) ----
-#define FGNN_PUT(t_, expr_)                                                        \
-    do {                                                                           \
-        if ((((t_) >> 2) % NW) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
-    } while (0)
-#pragma unroll
-    for (int s = 0; s < SA; ++s) FGNN_PUT(L::OFF_W1A + s, A.W[0][j * CIN + slab_ch<SA>(s, h)]);
-#pragma unroll
-    for (int s = 0; s < SB; ++s) FGNN_PUT(L::OFF_W1B + s, A.W[0][j * CIN + CA + slab_ch<SB>(s, h)]);
-#pragma unroll
-    for (int l = 1; l + 1 < DEPTH; ++l)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) FGNN_PUT(L::OFF_WH + 16 * (l - 1) + r, A.W[l][j * FGNN_H + ch_of(r, h)]);
-#pragma unroll
-    for (int l = 0; l + 1 < DEPTH; ++l)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) FGNN_PUT(L::OFF_BV + 16 * l + r, A.bias[l][ch_of(r, h)]);
-#pragma unroll
-    for (int l = 1; l < DEPTH; ++l)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) FGNN_PUT(L::OFF_WT + 16 * (l - 1) + r, A.W[l][ch_of(r, h) * FGNN_H + j]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) FGNN_PUT(L::OFF_WT0A + r, (j < CA) ? A.W[0][ch_of(r, h) * CIN + j] : 0.f);
-    if constexpr (CB > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) FGNN_PUT(L::OFF_WT0B + r, (j < CB) ? A.W[0][ch_of(r, h) * CIN + CA + j] : 0.f);
+    // ---- fill the operand sets: one independent (step, lane) element per thread and iteration ----
+    {
+        // every element is ONE unconditional load (pointer / index / validity chosen first)
+        auto operand = [&](int t, int l) -> float {
+            const int jj = l & 31, hh = l >> 5;
+            const float *ptr;
+            int idx;
+            bool ok = true;
+            if (t < L::OFF_W1B) {                       // forward layer 0, slab a
+                int sidx = t - L::OFF_W1A;
+                ok = sidx < SA;
+                sidx = ok ? sidx : 0;
+                ptr = A.W[0];
+                idx = jj * CIN + slab_ch<SA>(sidx, hh);
+            } else if (t < L::OFF_WH) {                 // forward layer 0, slab b
+                int sidx = t - L::OFF_W1B;
+                ok = sidx < SB;
+                sidx = ok ? sidx : 0;
+                ptr = A.W[0];
+                idx = jj * CIN + (CB > 0 ? CA : 0) + slab_ch<(SB > 0 ? SB : 1)>(sidx, hh);
+            } else if (t < L::OFF_BV) {                 // forward hidden layers 1..DEPTH-2
+                const int u = t - L::OFF_WH;
+                ptr = (u >> 4) == 0 ? A.W[1] : A.W[DEPTH > 2 ? 2 : 1];
+                idx = jj * FGNN_H + ch_of(u & 15, hh);
+            } else if (t < L::OFF_WT) {                 // biases of layers 0..DEPTH-2
+                const int u = t - L::OFF_BV;
+                ptr = (u >> 4) == 0 ? A.bias[0] : A.bias[DEPTH > 1 ? 1 : 0];
+                idx = ch_of(u & 15, hh);
+            } else if (t < L::OFF_WT0A) {               // W_l^T, l = 1..DEPTH-1
+                const int u = t - L::OFF_WT;
+                ptr = (u >> 4) == 0 ? A.W[DEPTH > 1 ? 1 : 0] : A.W[DEPTH > 2 ? 2 : 0];
+                idx = ch_of(u & 15, hh) * FGNN_H + jj;
+            } else if (t < L::OFF_WT0B) {               // W_0^T slab a
+                const int u = t - L::OFF_WT0A;
+                ok = jj < CA;
+                ptr = A.W[0];
+                idx = ch_of(u, hh) * CIN + (ok ? jj : 0);
+            } else {                                    // W_0^T slab b
+                const int u = t - L::OFF_WT0B;
+                ok = jj < CB;
+                ptr = A.W[0];
+                idx = ch_of(u, hh) * CIN + CA + (ok ? jj : 0);
+            }
+            const float v = ptr[idx];
+            return ok ? v : 0.f;
+        };
+        constexpr int TOTAL = L::NSTEPS * 64;
+#pragma unroll 4
+        for (int e = threadIdx.x; e < TOTAL; e += 64 * NW) {
+            const int t = e >> 6, l = e & 63;
+            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = operand(t, l);
+        }
     }
-#undef FGNN_PUT
     __syncthreads();
 
     // ---- persistent accumulators ----
@@ -503,7 +528,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         }
     }
 
-    // ---- workgroup reduction of the parameter gradients (fixed order: waves 4-7 fold into 0-3) ----
+    // ---- workgroup reduction of the parameter gradients (fixed order over the waves) ----
     // layout: [W0 (32*CIN) | b0 (32) | W1 (1024) | b1 (32) | ...]
     constexpr int PCOUNT = L::PCOUNT;
 #pragma unroll
@@ -527,36 +552,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             off += 32;
         }
     };
-    __syncthreads();                       // everyone done with the tile buffers
-    if (wv >= 4) put_partials(tiles + (wv - 4) * PCOUNT);
-    __syncthreads();
-    if (wv < 4) {
-        // fold the partner wave (wv + 4) into the registers, same element mapping as put_partials
-        const float *red = tiles + wv * PCOUNT;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = ch_of(r, h);
-            if (j < CA) dW0a[r] += red[o * CIN + j];
-            if (CB > 0 && j < CB) dW0b[r] += red[o * CIN + CA + j];
-        }
-        int off = 32 * CIN;
-#pragma unroll
-        for (int l = 0; l < DEPTH; ++l) {
-            if (l > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dWh[l - 1][r] += red[off + ch_of(r, h) * 32 + j];
-                off += 1024;
-            }
-            if (h == 0) db[l] += red[off + j];
-            off += 32;
-        }
-    }
-    __syncthreads();
-    if (wv < 4) put_partials(tiles + wv * PCOUNT);
+    __syncthreads();                       // everyone done with the operand sets and the tile buffers
+    put_partials(smem + wv * PCOUNT);      // the whole LDS allocation is free now
     __syncthreads();
     float *out = A.wpart + (long long)blockIdx.x * PCOUNT;
-    for (int e = threadIdx.x; e < PCOUNT; e += 64 * NW)
-        out[e] = (tiles[e] + tiles[PCOUNT + e]) + (tiles[2 * PCOUNT + e] + tiles[3 * PCOUNT + e]);
+    for (int e = threadIdx.x; e < PCOUNT; e += 64 * NW) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += smem[w * PCOUNT + e];      // fixed order
+        out[e] = a;
+    }
 }
 
 template <int CA, int CB, int DEPTH>
@@ -568,6 +573,7 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
         (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
+    // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
     hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;

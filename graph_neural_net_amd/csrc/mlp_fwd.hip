@@ -155,29 +155,49 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
     const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
     if (threadIdx.x == 0) *ctr = T0 + NW;     // the first NW tiles are assigned statically
 
-    // ---- fill the operand sets (float4 groups round-robin over the waves) ----
-#define FGNN_PUT(t_, expr_)                                                        \
-    do {                                                                           \
-        if ((((t_) >> 2) % NW) == wv) wl[((t_) >> 2) * 256 + lane * 4 + ((t_) & 3)] = (expr_); \
-    } while (0)
+    // ---- fill the operand sets: one independent (step, lane) element per thread and iteration ----
+    {
+        // every element is ONE unconditional load (pointer / index / validity chosen first)
+        auto operand = [&](int m, int t, int l) -> float {
+            const int jj = l & 31, hh = l >> 5;
+            const float *ptr;
+            int idx;
+            bool ok = true;
+            if (t < L::OFF_W1B) {
+                int sidx = t - L::OFF_W1A;
+                ok = sidx < SA;
+                sidx = ok ? sidx : 0;
+                ptr = A.W[m][0];
+                idx = jj * CIN + slab_ch<SA>(sidx, hh);
+            } else if (t < L::OFF_WH) {
+                int sidx = t - L::OFF_W1B;
+                ok = sidx < SB;
+                sidx = ok ? sidx : 0;
+                ptr = A.W[m][0];
+                idx = jj * CIN + (CB > 0 ? CA : 0) + slab_ch<(SB > 0 ? SB : 1)>(sidx, hh);
+            } else if (t < L::OFF_BV) {
+                const int u = t - L::OFF_WH;
+                ptr = (u >> 4) == 0 ? A.W[m][DEPTH > 1 ? 1 : 0] : A.W[m][DEPTH > 2 ? 2 : 0];
+                idx = jj * FGNN_H + ch_of(u & 15, hh);
+            } else {
+                const int u = t - L::OFF_BV;
+                const int l2 = u >> 4;
+                ptr = l2 == 0 ? A.bias[m][0] : (l2 == 1 ? A.bias[m][DEPTH > 1 ? 1 : 0] : A.bias[m][DEPTH > 2 ? 2 : 0]);
+                idx = ch_of(u & 15, hh);
+            }
+            const float v = ptr[idx];
+            return ok ? v : 0.f;
+        };
+        constexpr int PER = L::MLP_STEPS * 64;
 #pragma unroll
-    for (int m = 0; m < NMLP; ++m) {
-        const int base = m * L::MLP_STEPS;
-#pragma unroll
-        for (int s = 0; s < SA; ++s) FGNN_PUT(base + L::OFF_W1A + s, A.W[m][0][j * CIN + slab_ch<SA>(s, h)]);
-#pragma unroll
-        for (int s = 0; s < SB; ++s) FGNN_PUT(base + L::OFF_W1B + s, A.W[m][0][j * CIN + CA + slab_ch<SB>(s, h)]);
-#pragma unroll
-        for (int l = 1; l < DEPTH; ++l)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                FGNN_PUT(base + L::OFF_WH + 16 * (l - 1) + r, A.W[m][l][j * FGNN_H + ch_of(r, h)]);
-#pragma unroll
-        for (int l = 0; l < DEPTH; ++l)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) FGNN_PUT(base + L::OFF_BV + 16 * l + r, A.bias[m][l][ch_of(r, h)]);
+        for (int m = 0; m < NMLP; ++m) {
+#pragma unroll 4
+            for (int e = threadIdx.x; e < PER; e += 64 * NW) {
+                const int t = e >> 6, l = e & 63;
+                wl[m * PER + (t >> 2) * 256 + l * 4 + (t & 3)] = operand(m, t, l);
+            }
+        }
     }
-#undef FGNN_PUT
     __syncthreads();
 
     NormCache<SA> nca;
