@@ -34,7 +34,7 @@ class MlpFwdArgs(C.Structure):
                 ('z', C.c_void_p * 2),
                 ('ldz', C.c_longlong),
                 ('part', C.c_void_p * 2),
-                ('cnt', C.c_void_p)]
+                ('cnt', C.c_void_p), ('packed', C.c_void_p)]
 
 
 class MlpBwdArgs(C.Structure):
@@ -49,7 +49,7 @@ class MlpBwdArgs(C.Structure):
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
-                ('wpart', C.c_void_p), ('s12part', C.c_void_p)]
+                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p)]
 
 
 class GradJob(C.Structure):
@@ -57,7 +57,14 @@ class GradJob(C.Structure):
                 ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [('kind', C.c_int), ('ca', C.c_int), ('cb', C.c_int), ('depth', C.c_int), ('nmlp', C.c_int),
+                ('W', (C.c_void_p * FGNN_MAX_DEPTH) * 2), ('bias', (C.c_void_p * FGNN_MAX_DEPTH) * 2),
+                ('out', C.c_void_p)]
+
+
 MAX_GRAD_JOBS = 16
+MAX_PACK_JOBS = 24
 _VP, _LL, _I, _F = C.c_void_p, C.c_longlong, C.c_int, C.c_float
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -66,6 +73,8 @@ _SIGNATURES = {
     'fgnn_version': [],
     'fgnn_tiles_per_graph': [_I],
     'fgnn_mlp_bwd_num_workgroups': [],
+    'fgnn_pack_floats': [_I, _I, _I, _I, _I],
+    'fgnn_pack_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd': [C.POINTER(MlpFwdArgs), _VP],
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],

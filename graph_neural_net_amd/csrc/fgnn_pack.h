@@ -1,0 +1,96 @@
+// LDS operand images of the MLP kernels: layout + element definition shared by the kernels
+// (compile-time) and by fgnn_pack_operands (run-time, once per step per MLP).
+// An image is [k-step/4][lane][4] floats: element (step t, lane l) at (t>>2)*256 + l*4 + (t&3).
+#pragma once
+#include "fgnn_common.h"
+
+#define HD __host__ __device__ __forceinline__
+
+HD constexpr int pk_pad4(int x) { return (x + 3) & ~3; }
+HD constexpr int pk_slab_ch(int S, int k, int h) { return S == 16 ? (k & 3) + 8 * (k >> 2) + 4 * h : 2 * k + h; }
+HD constexpr int pk_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- forward image of ONE MLP: [W0 slab a | W0 slab b | W_1..W_{d-1} | b_0..b_{d-1}] ----
+struct PkFwd {
+    int off_w1a, off_w1b, off_wh, off_bv, steps;
+};
+HD constexpr PkFwd pk_fwd(int ca, int cb, int depth) {
+    PkFwd p{};
+    p.off_w1a = 0;
+    p.off_w1b = pk_pad4(ca / 2);
+    p.off_wh = p.off_w1b + pk_pad4(cb / 2);
+    p.off_bv = p.off_wh + 16 * (depth - 1);
+    p.steps = p.off_bv + 16 * depth;
+    return p;
+}
+// W[l]: conv weights (32, Cin_l) row-major, bias[l]: (32)
+HD float pk_fwd_value(const PkFwd &p, int ca, int cb, const float *const *W, const float *const *bias, int t, int l) {
+    const int jj = l & 31, hh = l >> 5, cin = ca + cb;
+    if (t < p.off_w1b) {
+        const int s = t - p.off_w1a;
+        return s < ca / 2 ? W[0][jj * cin + pk_slab_ch(ca / 2, s, hh)] : 0.f;
+    }
+    if (t < p.off_wh) {
+        const int s = t - p.off_w1b;
+        return s < cb / 2 ? W[0][jj * cin + ca + pk_slab_ch(cb / 2, s, hh)] : 0.f;
+    }
+    if (t < p.off_bv) {
+        const int u = t - p.off_wh;
+        return W[1 + (u >> 4)][jj * FGNN_H + pk_ch(u & 15, hh)];
+    }
+    const int u = t - p.off_bv;
+    return bias[u >> 4][pk_ch(u & 15, hh)];
+}
+
+// ---- backward image: [W0 a | W0 b | W_1..W_{d-2} (fwd) | b_0..b_{d-2} | W_1^T..W_{d-1}^T | W0^T a | W0^T b] ----
+struct PkBwd {
+    int off_w1a, off_w1b, off_wh, off_bv, off_wt, off_wt0a, off_wt0b, steps;
+};
+HD constexpr PkBwd pk_bwd(int ca, int cb, int depth) {
+    PkBwd p{};
+    p.off_w1a = 0;
+    p.off_w1b = pk_pad4(ca / 2);
+    p.off_wh = p.off_w1b + pk_pad4(cb / 2);
+    p.off_bv = p.off_wh + 16 * (depth > 2 ? depth - 2 : 0);
+    p.off_wt = p.off_bv + 16 * (depth > 1 ? depth - 1 : 0);
+    p.off_wt0a = p.off_wt + 16 * (depth > 1 ? depth - 1 : 0);
+    p.off_wt0b = p.off_wt0a + 16;
+    p.steps = p.off_wt0b + (cb > 0 ? 16 : 0);
+    return p;
+}
+HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, const float *const *bias, int t, int l) {
+    const int jj = l & 31, hh = l >> 5, cin = ca + cb;
+    if (t < p.off_w1b) {
+        const int s = t - p.off_w1a;
+        return s < ca / 2 ? W[0][jj * cin + pk_slab_ch(ca / 2, s, hh)] : 0.f;
+    }
+    if (t < p.off_wh) {
+        const int s = t - p.off_w1b;
+        return s < cb / 2 ? W[0][jj * cin + ca + pk_slab_ch(cb / 2, s, hh)] : 0.f;
+    }
+    if (t < p.off_bv) {
+        const int u = t - p.off_wh;
+        return W[1 + (u >> 4)][jj * FGNN_H + pk_ch(u & 15, hh)];
+    }
+    if (t < p.off_wt) {
+        const int u = t - p.off_bv;
+        return bias[u >> 4][pk_ch(u & 15, hh)];
+    }
+    if (t < p.off_wt0a) {
+        const int u = t - p.off_wt;
+        return W[1 + (u >> 4)][pk_ch(u & 15, hh) * FGNN_H + jj];
+    }
+    if (t < p.off_wt0b) {
+        const int u = t - p.off_wt0a;
+        return jj < ca ? W[0][pk_ch(u, hh) * cin + jj] : 0.f;
+    }
+    const int u = t - p.off_wt0b;
+    return jj < cb ? W[0][pk_ch(u, hh) * cin + ca + jj] : 0.f;
+}
+
+// copy a packed image (n4 float4s) into LDS with all threads of the workgroup
+DEVI void pk_copy_to_lds(float *lds, const float *packed, int n4, int nthreads) {
+    const float4 *src = reinterpret_cast<const float4 *>(packed);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    for (int e = threadIdx.x; e < n4; e += nthreads) dst[e] = src[e];
+}

@@ -21,6 +21,7 @@
 // Execution shape: one 512-thread workgroup per CU (2 waves per SIMD, <= 256 VGPRs), all
 // MFMA A-operands in workgroup-shared LDS, three aliased 32x36 LDS tiles per wave.
 #include "fgnn_common.h"
+#include "fgnn_pack.h"
 
 namespace {
 
@@ -135,14 +136,15 @@ template <int CA, int CB, int DEPTH>
 struct BwdLayout {
     static constexpr int SA = CA / 2, SB = CB / 2;
     static constexpr int pad4(int x) { return (x + 3) & ~3; }
-    static constexpr int OFF_W1A = 0;                                     // SA steps: forward layer 0, slab a
-    static constexpr int OFF_W1B = OFF_W1A + pad4(SA);                    // SB steps: forward layer 0, slab b
-    static constexpr int OFF_WH = OFF_W1B + pad4(SB);                     // 16*(DEPTH-2): forward layers 1..DEPTH-2
-    static constexpr int OFF_BV = OFF_WH + 16 * (DEPTH > 2 ? DEPTH - 2 : 0);   // 16*(DEPTH-1): biases 0..DEPTH-2
-    static constexpr int OFF_WT = OFF_BV + 16 * (DEPTH > 1 ? DEPTH - 1 : 0);   // 16*(DEPTH-1): W_l^T, l=1..DEPTH-1
-    static constexpr int OFF_WT0A = OFF_WT + 16 * (DEPTH > 1 ? DEPTH - 1 : 0); // 16: W_0^T slab a
-    static constexpr int OFF_WT0B = OFF_WT0A + 16;                        // 16: W_0^T slab b
-    static constexpr int NSTEPS = OFF_WT0B + (CB > 0 ? 16 : 0);
+    static constexpr PkBwd PK = pk_bwd(CA, CB, DEPTH);                    // single source of truth: fgnn_pack.h
+    static constexpr int OFF_W1A = PK.off_w1a;                            // SA steps: forward layer 0, slab a
+    static constexpr int OFF_W1B = PK.off_w1b;                            // SB steps: forward layer 0, slab b
+    static constexpr int OFF_WH = PK.off_wh;                              // 16*(DEPTH-2): forward layers 1..DEPTH-2
+    static constexpr int OFF_BV = PK.off_bv;                              // 16*(DEPTH-1): biases 0..DEPTH-2
+    static constexpr int OFF_WT = PK.off_wt;                              // 16*(DEPTH-1): W_l^T, l=1..DEPTH-1
+    static constexpr int OFF_WT0A = PK.off_wt0a;                          // 16: W_0^T slab a
+    static constexpr int OFF_WT0B = PK.off_wt0b;                          // 16: W_0^T slab b
+    static constexpr int NSTEPS = PK.steps;
     static constexpr int WEIGHT_F = NSTEPS * 64;                          // floats
     static constexpr int REC_F = 3 * 32 * 4;                              // per wave: nrm a, nrm b, coef
     static constexpr int SLOT_XA = 0, SLOT_XB = 1, NSLOT = 3;             // x tiles alias the dead h1 / dpre_1 slots
@@ -193,57 +195,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     float *XA = my + L::SLOT_XA * TILE_F;
     float *XB = my + L::SLOT_XB * TILE_F;
 
-    // ---- fill the operand sets: one independent (step, lane) element per thread and iteration ----
-    {
-        // every element is ONE unconditional load (pointer / index / validity chosen first)
-        auto operand = [&](int t, int l) -> float {
-            const int jj = l & 31, hh = l >> 5;
-            const float *ptr;
-            int idx;
-            bool ok = true;
-            if (t < L::OFF_W1B) {                       // forward layer 0, slab a
-                int sidx = t - L::OFF_W1A;
-                ok = sidx < SA;
-                sidx = ok ? sidx : 0;
-                ptr = A.W[0];
-                idx = jj * CIN + slab_ch<SA>(sidx, hh);
-            } else if (t < L::OFF_WH) {                 // forward layer 0, slab b
-                int sidx = t - L::OFF_W1B;
-                ok = sidx < SB;
-                sidx = ok ? sidx : 0;
-                ptr = A.W[0];
-                idx = jj * CIN + (CB > 0 ? CA : 0) + slab_ch<(SB > 0 ? SB : 1)>(sidx, hh);
-            } else if (t < L::OFF_BV) {                 // forward hidden layers 1..DEPTH-2
-                const int u = t - L::OFF_WH;
-                ptr = (u >> 4) == 0 ? A.W[1] : A.W[DEPTH > 2 ? 2 : 1];
-                idx = jj * FGNN_H + ch_of(u & 15, hh);
-            } else if (t < L::OFF_WT) {                 // biases of layers 0..DEPTH-2
-                const int u = t - L::OFF_BV;
-                ptr = (u >> 4) == 0 ? A.bias[0] : A.bias[DEPTH > 1 ? 1 : 0];
-                idx = ch_of(u & 15, hh);
-            } else if (t < L::OFF_WT0A) {               // W_l^T, l = 1..DEPTH-1
-                const int u = t - L::OFF_WT;
-                ptr = (u >> 4) == 0 ? A.W[DEPTH > 1 ? 1 : 0] : A.W[DEPTH > 2 ? 2 : 0];
-                idx = ch_of(u & 15, hh) * FGNN_H + jj;
-            } else if (t < L::OFF_WT0B) {               // W_0^T slab a
-                const int u = t - L::OFF_WT0A;
-                ok = jj < CA;
-                ptr = A.W[0];
-                idx = ch_of(u, hh) * CIN + (ok ? jj : 0);
-            } else {                                    // W_0^T slab b
-                const int u = t - L::OFF_WT0B;
-                ok = jj < CB;
-                ptr = A.W[0];
-                idx = ch_of(u, hh) * CIN + CA + (ok ? jj : 0);
-            }
-            const float v = ptr[idx];
-            return ok ? v : 0.f;
-        };
-        constexpr int TOTAL = L::NSTEPS * 64;
-#pragma unroll 4
-        for (int e = threadIdx.x; e < TOTAL; e += 64 * NW) {
+    // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
+    if (A.packed) {
+        pk_copy_to_lds(wl, A.packed, L::NSTEPS * 16, 64 * NW);
+    } else {
+        const float *Wp[FGNN_MAX_DEPTH] = {A.W[0], A.W[1], A.W[2]};
+        const float *Bp[FGNN_MAX_DEPTH] = {A.bias[0], A.bias[1], A.bias[2]};
+        constexpr PkBwd pk = L::PK;
+        for (int e = threadIdx.x; e < L::NSTEPS * 64; e += 64 * NW) {
             const int t = e >> 6, l = e & 63;
-            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = operand(t, l);
+            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(pk, CA, CB, Wp, Bp, t, l);
         }
     }
     __syncthreads();

@@ -22,6 +22,7 @@
 //   * tile statistics: the z tile is transposed through a wave-private LDS tile so that a
 //     lane owns one channel and sums its 16 pixels in registers (two-pass mean / M2).
 #include "fgnn_common.h"
+#include "fgnn_pack.h"
 
 namespace {
 
@@ -108,11 +109,12 @@ template <int CA, int CB, int NMLP, int DEPTH>
 struct FwdLayout {
     static constexpr int SA = CA / 2, SB = CB / 2;
     static constexpr int pad4(int x) { return (x + 3) & ~3; }
-    static constexpr int OFF_W1A = 0;
-    static constexpr int OFF_W1B = OFF_W1A + pad4(SA);
-    static constexpr int OFF_WH = OFF_W1B + pad4(SB);              // 16*(DEPTH-1)
-    static constexpr int OFF_BV = OFF_WH + 16 * (DEPTH - 1);       // 16*DEPTH
-    static constexpr int MLP_STEPS = OFF_BV + 16 * DEPTH;
+    static constexpr PkFwd PK = pk_fwd(CA, CB, DEPTH);             // single source of truth: fgnn_pack.h
+    static constexpr int OFF_W1A = PK.off_w1a;
+    static constexpr int OFF_W1B = PK.off_w1b;
+    static constexpr int OFF_WH = PK.off_wh;                       // 16*(DEPTH-1)
+    static constexpr int OFF_BV = PK.off_bv;                       // 16*DEPTH
+    static constexpr int MLP_STEPS = PK.steps;
     static constexpr int WEIGHT_F = NMLP * MLP_STEPS * 64;
     static constexpr int LDS_F = WEIGHT_F + NW * TILE_F + 4;
 };
@@ -155,46 +157,18 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
     const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
     if (threadIdx.x == 0) *ctr = T0 + NW;     // the first NW tiles are assigned statically
 
-    // ---- fill the operand sets: one independent (step, lane) element per thread and iteration ----
-    {
-        // every element is ONE unconditional load (pointer / index / validity chosen first)
-        auto operand = [&](int m, int t, int l) -> float {
-            const int jj = l & 31, hh = l >> 5;
-            const float *ptr;
-            int idx;
-            bool ok = true;
-            if (t < L::OFF_W1B) {
-                int sidx = t - L::OFF_W1A;
-                ok = sidx < SA;
-                sidx = ok ? sidx : 0;
-                ptr = A.W[m][0];
-                idx = jj * CIN + slab_ch<SA>(sidx, hh);
-            } else if (t < L::OFF_WH) {
-                int sidx = t - L::OFF_W1B;
-                ok = sidx < SB;
-                sidx = ok ? sidx : 0;
-                ptr = A.W[m][0];
-                idx = jj * CIN + (CB > 0 ? CA : 0) + slab_ch<(SB > 0 ? SB : 1)>(sidx, hh);
-            } else if (t < L::OFF_BV) {
-                const int u = t - L::OFF_WH;
-                ptr = (u >> 4) == 0 ? A.W[m][DEPTH > 1 ? 1 : 0] : A.W[m][DEPTH > 2 ? 2 : 0];
-                idx = jj * FGNN_H + ch_of(u & 15, hh);
-            } else {
-                const int u = t - L::OFF_BV;
-                const int l2 = u >> 4;
-                ptr = l2 == 0 ? A.bias[m][0] : (l2 == 1 ? A.bias[m][DEPTH > 1 ? 1 : 0] : A.bias[m][DEPTH > 2 ? 2 : 0]);
-                idx = ch_of(u & 15, hh);
-            }
-            const float v = ptr[idx];
-            return ok ? v : 0.f;
-        };
-        constexpr int PER = L::MLP_STEPS * 64;
+    // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
+    if (A.packed) {
+        pk_copy_to_lds(wl, A.packed, NMLP * L::MLP_STEPS * 16, 64 * NW);
+    } else {
+        constexpr PkFwd pk = L::PK;
 #pragma unroll
         for (int m = 0; m < NMLP; ++m) {
-#pragma unroll 4
-            for (int e = threadIdx.x; e < PER; e += 64 * NW) {
+            const float *Wp[FGNN_MAX_DEPTH] = {A.W[m][0], A.W[m][1], A.W[m][2]};
+            const float *Bp[FGNN_MAX_DEPTH] = {A.bias[m][0], A.bias[m][1], A.bias[m][2]};
+            for (int e = threadIdx.x; e < L::MLP_STEPS * 64; e += 64 * NW) {
                 const int t = e >> 6, l = e & 63;
-                wl[m * PER + (t >> 2) * 256 + l * 4 + (t & 3)] = operand(m, t, l);
+                wl[m * (L::MLP_STEPS * 64) + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(pk, CA, CB, Wp, Bp, t, l);
             }
         }
     }

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "fgnn_common.h"
+#include "fgnn_pack.h"
 
 static thread_local char g_err[512] = "";
 
@@ -268,7 +269,49 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J, in
     }
 }
 
+struct PackJobs {
+    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
+};
+
+// grid (blocks per job, njobs): writes the LDS operand image(s) of one MLP kernel launch
+__global__ __launch_bounds__(256) void pack_operands_kernel(const PackJobs J) {
+    const fgnn_pack_job &jb = J.job[blockIdx.y];
+    if (jb.kind == 0) {
+        const PkFwd p = pk_fwd(jb.ca, jb.cb, jb.depth);
+        const int per = p.steps * 64;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < per * jb.nmlp; e += gridDim.x * 256) {
+            const int m = e / per, r = e - m * per;
+            const int t = r >> 6, l = r & 63;
+            jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], jb.bias[m], t, l);
+        }
+    } else {
+        const PkBwd p = pk_bwd(jb.ca, jb.cb, jb.depth);
+        const int per = p.steps * 64;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+            const int t = e >> 6, l = e & 63;
+            jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], jb.bias[0], t, l);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp) {
+    return kind == 0 ? pk_fwd(ca, cb, depth).steps * 64 * nmlp : pk_bwd(ca, cb, depth).steps * 64;
+}
+
+extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *stream) {
+    FGNN_CHECK(jobs && njobs > 0 && njobs <= FGNN_MAX_PACK_JOBS, "fgnn_pack_operands: bad arguments (njobs=%d)", njobs);
+    PackJobs J;
+    for (int i = 0; i < njobs; ++i) {
+        FGNN_CHECK(jobs[i].out && jobs[i].depth >= 1 && jobs[i].depth <= FGNN_MAX_DEPTH && (jobs[i].nmlp == 1 || jobs[i].nmlp == 2),
+                   "fgnn_pack_operands: job %d malformed", i);
+        J.job[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(pack_operands_kernel, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
                                 int G, int C, int N, float eps, float *nrm, void *stream) {

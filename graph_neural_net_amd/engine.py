@@ -134,6 +134,15 @@ class FgnnEngine:
         # backward workspace (allocated lazily)
         self._bwd = None
         self.x = None
+        # LDS operand images of every MLP launch, re-packed once per step (fgnn_pack_operands)
+        self._packs = {}
+        for k in range(1, K + 1):
+            cin = layout.c0 if k == 1 else 32
+            self._packs[('f', k, 12)] = (0, cin, 0, 2, torch.empty(_lib.load().fgnn_pack_floats(0, cin, 0, layout.depth, 2), **f32))
+            self._packs[('f', k, 3)] = (0, 32, cin, 1, torch.empty(_lib.load().fgnn_pack_floats(0, 32, cin, layout.depth, 1), **f32))
+            for j in (1, 2):
+                self._packs[('b', k, j)] = (1, cin, 0, 1, torch.empty(_lib.load().fgnn_pack_floats(1, cin, 0, layout.depth, 1), **f32))
+            self._packs[('b', k, 3)] = (1, 32, cin, 1, torch.empty(_lib.load().fgnn_pack_floats(1, 32, cin, layout.depth, 1), **f32))
 
     # ------------------------------------------------------------------ helpers
     def _nv(self):
@@ -160,6 +169,24 @@ class FgnnEngine:
     def _slab_raw(self, t):
         return _lib.make_slab(t, 32 * self.ldp, self.ldp, 32)
 
+    def pack_operands(self, params):
+        """Pack the LDS operand images of all MLP launches of one step (one small launch)."""
+        L = self.layout
+        items = list(self._packs.items())
+        for lo in range(0, len(items), _lib.MAX_PACK_JOBS):
+            chunk = items[lo:lo + _lib.MAX_PACK_JOBS]
+            jobs = (_lib.PackJob * len(chunk))()
+            for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
+                jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
+                js = (1, 2) if which == 12 else (which,)
+                for m, j in enumerate(js):
+                    rec = L.mlp[(k, j)]
+                    for l in range(L.depth):
+                        jobs[i].W[m][l] = self._w(params, rec['w'][l])
+                        jobs[i].bias[m][l] = self._w(params, rec['b'][l])
+                jobs[i].out = buf.data_ptr()
+            _lib.call('fgnn_pack_operands', jobs, len(chunk), _lib.stream_ptr())
+
     def _mlp_fwd(self, params, k, js, a, b):
         L = self.layout
         args = _lib.MlpFwdArgs()
@@ -177,6 +204,7 @@ class FgnnEngine:
             args.part[m] = self.part[m].data_ptr()
         args.ldz = self.ldp
         args.cnt = self.cnt.data_ptr()
+        args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         for m, j in enumerate(js):
@@ -198,6 +226,7 @@ class FgnnEngine:
             self.nvalid.copy_(nvalid.to(torch.int32))
         self.x = x
         st = _lib.stream_ptr()
+        self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
             self._mlp_fwd(params, k, (1, 2), sin, None)
@@ -276,6 +305,7 @@ class FgnnEngine:
             args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'][(k, j)].data_ptr()
+        args.packed = self._packs[('b', k, j)][4].data_ptr()
         if emit:
             args.s12part = W['s12part'].data_ptr()
         _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),

@@ -54,6 +54,21 @@ int fgnn_tiles_per_graph(int N);
 /* workgroups the persistent MLP kernels launch (partials buffers are sized by it) */
 int fgnn_mlp_bwd_num_workgroups(void);
 
+/* ---- LDS operand images ------------------------------------------------------------------
+ * The MLP kernels keep their MFMA A-operands (weights, biases, transposed weights) in LDS.
+ * Weights are constant within a step, so the images of all MLP launches can be packed ONCE
+ * per step by one small launch and are then copied straight into LDS by every workgroup.
+ * kind 0 = forward image (nmlp MLPs), kind 1 = backward image (one MLP; uses W[0], bias[0]). */
+#define FGNN_MAX_PACK_JOBS 24
+typedef struct {
+    int kind, ca, cb, depth, nmlp;
+    const float *W[2][FGNN_MAX_DEPTH];
+    const float *bias[2][FGNN_MAX_DEPTH];
+    float *out;                              /* fgnn_pack_floats(kind, ca, cb, depth, nmlp) floats */
+} fgnn_pack_job;
+int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp);
+int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *stream);
+
 /* ---- MlpBlock_Real.forward minus the final normalisation ---------------------------
  * replaces models/layers.py:126-131 (conv1x1+ReLU chain, last conv without ReLU) and the
  * reductions of normalize (:72-73).  Computes, for nmlp (1 or 2) MLPs sharing one input
@@ -70,6 +85,9 @@ typedef struct {
     long long ldz;
     float *part[2];                         /* out (G, tpg, 32, 2) {mean, M2}            */
     float *cnt;                             /* out (G, tpg) valid pixels per tile        */
+    const float *packed;                    /* optional: operand image from fgnn_pack_operands
+                                               (kind 0) for exactly these weights; NULL = the kernel
+                                               builds it itself (slower prologue)              */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
 
@@ -159,6 +177,7 @@ typedef struct {
     float *s12part;                          /* optional out (G, tpg, 32, 2): per-tile {sum dxa, sum dxa*(z_a-mean_a)} of
                                                 the FINAL dxa values (needs a.C == 32, a.nrm and dxa) -- the GraphNorm
                                                 backward sums of the MLP that produced slab a */
+    const float *packed;                     /* optional: operand image from fgnn_pack_operands (kind 1) */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
