@@ -28,7 +28,6 @@ namespace {
 
 constexpr int TLD = 36;              // LDS tile row stride (floats)
 constexpr int TILE_F = 32 * TLD;
-constexpr int NW = 8;                // waves per workgroup
 
 struct TileCtx {
     int g, tt, p;
@@ -72,41 +71,29 @@ DEVI void load_raw(float (&x)[S > 0 ? S : 1], const View &v, const TileCtx &c, i
     }
 }
 
+// y = (x - mean) * a + beta with the per-graph records {mean, a, beta, -} read from wave-private LDS
 template <int S>
-struct NormCache {
-    float mean[S > 0 ? S : 1], a[S > 0 ? S : 1], beta[S > 0 ? S : 1];
-};
-
-template <int S>
-DEVI void load_norm(NormCache<S> &nc, const fgnn_slab &s, int g, int h) {
+DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const float *rec, bool on, bool valid, int h) {
     if constexpr (S > 0) {
-        if (s.nrm) {
-            const float4 *nr = reinterpret_cast<const float4 *>(s.nrm) + (long long)g * s.C;
+        if (on) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(rec);
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                const int ch = slab_ch<S>(k, h);
-                const float4 n = nr[ch];
-                nc.mean[k] = n.x;
-                nc.a[k] = n.y;
-                nc.beta[k] = s.beta ? s.beta[ch] : 0.f;
+                const float4 n = r4[slab_ch<S>(k, h)];
+                x[k] = valid ? (x[k] - n.x) * n.y + n.z : 0.f;
             }
         }
     }
 }
 
-template <int S>
-DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const NormCache<S> &nc, bool on, bool valid) {
-    if constexpr (S > 0) {
-        if (on) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) x[k] = valid ? (x[k] - nc.mean[k]) * nc.a[k] + nc.beta[k] : 0.f;
-        }
-    }
-}
-
 // LDS operand sets of one MLP (units: k-steps; one float per lane per step)
+// waves per workgroup: 3 per SIMD where the kernel fits 168 VGPRs, else 2 per SIMD
+template <int CA, int CB>
+constexpr int fwd_waves() { return 16; }
+
 template <int CA, int CB, int NMLP, int DEPTH>
 struct FwdLayout {
+    static constexpr int NW = fwd_waves<CA, CB>();
     static constexpr int SA = CA / 2, SB = CB / 2;
     static constexpr int pad4(int x) { return (x + 3) & ~3; }
     static constexpr PkFwd PK = pk_fwd(CA, CB, DEPTH);             // single source of truth: fgnn_pack.h
@@ -116,7 +103,8 @@ struct FwdLayout {
     static constexpr int OFF_BV = PK.off_bv;                       // 16*DEPTH
     static constexpr int MLP_STEPS = PK.steps;
     static constexpr int WEIGHT_F = NMLP * MLP_STEPS * 64;
-    static constexpr int LDS_F = WEIGHT_F + NW * TILE_F + 4;
+    static constexpr int REC_F = 2 * 32 * 4;                       // per wave: records of slab a, slab b
+    static constexpr int LDS_F = WEIGHT_F + NW * (TILE_F + REC_F) + 4;
 };
 
 template <int CNT>
@@ -133,17 +121,19 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int off_ste
 }
 
 template <int CA, int CB, int NMLP, int DEPTH>
-__global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_args A, const int tpg,
-                                                              const int total_tiles) {
+__global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_kernel(
+    const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
+    constexpr int NW = L::NW;
     constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int P = A.N * A.N;
     float *wl = smem;
     float *tl = smem + L::WEIGHT_F + wv * TILE_F;
-    int *ctr = reinterpret_cast<int *>(smem + L::WEIGHT_F + NW * TILE_F);
+    float *recA = smem + L::WEIGHT_F + NW * TILE_F + wv * L::REC_F, *recB = recA + 128;
+    int *ctr = reinterpret_cast<int *>(smem + L::WEIGHT_F + NW * (TILE_F + L::REC_F));
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
     View vz[NMLP];
@@ -174,8 +164,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
     }
     __syncthreads();
 
-    NormCache<SA> nca;
-    NormCache<SB> ncb;
+    const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     int cached_g = -1;
 
     int tile = T0 + wv;
@@ -188,8 +177,18 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
     while (tile < T1) {
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
         if (c.g != cached_g) {        // wave-uniform; issued before the prefetch (vmcnt is in-order)
-            load_norm<SA>(nca, A.a, c.g, h);
-            load_norm<SB>(ncb, A.b, c.g, h);
+            if (lane < 32) {
+                if (normA && lane < CA) {
+                    float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
+                    n.z = A.a.beta ? A.a.beta[lane] : 0.f;
+                    reinterpret_cast<float4 *>(recA)[lane] = n;
+                }
+                if (normB && lane < CB) {
+                    float4 n = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)c.g * A.b.C + lane];
+                    n.z = A.b.beta ? A.b.beta[lane] : 0.f;
+                    reinterpret_cast<float4 *>(recB)[lane] = n;
+                }
+            }
             cached_g = c.g;
         }
         // grab and prefetch this wave's next tile
@@ -202,8 +201,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
             load_raw<SA>(na, va, cn, h);
             load_raw<SB>(nb, vb, cn, h);
         }
-        apply_norm<SA>(xa, nca, A.a.nrm != nullptr, c.valid);
-        apply_norm<SB>(xb, ncb, A.b.nrm != nullptr, c.valid);
+        apply_norm<SA>(xa, recA, normA, c.valid, h);
+        apply_norm<SB>(xb, recB, normB, c.valid, h);
 
         const unsigned vmask = (unsigned)__ballot(c.valid);      // bit px = pixel valid (low half-wave)
         const float cnt = (float)__popc(vmask);
@@ -292,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_fwd_kernel(const fgnn_mlp_fwd_
 template <int CA, int CB, int NMLP, int DEPTH>
 int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
+    constexpr int NW = L::NW;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
