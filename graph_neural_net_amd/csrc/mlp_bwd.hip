@@ -20,6 +20,7 @@
 // are bit-reproducible run to run.
 // Execution shape: one 512-thread workgroup per CU (2 waves per SIMD, <= 256 VGPRs), all
 // MFMA A-operands in workgroup-shared LDS, three aliased 32x36 LDS tiles per wave.
+#include <stdlib.h>
 #include "fgnn_common.h"
 #include "fgnn_pack.h"
 
@@ -87,14 +88,15 @@ DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 
                         bool valid, int h) {
     if constexpr (S > 0) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+        if (on) {                       // wave-uniform: ONE branch, not one per element
 #pragma unroll
-        for (int k = 0; k < S; ++k) {
-            if (on) {
+            for (int k = 0; k < S; ++k) {
                 const float4 n = r4[slab_ch<S>(k, h)];
                 y[k] = valid ? (x[k] - n.x) * n.y + n.z : 0.f;
-            } else {
-                y[k] = x[k];
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < S; ++k) y[k] = x[k];
         }
     }
 }
@@ -171,7 +173,7 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int lane) {
 
 template <int CA, int CB, int DEPTH>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
-                                                              const int total_tiles) {
+                                                              const int total_tiles, const int ablate) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BwdLayout<CA, CB, DEPTH>;
@@ -264,8 +266,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         float dyr[16], zr[16], old[EARLY_RMW ? 16 : 1];
         const bool rmw = EARLY_RMW && A.dxa != nullptr && A.accumulate_a;
 
-        // ---- forward recompute of the hidden activations (ReLU masks kept as bitmasks) ----
-        unsigned hmask[DEPTH > 1 ? DEPTH - 1 : 1];
+        // ---- forward recompute of the hidden activations (kept in the LDS tiles S0 / S1) ----
         if constexpr (DEPTH > 1) {
             f32x16 acc;
             {
@@ -289,23 +290,25 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
             // this tile's dy / z (consumed after the recompute) and, when accumulating, the
             // current dx values (consumed at the very end) fly behind the recompute MFMAs
-            load_rows16(dyr, vdy, c, h);
-            load_rows16(zr, vz, c, h);
+            if (!(ablate & 2)) {
+                load_rows16(dyr, vdy, c, h);
+                load_rows16(zr, vz, c, h);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dyr[r] = 1.f; zr[r] = 0.5f; }
+            }
             if constexpr (EARLY_RMW) {
-                if (rmw) load_rows16(old, vdxa, c, h);
+                if (rmw && !(ablate & 1)) load_rows16(old, vdxa, c, h);
             }
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
                 float hid[16];
                 float *Hs = (l == 1) ? S0 : S1;
-                unsigned m = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     hid[r] = fmaxf(acc[r], 0.f);
-                    m |= (hid[r] > 0.f ? 1u : 0u) << r;
                     Hs[ch_of(r, h) * TLD + j] = hid[r];
                 }
-                hmask[l - 1] = m;
                 if (l + 1 < DEPTH) {
                     float bl[16], wf[16];
                     load_ops<L::OFF_BV + 16, 16>(bl, wl, lane);
@@ -345,17 +348,21 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             const float *In = (l == 2) ? S1 : S0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) Dt[ch_of(r, h) * TLD + j] = dpre[r];
-            float wt[16];
+            float wt[16], hsv[16];
             if (l == 1) load_ops<L::OFF_WT, 16>(wt, wl, lane);
             if (l == 2) load_ops<L::OFF_WT + (DEPTH > 2 ? 16 : 0), 16>(wt, wl, lane);
+            // h_{l-1} of this lane's (channel, pixel) pairs for the ReLU mask: read before the MFMA chain
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hsv[r] = In[ch_of(r, h) * TLD + j];
             f32x16 acc;
             zero16(acc);
+            if (!(ablate & 16)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-            dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
-            const unsigned m = hmask[l - 1];
+                for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
+            }
+            if (!(ablate & 4)) dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dpre[r] = ((m >> r) & 1u) ? acc[r] : 0.f;
+            for (int r = 0; r < 16; ++r) dpre[r] = hsv[r] > 0.f ? acc[r] : 0.f;
         }
 
         // ---- layer 0: D tile = (DEPTH == 1 ? S2 : (DEPTH == 2 ? S1 : S2)); x tiles re-staged now ----
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                     for (int r = 0; r < 16; ++r) dxb_acc = mfma32(wt[r], dpre[r], dxb_acc);
                 }
             }
-            dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
+            if (!(ablate & 4)) dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
             if constexpr (CB > 0) {
                 float dummy = 0.f;
                 dW0b = wgrad_tile<false>(Dt, XB, dW0b, dummy, lane);
@@ -423,20 +430,26 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 const int s0 = c.g * vdxa.gs4;
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ch = ch_of(r, h);
-                    const int vo = ch < CA ? voff : OOB_OFF;
-                    const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4;
-                    v[r] = dxa_acc[r];
-                    if constexpr (EARLY_RMW) {
-                        if (rmw) v[r] += old[r];
-                    } else {
-                        if (A.accumulate_a) v[r] += buf_load(vdxa, vo, so);
+                for (int r = 0; r < 16; ++r) v[r] = dxa_acc[r];
+                if constexpr (EARLY_RMW) {
+                    if (rmw) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] += old[r];
                     }
-                    buf_store(v[r], vdxa, vo, so);
+                } else {
+                    if (A.accumulate_a) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            v[r] += buf_load(vdxa, ch_of(r, h) < CA ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4);
+                    }
+                }
+                if (!(ablate & 1)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store(v[r], vdxa, ch_of(r, h) < CA ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4);
                 }
                 if constexpr (CA == 32 && CB == 0) {
-                    if (emit) {
+                    if (emit && !(ablate & 8)) {
                         // GraphNorm-backward sums of the producer of slab a over this tile:
                         // S1 = sum v, S2 = sum v * (z_a - mean_a); transposed through S1 / S2 so that
                         // lane (ch, h) sums 16 pixels of its channel.  v is 0 on invalid pixels.
@@ -471,15 +484,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 if (A.dxb) {
                     const int voff = lane_off<4>(vdxb, c, h);
                     const int s0 = c.g * vdxb.gs4;
+                    float vb2[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ch = ch_of(r, h);
-                        const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4;
-                        const int vo = ch < CB ? voff : OOB_OFF;
-                        float v = dxb_acc[r];
-                        if (A.accumulate_b) v += buf_load(vdxb, vo, so);
-                        buf_store(v, vdxb, vo, so);
+                    for (int r = 0; r < 16; ++r) vb2[r] = dxb_acc[r];
+                    if (A.accumulate_b) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            vb2[r] += buf_load(vdxb, ch_of(r, h) < CB ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4);
                     }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        buf_store(vb2[r], vdxb, ch_of(r, h) < CB ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxb.ld4);
                 }
             }
             if constexpr (CA == 32 && CB == 0) {
@@ -535,7 +550,8 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
         attr_set = true;
     }
     // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
+    static const int ablate = getenv("FGNN_ABLATE") ? atoi(getenv("FGNN_ABLATE")) : 0;   // profiling aid only
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total, ablate);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
