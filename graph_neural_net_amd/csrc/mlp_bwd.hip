@@ -197,19 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     float *XA = my + L::SLOT_XA * TILE_F;
     float *XB = my + L::SLOT_XB * TILE_F;
 
-    // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
-    if (A.packed) {
-        pk_copy_to_lds(wl, A.packed, L::NSTEPS * 16, 64 * NW);
-    } else {
-        const float *Wp[FGNN_MAX_DEPTH] = {A.W[0], A.W[1], A.W[2]};
-        const float *Bp[FGNN_MAX_DEPTH] = {A.bias[0], A.bias[1], A.bias[2]};
-        constexpr PkBwd pk = L::PK;
-        for (int e = threadIdx.x; e < L::NSTEPS * 64; e += 64 * NW) {
-            const int t = e >> 6, l = e & 63;
-            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(pk, CA, CB, Wp, Bp, t, l);
-        }
-    }
-    __syncthreads();
+    // (operand image copy moved below: the first tile's loads are issued first)
 
     // ---- persistent accumulators ----
     f32x16 dW0a, dW0b, dWh[DEPTH > 1 ? DEPTH - 1 : 1];
@@ -230,14 +218,48 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
 
+    // The first tile's input slabs and per-graph records are requested BEFORE the operand image
+    // is copied, so the dependent round trips of the prologue overlap into one.
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
+    float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), ra = rk, rb = rk;
+    int cached_g = -1;
     {
         const int t = T0 + wv;
         const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, A.nvalid, j);
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
+        if (t < T1 && lane < 32) {
+            rk = reinterpret_cast<const float4 *>(A.coef)[(long long)c.g * FGNN_H + lane];
+            if (normA && lane < CA) {
+                ra = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
+                ra.z = A.a.beta ? A.a.beta[lane] : 0.f;
+            }
+            if (normB && lane < CB) {
+                rb = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)c.g * A.b.C + lane];
+                rb.z = A.b.beta ? A.b.beta[lane] : 0.f;
+            }
+        }
+        if (t < T1) cached_g = c.g;
     }
-    int cached_g = -1;
+    // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
+    if (A.packed) {
+        pk_copy_to_lds(wl, A.packed, L::NSTEPS * 16, 64 * NW);
+    } else {
+        const float *Wp[FGNN_MAX_DEPTH] = {A.W[0], A.W[1], A.W[2]};
+        const float *Bp[FGNN_MAX_DEPTH] = {A.bias[0], A.bias[1], A.bias[2]};
+        constexpr PkBwd pk = L::PK;
+        for (int e = threadIdx.x; e < L::NSTEPS * 64; e += 64 * NW) {
+            const int t = e >> 6, l = e & 63;
+            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(pk, CA, CB, Wp, Bp, t, l);
+        }
+    }
+    if (lane < 32) {
+        reinterpret_cast<float4 *>(recK)[lane] = rk;
+        reinterpret_cast<float4 *>(recA)[lane] = ra;
+        reinterpret_cast<float4 *>(recB)[lane] = rb;
+    }
+    __syncthreads();
+
 
     for (int tile = T0 + wv; tile < T1; tile += NW) {
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);

@@ -15,8 +15,9 @@
 //   * all MFMA A-operands (weights, biases) live in workgroup-shared LDS, laid out
 //     [k-step/4][lane][4] so a ds_read_b128 returns four k-steps of a lane;
 //   * a tile = 32 consecutive pixels of one graph; every workgroup owns a contiguous tile
-//     range and its waves pull tiles from an LDS counter (dynamic balance inside the CU);
-//     the raw inputs of a wave's next tile are prefetched while the current one computes;
+//     range, wave w takes tiles w, w+NW, ... of it (waves w, w+4, ... share a SIMD, so the
+//     SIMDs stay balanced); the raw inputs of a wave's next tile are prefetched while the
+//     current one computes;
 //   * per-graph GraphNorm records of the input slabs are cached in registers and reloaded
 //     BEFORE the prefetch is issued (vmcnt is in-order);
 //   * tile statistics: the z tile is transposed through a wave-private LDS tile so that a
@@ -145,8 +146,31 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
     const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
     const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
-    if (threadIdx.x == 0) *ctr = T0 + NW;     // the first NW tiles are assigned statically
+    (void)ctr;
 
+    // The first tile's input slabs and per-graph records are requested BEFORE the operand image
+    // is copied, so the three dependent round trips of the prologue overlap into one.
+    const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
+    int tile = T0 + wv;
+    float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
+    int cached_g = -1;
+    {
+        const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, A.nvalid, j);
+        load_raw<SA>(xa, va, c, h);
+        load_raw<SB>(xb, vb, c, h);
+        if (tile < T1 && lane < 32) {
+            if (normA && lane < CA) {
+                ra = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
+                ra.z = A.a.beta ? A.a.beta[lane] : 0.f;
+            }
+            if (normB && lane < CB) {
+                rb = reinterpret_cast<const float4 *>(A.b.nrm)[(long long)c.g * A.b.C + lane];
+                rb.z = A.b.beta ? A.b.beta[lane] : 0.f;
+            }
+        }
+        if (tile < T1) cached_g = c.g;
+    }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
         pk_copy_to_lds(wl, A.packed, NMLP * L::MLP_STEPS * 16, 64 * NW);
@@ -162,18 +186,12 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
             }
         }
     }
+    if (lane < 32) {
+        reinterpret_cast<float4 *>(recA)[lane] = ra;
+        reinterpret_cast<float4 *>(recB)[lane] = rb;
+    }
     __syncthreads();
 
-    const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
-    int cached_g = -1;
-
-    int tile = T0 + wv;
-    float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
-    {
-        const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, A.nvalid, j);
-        load_raw<SA>(xa, va, c, h);
-        load_raw<SB>(xb, vb, c, h);
-    }
     while (tile < T1) {
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
         if (c.g != cached_g) {        // wave-uniform; issued before the prefetch (vmcnt is in-order)
@@ -191,10 +209,8 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
             }
             cached_g = c.g;
         }
-        // grab and prefetch this wave's next tile
-        int next = 0;
-        if (lane == 0) next = atomicAdd(ctr, 1);
-        next = __builtin_amdgcn_readfirstlane(next);
+        // prefetch this wave's next tile (static strided assignment)
+        const int next = tile + NW;
         float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
         {
             const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, A.nvalid, j);
