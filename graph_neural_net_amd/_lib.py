@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
 FGNN_H = 32
 FGNN_TILE = 32
 FGNN_MAX_DEPTH = 3
+FGNN_SCORE_SPLIT = 4
 
 c_float_p = C.c_void_p   # device pointers travel as integers
 
@@ -77,6 +78,8 @@ _SIGNATURES = {
     'fgnn_pack_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd': [C.POINTER(MlpFwdArgs), _VP],
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
+    'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
+    'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_chan_matmul_fwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP],

@@ -45,8 +45,16 @@ DEVI void chan_combine(float &n, float &mean, float &m2, float nb, float mb, flo
 }
 
 // one wave per (g,c): lanes take tiles lane, lane+64, ... then a fixed shuffle tree.
-__global__ void gn_finalize_kernel(const float *part, const float *cnt, const float *gw, const int *nvalid,
-                                   int G, int C, int N, int tpg, float eps, float *nrm) {
+struct FinalizeJobs {
+    const float *part[2];
+    const float *gw[2];
+    float *nrm[2];
+};
+__global__ void gn_finalize_kernel(const FinalizeJobs J, const float *cnt, const int *nvalid,
+                                   int G, int C, int N, int tpg, float eps) {
+    const float *part = J.part[blockIdx.y];
+    const float *gw = J.gw[blockIdx.y];
+    float *nrm = J.nrm[blockIdx.y];
     const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (idx >= G * C) return;
     const int lane = threadIdx.x & 63;
@@ -138,7 +146,15 @@ __global__ void gn_bwd_stats_kernel(const float *dy, long long dg, long long ldd
 }
 
 // coef[g,c] = {mean, ca, cb, cc}: dz = ca*dy + cb*(z-mean) + cc  
-__global__ void gn_bwd_coef_kernel(const float *s12, const float *nrm, const int *nvalid, int G, int C, int N, float *coef) {
+struct CoefJobs {
+    const float *s12[2];
+    const float *nrm[2];
+    float *coef[2];
+};
+__global__ void gn_bwd_coef_kernel(const CoefJobs J, const int *nvalid, int G, int C, int N) {
+    const float *s12 = J.s12[blockIdx.y];
+    const float *nrm = J.nrm[blockIdx.y];
+    float *coef = J.coef[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= G * C) return;
     const int g = idx / C;
@@ -239,9 +255,17 @@ __global__ void gn_bwd_apply_kernel(const float *dy, long long dg, long long ldd
 DEVI void reduce_cols(const float *in, int rows, int cols, float scale, float *out, int cblock, float *sm) {
     const int tid = threadIdx.x, cl = tid & 63, rg = tid >> 6;
     const int i = cblock * 64 + cl;
+    const int ic = i < cols ? i : 0;              // clamped: loads stay unconditional
     float a = 0.f;
-    if (i < cols)
-        for (int r = rg; r < rows; r += 4) a += in[(long long)r * cols + i];
+    int r = rg;
+    for (; r + 28 < rows; r += 32) {              // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = in[(long long)(r + 4 * k) * cols + ic];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += v[k];
+    }
+    for (; r < rows; r += 4) a += in[(long long)r * cols + ic];
     sm[tid] = a;
     __syncthreads();
     if (tid < 64 && i < cols) out[i] = ((sm[tid] + sm[64 + tid]) + (sm[128 + tid] + sm[192 + tid])) * scale;
@@ -317,8 +341,21 @@ extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float
                                 int G, int C, int N, float eps, float *nrm, void *stream) {
     FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, cnt,
-                       gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm);
+    FinalizeJobs J = {{part, nullptr}, {gn_weight, nullptr}, {nrm, nullptr}};
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
+                       nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                                 const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
+                                 float *nrm0, float *nrm1, void *stream) {
+    FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize2: bad arguments");
+    const int tot = G * C;
+    FinalizeJobs J = {{part0, part1}, {gn_weight0, gn_weight1}, {nrm0, nrm1}};
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
+                       nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -359,8 +396,9 @@ extern "C" int fgnn_gn_bwd_coef(const float *s12, const float *nrm, const int *n
                                 float *coef, float *dgn_w, float *dgn_b, void *stream) {
     FGNN_CHECK(s12 && nrm && coef && G > 0 && C > 0 && N > 0, "fgnn_gn_bwd_coef: bad arguments");
     const int tot = G * C;
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, s12, nrm,
-                       nvalid, G, C, N, coef);
+    CoefJobs J = {{s12, nullptr}, {nrm, nullptr}, {coef, nullptr}};
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((tot + 255) / 256, 1), dim3(256), 0, (hipStream_t)stream, J,
+                       nvalid, G, C, N);
     FGNN_LAUNCH_CHECK();
     if (dgn_w || dgn_b) {
         hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s12, nrm, G, C,
@@ -418,6 +456,16 @@ extern "C" int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_
     }
     hipLaunchKernelGGL(grad_finalize_kernel, dim3((maxc + 63) / 64 + 1, njobs), dim3(256), 0, (hipStream_t)stream, J,
                        num_wg, G, C);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_gn_bwd_coef2(const float *s12_0, const float *s12_1, const float *nrm0, const float *nrm1,
+                                 const int *nvalid, int G, int C, int N, float *coef0, float *coef1, void *stream) {
+    FGNN_CHECK(s12_0 && s12_1 && nrm0 && nrm1 && coef0 && coef1 && G > 0 && C > 0 && N > 0, "fgnn_gn_bwd_coef2: bad arguments");
+    const int tot = G * C;
+    CoefJobs J = {{s12_0, s12_1}, {nrm0, nrm1}, {coef0, coef1}};
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((tot + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, J, nvalid, G, C, N);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -123,7 +123,8 @@ __global__ void colmax_bwd_kernel(const float *de, const int *idx, const int *nv
     }
 }
 
-// one workgroup per pair b.  e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j].
+// grid (B, FGNN_SCORE_SPLIT): workgroup (b, rp) owns a contiguous block of rows of pair b.
+// e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j]; lse_i; partial loss of its rows.
 __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, const float *e2, const int *nvalid,
                                                            int C, int N, float *scores, float *lse,
                                                            float *pair_loss) {
@@ -132,6 +133,9 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     float *red = s2 + (size_t)C * N;     // 4 floats
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = nvalid_of(nvalid, b, N);
+    const int rows = (N + FGNN_SCORE_SPLIT - 1) / FGNN_SCORE_SPLIT;
+    const int i0 = blockIdx.y * rows;
+    const int i1 = (i0 + rows < N) ? i0 + rows : N;
     const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
     for (int e = tid; e < C * N; e += 256) {
         s1[e] = p1[e];
@@ -139,8 +143,9 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     }
     __syncthreads();
     float *S = scores + (long long)b * N * N;
-    for (int e = tid; e < N * N; e += 256) {
-        const int i = e / N, j = e - i * N;
+    const float invN = 1.f / (float)N;
+    for (int e = i0 * N + tid; e < i1 * N; e += 256) {
+        const int i = (int)(((float)e + 0.5f) * invN), j = e - i * N;
         float acc = 0.f;
         if (i < nv && j < nv)
             for (int c = 0; c < C; ++c) acc = fmaf(s1[c * N + i], s2[c * N + j], acc);
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     }
     __syncthreads();   // workgroup-scope visibility of S for the row pass below
     float wl = 0.f;
-    for (int i = wave; i < N; i += 4) {
+    for (int i = i0 + wave; i < i1; i += 4) {
         float l = 0.f;
         if (i < nv) {
             float mx = -FLT_MAX;
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     }
     if (lane == 0) red[wave] = wl;
     __syncthreads();
-    if (tid == 0 && pair_loss) pair_loss[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0 && pair_loss) pair_loss[b * FGNN_SCORE_SPLIT + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
@@ -325,7 +330,7 @@ extern "C" int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nv
     FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_fwd: C*N=%d too large for LDS staging", C * N);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)score_ce_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, C, N, scores,
+    hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B, FGNN_SCORE_SPLIT), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, C, N, scores,
                        lse, pair_loss);
     FGNN_LAUNCH_CHECK();
     return 0;

@@ -128,7 +128,7 @@ class FgnnEngine:
         self.B = G // 2
         self.scores = torch.empty(self.B, N, N, **f32)
         self.lse = torch.empty(self.B, N, **f32)
-        self.pair_loss = torch.empty(self.B, **f32)
+        self.pair_loss = torch.empty(self.B * _lib.FGNN_SCORE_SPLIT, **f32)
         self.loss = torch.empty(1, **f32)
         self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
         # backward workspace (allocated lazily)
@@ -207,11 +207,16 @@ class FgnnEngine:
         args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
-        for m, j in enumerate(js):
-            rec = L.mlp[(k, j)]
-            _lib.call('fgnn_gn_finalize', _lib.ptr(self.part[m]), _lib.ptr(self.cnt),
+        if len(js) == 2:
+            r0, r1 = L.mlp[(k, js[0])], L.mlp[(k, js[1])]
+            _lib.call('fgnn_gn_finalize2', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, r0['gn_w'])), C.c_void_p(self._w(params, r1['gn_w'])), self._nv(),
+                      self.G, 32, self.N, EPS, _lib.ptr(self.nrm[(k, js[0])]), _lib.ptr(self.nrm[(k, js[1])]), st)
+        else:
+            rec = L.mlp[(k, js[0])]
+            _lib.call('fgnn_gn_finalize', _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
                       C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, EPS,
-                      _lib.ptr(self.nrm[(k, j)]), st)
+                      _lib.ptr(self.nrm[(k, js[0])]), st)
 
     # ------------------------------------------------------------------ forward
     def embed(self, params, x, nvalid=None):
@@ -249,7 +254,8 @@ class FgnnEngine:
         if total_nodes is None:
             total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
         self.total_nodes = float(total_nodes)
-        _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B, 1, 1.0 / self.total_nodes, _lib.ptr(self.loss), st)
+        _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
+                  _lib.ptr(self.loss), st)
         return self.scores, self.loss
 
     # ------------------------------------------------------------------ backward
@@ -350,8 +356,9 @@ class FgnnEngine:
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            self._coef((k, 1), 0)
-            self._coef((k, 2), 1)
+            _lib.call('fgnn_gn_bwd_coef2', _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
+                      _lib.ptr(self.nrm[(k, 1)]), _lib.ptr(self.nrm[(k, 2)]), self._nv(), self.G, 32, self.N,
+                      _lib.ptr(W['coef'][0]), _lib.ptr(W['coef'][1]), st)
             self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
             self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
             if not first:

@@ -98,6 +98,10 @@ int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
  *   var = M2/m, r2 = 1/(var+eps), q = 1/(2 sqrt(n (var+eps))), a = gn_weight[c] * q.     */
 int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight /* (C) or NULL=1 */,
                      const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
+/* two MLPs (sharing cnt, e.g. mlp1 / mlp2 of one fgnn_mlp_fwd call) in one launch */
+int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                      const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
+                      float *nrm0, float *nrm1, void *stream);
 /* same record computed directly from a dense (G, C, ldp) tensor (two-pass), any C */
 int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float *gn_weight,
                   const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
@@ -117,7 +121,9 @@ int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *
 
 /* ---- Siamese scoring + triplet_loss (models/trainers.py:67, toolbox/losses.py:20-34) ---
  * e1,e2: (B, C, N).  scores[b] = e1[b]^T e2[b] (B,N,N); lse (B,N) row log-sum-exp;
- * pair_loss[b] = sum_i (lse_i - scores[b,i,i]) over valid rows.                          */
+ * pair_loss (B * FGNN_SCORE_SPLIT): partial sums of (lse_i - scores[b,i,i]) over the valid rows of
+ * FGNN_SCORE_SPLIT row blocks per pair (the loss of pair b is the sum of its FGNN_SCORE_SPLIT entries). */
+#define FGNN_SCORE_SPLIT 4
 int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
                       float *scores, float *lse, float *pair_loss, void *stream);
 /* d e1, d e2 of loss = sum_b pair_loss[b] * (*gscale)   (gscale: device scalar = grad / sum n) */
@@ -149,6 +155,9 @@ int fgnn_gn_bwd_stats(const float *dy, long long dgstride, long long ldd,
 int fgnn_gn_bwd_coef(const float *s12, const float *nrm, const int *nvalid, int G, int C, int N,
                      float *coef /* (G*C*4) */, float *dgn_w /* (C) or NULL */, float *dgn_b /* (C) or NULL */,
                      void *stream);
+/* coefficients of two MLPs in one launch (no affine gradients) */
+int fgnn_gn_bwd_coef2(const float *s12_0, const float *s12_1, const float *nrm0, const float *nrm1,
+                      const int *nvalid, int G, int C, int N, float *coef0, float *coef1, void *stream);
 /* same coefficients from per-tile partial sums (G, tpg, C, 2) as emitted by fgnn_mlp_bwd
  * (s12part); also writes the summed s12 (G*C*2) for the affine gradients.                  */
 int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,

@@ -82,7 +82,7 @@ def test_score_and_ce(B, Cc, N):
     e1d, e2d = e1.to(DEV), e2.to(DEV)
     scores = torch.empty(B, N, N, device=DEV)
     lse = torch.empty(B, N, device=DEV)
-    pl = torch.empty(B, device=DEV)
+    pl = torch.empty(B * _lib.FGNN_SCORE_SPLIT, device=DEV)
     _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1d), _lib.ptr(e2d), None, B, Cc, N, _lib.ptr(scores), _lib.ptr(lse),
               _lib.ptr(pl), _lib.stream_ptr())
     a, b = e1.double().requires_grad_(True), e2.double().requires_grad_(True)
