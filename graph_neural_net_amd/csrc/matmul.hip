@@ -230,10 +230,6 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd_kernel(const fgnn_slab ya
 // registers, written to LDS, ONE barrier -- and the four waves then run their MFMA chains
 // and epilogues independently.
 // ---------------------------------------------------------------------------------------
-// LDS row stride of the single-tile path: odd (conflict-free column reads) and >= N + 1 so that the
-// K-padding column of an odd N is a zero; smaller than 65 when N < 64 -> more workgroups per CU.
-__host__ __device__ inline int fast_ld(int N) { return (N + 1) | 1; }
-
 // Unconditional (address-clamped) loads + selects: a predicated load would become one branch
 // region per element, each waiting for its own round trip.
 // v = operand value (normalised, 0 in padding); u = z - mean (0 in padding) when WANT_U.
@@ -250,28 +246,27 @@ DEVI void load_tile_regs(float (&v)[16], float (&u)[16], const float *mat, int N
         if (WANT_U) u[k] = ok ? d : 0.f;
     }
 }
-DEVI void store_tile_lds(float *lds, int ld, const float (&v)[16], int tid) {
+DEVI void store_tile_lds(float *lds, const float (&v)[16], int tid) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int e = tid + 256 * k;
-        if ((e & 63) < ld) lds[(e >> 6) * ld + (e & 63)] = v[k];
+        lds[(e >> 6) * LDS_LD + (e & 63)] = v[k];
     }
 }
 // D fragment of one quadrant -> LDS tile (row stride LDS_LD)
-DEVI void frag_to_lds(float *lds, int ld, int row0, int col0, const f32x16 &acc, int lane) {
+DEVI void frag_to_lds(float *lds, int row0, int col0, const f32x16 &acc, int lane) {
     const int j = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        if (col0 + j < ld) lds[(row0 + ch_of(r, h)) * ld + col0 + j] = acc[r];
+    for (int r = 0; r < 16; ++r) lds[(row0 + ch_of(r, h)) * LDS_LD + col0 + j] = acc[r];
 }
 // LDS tile -> global (coalesced rows), optionally accumulating S1 = sum t, S2 = sum t * u
 template <bool WANT_S>
-DEVI void tile_to_global(float *out, const float *lds, int ld, int N, const float (&u)[16], float &s1, float &s2, int tid) {
+DEVI void tile_to_global(float *out, const float *lds, int N, const float (&u)[16], float &s1, float &s2, int tid) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int e = tid + 256 * k;
         const int r = e >> 6, c = e & 63;
-        const float t = c < ld ? lds[r * ld + c] : 0.f;
+        const float t = lds[r * LDS_LD + c];
         if (r < N && c < N) out[r * N + c] = t;
         if (WANT_S) {
             s1 += t;
@@ -283,9 +278,8 @@ DEVI void tile_to_global(float *out, const float *lds, int ld, int N, const floa
 __global__ __launch_bounds__(256) void chan_matmul_fwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                const int *nvalid, int N, float *out,
                                                                long long ogstride, long long ldo) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
-    const int LD = fast_ld(N);                  // odd row stride >= N + 1 (zero K-padding column)
-    float *As = dsm, *Bs = dsm + TM * LD;
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];
     const int C = ya.C;
     const int gc = blockIdx.x;
     const int g = gc / C, c = gc - g * C;
@@ -302,23 +296,23 @@ __global__ __launch_bounds__(256) void chan_matmul_fwd1_kernel(const fgnn_slab y
         float va[16], vb[16];
         load_tile_regs<false>(va, dummy, A, N, nv, na, tid);
         load_tile_regs<false>(vb, dummy, B, N, nv, nb, tid);
-        store_tile_lds(As, LD, va, tid);
-        store_tile_lds(Bs, LD, vb, tid);
+        store_tile_lds(As, va, tid);
+        store_tile_lds(Bs, vb, tid);
     }
     __syncthreads();
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     if (32 * qi < N && 32 * qj < N) {
-        const float *ap = As + (32 * qi + j) * LD + h;
-        const float *bp = Bs + h * LD + (32 * qj + j < LD ? 32 * qj + j : 0);
-        for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LD], acc);
+        const float *ap = As + (32 * qi + j) * LDS_LD + h;
+        const float *bp = Bs + h * LDS_LD + 32 * qj + j;
+        for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
     }
     __syncthreads();                                   // all waves done reading As
-    frag_to_lds(As, LD, 32 * qi, 32 * qj, acc, lane);
+    frag_to_lds(As, 32 * qi, 32 * qj, acc, lane);
     __syncthreads();
     float s1 = 0.f, s2 = 0.f;
-    tile_to_global<false>(O, As, LD, N, dummy, s1, s2, tid);
+    tile_to_global<false>(O, As, N, dummy, s1, s2, tid);
 }
 
 __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
@@ -326,10 +320,10 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
                                                                const int *nvalid, int N, float *da, float *db,
                                                                long long ogstride, long long ldo, float *s12a,
                                                                float *s12b) {
-    extern __shared__ __attribute__((aligned(16))) float dsm[];
+    __shared__ float As[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];
+    __shared__ float Ds[TM * LDS_LD];
     __shared__ float red[4][4];
-    const int LD = fast_ld(N);
-    float *As = dsm, *Bs = dsm + TM * LD, *Ds = dsm + 2 * TM * LD;
     const int C = ya.C;
     const int gc = blockIdx.x;
     const int g = gc / C, c = gc - g * C;
@@ -351,9 +345,9 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
         load_tile_regs<true>(va, ua, A, N, nv, na, tid);
         load_tile_regs<true>(vb, ub, B, N, nv, nb, tid);
         load_tile_regs<false>(vd, dummy, D, N, nv, none, tid);
-        store_tile_lds(As, LD, va, tid);
-        store_tile_lds(Bs, LD, vb, tid);
-        store_tile_lds(Ds, LD, vd, tid);
+        store_tile_lds(As, va, tid);
+        store_tile_lds(Bs, vb, tid);
+        store_tile_lds(Ds, vd, tid);
     }
     __syncthreads();
     const bool live = 32 * qi < N && 32 * qj < N;
@@ -366,25 +360,25 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
     if (live) {
         // dA[i][k] = sum_j dM[i][j] Yb[k][j]
         {
-            const float *ap = Ds + (32 * qi + j) * LD + h;
-            const float *bp = Bs + (32 * qj + j) * LD + h;
+            const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
             for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
         }
         // dB[k][j] = sum_i Ya[i][k] dM[i][j]
         {
-            const float *ap = As + h * LD + (32 * qi + j < LD ? 32 * qi + j : 0);
-            const float *bp = Ds + h * LD + (32 * qj + j < LD ? 32 * qj + j : 0);
-            for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LD], bp[k * LD], accB);
+            const float *ap = As + h * LDS_LD + 32 * qi + j;
+            const float *bp = Ds + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
         }
     }
     __syncthreads();                                   // all products done: As / Bs are free
-    frag_to_lds(Bs, LD, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
-    frag_to_lds(As, LD, 32 * qi, 32 * qj, accB, lane);     // dB -> As
+    frag_to_lds(Bs, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
+    frag_to_lds(As, 32 * qi, 32 * qj, accB, lane);     // dB -> As
     __syncthreads();
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     if (s12a) {
-        tile_to_global<true>(OA, Bs, LD, N, ua, sa1, sa2, tid);
-        tile_to_global<true>(OB, As, LD, N, ub, sb1, sb2, tid);
+        tile_to_global<true>(OA, Bs, N, ua, sa1, sa2, tid);
+        tile_to_global<true>(OB, As, N, ub, sb1, sb2, tid);
         sa1 = wave_sum(sa1);
         sa2 = wave_sum(sa2);
         sb1 = wave_sum(sb1);
@@ -402,8 +396,8 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
             *dst = v;
         }
     } else {
-        tile_to_global<false>(OA, Bs, LD, N, dummy, sa1, sa2, tid);
-        tile_to_global<false>(OB, As, LD, N, dummy, sb1, sb2, tid);
+        tile_to_global<false>(OA, Bs, N, dummy, sa1, sa2, tid);
+        tile_to_global<false>(OB, As, N, dummy, sb1, sb2, tid);
     }
 }
 
@@ -416,7 +410,7 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     FGNN_CHECK((long long)G * ya->C <= 65535 * 1024ll, "fgnn_chan_matmul_fwd: G*C too large");
     const int t = (N + TM - 1) / TM;
     if (t == 1) {
-        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(G * ya->C), dim3(256), 2 * TM * fast_ld(N) * 4, (hipStream_t)stream, *ya, *yb, nvalid,
+        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
                            N, out, ogstride, ldo);
         FGNN_LAUNCH_CHECK();
         return 0;
@@ -437,7 +431,7 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     const int t = (N + TM - 1) / TM;
     const bool fused = s12a && t == 1;
     if (t == 1) {
-        hipLaunchKernelGGL(chan_matmul_bwd1_kernel, dim3(G * ya->C), dim3(256), 3 * TM * fast_ld(N) * 4, (hipStream_t)stream, *ya, *yb, dm,
+        hipLaunchKernelGGL(chan_matmul_bwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
                            dmgstride, ldm, nvalid, N, da, db, ogstride, ldo, s12a, s12b);
         FGNN_LAUNCH_CHECK();
         return 0;
