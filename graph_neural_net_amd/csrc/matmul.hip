@@ -259,15 +259,18 @@ DEVI void frag_to_lds(float *lds, int row0, int col0, const f32x16 &acc, int lan
 #pragma unroll
     for (int r = 0; r < 16; ++r) lds[(row0 + ch_of(r, h)) * LDS_LD + col0 + j] = acc[r];
 }
-// LDS tile -> global (coalesced rows), optionally accumulating S1 = sum t, S2 = sum t * u
+// LDS tile -> global (coalesced rows, buffer stores: out-of-matrix lanes use OOB_OFF and are dropped),
+// optionally accumulating S1 = sum t, S2 = sum t * u
 template <bool WANT_S>
-DEVI void tile_to_global(float *out, const float *lds, int N, const float (&u)[16], float &s1, float &s2, int tid) {
+DEVI void tile_to_global(const View &ov, int mat_off4, const float *lds, int N, const float (&u)[16], float &s1,
+                         float &s2, int tid) {
+    const int c = tid & 63, r0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int voff = c < N ? (r0 * N + c) * 4 : OOB_OFF;
+    const float *lp = lds + r0 * LDS_LD + c;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int e = tid + 256 * k;
-        const int r = e >> 6, c = e & 63;
-        const float t = lds[r * LDS_LD + c];
-        if (r < N && c < N) out[r * N + c] = t;
+        const float t = lp[4 * k * LDS_LD];
+        buf_store(t, ov, r0 + 4 * k < N ? voff : OOB_OFF, mat_off4 + k * 16 * N);
         if (WANT_S) {
             s1 += t;
             s2 += t * u[k];
@@ -275,49 +278,82 @@ DEVI void tile_to_global(float *out, const float *lds, int N, const float (&u)[1
     }
 }
 
-__global__ __launch_bounds__(256) void chan_matmul_fwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
-                                                               const int *nvalid, int N, float *out,
+// raw (un-normalised) loads of one matrix: issued early, consumed one iteration later.
+// Buffer addressing: one VGPR offset per thread, the matrix / row-block offsets in SGPRs; padding
+// lanes use OOB_OFF (load returns 0) -- no 64-bit address registers, no branches.
+DEVI void load_tile_raw(float (&x)[16], const View &v, int mat_off4, int N, int nv, int tid) {
+    const int c = tid & 63, r0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int voff = c < nv ? (r0 * N + c) * 4 : OOB_OFF;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + 4 * k;                      // wave-uniform
+        x[k] = buf_load(v, r < nv ? voff : OOB_OFF, mat_off4 + k * 16 * N);
+    }
+}
+// raw -> operand value v (normalised, 0 in padding) and optionally u = z - mean
+template <bool WANT_U>
+DEVI void finish_tile(float (&v)[16], float (&u)[16], const float (&x)[16], int nv, const NormRec &nr, int tid) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + 256 * k;
+        const int r = e >> 6, c = e & 63;
+        const bool ok = r < nv && c < nv;
+        const float d = x[k] - nr.mean;
+        v[k] = ok ? (nr.on ? d * nr.a + nr.beta : x[k]) : 0.f;
+        if (WANT_U) u[k] = ok ? d : 0.f;
+    }
+}
+
+// One workgroup per (g,c) matrix.  (A persistent, software-pipelined variant was measured slower:
+// the kernel is instruction-issue bound, not load-latency bound, and the prefetch registers spilled.)
+__global__ __launch_bounds__(256, 4) void chan_matmul_fwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                               const int *nvalid, int N, int M, float *out,
                                                                long long ogstride, long long ldo) {
     __shared__ float As[TM * LDS_LD];
     __shared__ float Bs[TM * LDS_LD];
     const int C = ya.C;
-    const int gc = blockIdx.x;
-    const int g = gc / C, c = gc - g * C;
-    const int nv = nvalid_of(nvalid, g, N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = wave >> 1, qj = wave & 1;
     const int j = lane & 31, h = lane >> 5;
-    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
-    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
-    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
-    float *O = out + (long long)g * ogstride + (long long)c * ldo;
-    float dummy[16];
+    float xa[16], xb[16], dummy[16];
+    const int G = M / C;
+    const View vA = make_view(ya.ptr, ya.gstride, ya.ldp, G), vB = make_view(yb.ptr, yb.gstride, yb.ldp, G);
+    const View vO = make_view(out, ogstride, ldo, G);
+    const int gc = blockIdx.x;
     {
-        float va[16], vb[16];
-        load_tile_regs<false>(va, dummy, A, N, nv, na, tid);
-        load_tile_regs<false>(vb, dummy, B, N, nv, nb, tid);
-        store_tile_lds(As, va, tid);
-        store_tile_lds(Bs, vb, tid);
-    }
-    __syncthreads();
-    f32x16 acc;
+        const int g = gc / C, c = gc - g * C;
+        const int nv = nvalid_of(nvalid, g, N);
+        load_tile_raw(xa, vA, g * vA.gs4 + c * vA.ld4, N, nv, tid);
+        load_tile_raw(xb, vB, g * vB.gs4 + c * vB.ld4, N, nv, tid);
+        const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+        const int o_off = g * vO.gs4 + c * vO.ld4;
+        {
+            float va[16], vb[16];
+            finish_tile<false>(va, dummy, xa, nv, na, tid);
+            finish_tile<false>(vb, dummy, xb, nv, nb, tid);
+            store_tile_lds(As, va, tid);
+            store_tile_lds(Bs, vb, tid);
+        }
+        __syncthreads();
+        f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    if (32 * qi < N && 32 * qj < N) {
-        const float *ap = As + (32 * qi + j) * LDS_LD + h;
-        const float *bp = Bs + h * LDS_LD + 32 * qj + j;
-        for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (32 * qi < N && 32 * qj < N) {
+            const float *ap = As + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Bs + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < N; k += 2) acc = mfma32(ap[k], bp[k * LDS_LD], acc);
+        }
+        __syncthreads();                                   // all waves done reading As
+        frag_to_lds(As, 32 * qi, 32 * qj, acc, lane);
+        __syncthreads();
+        float s1 = 0.f, s2 = 0.f;
+        tile_to_global<false>(vO, o_off, As, N, dummy, s1, s2, tid);
     }
-    __syncthreads();                                   // all waves done reading As
-    frag_to_lds(As, 32 * qi, 32 * qj, acc, lane);
-    __syncthreads();
-    float s1 = 0.f, s2 = 0.f;
-    tile_to_global<false>(O, As, N, dummy, s1, s2, tid);
 }
 
-__global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
+__global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                const float *dm, long long dmg, long long ldm,
-                                                               const int *nvalid, int N, float *da, float *db,
+                                                               const int *nvalid, int N, int M, float *da, float *db,
                                                                long long ogstride, long long ldo, float *s12a,
                                                                float *s12b) {
     __shared__ float As[TM * LDS_LD];
@@ -325,79 +361,85 @@ __global__ __launch_bounds__(256) void chan_matmul_bwd1_kernel(const fgnn_slab y
     __shared__ float Ds[TM * LDS_LD];
     __shared__ float red[4][4];
     const int C = ya.C;
-    const int gc = blockIdx.x;
-    const int g = gc / C, c = gc - g * C;
-    const int nv = nvalid_of(nvalid, g, N);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = wave >> 1, qj = wave & 1;
     const int j = lane & 31, h = lane >> 5;
-    const float *A = ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp;
-    const float *B = yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp;
-    const float *D = dm + (long long)g * dmg + (long long)c * ldm;
-    const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
     NormRec none;
     none.on = false; none.mean = 0.f; none.a = 1.f; none.beta = 0.f;
-    float *OA = da + (long long)g * ogstride + (long long)c * ldo;
-    float *OB = db + (long long)g * ogstride + (long long)c * ldo;
-    float ua[16], ub[16], dummy[16];
+    float xa[16], xb[16], xd[16], dummy[16];
+    const int G = M / C;
+    const View vA = make_view(ya.ptr, ya.gstride, ya.ldp, G), vB = make_view(yb.ptr, yb.gstride, yb.ldp, G);
+    const View vD = make_view(dm, dmg, ldm, G);
+    const View vOA = make_view(da, ogstride, ldo, G), vOB = make_view(db, ogstride, ldo, G);
+    const int gc = blockIdx.x;
     {
-        float va[16], vb[16], vd[16];
-        load_tile_regs<true>(va, ua, A, N, nv, na, tid);
-        load_tile_regs<true>(vb, ub, B, N, nv, nb, tid);
-        load_tile_regs<false>(vd, dummy, D, N, nv, none, tid);
-        store_tile_lds(As, va, tid);
-        store_tile_lds(Bs, vb, tid);
-        store_tile_lds(Ds, vd, tid);
-    }
-    __syncthreads();
-    const bool live = 32 * qi < N && 32 * qj < N;
-    f32x16 accA, accB;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        accA[r] = 0.f;
-        accB[r] = 0.f;
-    }
-    if (live) {
-        // dA[i][k] = sum_j dM[i][j] Yb[k][j]
+        const int g = gc / C, c = gc - g * C;
+        const int nv = nvalid_of(nvalid, g, N);
+        load_tile_raw(xa, vA, g * vA.gs4 + c * vA.ld4, N, nv, tid);
+        load_tile_raw(xb, vB, g * vB.gs4 + c * vB.ld4, N, nv, tid);
+        load_tile_raw(xd, vD, g * vD.gs4 + c * vD.ld4, N, nv, tid);
+        const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+        const int o_off = g * vOA.gs4 + c * vOA.ld4;
+        float ua[16], ub[16];
         {
-            const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
-            const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
-            for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
-        }
-        // dB[k][j] = sum_i Ya[i][k] dM[i][j]
-        {
-            const float *ap = As + h * LDS_LD + 32 * qi + j;
-            const float *bp = Ds + h * LDS_LD + 32 * qj + j;
-            for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
-        }
-    }
-    __syncthreads();                                   // all products done: As / Bs are free
-    frag_to_lds(Bs, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
-    frag_to_lds(As, 32 * qi, 32 * qj, accB, lane);     // dB -> As
-    __syncthreads();
-    float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
-    if (s12a) {
-        tile_to_global<true>(OA, Bs, N, ua, sa1, sa2, tid);
-        tile_to_global<true>(OB, As, N, ub, sb1, sb2, tid);
-        sa1 = wave_sum(sa1);
-        sa2 = wave_sum(sa2);
-        sb1 = wave_sum(sb1);
-        sb2 = wave_sum(sb2);
-        if (lane == 0) {
-            red[wave][0] = sa1;
-            red[wave][1] = sa2;
-            red[wave][2] = sb1;
-            red[wave][3] = sb2;
+            float va[16], vb[16], vd[16];
+            finish_tile<true>(va, ua, xa, nv, na, tid);
+            finish_tile<true>(vb, ub, xb, nv, nb, tid);
+            finish_tile<false>(vd, dummy, xd, nv, none, tid);
+            store_tile_lds(As, va, tid);
+            store_tile_lds(Bs, vb, tid);
+            store_tile_lds(Ds, vd, tid);
         }
         __syncthreads();
-        if (tid < 4) {
-            const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-            float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
-            *dst = v;
+        const bool live = 32 * qi < N && 32 * qj < N;
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accA[r] = 0.f;
+            accB[r] = 0.f;
         }
-    } else {
-        tile_to_global<false>(OA, Bs, N, dummy, sa1, sa2, tid);
-        tile_to_global<false>(OB, As, N, dummy, sb1, sb2, tid);
+        if (live) {
+            // dA[i][k] = sum_j dM[i][j] Yb[k][j]
+            {
+                const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
+                const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
+                for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
+            }
+            // dB[k][j] = sum_i Ya[i][k] dM[i][j]
+            {
+                const float *ap = As + h * LDS_LD + 32 * qi + j;
+                const float *bp = Ds + h * LDS_LD + 32 * qj + j;
+                for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
+            }
+        }
+        __syncthreads();                                   // all products done: As / Bs are free
+        frag_to_lds(Bs, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
+        frag_to_lds(As, 32 * qi, 32 * qj, accB, lane);     // dB -> As
+        __syncthreads();
+        float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+        if (s12a) {
+            tile_to_global<true>(vOA, o_off, Bs, N, ua, sa1, sa2, tid);
+            tile_to_global<true>(vOB, o_off, As, N, ub, sb1, sb2, tid);
+            sa1 = wave_sum(sa1);
+            sa2 = wave_sum(sa2);
+            sb1 = wave_sum(sb1);
+            sb2 = wave_sum(sb2);
+            if (lane == 0) {
+                red[wave][0] = sa1;
+                red[wave][1] = sa2;
+                red[wave][2] = sb1;
+                red[wave][3] = sb2;
+            }
+            __syncthreads();
+            if (tid < 4) {
+                const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+                float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
+                *dst = v;
+            }
+        } else {
+            tile_to_global<false>(vOA, o_off, Bs, N, dummy, sa1, sa2, tid);
+            tile_to_global<false>(vOB, o_off, As, N, dummy, sb1, sb2, tid);
+        }
     }
 }
 
@@ -410,8 +452,12 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     FGNN_CHECK((long long)G * ya->C <= 65535 * 1024ll, "fgnn_chan_matmul_fwd: G*C too large");
     const int t = (N + TM - 1) / TM;
     if (t == 1) {
-        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
-                           N, out, ogstride, ldo);
+        FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4,
+                   "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
+        FGNN_CHECK((long long)G * ogstride < 0x7fffffffll / 4, "fgnn_chan_matmul_fwd: output exceeds 2 GiB");
+        const int M = G * ya->C;
+        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
+                           N, M, out, ogstride, ldo);
         FGNN_LAUNCH_CHECK();
         return 0;
     }
@@ -431,8 +477,13 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     const int t = (N + TM - 1) / TM;
     const bool fused = s12a && t == 1;
     if (t == 1) {
-        hipLaunchKernelGGL(chan_matmul_bwd1_kernel, dim3(G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
-                           dmgstride, ldm, nvalid, N, da, db, ogstride, ldo, s12a, s12b);
+        FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
+                   (long long)G * dmgstride < 0x7fffffffll / 4,
+                   "fgnn_chan_matmul_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
+        FGNN_CHECK((long long)G * ogstride < 0x7fffffffll / 4, "fgnn_chan_matmul_bwd: output exceeds 2 GiB");
+        const int M = G * ya->C;
+        hipLaunchKernelGGL(chan_matmul_bwd1_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, dm,
+                           dmgstride, ldm, nvalid, N, M, da, db, ogstride, ldo, s12a, s12b);
         FGNN_LAUNCH_CHECK();
         return 0;
     }
