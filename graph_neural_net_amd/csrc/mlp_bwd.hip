@@ -20,7 +20,6 @@
 // are bit-reproducible run to run.
 // Execution shape: one 512-thread workgroup per CU (2 waves per SIMD, <= 256 VGPRs), all
 // MFMA A-operands in workgroup-shared LDS, three aliased 32x36 LDS tiles per wave.
-#include <stdlib.h>
 #include "fgnn_common.h"
 #include "fgnn_pack.h"
 
@@ -89,10 +88,13 @@ DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 
     if constexpr (S > 0) {
         const float4 *r4 = reinterpret_cast<const float4 *>(rec);
         if (on) {                       // wave-uniform: ONE branch, not one per element
+            // multiply by a 0/1 mask instead of `valid ? .. : 0`: the ternary is turned into divergent
+            // control flow around the LDS reads, with a full-array phi copy per element
+            const float vf = valid ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 const float4 n = r4[slab_ch<S>(k, h)];
-                y[k] = valid ? (x[k] - n.x) * n.y + n.z : 0.f;
+                y[k] = ((x[k] - n.x) * n.y + n.z) * vf;
             }
         } else {
 #pragma unroll
@@ -173,7 +175,7 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int lane) {
 
 template <int CA, int CB, int DEPTH>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
-                                                              const int total_tiles, const int ablate) {
+                                                              const int total_tiles) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BwdLayout<CA, CB, DEPTH>;
@@ -312,15 +314,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
             // this tile's dy / z (consumed after the recompute) and, when accumulating, the
             // current dx values (consumed at the very end) fly behind the recompute MFMAs
-            if (!(ablate & 2)) {
-                load_rows16(dyr, vdy, c, h);
-                load_rows16(zr, vz, c, h);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { dyr[r] = 1.f; zr[r] = 0.5f; }
-            }
+            load_rows16(dyr, vdy, c, h);
+            load_rows16(zr, vz, c, h);
             if constexpr (EARLY_RMW) {
-                if (rmw && !(ablate & 1)) load_rows16(old, vdxa, c, h);
+                if (rmw) load_rows16(old, vdxa, c, h);
             }
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
@@ -354,10 +351,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         float dpre[16];
         {
             const float4 *kp = reinterpret_cast<const float4 *>(recK) + 4 * h;
+            const float vf = c.valid ? 1.f : 0.f;      // mask multiply, see norm_from_lds
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float4 k = kp[(r & 3) + 8 * (r >> 2)];
-                dpre[r] = c.valid ? k.y * dyr[r] + k.z * (zr[r] - k.x) + k.w : 0.f;
+                dpre[r] = (k.y * dyr[r] + k.z * (zr[r] - k.x) + k.w) * vf;
             }
         }
 
@@ -378,11 +376,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             for (int r = 0; r < 16; ++r) hsv[r] = In[ch_of(r, h) * TLD + j];
             f32x16 acc;
             zero16(acc);
-            if (!(ablate & 16)) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
-            }
-            if (!(ablate & 4)) dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
+            for (int r = 0; r < 16; ++r) acc = mfma32(wt[r], dpre[r], acc);
+            dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpre[r] = hsv[r] > 0.f ? acc[r] : 0.f;
         }
@@ -442,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                     for (int r = 0; r < 16; ++r) dxb_acc = mfma32(wt[r], dpre[r], dxb_acc);
                 }
             }
-            if (!(ablate & 4)) dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
+            dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
             if constexpr (CB > 0) {
                 float dummy = 0.f;
                 dW0b = wgrad_tile<false>(Dt, XB, dW0b, dummy, lane);
@@ -465,13 +461,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                             v[r] += buf_load(vdxa, ch_of(r, h) < CA ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4);
                     }
                 }
-                if (!(ablate & 1)) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        buf_store(v[r], vdxa, ch_of(r, h) < CA ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4);
-                }
+                for (int r = 0; r < 16; ++r)
+                    buf_store(v[r], vdxa, ch_of(r, h) < CA ? voff : OOB_OFF, s0 + ((r & 3) + 8 * (r >> 2)) * vdxa.ld4);
                 if constexpr (CA == 32 && CB == 0) {
-                    if (emit && !(ablate & 8)) {
+                    if (emit) {
                         // GraphNorm-backward sums of the producer of slab a over this tile:
                         // S1 = sum v, S2 = sum v * (z_a - mean_a); transposed through S1 / S2 so that
                         // lane (ch, h) sums 16 pixels of its channel.  v is 0 on invalid pixels.
@@ -572,8 +566,7 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
         attr_set = true;
     }
     // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    static const int ablate = getenv("FGNN_ABLATE") ? atoi(getenv("FGNN_ABLATE")) : 0;   // profiling aid only
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total, ablate);
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -78,10 +78,13 @@ DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const float *rec, bool on, bool 
     if constexpr (S > 0) {
         if (on) {
             const float4 *r4 = reinterpret_cast<const float4 *>(rec);
+            // 0/1 mask multiply instead of `valid ? .. : 0` (the ternary becomes divergent control flow
+            // around the LDS reads with a full-array phi copy per element)
+            const float vf = valid ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 const float4 n = r4[slab_ch<S>(k, h)];
-                x[k] = valid ? (x[k] - n.x) * n.y + n.z : 0.f;
+                x[k] = ((x[k] - n.x) * n.y + n.z) * vf;
             }
         }
     }
