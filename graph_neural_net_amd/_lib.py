@@ -46,7 +46,7 @@ class MlpBwdArgs(C.Structure):
                 ('bias', C.c_void_p * FGNN_MAX_DEPTH),
                 ('dy', C.c_void_p), ('dgstride', C.c_longlong), ('ldd', C.c_longlong),
                 ('z', C.c_void_p), ('zgstride', C.c_longlong), ('ldz', C.c_longlong),
-                ('coef', C.c_void_p),
+                ('coef', C.c_void_p), ('s12', C.c_void_p), ('znrm', C.c_void_p),
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),

@@ -103,6 +103,23 @@ DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 
     }
 }
 
+// dz coefficients {mean, ca, cb, cc} of channel `ch` of graph g: precomputed (A.coef) or derived here
+// from the GraphNorm-backward sums S1,S2 and the output's GraphNorm record:
+//   dz = a*dy - a*S2*r2/m * (z - mean) - a*S1/m
+DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch) {
+    if (A.coef) return reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + ch];
+    const float4 n = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + ch];
+    const float2 sv = reinterpret_cast<const float2 *>(A.s12)[(long long)g * FGNN_H + ch];
+    const float nv = (float)nvalid_of(A.nvalid, g, A.N);
+    const float m = nv * nv;
+    float4 k;
+    k.x = n.x;
+    k.y = n.y;
+    k.z = m > 0.f ? -n.y * sv.y * n.w / m : 0.f;
+    k.w = m > 0.f ? -n.y * sv.x / m : 0.f;
+    return k;
+}
+
 // dW += Dt (rows = out channel) x In (rows = in channel), contraction over the 32 pixels.
 // The Dt fragments of lane (o, h) are 16 pixels of channel o, so the bias gradient
 // db[o] = sum_px Dt[o][px] falls out of the same LDS reads (WITH_DB).
@@ -231,7 +248,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
         if (t < T1 && lane < 32) {
-            rk = reinterpret_cast<const float4 *>(A.coef)[(long long)c.g * FGNN_H + lane];
+            rk = coef_record(A, c.g, lane);
             if (normA && lane < CA) {
                 ra = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
                 ra.z = A.a.beta ? A.a.beta[lane] : 0.f;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the loads
             // below so that the in-order vmcnt wait does not drain them.
             if (lane < 32) {
-                float4 k4 = reinterpret_cast<const float4 *>(A.coef)[(long long)c.g * FGNN_H + lane];
+                const float4 k4 = coef_record(A, c.g, lane);
                 reinterpret_cast<float4 *>(recK)[lane] = k4;
                 if (normA && lane < CA) {
                     float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
@@ -598,7 +615,8 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a->depth >= 1 && a->depth <= FGNN_MAX_DEPTH, "fgnn_mlp_bwd: depth %d not in 1..%d", a->depth, FGNN_MAX_DEPTH);
     FGNN_CHECK(a->a.ptr && a->a.C > 0, "fgnn_mlp_bwd: slab a missing");
     FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_bwd: slab b has channels but no pointer");
-    FGNN_CHECK(a->dy && a->z && a->coef && a->wpart, "fgnn_mlp_bwd: missing dy/z/coef/wpart");
+    FGNN_CHECK(a->dy && a->z && a->wpart, "fgnn_mlp_bwd: missing dy/z/wpart");
+    FGNN_CHECK(a->coef || (a->s12 && a->znrm), "fgnn_mlp_bwd: need coef, or s12 + znrm");
     {
         const long long lim = 0x7fffffffll / 4, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&

@@ -44,33 +44,42 @@ DEVI void chan_combine(float &n, float &mean, float &m2, float nb, float mb, flo
     }
 }
 
-// one wave per (g,c): lanes take tiles lane, lane+64, ... then a fixed shuffle tree.
+// one 256-thread block per (graph, MLP): thread (c = tid % 32 (+32 per pass), part = tid / 32) combines
+// the tiles part, part+8, ... of channel c (coalesced: the 32 channels of a tile are contiguous), then
+// the 8 parts are combined through LDS in a fixed order.
 struct FinalizeJobs {
     const float *part[2];
     const float *gw[2];
     float *nrm[2];
 };
-__global__ void gn_finalize_kernel(const FinalizeJobs J, const float *cnt, const int *nvalid,
-                                   int G, int C, int N, int tpg, float eps) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, const float *cnt, const int *nvalid,
+                                                         int G, int C, int N, int tpg, float eps) {
+    __shared__ float sm[3][8][32];
     const float *part = J.part[blockIdx.y];
     const float *gw = J.gw[blockIdx.y];
     float *nrm = J.nrm[blockIdx.y];
-    const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
-    if (idx >= G * C) return;
-    const int lane = threadIdx.x & 63;
-    const int g = idx / C, c = idx - g * C;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int t = lane; t < tpg; t += WAVE) {
-        const float nb = cnt[(long long)g * tpg + t];
-        const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
-        chan_combine(n, mean, m2, nb, pm.x, pm.y);
-    }
+    const int g = blockIdx.x, cl = threadIdx.x & 31, p8 = threadIdx.x >> 5;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cl;
+        float n = 0.f, mean = 0.f, m2 = 0.f;
+        if (c < C) {
+            for (int t = p8; t < tpg; t += 8) {
+                const float nb = cnt[(long long)g * tpg + t];
+                const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
+                chan_combine(n, mean, m2, nb, pm.x, pm.y);
+            }
+        }
+        sm[0][p8][cl] = n;
+        sm[1][p8][cl] = mean;
+        sm[2][p8][cl] = m2;
+        __syncthreads();
+        if (p8 == 0 && c < C) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float nb = __shfl_down(n, off), mb = __shfl_down(mean, off), m2b = __shfl_down(m2, off);
-        chan_combine(n, mean, m2, nb, mb, m2b);
+            for (int k = 1; k < 8; ++k) chan_combine(n, mean, m2, sm[0][k][cl], sm[1][k][cl], sm[2][k][cl]);
+            write_nrm(nrm, (long long)g * C + c, mean, m2, n, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
+        }
+        __syncthreads();
     }
-    if (lane == 0) write_nrm(nrm, idx, mean, m2, n, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
 }
 
 // one wave per (g,c): two-pass mean / M2 over the valid n x n region.
@@ -342,7 +351,8 @@ extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float
     FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part, nullptr}, {gn_weight, nullptr}, {nrm, nullptr}};
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
+    (void)tot;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
                        nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -354,7 +364,8 @@ extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const f
     FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize2: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part0, part1}, {gn_weight0, gn_weight1}, {nrm0, nrm1}};
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
+    (void)tot;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
                        nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
     FGNN_LAUNCH_CHECK();
     return 0;

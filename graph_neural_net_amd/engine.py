@@ -289,6 +289,7 @@ class FgnnEngine:
                   _lib.ptr(W['coef'][slot]), None, None, _lib.stream_ptr())
 
     def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
+        """coef: precomputed coefficient buffer, or None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)]."""
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
@@ -304,7 +305,11 @@ class FgnnEngine:
             args.bias[l] = self._w(params, rec['b'][l])
         args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
-        args.coef = coef.data_ptr()
+        if coef is not None:
+            args.coef = coef.data_ptr()
+        else:
+            args.s12 = W['s12'][(k, j)].data_ptr()
+            args.znrm = self.nrm[(k, j)].data_ptr()
         if dxa is not None:
             args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), gs, self.ldp
         if dxb is not None:
@@ -345,22 +350,20 @@ class FgnnEngine:
         out = self._slab_z(K, 3, params)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
                   _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
-        self._coef((K, 3), 2)
         for k in range(K, 0, -1):
             sin = self._slab_in(k, params)
             first = (k == 1)
             din = None if first else W['dy'][(K - k + 1) % 2]
-            # mlp3: inputs [mult ; in]
-            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, W['coef'][2], W['dmult'], din, False, False)
+            # mlp3: inputs [mult ; in].  Last block: dz coefficients derived in-kernel from the pooling's
+            # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, None if k == K else W['coef'][2],
+                          W['dmult'], din, False, False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            _lib.call('fgnn_gn_bwd_coef2', _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
-                      _lib.ptr(self.nrm[(k, 1)]), _lib.ptr(self.nrm[(k, 2)]), self._nv(), self.G, 32, self.N,
-                      _lib.ptr(W['coef'][0]), _lib.ptr(W['coef'][1]), st)
-            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
-            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
+            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False)
+            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first)
             if not first:
                 _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)

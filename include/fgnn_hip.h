@@ -178,7 +178,9 @@ typedef struct {
     const float *bias[FGNN_MAX_DEPTH];
     const float *dy;  long long dgstride, ldd;   /* grad of the normalised output (G,32,ldd) */
     const float *z;   long long zgstride, ldz;   /* saved pre-norm output                    */
-    const float *coef;                       /* (G*32*4) from fgnn_gn_bwd_coef           */
+    const float *coef;                       /* (G*32*4) from fgnn_gn_bwd_coef*, or NULL: then the kernel */
+    const float *s12;                        /*   derives it from s12 (G*32*2) = {sum dy, sum dy*(z-mean)}  */
+    const float *znrm;                       /*   and znrm (G*32*4), the GraphNorm record of z              */
     float *dxa; long long dxa_gstride, dxa_ld;   /* out: grad wrt slab a (NULL = not needed) */
     float *dxb; long long dxb_gstride, dxb_ld;   /* out: grad wrt slab b (NULL = not needed) */
     int accumulate_a, accumulate_b;          /* 1: dx += (read-modify-write)             */

@@ -23,8 +23,7 @@ def run(B, N, reps=20):
     for tag, e0, e1 in rec:
         a = acc.setdefault(tag, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
     print('B=%d N=%d (tiles=%d)' % (B, N, 2 * B * ((N * N + 31) // 32)))
-    for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-        print('   %-28s avg %7.1f us' % (k, v[1] / v[0] * 1e3))
+    print('   ' + '  '.join('%s=%.1f' % (k.replace('fgnn_','').replace('chan_',''), v[1] / v[0] * 1e3) for k, v in sorted(acc.items()) if 'mlp' in k or 'matmul' in k))
 
-run(1, 8)      # 4 tiles: everything is fixed cost
-run(32, 50)
+for b in (1, 8, 16, 32, 64, 128):
+    run(b, 50, reps=10)
