@@ -44,9 +44,9 @@ DEVI void chan_combine(float &n, float &mean, float &m2, float nb, float mb, flo
     }
 }
 
-// one 256-thread block per (graph, MLP): thread (c = tid % 32 (+32 per pass), part = tid / 32) combines
-// the tiles part, part+8, ... of channel c (coalesced: the 32 channels of a tile are contiguous), then
-// the 8 parts are combined through LDS in a fixed order.
+// one wave per (g, c, MLP): exact two-level decomposition with plain (fixed-tree) wave sums,
+//   mean = sum_t n_t mean_t / sum_t n_t,   M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
+// (no cancellation: the between-tile term is formed from differences of means).
 struct FinalizeJobs {
     const float *part[2];
     const float *gw[2];
@@ -54,31 +54,59 @@ struct FinalizeJobs {
 };
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, const float *cnt, const int *nvalid,
                                                          int G, int C, int N, int tpg, float eps) {
-    __shared__ float sm[3][8][32];
     const float *part = J.part[blockIdx.y];
     const float *gw = J.gw[blockIdx.y];
     float *nrm = J.nrm[blockIdx.y];
-    const int g = blockIdx.x, cl = threadIdx.x & 31, p8 = threadIdx.x >> 5;
-    for (int c0 = 0; c0 < C; c0 += 32) {
-        const int c = c0 + cl;
-        float n = 0.f, mean = 0.f, m2 = 0.f;
-        if (c < C) {
-            for (int t = p8; t < tpg; t += 8) {
-                const float nb = cnt[(long long)g * tpg + t];
-                const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
-                chan_combine(n, mean, m2, nb, pm.x, pm.y);
-            }
-        }
-        sm[0][p8][cl] = n;
-        sm[1][p8][cl] = mean;
-        sm[2][p8][cl] = m2;
-        __syncthreads();
-        if (p8 == 0 && c < C) {
+    const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (idx >= G * C) return;
+    const int lane = threadIdx.x & 63;
+    const int g = idx / C, c = idx - g * C;
+    float nb[4], mb[4], qb[4];           // up to 256 tiles per graph in registers (N <= 90); else looped below
+    float sn = 0.f, sm = 0.f;
+    const int nt = (tpg + WAVE - 1) / WAVE;
+    if (nt <= 4) {
 #pragma unroll
-            for (int k = 1; k < 8; ++k) chan_combine(n, mean, m2, sm[0][k][cl], sm[1][k][cl], sm[2][k][cl]);
-            write_nrm(nrm, (long long)g * C + c, mean, m2, n, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
+        for (int k = 0; k < 4; ++k) {
+            const int t = lane + WAVE * k;
+            const bool ok = t < tpg;
+            const int tc = ok ? t : 0;
+            const float n = cnt[(long long)g * tpg + tc];
+            const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + tc) * C + c];
+            nb[k] = ok ? n : 0.f;
+            mb[k] = pm.x;
+            qb[k] = ok ? pm.y : 0.f;
+            sn += nb[k];
+            sm += nb[k] * mb[k];
         }
-        __syncthreads();
+        sn = wave_sum(sn);
+        sm = wave_sum(sm);
+        const float mean = sn > 0.f ? sm / sn : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float d = mb[k] - mean;
+            m2 += qb[k] + nb[k] * d * d;
+        }
+        m2 = wave_sum(m2);
+        if (lane == 0) write_nrm(nrm, idx, mean, m2, sn, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
+    } else {
+        for (int t = lane; t < tpg; t += WAVE) {
+            const float n = cnt[(long long)g * tpg + t];
+            sn += n;
+            sm += n * reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c].x;
+        }
+        sn = wave_sum(sn);
+        sm = wave_sum(sm);
+        const float mean = sn > 0.f ? sm / sn : 0.f;
+        float m2 = 0.f;
+        for (int t = lane; t < tpg; t += WAVE) {
+            const float n = cnt[(long long)g * tpg + t];
+            const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
+            const float d = pm.x - mean;
+            m2 += pm.y + n * d * d;
+        }
+        m2 = wave_sum(m2);
+        if (lane == 0) write_nrm(nrm, idx, mean, m2, sn, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
     }
 }
 
@@ -351,8 +379,7 @@ extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float
     FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part, nullptr}, {gn_weight, nullptr}, {nrm, nullptr}};
-    (void)tot;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
                        nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -364,8 +391,7 @@ extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const f
     FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize2: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part0, part1}, {gn_weight0, gn_weight1}, {nrm0, nrm1}};
-    (void)tot;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
                        nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
     FGNN_LAUNCH_CHECK();
     return 0;
