@@ -106,13 +106,16 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
+    ap.add_argument('--backend', default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets "
+                                                    'several ranks share one GPU for functional tests')
     args = ap.parse_args()
 
-    rank, local_rank, world = dp.init_process_group()
+    rank, local_rank, world = dp.init_process_group(args.backend)
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU; there is no CPU fallback for the product path')
+    local_rank = local_rank % torch.cuda.device_count()     # (only differs in the shared-GPU functional test)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 

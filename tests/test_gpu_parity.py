@@ -167,3 +167,38 @@ def test_full_size_properties():
     sd = {k: v.clone() for k, v in lay.unflatten(params.cpu()).items()}
     s_ref = O.siamese_scores(x1[:2], x2[:2], sd)
     assert rel(s1[:2].cpu(), s_ref) < E2E_FWD_TOL
+
+
+def test_cfg4_shape_n200_dense_er_fp32():
+    """BASELINE config 3 shape (N=200 dense ER, p=0.5) in fp32: exercises the multi-tile matmul path,
+    6.4 k-column score rows and the generic pooling kernel.  One pair (the oracle needs seconds)."""
+    torch.manual_seed(4)
+    sd = O.init_state_dict(num_blocks=4)
+    x1, x2 = synthetic.make_batch(4000, 1, 200, 'ErdosRenyi', 0.5, 0.1)
+    s_ref, l_ref, g_ref = O.step_fwd_bwd(x1, x2, sd)
+    _, _, _, scores, loss, grads = _run_engine(sd, x1, x2, 4)
+    assert rel(scores, s_ref) < 1e-4
+    assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
+    assert (a - b).norm() / b.norm() < 2e-3
+
+
+def test_cfg5_shape_ragged_30_120():
+    """BASELINE config 4 shape: variable-N batch, n in [30, 120] (8 pairs), against per-graph dense oracle runs."""
+    torch.manual_seed(5)
+    sd = O.init_state_dict(num_blocks=4)
+    xs, ys = synthetic.make_ragged_batch(5000, 8, 30, 120)
+    s_ref, l_ref, g_ref = O.step_fwd_bwd_ragged(xs, ys, sd)
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    eng, params, lay, scores, loss, grads = _run_engine(sd, x1, x2, 4, nvalid=nv)
+    for i, n in enumerate(nv.tolist()):
+        assert rel(scores[i, :n, :n], s_ref[i]) < 1e-4
+        assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
+    assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
+    assert (a - b).norm() / b.norm() < 2e-3
