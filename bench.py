@@ -198,6 +198,14 @@ def main():
             ach = by / dur / 1e9
             roofline = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': ach / HBM_PEAK_GBS, 'traffic': None}
+        try:   # HBM traffic of that kernel from the committed PMC passes (same workload), if present
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                tr = json.load(f)
+            if dom in tr and (B, N) == (32, 50):
+                roofline['traffic'] = tr[dom]['bytes']
+                roofline['traffic_source'] = tr.get('_source')
+        except (OSError, ValueError):
+            pass
         roofline.update({'kernel': dom, 'avg_launch_ms': summary[dom]['avg_ms'],
                          'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
                          'alt_hbm_gbs': by / dur / 1e9, 'alt_mfma_tflops': fl / dur / 1e12})
