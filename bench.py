@@ -38,9 +38,6 @@ def kernel_model(tag, G, N):
     if tag.startswith('mlp_bwd['):
         cin, dx = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
         return 4.0 * G * P * (cin + 64 + dx), 4.0 * G * P * (cin * 32 + 2 * 1024)
-    if tag.startswith('mlp_bwd2['):      # two MLPs (mlp1 + mlp2 of a block) in one launch
-        cin, dx = [int(v.split('=')[1]) for v in tag[9:-1].split(',')]
-        return 2 * 4.0 * G * P * (cin + 64 + dx), 2 * 4.0 * G * P * (cin * 32 + 2 * 1024)
     if tag == 'fgnn_chan_matmul_fwd':
         return 4.0 * G * 32 * P * 3, 2.0 * G * 32 * N ** 3
     if tag == 'fgnn_chan_matmul_bwd':

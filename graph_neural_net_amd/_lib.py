@@ -44,7 +44,7 @@ class MlpBwdArgs(C.Structure):
                 ('a', Slab), ('b', Slab),
                 ('W', C.c_void_p * FGNN_MAX_DEPTH),
                 ('bias', C.c_void_p * FGNN_MAX_DEPTH),
-                ('dy', C.c_void_p), ('dgstride', C.c_longlong), ('ldd', C.c_longlong), ('dy2', C.c_void_p),
+                ('dy', C.c_void_p), ('dgstride', C.c_longlong), ('ldd', C.c_longlong),
                 ('z', C.c_void_p), ('zgstride', C.c_longlong), ('ldz', C.c_longlong),
                 ('coef', C.c_void_p), ('s12', C.c_void_p), ('znrm', C.c_void_p),
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
@@ -92,11 +92,10 @@ _SIGNATURES = {
     'fgnn_colmax_bwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab), _VP, _VP],
     'fgnn_gn_bwd_stats': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _VP],
     'fgnn_gn_bwd_coef': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
-    'fgnn_gn_bwd_coef_tiles': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_gn_bwd_coef_tiles': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_grad_finalize': [_VP, _I, _I, _I, _I, _VP],
     'fgnn_gn_bwd_apply': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_mlp_bwd': [C.POINTER(MlpBwdArgs), _VP],
-    'fgnn_mlp_bwd2': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
     'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],

@@ -191,14 +191,8 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int lane) {
 }
 
 template <int CA, int CB, int DEPTH>
-__global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A0, const fgnn_mlp_bwd_args A1,
-                                                              const int tpg, const int total_tiles) {
-    // dual launch: workgroups [0, BWD_WG) run A0, [BWD_WG, 2*BWD_WG) run A1 (two independent MLPs of the
-    // same shape, e.g. mlp1 / mlp2 of one block); a CU starts its A1 workgroup as soon as its A0 one is
-    // done, without the inter-kernel barrier (and second launch) two separate launches would cost.
-    const bool second = blockIdx.x >= BWD_WG;
-    const fgnn_mlp_bwd_args &A = second ? A1 : A0;
-    const int wg = second ? blockIdx.x - BWD_WG : blockIdx.x;
+__global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
+                                                              const int total_tiles) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BwdLayout<CA, CB, DEPTH>;
@@ -209,7 +203,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
     const View vdy = make_view(A.dy, A.dgstride, A.ldd, A.G);
-    const View vdy2 = make_view(A.dy2, A.dgstride, A.ldd, A.G);
     const View vz = make_view(A.z, A.zgstride, A.ldz, A.G);
     const View vdxa = make_view(A.dxa, A.dxa_gstride, A.dxa_ld, A.G);
     const View vdxb = make_view(A.dxb, A.dxb_gstride, A.dxb_ld, A.G);
@@ -237,10 +230,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
 
     // static, strided tile assignment inside the workgroup's contiguous range: the order in
     // which a wave accumulates its weight gradients is fixed -> bit-reproducible results
-    const int nwg = BWD_WG;
+    const int nwg = gridDim.x;
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = wg * q + (wg < rem ? wg : rem);
-    const int T1 = T0 + q + (wg < rem ? 1 : 0);
+    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
 
@@ -340,12 +333,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             // current dx values (consumed at the very end) fly behind the recompute MFMAs
             load_rows16(dyr, vdy, c, h);
             load_rows16(zr, vz, c, h);
-            if (A.dy2) {                         // dy = dy + dy2 (gradient arriving in two parts)
-                float d2[16];
-                load_rows16(d2, vdy2, c, h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dyr[r] += d2[r];
-            }
             if constexpr (EARLY_RMW) {
                 if (rmw) load_rows16(old, vdxa, c, h);
             }
@@ -373,12 +360,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         if constexpr (DEPTH == 1) {
             load_rows16(dyr, vdy, c, h);
             load_rows16(zr, vz, c, h);
-            if (A.dy2) {
-                float d2[16];
-                load_rows16(d2, vdy2, c, h);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dyr[r] += d2[r];
-            }
             if constexpr (EARLY_RMW) {
                 if (rmw) load_rows16(old, vdxa, c, h);
             }
@@ -583,7 +564,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     __syncthreads();                       // everyone done with the operand sets and the tile buffers
     put_partials(smem + wv * PCOUNT);      // the whole LDS allocation is free now
     __syncthreads();
-    float *out = A.wpart + (long long)wg * PCOUNT;
+    float *out = A.wpart + (long long)blockIdx.x * PCOUNT;
     for (int e = threadIdx.x; e < PCOUNT; e += 64 * NW) {
         float a = 0.f;
 #pragma unroll
@@ -593,7 +574,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
 }
 
 template <int CA, int CB, int DEPTH>
-int launch_bwd(const fgnn_mlp_bwd_args *a, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
+int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = BwdLayout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
@@ -602,17 +583,16 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, const fgnn_mlp_bwd_args *a2, int tpg,
         attr_set = true;
     }
     // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(a2 ? 2 * BWD_WG : BWD_WG), dim3(64 * NW), LDS, st, *a,
-                       a2 ? *a2 : *a, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 
 template <int DEPTH>
-int dispatch_c(const fgnn_mlp_bwd_args *a, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
+int dispatch_c(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     const int ca = a->a.C, cb = a->b.C;
 #define FGNN_CASE(A_, B_) \
-    if (ca == A_ && cb == B_) return launch_bwd<A_, B_, DEPTH>(a, a2, tpg, total, st);
+    if (ca == A_ && cb == B_) return launch_bwd<A_, B_, DEPTH>(a, tpg, total, st);
     FGNN_CASE(2, 0)
     FGNN_CASE(16, 0)
     FGNN_CASE(32, 0)
@@ -629,7 +609,7 @@ extern "C" int fgnn_mlp_bwd_num_workgroups(void) { return BWD_WG; }
 
 extern "C" int fgnn_mlp_param_count(int Cin, int depth) { return 32 * Cin + 32 + (depth - 1) * (32 * 32 + 32); }
 
-static int check_bwd_args(const fgnn_mlp_bwd_args *a) {
+extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a != nullptr, "fgnn_mlp_bwd: null args");
     FGNN_CHECK(a->G > 0 && a->N > 0, "fgnn_mlp_bwd: bad G=%d N=%d", a->G, a->N);
     FGNN_CHECK(a->depth >= 1 && a->depth <= FGNN_MAX_DEPTH, "fgnn_mlp_bwd: depth %d not in 1..%d", a->depth, FGNN_MAX_DEPTH);
@@ -644,31 +624,11 @@ static int check_bwd_args(const fgnn_mlp_bwd_args *a) {
                    "fgnn_mlp_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     }
     for (int l = 0; l < a->depth; ++l) FGNN_CHECK(a->W[l] && a->bias[l], "fgnn_mlp_bwd: missing weights layer %d", l);
-    return 0;
-}
-
-static int run_bwd(const fgnn_mlp_bwd_args *a, const fgnn_mlp_bwd_args *a2, void *stream) {
     const int tpg = fgnn_tiles_per_graph(a->N);
     const long long total = (long long)a->G * tpg;
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_bwd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    if (a->depth == 1) return dispatch_c<1>(a, a2, tpg, (int)total, st);
-    if (a->depth == 2) return dispatch_c<2>(a, a2, tpg, (int)total, st);
-    return dispatch_c<3>(a, a2, tpg, (int)total, st);
-}
-
-extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
-    if (int rc = check_bwd_args(a)) return rc;
-    return run_bwd(a, nullptr, stream);
-}
-
-extern "C" int fgnn_mlp_bwd2(const fgnn_mlp_bwd_args *a0, const fgnn_mlp_bwd_args *a1, void *stream) {
-    if (int rc = check_bwd_args(a0)) return rc;
-    if (int rc = check_bwd_args(a1)) return rc;
-    FGNN_CHECK(a0->G == a1->G && a0->N == a1->N && a0->depth == a1->depth && a0->a.C == a1->a.C && a0->b.C == a1->b.C,
-               "fgnn_mlp_bwd2: the two MLPs must have the same shape");
-    FGNN_CHECK(a0->wpart != a1->wpart, "fgnn_mlp_bwd2: the two MLPs need separate wpart buffers");
-    FGNN_CHECK(!(a0->dxa && a0->dxa == a1->dxa) && !(a0->dxb && a0->dxb == a1->dxb),
-               "fgnn_mlp_bwd2: the two MLPs run concurrently and must not write the same dx tensor");
-    return run_bwd(a0, a1, stream);
+    if (a->depth == 1) return dispatch_c<1>(a, tpg, (int)total, st);
+    if (a->depth == 2) return dispatch_c<2>(a, tpg, (int)total, st);
+    return dispatch_c<3>(a, tpg, (int)total, st);
 }

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float *s12, co
 
 // sums per-tile {S1,S2} partials (G,tpg,C,2) over the tiles (one wave per (g,c), fixed tree),
 // writes s12 (G*C*2) and the dz coefficients.
-__global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *s12part2, const float *nrm, const int *nvalid,
-                                         int G, int C, int N, int tpg, float *s12, float *coef) {
+__global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                         int tpg, float *s12, float *coef) {
     const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (idx >= G * C) return;
     const int lane = threadIdx.x & 63;
@@ -255,11 +255,6 @@ __global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *s12p
         const float2 p = reinterpret_cast<const float2 *>(s12part)[((long long)g * tpg + t) * C + c];
         s1 += p.x;
         s2 += p.y;
-        if (s12part2) {          // gradient assembled from two producers: the sums are linear
-            const float2 p2 = reinterpret_cast<const float2 *>(s12part2)[((long long)g * tpg + t) * C + c];
-            s1 += p2.x;
-            s2 += p2.y;
-        }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
@@ -476,12 +471,12 @@ extern "C" int fgnn_sum_scale(const float *in, int rows, int cols, float scale, 
     return 0;
 }
 
-extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *s12part2, const float *nrm, const int *nvalid,
-                                      int G, int C, int N, float *s12, float *coef, void *stream) {
+extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                      float *s12, float *coef, void *stream) {
     FGNN_CHECK(s12part && nrm && s12 && coef && G > 0 && C > 0 && N > 0, "fgnn_gn_bwd_coef_tiles: bad arguments");
     const int tot = G * C;
-    hipLaunchKernelGGL(gn_bwd_coef_tiles_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, s12part, s12part2,
-                       nrm, nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef);
+    hipLaunchKernelGGL(gn_bwd_coef_tiles_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, s12part, nrm,
+                       nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -269,15 +269,13 @@ class FgnnEngine:
         keys = [(k, j) for k in range(1, L.num_blocks + 1) for j in (1, 2, 3)]
         self._bwd = {
             'dE': torch.empty(self.G, 32, self.N, **f32),
-            'dy': [act(), act()],        # d_in part 1 (mlp3's dxb + mlp1's dx), ping-pong over blocks
-            'dyb': [act(), act()],       # d_in part 2 (mlp2's dx): mlp1 / mlp2 backward run as ONE dual launch
+            'dy': [act(), act()],
             'dmult': act(), 'dy1': act(), 'dy2': act(),
             # per-MLP GraphNorm-backward sums and workgroup partials live until the final
             # fgnn_grad_finalize launch
             's12': {kj: torch.empty(self.G * 32 * 2, **f32) for kj in keys},
             'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32) for kj in keys},
             's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
-            's12part2': torch.empty(self.G * self.tpg * 32 * 2, **f32),
             'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
             'nwg': nwg,
             'gscale': torch.empty(1, **f32),
@@ -290,9 +288,8 @@ class FgnnEngine:
         _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12'][kj]), _lib.ptr(self.nrm[kj]), self._nv(), self.G, 32, self.N,
                   _lib.ptr(W['coef'][slot]), None, None, _lib.stream_ptr())
 
-    def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=None, dy2=None):
-        """coef: precomputed coefficient buffer, or None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)].
-        emit: buffer receiving the per-tile S1/S2 partials of this kernel's final dxa values (or None)."""
+    def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
+        """coef: precomputed coefficient buffer, or None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)]."""
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
@@ -307,8 +304,6 @@ class FgnnEngine:
             args.W[l] = self._w(params, rec['w'][l])
             args.bias[l] = self._w(params, rec['b'][l])
         args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
-        if dy2 is not None:
-            args.dy2 = dy2.data_ptr()
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
         if coef is not None:
             args.coef = coef.data_ptr()
@@ -322,15 +317,11 @@ class FgnnEngine:
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'][(k, j)].data_ptr()
         args.packed = self._packs[('b', k, j)][4].data_ptr()
-        if emit is not None:
-            args.s12part = emit.data_ptr()
-        tag = 'mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
-                                        (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0))
-        return args, tag
-
-    def _mlp_bwd(self, *a, **kw):
-        args, tag = self._mlp_bwd_args(*a, **kw)
-        _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(), tag=tag)
+        if emit:
+            args.s12part = W['s12part'].data_ptr()
+        _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
+                  tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
+                                                (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 
     def backward(self, params, grads, grad_scale=1.0):
         """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer."""
@@ -355,7 +346,7 @@ class FgnnEngine:
         st = _lib.stream_ptr()
         gs = 32 * self.ldp
         K = L.num_blocks
-        dy, dyb = W['dy'][0], None
+        dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
                   _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
@@ -363,28 +354,20 @@ class FgnnEngine:
             sin = self._slab_in(k, params)
             first = (k == 1)
             din = None if first else W['dy'][(K - k + 1) % 2]
-            dinb = None if first else W['dyb'][(K - k + 1) % 2]
-            # mlp3: inputs [mult ; in]; its output gradient arrives in two parts (dy + dyb) except for the last
-            # block.  Last block: dz coefficients derived in-kernel from the pooling's S1/S2; other blocks:
-            # from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
+            # mlp3: inputs [mult ; in].  Last block: dz coefficients derived in-kernel from the pooling's
+            # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, None if k == K else W['coef'][2],
-                          W['dmult'], din, False, False, dy2=dyb)
+                          W['dmult'], din, False, False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            # mlp1 and mlp2 backward in ONE dual launch: mlp1 accumulates into d_in (on top of mlp3's dxb),
-            # mlp2 stores into the second part; both emit the S1/S2 tile partials of their own contribution.
-            a1, t1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], None, din, None, True, False,
-                                        emit=None if first else W['s12part'])
-            a2, _ = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], None, dinb, None, False, False,
-                                       emit=None if first else W['s12part2'])
-            _lib.call('fgnn_mlp_bwd2', C.byref(a1), C.byref(a2), st, tag=t1.replace('mlp_bwd[', 'mlp_bwd2['))
+            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False)
+            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first)
             if not first:
-                _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(W['s12part2']),
-                          _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(), self.G, 32, self.N,
-                          _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
-            dy, dyb = din, dinb
+                _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
+                          self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
+            dy = din
         # ---- one launch: reduce the workgroup partials + GraphNorm affine gradients of all MLPs ----
         keys = [(k, j) for k in range(1, K + 1) for j in (1, 2, 3)]
         for lo in range(0, len(keys), _lib.MAX_GRAD_JOBS):

@@ -160,8 +160,7 @@ int fgnn_gn_bwd_coef2(const float *s12_0, const float *s12_1, const float *nrm0,
                       const int *nvalid, int G, int C, int N, float *coef0, float *coef1, void *stream);
 /* same coefficients from per-tile partial sums (G, tpg, C, 2) as emitted by fgnn_mlp_bwd
  * (s12part); also writes the summed s12 (G*C*2) for the affine gradients.                  */
-int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *s12part2 /* optional second producer */,
-                           const float *nrm, const int *nvalid, int G, int C, int N,
+int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
                            float *s12, float *coef, void *stream);
 /* dense dz = ca*dy + cb*(z-mean) + cc on valid entries (module-level GraphNorm backward) */
 int fgnn_gn_bwd_apply(const float *dy, long long dgstride, long long ldd,
@@ -178,7 +177,6 @@ typedef struct {
     const float *W[FGNN_MAX_DEPTH];
     const float *bias[FGNN_MAX_DEPTH];
     const float *dy;  long long dgstride, ldd;   /* grad of the normalised output (G,32,ldd) */
-    const float *dy2;                        /* optional second part of that gradient (same strides): dy + dy2 */
     const float *z;   long long zgstride, ldz;   /* saved pre-norm output                    */
     const float *coef;                       /* (G*32*4) from fgnn_gn_bwd_coef*, or NULL: then the kernel */
     const float *s12;                        /*   derives it from s12 (G*32*2) = {sum dy, sum dy*(z-mean)}  */
@@ -193,10 +191,6 @@ typedef struct {
     const float *packed;                     /* optional: operand image from fgnn_pack_operands (kind 1) */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
-/* two independent MLPs of identical shape (mlp1 / mlp2 of one block) in ONE launch; they must not share
- * dx outputs or wpart (let one accumulate into d_in and the other store into a second buffer, consumed
- * through `dy2` / a second s12part by the previous block).                                        */
-int fgnn_mlp_bwd2(const fgnn_mlp_bwd_args *args0, const fgnn_mlp_bwd_args *args1, void *stream);
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
  * layout [W0 (32*Cin) | b0 (32) | W1 (32*32) | b1 (32) | ...]                           */
 int fgnn_mlp_param_count(int Cin, int depth);
