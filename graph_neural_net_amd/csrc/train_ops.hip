@@ -1,0 +1,75 @@
+// Training-step helpers next to the hot path: fused Adam over the flat parameter
+// buffer (models/trainers.py:92-104 uses torch.optim.Adam, amsgrad=False) and the argmax accuracy
+// metric (toolbox/metrics.py:119-141) on the device.
+#include "fgnn_common.h"
+
+namespace {
+
+// torch.optim.Adam single-tensor semantics (no weight decay, no amsgrad):
+//   m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float *p, const float *g, float *m, float *v, int n, float step_size, float w1,
+                            float beta2, float w2, float inv_sqrt_bc2, float eps, float grad_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (gi - m[i]) * w1;
+    const float vi = v[i] * beta2 + gi * gi * w2;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+// one workgroup per pair: rows i < nv with argmax_j scores[i][j] (first maximum) == i
+__global__ __launch_bounds__(256) void accuracy_max_kernel(const float *scores, const int *nvalid, int N, int *correct) {
+    __shared__ int red[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = nvalid_of(nvalid, b, N);
+    const float *S = scores + (long long)b * N * N;
+    int cnt = 0;
+    for (int i = wave; i < nv; i += 4) {
+        float best = -3.402823466e+38f;
+        int bj = 0x7fffffff;
+        for (int j = lane; j < nv; j += WAVE) {
+            const float v = S[(long long)i * N + j];
+            if (v > best) {
+                best = v;
+                bj = j;
+            }
+        }
+        // wave arg-max with ties resolved towards the smaller index (np.argmax)
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oj = __shfl_xor(bj, o);
+            if (ob > best || (ob == best && oj < bj)) {
+                best = ob;
+                bj = oj;
+            }
+        }
+        if (bj == i) ++cnt;
+    }
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) correct[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace
+
+extern "C" int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, float lr,
+                              float beta1, float beta2, float eps, int step, float grad_scale, void *stream) {
+    FGNN_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "fgnn_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n, (float)(lr / bc1), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
+                       grad_scale);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int *correct, void *stream) {
+    FGNN_CHECK(scores && correct && B > 0 && N > 0, "fgnn_accuracy_max: bad arguments");
+    hipLaunchKernelGGL(accuracy_max_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, scores, nvalid, N, correct);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,45 @@
+"""Optimizer / scheduler next to the hot path: Adam over the flat
+parameter buffer as ONE fused HIP kernel right after the gradient all-reduce, and the reference's
+ReduceLROnPlateau policy (models/trainers.py:92-104: Adam lr 1e-3, factor 0.5, patience 3, min_lr 1e-5)."""
+import torch
+
+from . import _lib
+
+
+class FlatAdam:
+    """torch.optim.Adam(amsgrad=False, weight_decay=0) semantics on one flat fp32 device buffer."""
+
+    def __init__(self, params_flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if not params_flat.is_cuda:
+            raise RuntimeError('FlatAdam: parameters must live on the GPU (no CPU path)')
+        self.params = params_flat
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.exp_avg = torch.zeros_like(params_flat)
+        self.exp_avg_sq = torch.zeros_like(params_flat)
+        self.t = 0
+
+    def step(self, grads_flat, grad_scale=1.0):
+        self.t += 1
+        _lib.call('fgnn_adam_step', _lib.ptr(self.params), _lib.ptr(grads_flat), _lib.ptr(self.exp_avg),
+                  _lib.ptr(self.exp_avg_sq), self.params.numel(), float(self.lr), float(self.betas[0]),
+                  float(self.betas[1]), float(self.eps), self.t, float(grad_scale), _lib.stream_ptr())
+
+
+class ReduceLROnPlateau:
+    """mode='min', relative threshold 1e-4 -- the torch defaults the reference relies on."""
+
+    def __init__(self, optimizer, factor=0.5, patience=3, min_lr=1e-5, threshold=1e-4):
+        self.opt, self.factor, self.patience, self.min_lr, self.threshold = optimizer, factor, patience, min_lr, threshold
+        self.best = float('inf')
+        self.bad = 0
+
+    def step(self, metric):
+        if metric < self.best * (1.0 - self.threshold):
+            self.best = metric
+            self.bad = 0
+        else:
+            self.bad += 1
+        if self.bad > self.patience:
+            self.opt.lr = max(self.opt.lr * self.factor, self.min_lr)
+            self.bad = 0
+        return self.opt.lr

@@ -118,3 +118,37 @@ def test_unsupported_shapes_fail_loudly():
     args.G, args.N, args.depth, args.nmlp = 1, 4, 3, 1
     with pytest.raises(RuntimeError, match='fgnn_mlp_fwd'):
         _lib.call('fgnn_mlp_fwd', C.byref(args), _lib.stream_ptr())
+
+
+def test_adam_step_matches_torch_adam():
+    from graph_neural_net_amd.optim import FlatAdam
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(40000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt_ref = torch.optim.Adam([ref], lr=1e-3, amsgrad=False)
+    pd = p0.clone().to(DEV)
+    opt = FlatAdam(pd, lr=1e-3)
+    for t in range(5):
+        grad = torch.randn(40000, generator=g) * (10.0 ** (t - 2))
+        ref.grad = grad.clone()
+        opt_ref.step()
+        opt.step(grad.to(DEV))
+        assert rel(pd.cpu(), ref.detach()) < 1e-6, t
+    assert rel(opt.exp_avg.cpu(), opt_ref.state[ref]['exp_avg']) < 1e-6
+    assert rel(opt.exp_avg_sq.cpu(), opt_ref.state[ref]['exp_avg_sq']) < 1e-6
+
+
+def test_accuracy_max_bit_exact():
+    import numpy as np
+    from graph_neural_net_amd.masked import from_list
+    from graph_neural_net_amd.metrics import accuracy_max
+    g = torch.Generator().manual_seed(1)
+    w = torch.randint(-2, 3, (5, 50, 50), generator=g).float()       # ties on purpose
+    w[0] = torch.eye(50) * 10
+    acc, n = accuracy_max(w.to(DEV))
+    ref = sum(int(np.sum(np.argmax(x.numpy(), 1) == np.arange(50))) for x in w)
+    assert (acc, n) == (ref, 250)
+    lst = [torch.randn(k, k, generator=g) for k in (7, 12, 9)]
+    acc, n = accuracy_max(from_list([t.to(DEV) for t in lst], dims=(0, 1)))
+    ref = sum(int(np.sum(np.argmax(x.numpy(), 1) == np.arange(len(x)))) for x in lst)
+    assert (acc, n) == (ref, 28)

@@ -202,3 +202,31 @@ def test_cfg5_shape_ragged_30_120():
     a = torch.cat([grads[k].reshape(-1).double() for k in keys])
     b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
     assert (a - b).norm() / b.norm() < 2e-3
+
+
+def test_training_step_matches_oracle_plus_torch_adam():
+    """engine step + fused Adam == oracle autograd + torch.optim.Adam on the CPU (2 steps), and the loss goes down."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    torch.manual_seed(6)
+    sd = O.init_state_dict(num_blocks=2)
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    x1, x2 = synthetic.make_batch(6000, 4, 16, 'ErdosRenyi', 0.3, 0.05)
+    tr = FgnnTrainer(lay, lay.flatten(sd, DEV), lr=1e-3)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(ref.values()), lr=1e-3)
+    losses = []
+    for _ in range(2):
+        loss, _ = tr.train_step(x1.to(DEV), x2.to(DEV))
+        opt.zero_grad()
+        l_ref = O.triplet_loss_mean(O.siamese_scores(x1, x2, ref))
+        l_ref.backward()
+        opt.step()
+        assert abs(loss.item() - l_ref.item()) < 2e-5 * abs(l_ref.item())
+        losses.append(loss.item())
+    got = lay.unflatten(tr.params.cpu())
+    for k, v in ref.items():
+        if not is_zero_grad(k):          # Adam normalises the fp32-noise gradients of these biases to +-lr steps
+            assert rel(got[k], v.detach()) < 1e-4, (k, rel(got[k], v.detach()))
+    for _ in range(20):
+        loss, _ = tr.train_step(x1.to(DEV), x2.to(DEV))
+    assert loss.item() < losses[0]
