@@ -55,14 +55,16 @@ __global__ __launch_bounds__(256) void accuracy_max_kernel(const float *scores, 
 
 }  // namespace
 
-extern "C" int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, float lr,
-                              float beta1, float beta2, float eps, int step, float grad_scale, void *stream) {
+extern "C" int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, double lr,
+                              double beta1, double beta2, double eps, int step, double grad_scale, void *stream) {
     FGNN_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "fgnn_adam_step: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    // hyper-parameters arrive as doubles (like the Python floats torch.optim.Adam works with) and are
+    // rounded to fp32 only after 1 - beta etc. have been formed
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, n, (float)(lr / bc1), 1.0f - beta1, beta2, 1.0f - beta2, (float)(1.0 / sqrt(bc2)), eps,
-                       grad_scale);
+                       exp_avg_sq, n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                       (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -217,8 +217,8 @@ int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *
 /* ---- next to the hot path -------------------------------------------
  * Fused Adam over a flat fp32 buffer: torch.optim.Adam(amsgrad=False, weight_decay=0) single-tensor
  * semantics (models/trainers.py:92-104); grads are multiplied by grad_scale first; step >= 1.      */
-int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, float lr,
-                   float beta1, float beta2, float eps, int step, float grad_scale, void *stream);
+int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, double lr,
+                   double beta1, double beta2, double eps, int step, double grad_scale, void *stream);
 /* accuracy_max (toolbox/metrics.py:119-141): correct[b] = #{i < n_b : argmax_j scores[b,i,j] == i},
  * first maximum on ties (np.argmax); int32, bit-exact.                                              */
 int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int *correct, void *stream);
