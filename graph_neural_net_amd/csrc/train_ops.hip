@@ -75,3 +75,44 @@ extern "C" int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, 
     FGNN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- input pipeline ------------------------------------------------
+// The hot path's inputs are 0/1 adjacency matrices plus diag(degree) (loaders/data_generator.py:118-125).
+// They travel to the device bit-packed (N*ceil(N/32) words per graph, 64x less PCIe traffic than fp32)
+// and are expanded here: x[g,0] = W, x[g,1] = diag(row sums); padding beyond nvalid[g] is zero.
+namespace {
+__global__ void expand_adjacency_kernel(const unsigned *bits, const int *nvalid, int G, int N, int words, float *x) {
+    // one thread per output element: coalesced stores of both channels
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long P = (long long)N * N;
+    if (t >= (long long)G * P) return;
+    const int g = (int)(t / P);
+    const int p = (int)(t - (long long)g * P);
+    const int i = p / N, j = p - i * N;
+    const int nv = nvalid_of(nvalid, g, N);
+    const unsigned *row = bits + ((long long)g * N + i) * words;
+    const bool on = i < nv && j < nv && ((row[j >> 5] >> (j & 31)) & 1u);
+    float deg = 0.f;
+    if (i == j && i < nv) {
+        int d = 0;
+        for (int k = 0; k < words; ++k) {
+            const int left = nv - 32 * k;  // valid bits in this word
+            const unsigned m = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+            d += __popc(row[k] & m);
+        }
+        deg = (float)d;
+    }
+    float *xg = x + (long long)g * 2 * P;
+    xg[p] = on ? 1.f : 0.f;
+    xg[P + p] = deg;
+}
+}  // namespace
+
+extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N, float *x, void *stream) {
+    FGNN_CHECK(bits && x && G > 0 && N > 0, "fgnn_expand_adjacency: bad arguments");
+    const long long tot = (long long)G * N * N;
+    hipLaunchKernelGGL(expand_adjacency_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       bits, nvalid, G, N, (N + 31) / 32, x);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -116,3 +116,16 @@ def make_ragged_batch(seed, batch, n_lo, n_hi, family='ErdosRenyi', edge_density
         xs.append(torch.from_numpy(a))
         ys.append(torch.from_numpy(b))
     return xs, ys
+
+
+def pack_adjacency(w_batch):
+    """(G, n, n) 0/1 adjacency (numpy) -> (G, n, ceil(n/32)) uint32, bit j of word row i = W[i][j]
+    (little-endian bit order): the compact wire format expanded on the device by
+    ``inputs.expand_adjacency``."""
+    w = np.asarray(w_batch) != 0
+    g, n, _ = w.shape
+    words = (n + 31) // 32
+    padded = np.zeros((g, n, words * 32), dtype=bool)
+    padded[:, :, :n] = w
+    bits = np.packbits(padded.reshape(g, n, words, 32), axis=-1, bitorder='little')
+    return np.ascontiguousarray(bits).view(np.uint32).reshape(g, n, words)

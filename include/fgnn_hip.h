@@ -223,6 +223,10 @@ int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp
  * first maximum on ties (np.argmax); int32, bit-exact.                                              */
 int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int *correct, void *stream);
 
+/* Input expansion (loaders/data_generator.py:118-125): bits (G, N, ceil(N/32)) uint32, bit j of row i =
+ * W[i][j]  ->  x (G, 2, N, N) fp32 with x[g,0] = W, x[g,1] = diag(row sums); exact 0/1/integer values. */
+int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N, float *x, void *stream);
+
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);
 

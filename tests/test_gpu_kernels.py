@@ -152,3 +152,28 @@ def test_accuracy_max_bit_exact():
     acc, n = accuracy_max(from_list([t.to(DEV) for t in lst], dims=(0, 1)))
     ref = sum(int(np.sum(np.argmax(x.numpy(), 1) == np.arange(len(x)))) for x in lst)
     assert (acc, n) == (ref, 28)
+
+
+def test_expand_adjacency_bit_exact():
+    import numpy as np
+    from graph_neural_net_amd import synthetic
+    from graph_neural_net_amd.inputs import expand_adjacency
+    rng = np.random.default_rng(0)
+    for n in (50, 33, 7):
+        ws = np.stack([synthetic.erdos_renyi(rng, n, 0.3) for _ in range(5)])
+        ref = np.stack([synthetic.tensor_representation(w) for w in ws])
+        bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
+        x = expand_adjacency(bits, n)
+        assert torch.equal(x.cpu(), torch.from_numpy(ref))
+    # ragged: graphs of 20 and 41 vertices padded to 41, garbage bits in the padding must be ignored
+    n = 41
+    small, big = synthetic.erdos_renyi(rng, 20, 0.5), synthetic.erdos_renyi(rng, n, 0.5)
+    ws = np.ones((2, n, n), dtype=np.float32)
+    ws[0, :20, :20] = small
+    ws[1] = big
+    ref = np.zeros((2, 2, n, n), dtype=np.float32)
+    ref[0, :, :20, :20] = synthetic.tensor_representation(small)
+    ref[1] = synthetic.tensor_representation(big)
+    bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
+    x = expand_adjacency(bits, n, nvalid=torch.tensor([20, n], dtype=torch.int32))
+    assert torch.equal(x.cpu(), torch.from_numpy(ref))

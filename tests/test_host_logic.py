@@ -121,3 +121,12 @@ def test_shard_range_partitions():
             lo, hi = dp.shard_range(n, r, w)
             cover += list(range(lo, hi))
         assert cover == list(range(n))
+
+
+def test_pack_adjacency_roundtrip():
+    rng = np.random.default_rng(1)
+    w = np.stack([synthetic.erdos_renyi(rng, 37, 0.4) for _ in range(3)])
+    bits = synthetic.pack_adjacency(w)
+    assert bits.shape == (3, 37, 2) and bits.dtype == np.uint32
+    back = ((bits[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(3, 37, 64)[:, :, :37]
+    assert (back == (w != 0)).all()
