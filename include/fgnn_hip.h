@@ -94,7 +94,7 @@ int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
 /* ---- GraphNorm statistics ------------------------------------------------------------
  * replaces torch.mean / torch.var(unbiased=False) over (N,N) and the scale of normalize
  * (models/layers.py:71-80) incl. the ragged n = sum(mask) (:79).  Combines the tile
- * partials (Chan's parallel update, fixed order) into nrm[g,c] = {mean, a, q, r2} with
+ * partials (two fixed-order wave sums: grand mean, then M2 + m (mean_t - mean)^2) into nrm[g,c] = {mean, a, q, r2} with
  *   var = M2/m, r2 = 1/(var+eps), q = 1/(2 sqrt(n (var+eps))), a = gn_weight[c] * q.     */
 int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight /* (C) or NULL=1 */,
                      const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
