@@ -31,22 +31,24 @@ constexpr int TLD = 36;              // LDS tile row stride (floats)
 constexpr int TILE_F = 32 * TLD;
 
 struct TileCtx {
-    int g, tt, p;
-    bool inb, valid;
+    int g, tt, p, i, jj;
+    bool inb;
 };
 
-DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, const int *nvalid, int j) {
+// The valid-vertex count of the graph is NOT read here: a global load at the top of every tile makes
+// the compiler drain the whole memory pipeline (s_waitcnt vmcnt(0): next-tile prefetch AND the previous
+// tile's stores).  It is fetched once per graph change, next to the per-graph records.
+DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, int j) {
     TileCtx c;
     c.g = __builtin_amdgcn_readfirstlane(active ? tile / tpg : 0);
     c.tt = active ? tile - c.g * tpg : 0;
     c.p = c.tt * FGNN_TILE + j;
     c.inb = active && c.p < P;
-    const int i = c.p / N;
-    const int jj = c.p - i * N;
-    const int nv = nvalid_of(nvalid, c.g, N);
-    c.valid = c.inb && i < nv && jj < nv;
+    c.i = c.p / N;
+    c.jj = c.p - c.i * N;
     return c;
 }
+DEVI bool tile_valid(const TileCtx &c, int nv) { return c.inb && c.i < nv && c.jj < nv; }
 
 // channel contracted by k-step k in half-wave h for a slab with S = C/2 steps: 32-channel
 // slabs use the accumulator-fragment pairing (same as the hidden layers), narrower ones (2k, 2k+1)
@@ -157,9 +159,9 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     int tile = T0 + wv;
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-    int cached_g = -1;
+    int cached_g = -1, cur_nv = A.N;
     {
-        const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, A.nvalid, j);
+        const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, j);
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
         if (tile < T1 && lane < 32) {
@@ -172,7 +174,10 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
                 rb.z = A.b.beta ? A.b.beta[lane] : 0.f;
             }
         }
-        if (tile < T1) cached_g = c.g;
+        if (tile < T1) {
+            cached_g = c.g;
+            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
+        }
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
@@ -196,7 +201,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     __syncthreads();
 
     while (tile < T1) {
-        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
+        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, j);
         if (c.g != cached_g) {        // wave-uniform; issued before the prefetch (vmcnt is in-order)
             if (lane < 32) {
                 if (normA && lane < CA) {
@@ -211,19 +216,21 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
                 }
             }
             cached_g = c.g;
+            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
         }
+        const bool c_valid = tile_valid(c, cur_nv);
         // prefetch this wave's next tile (static strided assignment)
         const int next = tile + NW;
         float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
         {
-            const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, A.nvalid, j);
+            const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, j);
             load_raw<SA>(na, va, cn, h);
             load_raw<SB>(nb, vb, cn, h);
         }
-        apply_norm<SA>(xa, recA, normA, c.valid, h);
-        apply_norm<SB>(xb, recB, normB, c.valid, h);
+        apply_norm<SA>(xa, recA, normA, c_valid, h);
+        apply_norm<SB>(xb, recB, normB, c_valid, h);
 
-        const unsigned vmask = (unsigned)__ballot(c.valid);      // bit px = pixel valid (low half-wave)
+        const unsigned vmask = (unsigned)__ballot(c_valid);      // bit px = pixel valid (low half-wave)
         const float cnt = (float)__popc(vmask);
         const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
 #pragma unroll
@@ -265,7 +272,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int chl = (r & 3) + 8 * (r >> 2);   // channel minus 4*h
-                const float v = c.valid ? acc[r] : 0.f;
+                const float v = c_valid ? acc[r] : 0.f;
                 buf_store(v, vz[m], zoff, zs0 + chl * vz[m].ld4);
                 tl[(chl + 4 * h) * TLD + j] = v;
             }

@@ -25,5 +25,5 @@ def run(B, N, reps=20):
     print('B=%d N=%d (tiles=%d)' % (B, N, 2 * B * ((N * N + 31) // 32)))
     print('   ' + '  '.join('%s=%.1f' % (k.replace('fgnn_','').replace('chan_',''), v[1] / v[0] * 1e3) for k, v in sorted(acc.items()) if 'mlp' in k or 'matmul' in k))
 
-for b in (1, 8, 16, 32, 64, 128):
+for b in ([int(a) for a in sys.argv[1:]] or (1, 8, 16, 32, 64, 128)):
     run(b, 50, reps=10)

@@ -130,3 +130,27 @@ def test_pack_adjacency_roundtrip():
     assert bits.shape == (3, 37, 2) and bits.dtype == np.uint32
     back = ((bits[:, :, :, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(3, 37, 64)[:, :, :37]
     assert (back == (w != 0)).all()
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """A Lightning-style {'state_dict': ...} file written in the reference's key/shape convention loads into the flat layout
+    (hyper-parameters inferred from the shapes) and round-trips bit-exactly."""
+    from graph_neural_net_amd import checkpoint
+    from graph_neural_net_amd.engine import ParamLayout
+    torch.manual_seed(5)
+    lay0 = ParamLayout(2, 3, 32, 32, 2)
+    sd = {k: v.clone() for k, v in lay0.unflatten(lay0.init_flat(5, 'cpu')).items()}
+    f = tmp_path / 'epoch.1-step.2.ckpt'
+    torch.save({'epoch': 1, 'state_dict': {'node_embedder.' + k: v for k, v in sd.items()}}, f)
+    layout, flat = checkpoint.load_checkpoint(str(f), 'cpu')
+    assert (layout.num_blocks, layout.depth, layout.c0) == (3, 2, 2)
+    ref_layout = ParamLayout(2, 3, 32, 32, 2)
+    assert torch.equal(flat, ref_layout.flatten(sd, 'cpu'))
+    g = tmp_path / 'out.ckpt'
+    checkpoint.save_checkpoint(str(g), layout, flat)
+    back = torch.load(str(g), weights_only=False)['state_dict']
+    assert set(back) == {'node_embedder.' + k for k in sd}
+    assert all(torch.equal(back['node_embedder.' + k], sd[k]) for k in sd)
+    bad = dict(sd); bad.pop(next(iter(bad)))
+    with pytest.raises(RuntimeError):
+        checkpoint.load_checkpoint({'state_dict': bad}, 'cpu', layout=layout)
