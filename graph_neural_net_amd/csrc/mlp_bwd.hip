@@ -23,6 +23,20 @@
 #include "fgnn_common.h"
 #include "fgnn_pack.h"
 
+#ifdef FGNN_PHASES
+// Debug build only (make phases): per-wave cycle stamps of the tile phases, summed over the wave's
+// tiles and written to a buffer set by fgnn_debug_phase_buffer().  Not part of the shipped library.
+__device__ unsigned long long *g_phase_buf = nullptr;
+__device__ int g_phase_sel = 0;       // CA * 100 + CB of the variant that records
+#define PH_DECL unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = __builtin_amdgcn_s_memtime();
+#define PH(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_last_; ph_last_ = t_; }
+#define PH_FLUSH if (g_phase_buf && g_phase_sel == CA * 100 + CB && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) g_phase_buf[((long long)blockIdx.x * NW + wv) * 12 + k_] = ph_[k_]; }
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_FLUSH
+#endif
+
 namespace {
 
 constexpr int TLD = 36;              // LDS tile row stride (floats): 144 B rows, 16-B aligned
@@ -30,22 +44,24 @@ constexpr int TILE_F = 32 * TLD;     // floats per 32-row tile
 constexpr int BWD_WG = 256;          // persistent workgroups (one per CU)
 
 struct TileCtx {
-    int g, tt, p;
-    bool inb, valid;
+    int g, tt, p, i, jj;
+    bool inb;
 };
 
-DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, const int *nvalid, int j) {
+// The valid-vertex count of the graph is NOT read here: a global load at the top of every tile makes
+// the compiler drain the whole memory pipeline (s_waitcnt vmcnt(0): next-tile prefetch AND the previous
+// tile's stores).  It is fetched once per graph change, next to the per-graph records.
+DEVI TileCtx decode_tile(int tile, bool active, int tpg, int N, int P, int j) {
     TileCtx c;
     c.g = __builtin_amdgcn_readfirstlane(active ? tile / tpg : 0);
     c.tt = active ? tile - c.g * tpg : 0;
     c.p = c.tt * FGNN_TILE + j;
     c.inb = active && c.p < P;
-    const int i = c.p / N;
-    const int jj = c.p - i * N;
-    const int nv = nvalid_of(nvalid, c.g, N);
-    c.valid = c.inb && i < nv && jj < nv;
+    c.i = c.p / N;
+    c.jj = c.p - c.i * N;
     return c;
 }
+DEVI bool tile_valid(const TileCtx &c, int nv) { return c.inb && c.i < nv && c.jj < nv; }
 
 // channel contracted by k-step k in half-wave h (same convention as mlp_fwd.hip)
 template <int S>
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const View vdxa = make_view(A.dxa, A.dxa_gstride, A.dxa_ld, A.G);
     const View vdxb = make_view(A.dxb, A.dxb_gstride, A.dxb_ld, A.G);
 
+    PH_DECL
     float *wl = smem;                                   // shared operand sets
     float *rec = smem + L::WEIGHT_F + wv * L::REC_F;    // wave-private per-graph records
     float *recA = rec, *recB = rec + 128, *recK = rec + 256;
@@ -241,10 +258,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     // is copied, so the dependent round trips of the prologue overlap into one.
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), ra = rk, rb = rk;
-    int cached_g = -1;
+    int cached_g = -1, cur_nv = A.N;
     {
         const int t = T0 + wv;
-        const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, A.nvalid, j);
+        const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, j);
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
         if (t < T1 && lane < 32) {
@@ -258,7 +275,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 rb.z = A.b.beta ? A.b.beta[lane] : 0.f;
             }
         }
-        if (t < T1) cached_g = c.g;
+        if (t < T1) {
+            cached_g = c.g;
+            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
+        }
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
@@ -278,10 +298,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         reinterpret_cast<float4 *>(recB)[lane] = rb;
     }
     __syncthreads();
-
-
+    PH(9)               // prologue: first loads issued, operand image copied, barrier
     for (int tile = T0 + wv; tile < T1; tile += NW) {
-        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, A.nvalid, j);
+        const TileCtx c = decode_tile(tile, true, tpg, A.N, P, j);
         if (c.g != cached_g) {
             // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the loads
             // below so that the in-order vmcnt wait does not drain them.
@@ -300,7 +319,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 }
             }
             cached_g = c.g;
+            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
         }
+        const bool c_valid = tile_valid(c, cur_nv);
         // early read-modify-write prefetch of dx only exists in the single-slab variants
         // (mlp1 / mlp2 accumulating into d_in); two-slab kernels re-read at the store
         constexpr bool EARLY_RMW = (CB == 0);
@@ -312,8 +333,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             f32x16 acc;
             {
                 float ya[SA > 0 ? SA : 1], yb[SB > 0 ? SB : 1];
-                norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
-                norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
+                norm_from_lds<SA>(ya, xa, recA, normA, c_valid, h);
+                norm_from_lds<SB>(yb, xb, recB, normB, c_valid, h);
+                PH(0)   // tile decode, records, x arrived + normalised
                 float b0[16];
                 load_ops<L::OFF_BV, 16>(b0, wl, lane);
 #pragma unroll
@@ -336,6 +358,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             if constexpr (EARLY_RMW) {
                 if (rmw) load_rows16(old, vdxa, c, h);
             }
+            PH(1)       // layer-0 recompute issued, dy / z / old requested
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
                 float hid[16];
@@ -364,11 +387,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 if (rmw) load_rows16(old, vdxa, c, h);
             }
         }
+        PH(2)           // hidden activations recomputed and staged
         // ---- dz from (dy, z, coef) ----
         float dpre[16];
         {
             const float4 *kp = reinterpret_cast<const float4 *>(recK) + 4 * h;
-            const float vf = c.valid ? 1.f : 0.f;      // mask multiply, see norm_from_lds
+            const float vf = c_valid ? 1.f : 0.f;      // mask multiply, see norm_from_lds
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float4 k = kp[(r & 3) + 8 * (r >> 2)];
@@ -376,6 +400,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
         }
 
+        PH(3)           // dz (waits for dy, z)
         // ---- backward through the hidden layers: l = DEPTH-1 .. 1 ----
         //   l == DEPTH-1 : D tile = S2, input tile = (DEPTH == 3 ? S1 : S0)
         //   l == 1 (DEPTH == 3): D tile = S1 (h2 is dead), input tile = S0
@@ -398,6 +423,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             dWh[l - 1] = wgrad_tile<true>(Dt, In, dWh[l - 1], db[l], lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpre[r] = hsv[r] > 0.f ? acc[r] : 0.f;
+            PH(4 + (DEPTH - 1 - l))   // hidden layer backward (dgrad + wgrad + mask)
         }
 
         // ---- layer 0: D tile = (DEPTH == 1 ? S2 : (DEPTH == 2 ? S1 : S2)); x tiles re-staged now ----
@@ -407,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             for (int r = 0; r < 16; ++r) Dt[ch_of(r, h) * TLD + j] = dpre[r];
             {
                 float ya[SA > 0 ? SA : 1];
-                norm_from_lds<SA>(ya, xa, recA, normA, c.valid, h);
+                norm_from_lds<SA>(ya, xa, recA, normA, c_valid, h);
                 if constexpr (CA < 32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) XA[ch_of(r, h) * TLD + j] = 0.f;
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
             if constexpr (CB > 0) {
                 float yb[SB > 0 ? SB : 1];
-                norm_from_lds<SB>(yb, xb, recB, normB, c.valid, h);
+                norm_from_lds<SB>(yb, xb, recB, normB, c_valid, h);
                 if constexpr (CB < 32) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) XB[ch_of(r, h) * TLD + j] = 0.f;
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             float nxa[(CA == 32 && CB == 0) ? 16 : 1];
             {
                 const int tn = tile + NW;
-                const TileCtx cn = decode_tile(tn, tn < T1, tpg, A.N, P, A.nvalid, j);
+                const TileCtx cn = decode_tile(tn, tn < T1, tpg, A.N, P, j);
                 if constexpr (CA == 32 && CB == 0) {
                     load_raw<SA>(nxa, va, cn, h);
                 } else {
@@ -438,6 +464,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                     load_raw<SB>(xb, vb, cn, h);
                 }
             }
+            PH(6)       // layer-0 staging, next x requested
             f32x16 dxa_acc, dxb_acc;
             if (A.dxa) {
                 float wt[16];
@@ -460,6 +487,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 float dummy = 0.f;
                 dW0b = wgrad_tile<false>(Dt, XB, dW0b, dummy, lane);
             }
+            PH(7)       // layer-0 dgrad + wgrad issued
             if (A.dxa) {
                 const int voff = lane_off<4>(vdxa, c, h);
                 const int s0 = c.g * vdxa.gs4;
@@ -490,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                         for (int r = 0; r < 16; ++r) {
                             const int ch = ch_of(r, h);
                             const float mean = reinterpret_cast<const float4 *>(recA)[ch].x;
-                            S1[ch * TLD + j] = c.valid ? v[r] : 0.f;
+                            S1[ch * TLD + j] = c_valid ? v[r] : 0.f;
                             S2[ch * TLD + j] = xa[r] - mean;
                         }
                         const float4 *vp = reinterpret_cast<const float4 *>(S1 + j * TLD + 16 * h);
@@ -534,6 +562,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
 #pragma unroll
                 for (int s = 0; s < SA; ++s) xa[s] = nxa[s];
             }
+            PH(8)       // dx stores (+ S1/S2 emission)
         }
     }
 
@@ -562,6 +591,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         }
     };
     __syncthreads();                       // everyone done with the operand sets and the tile buffers
+    PH(10)              // waiting for the slowest wave of the workgroup
     put_partials(smem + wv * PCOUNT);      // the whole LDS allocation is free now
     __syncthreads();
     float *out = A.wpart + (long long)blockIdx.x * PCOUNT;
@@ -571,6 +601,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         for (int w = 0; w < NW; ++w) a += smem[w * PCOUNT + e];      // fixed order
         out[e] = a;
     }
+    PH(11)              // workgroup reduction + partial store
+    PH_FLUSH
 }
 
 template <int CA, int CB, int DEPTH>
@@ -604,6 +636,14 @@ int dispatch_c(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef FGNN_PHASES
+extern "C" int fgnn_debug_phase_buffer(void *p, int ca, int cb) {
+    const int sel = ca * 100 + cb;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_sel), &sel, sizeof(sel)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int fgnn_mlp_bwd_num_workgroups(void) { return BWD_WG; }
 
