@@ -77,6 +77,13 @@ DEVI void buf_store(float x, const View &v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), v.r, voff, soff, 0);
 }
 
+// max(x, 0) as ONE instruction (v_max_i32 on the bit pattern: negative floats are negative ints).
+// fmaxf / a float compare-select both become TWO v_max_f32 (operand canonicalisation for sNaN first).
+DEVI float relu1(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+
 DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
 
 // error plumbing shared by the launchers

@@ -1,6 +1,8 @@
 // LDS operand images of the MLP kernels: layout + element definition shared by the kernels
 // (compile-time) and by fgnn_pack_operands (run-time, once per step per MLP).
-// An image is [k-step/4][lane][4] floats: element (step t, lane l) at (t>>2)*256 + l*4 + (t&3).
+// The weight part of an image is [k-step/4][lane][4] floats: element (step t, lane l) at
+// (t>>2)*256 + l*4 + (t&3).  Biases follow as a compact tail [layer][half-wave h][16] (the value a lane
+// needs, bias[ch_of(r, h)], depends on h and r only: a broadcast ds_read_b128 instead of 16 steps).
 #pragma once
 #include "fgnn_common.h"
 
@@ -10,21 +12,25 @@ HD constexpr int pk_pad4(int x) { return (x + 3) & ~3; }
 HD constexpr int pk_slab_ch(int S, int k, int h) { return S == 16 ? (k & 3) + 8 * (k >> 2) + 4 * h : 2 * k + h; }
 HD constexpr int pk_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-// ---- forward image of ONE MLP: [W0 slab a | W0 slab b | W_1..W_{d-1} | b_0..b_{d-1}] ----
+// ---- forward image of ONE MLP: [W0 slab a | W0 slab b | W_1..W_{d-1}] + bias tail b_0..b_{d-1} ----
 struct PkFwd {
-    int off_w1a, off_w1b, off_wh, off_bv, steps;
+    int off_w1a, off_w1b, off_wh, steps, bias_f, nbias, floats;
 };
 HD constexpr PkFwd pk_fwd(int ca, int cb, int depth) {
     PkFwd p{};
     p.off_w1a = 0;
     p.off_w1b = pk_pad4(ca / 2);
     p.off_wh = p.off_w1b + pk_pad4(cb / 2);
-    p.off_bv = p.off_wh + 16 * (depth - 1);
-    p.steps = p.off_bv + 16 * depth;
+    p.steps = p.off_wh + 16 * (depth - 1);
+    p.bias_f = p.steps * 64;
+    p.nbias = depth;
+    p.floats = p.bias_f + 32 * p.nbias;
     return p;
 }
+// element idx (= layer*32 + h*16 + r) of a bias tail
+HD float pk_bias_value(const float *const *bias, int idx) { return bias[idx >> 5][pk_ch(idx & 15, (idx >> 4) & 1)]; }
 // W[l]: conv weights (32, Cin_l) row-major, bias[l]: (32)
-HD float pk_fwd_value(const PkFwd &p, int ca, int cb, const float *const *W, const float *const *bias, int t, int l) {
+HD float pk_fwd_value(const PkFwd &p, int ca, int cb, const float *const *W, int t, int l) {
     const int jj = l & 31, hh = l >> 5, cin = ca + cb;
     if (t < p.off_w1b) {
         const int s = t - p.off_w1a;
@@ -34,31 +40,29 @@ HD float pk_fwd_value(const PkFwd &p, int ca, int cb, const float *const *W, con
         const int s = t - p.off_w1b;
         return s < cb / 2 ? W[0][jj * cin + ca + pk_slab_ch(cb / 2, s, hh)] : 0.f;
     }
-    if (t < p.off_bv) {
-        const int u = t - p.off_wh;
-        return W[1 + (u >> 4)][jj * FGNN_H + pk_ch(u & 15, hh)];
-    }
-    const int u = t - p.off_bv;
-    return bias[u >> 4][pk_ch(u & 15, hh)];
+    const int u = t - p.off_wh;
+    return W[1 + (u >> 4)][jj * FGNN_H + pk_ch(u & 15, hh)];
 }
 
-// ---- backward image: [W0 a | W0 b | W_1..W_{d-2} (fwd) | b_0..b_{d-2} | W_1^T..W_{d-1}^T | W0^T a | W0^T b] ----
+// ---- backward image: [W0 a | W0 b | W_1..W_{d-2} (fwd) | W_1^T..W_{d-1}^T | W0^T a | W0^T b] + bias tail b_0..b_{d-2} ----
 struct PkBwd {
-    int off_w1a, off_w1b, off_wh, off_bv, off_wt, off_wt0a, off_wt0b, steps;
+    int off_w1a, off_w1b, off_wh, off_wt, off_wt0a, off_wt0b, steps, bias_f, nbias, floats;
 };
 HD constexpr PkBwd pk_bwd(int ca, int cb, int depth) {
     PkBwd p{};
     p.off_w1a = 0;
     p.off_w1b = pk_pad4(ca / 2);
     p.off_wh = p.off_w1b + pk_pad4(cb / 2);
-    p.off_bv = p.off_wh + 16 * (depth > 2 ? depth - 2 : 0);
-    p.off_wt = p.off_bv + 16 * (depth > 1 ? depth - 1 : 0);
+    p.off_wt = p.off_wh + 16 * (depth > 2 ? depth - 2 : 0);
     p.off_wt0a = p.off_wt + 16 * (depth > 1 ? depth - 1 : 0);
     p.off_wt0b = p.off_wt0a + 16;
     p.steps = p.off_wt0b + (cb > 0 ? 16 : 0);
+    p.bias_f = p.steps * 64;
+    p.nbias = depth > 1 ? depth - 1 : 0;
+    p.floats = p.bias_f + 32 * p.nbias;
     return p;
 }
-HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, const float *const *bias, int t, int l) {
+HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, int t, int l) {
     const int jj = l & 31, hh = l >> 5, cin = ca + cb;
     if (t < p.off_w1b) {
         const int s = t - p.off_w1a;
@@ -68,13 +72,9 @@ HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, con
         const int s = t - p.off_w1b;
         return s < cb / 2 ? W[0][jj * cin + ca + pk_slab_ch(cb / 2, s, hh)] : 0.f;
     }
-    if (t < p.off_bv) {
+    if (t < p.off_wt) {
         const int u = t - p.off_wh;
         return W[1 + (u >> 4)][jj * FGNN_H + pk_ch(u & 15, hh)];
-    }
-    if (t < p.off_wt) {
-        const int u = t - p.off_bv;
-        return bias[u >> 4][pk_ch(u & 15, hh)];
     }
     if (t < p.off_wt0a) {
         const int u = t - p.off_wt;

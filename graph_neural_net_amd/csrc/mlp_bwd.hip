@@ -177,12 +177,12 @@ struct BwdLayout {
     static constexpr int OFF_W1A = PK.off_w1a;                            // SA steps: forward layer 0, slab a
     static constexpr int OFF_W1B = PK.off_w1b;                            // SB steps: forward layer 0, slab b
     static constexpr int OFF_WH = PK.off_wh;                              // 16*(DEPTH-2): forward layers 1..DEPTH-2
-    static constexpr int OFF_BV = PK.off_bv;                              // 16*(DEPTH-1): biases 0..DEPTH-2
+    static constexpr int BIAS_F = PK.bias_f;                              // compact bias tail b_0..b_{DEPTH-2}: [layer][h][16]
     static constexpr int OFF_WT = PK.off_wt;                              // 16*(DEPTH-1): W_l^T, l=1..DEPTH-1
     static constexpr int OFF_WT0A = PK.off_wt0a;                          // 16: W_0^T slab a
     static constexpr int OFF_WT0B = PK.off_wt0b;                          // 16: W_0^T slab b
     static constexpr int NSTEPS = PK.steps;
-    static constexpr int WEIGHT_F = NSTEPS * 64;                          // floats
+    static constexpr int WEIGHT_F = PK.floats;                            // floats
     static constexpr int REC_F = 3 * 32 * 4;                              // per wave: nrm a, nrm b, coef
     static constexpr int SLOT_XA = 0, SLOT_XB = 1, NSLOT = 3;             // x tiles alias the dead h1 / dpre_1 slots
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
@@ -203,6 +203,19 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int lane) {
         if (4 * q + 1 < CNT) dst[4 * q + 1] = v.y;
         if (4 * q + 2 < CNT) dst[4 * q + 2] = v.z;
         if (4 * q + 3 < CNT) dst[4 * q + 3] = v.w;
+    }
+}
+
+// bias[ch_of(r, h)], r = 0..15, of one layer from the compact tail (broadcast reads)
+DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
+    const float4 *p = reinterpret_cast<const float4 *>(tail + layer * 32 + h * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = p[q];
+        dst[4 * q + 0] = v.x;
+        dst[4 * q + 1] = v.y;
+        dst[4 * q + 2] = v.z;
+        dst[4 * q + 3] = v.w;
     }
 }
 
@@ -282,14 +295,18 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
-        pk_copy_to_lds(wl, A.packed, L::NSTEPS * 16, 64 * NW);
+        pk_copy_to_lds(wl, A.packed, L::WEIGHT_F / 4, 64 * NW);
     } else {
         const float *Wp[FGNN_MAX_DEPTH] = {A.W[0], A.W[1], A.W[2]};
         const float *Bp[FGNN_MAX_DEPTH] = {A.bias[0], A.bias[1], A.bias[2]};
         constexpr PkBwd pk = L::PK;
-        for (int e = threadIdx.x; e < L::NSTEPS * 64; e += 64 * NW) {
-            const int t = e >> 6, l = e & 63;
-            wl[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(pk, CA, CB, Wp, Bp, t, l);
+        for (int e = threadIdx.x; e < L::WEIGHT_F; e += 64 * NW) {
+            if (e < L::BIAS_F) {
+                const int t = e >> 6, l = e & 63;
+                wl[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(pk, CA, CB, Wp, t, l);
+            } else {
+                wl[e] = pk_bias_value(Bp, e - L::BIAS_F);
+            }
         }
     }
     if (lane < 32) {
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 norm_from_lds<SB>(yb, xb, recB, normB, c_valid, h);
                 PH(0)   // tile decode, records, x arrived + normalised
                 float b0[16];
-                load_ops<L::OFF_BV, 16>(b0, wl, lane);
+                load_bias(b0, wl + L::BIAS_F, 0, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = b0[r];
                 float w1a[SA > 0 ? SA : 1];
@@ -365,12 +382,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 float *Hs = (l == 1) ? S0 : S1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    hid[r] = fmaxf(acc[r], 0.f);
+                    hid[r] = relu1(acc[r]);
                     Hs[ch_of(r, h) * TLD + j] = hid[r];
                 }
                 if (l + 1 < DEPTH) {
                     float bl[16], wf[16];
-                    load_ops<L::OFF_BV + 16, 16>(bl, wl, lane);
+                    load_bias(bl, wl + L::BIAS_F, 1, h);
                     load_ops<L::OFF_WH, 16>(wf, wl, lane);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = bl[r];

@@ -106,9 +106,10 @@ struct FwdLayout {
     static constexpr int OFF_W1A = PK.off_w1a;
     static constexpr int OFF_W1B = PK.off_w1b;
     static constexpr int OFF_WH = PK.off_wh;                       // 16*(DEPTH-1)
-    static constexpr int OFF_BV = PK.off_bv;                       // 16*DEPTH
+    static constexpr int BIAS_F = PK.bias_f;                       // compact bias tail: [layer][h][16]
     static constexpr int MLP_STEPS = PK.steps;
-    static constexpr int WEIGHT_F = NMLP * MLP_STEPS * 64;
+    static constexpr int MLP_F = PK.floats;                        // floats per MLP image
+    static constexpr int WEIGHT_F = NMLP * MLP_F;
     static constexpr int REC_F = 2 * 32 * 4;                       // per wave: records of slab a, slab b
     static constexpr int LDS_F = WEIGHT_F + NW * (TILE_F + REC_F) + 4;
 };
@@ -123,6 +124,19 @@ DEVI void load_ops(float (&dst)[CNT > 0 ? CNT : 1], const float *wl, int off_ste
         if (4 * q + 1 < CNT) dst[4 * q + 1] = v.y;
         if (4 * q + 2 < CNT) dst[4 * q + 2] = v.z;
         if (4 * q + 3 < CNT) dst[4 * q + 3] = v.w;
+    }
+}
+
+// bias[ch_of(r, h)], r = 0..15, of one layer from the compact tail (broadcast reads)
+DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
+    const float4 *p = reinterpret_cast<const float4 *>(tail + layer * 32 + h * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = p[q];
+        dst[4 * q + 0] = v.x;
+        dst[4 * q + 1] = v.y;
+        dst[4 * q + 2] = v.z;
+        dst[4 * q + 3] = v.w;
     }
 }
 
@@ -181,16 +195,20 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
-        pk_copy_to_lds(wl, A.packed, NMLP * L::MLP_STEPS * 16, 64 * NW);
+        pk_copy_to_lds(wl, A.packed, L::WEIGHT_F / 4, 64 * NW);
     } else {
         constexpr PkFwd pk = L::PK;
 #pragma unroll
         for (int m = 0; m < NMLP; ++m) {
             const float *Wp[FGNN_MAX_DEPTH] = {A.W[m][0], A.W[m][1], A.W[m][2]};
             const float *Bp[FGNN_MAX_DEPTH] = {A.bias[m][0], A.bias[m][1], A.bias[m][2]};
-            for (int e = threadIdx.x; e < L::MLP_STEPS * 64; e += 64 * NW) {
-                const int t = e >> 6, l = e & 63;
-                wl[m * (L::MLP_STEPS * 64) + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(pk, CA, CB, Wp, Bp, t, l);
+            for (int e = threadIdx.x; e < L::MLP_F; e += 64 * NW) {
+                if (e < L::BIAS_F) {
+                    const int t = e >> 6, l = e & 63;
+                    wl[m * L::MLP_F + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(pk, CA, CB, Wp, t, l);
+                } else {
+                    wl[m * L::MLP_F + e] = pk_bias_value(Bp, e - L::BIAS_F);
+                }
             }
         }
     }
@@ -235,11 +253,11 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
 #pragma unroll
         for (int m = 0; m < NMLP; ++m) {
-            const float *wm = wl + m * (L::MLP_STEPS * 64);
+            const float *wm = wl + m * L::MLP_F;
             f32x16 acc;
             {
                 float b0[16];
-                load_ops<16>(b0, wm, L::OFF_BV, lane);
+                load_bias(b0, wm + L::BIAS_F, 0, h);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = b0[r];
                 float w1a[SA > 0 ? SA : 1];
@@ -256,11 +274,11 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
                 float hid[16], bl[16], wh[16];
-                load_ops<16>(bl, wm, L::OFF_BV + 16 * l, lane);
+                load_bias(bl, wm + L::BIAS_F, l, h);
                 load_ops<16>(wh, wm, L::OFF_WH + 16 * (l - 1), lane);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    hid[r] = fmaxf(acc[r], 0.f);
+                    hid[r] = relu1(acc[r]);
                     acc[r] = bl[r];
                 }
 #pragma unroll

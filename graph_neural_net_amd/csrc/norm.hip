@@ -339,18 +339,25 @@ __global__ __launch_bounds__(256) void pack_operands_kernel(const PackJobs J) {
     const fgnn_pack_job &jb = J.job[blockIdx.y];
     if (jb.kind == 0) {
         const PkFwd p = pk_fwd(jb.ca, jb.cb, jb.depth);
-        const int per = p.steps * 64;
+        const int per = p.floats;
         for (int e = blockIdx.x * 256 + threadIdx.x; e < per * jb.nmlp; e += gridDim.x * 256) {
             const int m = e / per, r = e - m * per;
-            const int t = r >> 6, l = r & 63;
-            jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], jb.bias[m], t, l);
+            if (r < p.bias_f) {
+                const int t = r >> 6, l = r & 63;
+                jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l);
+            } else {
+                jb.out[m * per + r] = pk_bias_value(jb.bias[m], r - p.bias_f);
+            }
         }
     } else {
         const PkBwd p = pk_bwd(jb.ca, jb.cb, jb.depth);
-        const int per = p.steps * 64;
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
-            const int t = e >> 6, l = e & 63;
-            jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], jb.bias[0], t, l);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.floats; e += gridDim.x * 256) {
+            if (e < p.bias_f) {
+                const int t = e >> 6, l = e & 63;
+                jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l);
+            } else {
+                jb.out[e] = pk_bias_value(jb.bias[0], e - p.bias_f);
+            }
         }
     }
 }
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(256) void pack_operands_kernel(const PackJobs J) {
 }  // namespace
 
 extern "C" int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp) {
-    return kind == 0 ? pk_fwd(ca, cb, depth).steps * 64 * nmlp : pk_bwd(ca, cb, depth).steps * 64;
+    return kind == 0 ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;
 }
 
 extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *stream) {
