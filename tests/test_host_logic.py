@@ -154,3 +154,12 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     bad = dict(sd); bad.pop(next(iter(bad)))
     with pytest.raises(RuntimeError):
         checkpoint.load_checkpoint({'state_dict': bad}, 'cpu', layout=layout)
+
+
+def test_bucket_by_size_partitions_and_orders():
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    sizes = [30, 120, 47, 48, 49, 16, 17, 120]
+    b = FgnnTrainer.bucket_by_size(sizes, 16)
+    assert [n for n, _ in b] == [16, 32, 48, 64, 128]
+    assert dict(b)[48] == [2, 3] and dict(b)[64] == [4] and dict(b)[128] == [1, 7]
+    assert sorted(i for _, idx in b for i in idx) == list(range(len(sizes)))
