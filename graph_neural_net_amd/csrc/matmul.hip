@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
 // Whole matrix per workgroup, 64 < N <= 256 (cfg4 N = 200, ragged batches padded past 64).
 // One 512-thread workgroup owns one (g,c) matrix: every operand element is read from HBM once,
 // streamed through double-buffered LDS panels in 32-wide k chunks, and all ceil(nv/32)^2 output
-// tiles of 32x32 live in the accumulators of the eight waves (<= MAXT tiles per wave).  Work is
+// tiles of 32x32 live in the accumulators of the eight waves (<= NT*NT/8 tiles per wave).  Work is
 // limited to the valid nv x nv part of a ragged graph; the padding of the output is zero-filled.
 //   Out[m][n] = sum_k OpA(m,k) OpB(k,n),  OpA(m,k) = A_KC ? MA[m][k] : MA[k][m],
 //                                         OpB(k,n) = B_KC ? MB[n][k] : MB[k][n]
@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
 // A K-contiguous (KC) panel is stored [x][kk] with a 36-float row stride (conflict-free
 // ds_read_b128 of 4 k-steps), a K-row (KR) panel [kk][x] (conflict-free ds_read_b32).
 // Inside a chunk k-step s of half-wave h contracts k = 16h + s.
+// NT (4 or 8) is the compile-time bound on tiles per side: panel shapes, sweep counts and all LDS
+// offsets are constants, every staging load / store is unconditional (out-of-range lanes read 0
+// through the buffer descriptor and land in panel rows that are never consumed).
 // =======================================================================================
 constexpr int BIG_NW = 8, BIG_THREADS = 64 * BIG_NW, BIG_KC = 32, BIG_LDK = 36;
 
@@ -465,72 +468,65 @@ struct BigSrc {
     NormRec nr;
 };
 
-DEVI int big_panel_floats(bool kc, int X) { return kc ? X * BIG_LDK : BIG_KC * X; }
+template <int NT>
+struct BigCfg {
+    static constexpr int XM = 32 * NT;                       // panel extent (rows of a KC panel, columns of a KR one)
+    static constexpr int MAXT = NT * NT / BIG_NW;            // tiles per wave
+    static constexpr int SWEEPS = XM * BIG_KC / BIG_THREADS; // elements per thread per panel
+    static constexpr int KC_F = XM * BIG_LDK, KR_F = BIG_KC * XM;
+    static constexpr int BUF_F = 2 * KC_F;                   // one buffer holds the largest pair (KC + KC)
+    static constexpr int LDS_BYTES = 2 * BUF_F * 4;
+};
 
-// global -> registers: the k0 chunk of one operand (X = 32*ntv rows/cols of the valid region)
-template <bool KC>
-DEVI void big_load(float (&x)[16], const BigSrc &s, int N, int nv, int X, int k0, int tid) {
+// global -> registers: the k0 chunk of one operand
+template <int NT, bool KC>
+DEVI void big_load(float (&x)[BigCfg<NT>::SWEEPS], const BigSrc &s, int N, int nv, int k0, int tid) {
+    using Cf = BigCfg<NT>;
     if (KC) {
         const int kk = tid & 31, xr = tid >> 5;                      // 16 rows per sweep
-        const int koff = (k0 + kk) < nv ? (k0 + kk) * 4 : OOB_OFF;
+        const int base = (k0 + kk) < nv ? (xr * N + k0 + kk) * 4 : OOB_OFF;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = xr + 16 * i;
-            x[i] = buf_load(s.v, (r < nv && koff != OOB_OFF) ? r * N * 4 + koff : OOB_OFF, s.off4);
-        }
+        for (int i = 0; i < Cf::SWEEPS; ++i)
+            x[i] = buf_load(s.v, (xr + 16 * i) < nv ? base : OOB_OFF, s.off4 + 16 * i * N * 4);
     } else {
-        int kk = tid / X, c = tid - kk * X;                          // linear walk over [32][X]
-        const int dk = BIG_THREADS / X, dc = BIG_THREADS - dk * X;
+        constexpr int RPS = BIG_THREADS / Cf::XM;                    // k rows per sweep
+        const int kk = tid / Cf::XM, c = tid % Cf::XM;
+        const int base = c < nv ? ((k0 + kk) * N + c) * 4 : OOB_OFF;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool ok = kk < BIG_KC && (k0 + kk) < nv && c < nv;
-            x[i] = buf_load(s.v, ok ? ((k0 + kk) * N + c) * 4 : OOB_OFF, s.off4);
-            kk += dk;
-            c += dc;
-            if (c >= X) {
-                c -= X;
-                ++kk;
-            }
-        }
+        for (int i = 0; i < Cf::SWEEPS; ++i)
+            x[i] = buf_load(s.v, (k0 + kk + RPS * i) < nv ? base : OOB_OFF, s.off4 + RPS * i * N * 4);
     }
 }
 
 // registers -> LDS panel, normalising on the way (padding stays exactly 0)
-template <bool KC>
-DEVI void big_stage(float *P, const float (&x)[16], const BigSrc &s, int nv, int X, int k0, int tid) {
+template <int NT, bool KC>
+DEVI void big_stage(float *P, const float (&x)[BigCfg<NT>::SWEEPS], const BigSrc &s, int nv, int k0, int tid) {
+    using Cf = BigCfg<NT>;
     if (KC) {
         const int kk = tid & 31, xr = tid >> 5;
         const bool kok = (k0 + kk) < nv;
+        float *dst = P + xr * BIG_LDK + kk;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = xr + 16 * i;
-            if (r < X) {
-                const float m = (kok && r < nv) ? 1.f : 0.f;
-                P[r * BIG_LDK + kk] = s.nr.on ? ((x[i] - s.nr.mean) * s.nr.a + s.nr.beta) * m : x[i];
-            }
+        for (int i = 0; i < Cf::SWEEPS; ++i) {
+            const float m = (kok && (xr + 16 * i) < nv) ? 1.f : 0.f;
+            dst[16 * i * BIG_LDK] = s.nr.on ? ((x[i] - s.nr.mean) * s.nr.a + s.nr.beta) * m : x[i];
         }
     } else {
-        int kk = tid / X, c = tid - kk * X;
-        const int dk = BIG_THREADS / X, dc = BIG_THREADS - dk * X;
+        constexpr int RPS = BIG_THREADS / Cf::XM;
+        const int kk = tid / Cf::XM, c = tid % Cf::XM;
+        const bool cok = c < nv;
+        float *dst = P + kk * Cf::XM + c;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (kk < BIG_KC) {
-                const float m = ((k0 + kk) < nv && c < nv) ? 1.f : 0.f;
-                P[kk * X + c] = s.nr.on ? ((x[i] - s.nr.mean) * s.nr.a + s.nr.beta) * m : x[i];
-            }
-            kk += dk;
-            c += dc;
-            if (c >= X) {
-                c -= X;
-                ++kk;
-            }
+        for (int i = 0; i < Cf::SWEEPS; ++i) {
+            const float m = (cok && (k0 + kk + RPS * i) < nv) ? 1.f : 0.f;
+            dst[RPS * i * Cf::XM] = s.nr.on ? ((x[i] - s.nr.mean) * s.nr.a + s.nr.beta) * m : x[i];
         }
     }
 }
 
 // the 16 k-steps of one 32-row (or 32-column) strip `t` of a panel, for lane (j, h)
-template <bool KC>
-DEVI void big_operand(float (&o)[16], const float *P, int X, int t, int j, int h) {
+template <int NT, bool KC>
+DEVI void big_operand(float (&o)[16], const float *P, int t, int j, int h) {
     if (KC) {
         const float4 *p = reinterpret_cast<const float4 *>(P + (32 * t + j) * BIG_LDK + 16 * h);
 #pragma unroll
@@ -542,54 +538,58 @@ DEVI void big_operand(float (&o)[16], const float *P, int X, int t, int j, int h
             o[4 * q + 3] = v.w;
         }
     } else {
-        const float *p = P + (16 * h) * X + 32 * t + j;
+        const float *p = P + (16 * h) * BigCfg<NT>::XM + 32 * t + j;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) o[s] = p[s * X];
+        for (int s = 0; s < 16; ++s) o[s] = p[s * BigCfg<NT>::XM];
     }
 }
 
 // acc[ti] (tile wv + 8*ti of the ntv x ntv valid tiles) += OpA OpB over all k chunks
-template <int MAXT, bool A_KC, bool B_KC>
-DEVI void big_gemm(f32x16 (&acc)[MAXT], const BigSrc &A, const BigSrc &B, float *lds, int N, int nv, int ntv, int tid) {
+template <int NT, bool A_KC, bool B_KC>
+DEVI void big_gemm(f32x16 (&acc)[BigCfg<NT>::MAXT], const BigSrc &A, const BigSrc &B, float *lds, int N, int nv,
+                   int ntv, int tid) {
+    using Cf = BigCfg<NT>;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const int X = 32 * ntv, T = ntv * ntv;
-    const int fa = big_panel_floats(A_KC, X), fb = big_panel_floats(B_KC, X);
-    float *PA[2] = {lds, lds + fa + fb};
-    float *PB[2] = {lds + fa, lds + 2 * fa + fb};
+    const int T = ntv * ntv;
+    constexpr int FA = A_KC ? Cf::KC_F : Cf::KR_F;
+    // (plain offsets from the __shared__ base: a runtime-indexed array of pointers makes the compiler
+    //  lose the LDS address space and emit flat_load instead of ds_read)
 #pragma unroll
-    for (int ti = 0; ti < MAXT; ++ti)
+    for (int ti = 0; ti < Cf::MAXT; ++ti)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
     const int nkc = (nv + BIG_KC - 1) / BIG_KC;
-    float xa[16], xb[16];
-    big_load<A_KC>(xa, A, N, nv, X, 0, tid);
-    big_load<B_KC>(xb, B, N, nv, X, 0, tid);
-    big_stage<A_KC>(PA[0], xa, A, nv, X, 0, tid);
-    big_stage<B_KC>(PB[0], xb, B, nv, X, 0, tid);
+    float xa[Cf::SWEEPS], xb[Cf::SWEEPS];
+    big_load<NT, A_KC>(xa, A, N, nv, 0, tid);
+    big_load<NT, B_KC>(xb, B, N, nv, 0, tid);
+    big_stage<NT, A_KC>(lds, xa, A, nv, 0, tid);
+    big_stage<NT, B_KC>(lds + FA, xb, B, nv, 0, tid);
     __syncthreads();
     for (int c = 0; c < nkc; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < nkc;
         if (more) {
-            big_load<A_KC>(xa, A, N, nv, X, (c + 1) * BIG_KC, tid);
-            big_load<B_KC>(xb, B, N, nv, X, (c + 1) * BIG_KC, tid);
+            big_load<NT, A_KC>(xa, A, N, nv, (c + 1) * BIG_KC, tid);
+            big_load<NT, B_KC>(xb, B, N, nv, (c + 1) * BIG_KC, tid);
         }
+        const float *pa = lds + cur * Cf::BUF_F, *pb = pa + FA;
 #pragma unroll
-        for (int ti = 0; ti < MAXT; ++ti) {
+        for (int ti = 0; ti < Cf::MAXT; ++ti) {
             const int t = wv + BIG_NW * ti;
             if (t < T) {
                 const int tm = t / ntv, tn = t - tm * ntv;
                 float a[16], b[16];
-                big_operand<A_KC>(a, PA[cur], X, tm, j, h);
-                big_operand<B_KC>(b, PB[cur], X, tn, j, h);
+                big_operand<NT, A_KC>(a, pa, tm, j, h);
+                big_operand<NT, B_KC>(b, pb, tn, j, h);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) acc[ti] = mfma32(a[s], b[s], acc[ti]);
             }
         }
         if (more) {
-            big_stage<A_KC>(PA[cur ^ 1], xa, A, nv, X, (c + 1) * BIG_KC, tid);
-            big_stage<B_KC>(PB[cur ^ 1], xb, B, nv, X, (c + 1) * BIG_KC, tid);
+            float *nx = lds + (cur ^ 1) * Cf::BUF_F;
+            big_stage<NT, A_KC>(nx, xa, A, nv, (c + 1) * BIG_KC, tid);
+            big_stage<NT, B_KC>(nx + FA, xb, B, nv, (c + 1) * BIG_KC, tid);
         }
         __syncthreads();
     }
@@ -597,33 +597,35 @@ DEVI void big_gemm(f32x16 (&acc)[MAXT], const BigSrc &A, const BigSrc &B, float 
 
 // accumulators -> global (rows/cols >= N dropped), optionally S1 = sum t, S2 = sum t * (raw - mean) over
 // the valid entries, `raw` re-read from the un-normalised slab
-template <int MAXT, bool WANT_S>
-DEVI void big_store(const f32x16 (&acc)[MAXT], const View &ov, int o_off4, const BigSrc &raw, int N, int nv, int ntv,
-                    float &s1, float &s2, int tid) {
+template <int NT, bool WANT_S>
+DEVI void big_store(const f32x16 (&acc)[BigCfg<NT>::MAXT], const View &ov, int o_off4, const BigSrc &raw, int N,
+                    int nv, int ntv, float &s1, float &s2, int tid) {
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int T = ntv * ntv;
 #pragma unroll
-    for (int ti = 0; ti < MAXT; ++ti) {
+    for (int ti = 0; ti < BigCfg<NT>::MAXT; ++ti) {
         const int t = wv + BIG_NW * ti;
         if (t < T) {
             const int tm = t / ntv, tn = t - tm * ntv;
             const int col = 32 * tn + j;
             const int rowb = 32 * tm + 4 * h;
+            const int base = col < N ? (rowb * N + col) * 4 : OOB_OFF;
+            const int vbase = col < nv ? (rowb * N + col) * 4 : OOB_OFF;
             float u[16];
             if (WANT_S) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + (r & 3) + 8 * (r >> 2);
-                    u[r] = buf_load(raw.v, (row < nv && col < nv) ? (row * N + col) * 4 : OOB_OFF, raw.off4);
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    u[r] = buf_load(raw.v, (rowb + dr) < nv ? vbase : OOB_OFF, raw.off4 + dr * N * 4);
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rowb + (r & 3) + 8 * (r >> 2);
-                buf_store(acc[ti][r], ov, (row < N && col < N) ? (row * N + col) * 4 : OOB_OFF, o_off4);
+                const int dr = (r & 3) + 8 * (r >> 2);
+                buf_store(acc[ti][r], ov, (rowb + dr) < N ? base : OOB_OFF, o_off4 + dr * N * 4);
                 if (WANT_S) {
-                    const float m = (row < nv && col < nv) ? 1.f : 0.f;
+                    const float m = ((rowb + dr) < nv && col < nv) ? 1.f : 0.f;
                     s1 += acc[ti][r] * m;
                     s2 += acc[ti][r] * ((u[r] - raw.nr.mean) * m);
                 }
@@ -641,12 +643,11 @@ DEVI void big_zero_fill(const View &ov, int o_off4, int N, int X, int tid) {
     }
 }
 
-DEVI BigSrc big_src(const fgnn_slab &s, int G, int g, int c, bool normalise) {
+DEVI BigSrc big_src(const fgnn_slab &s, int G, int g, int c) {
     BigSrc b;
     b.v = make_view(s.ptr, s.gstride, s.ldp, G);
     b.off4 = g * b.v.gs4 + c * b.v.ld4;
     b.nr = norm_of(s, g, c);
-    if (!normalise) b.nr.on = false;
     return b;
 }
 DEVI BigSrc big_src_plain(const float *p, long long gs, long long ld, int G, int g, int c) {
@@ -660,25 +661,25 @@ DEVI BigSrc big_src_plain(const float *p, long long gs, long long ld, int G, int
     return b;
 }
 
-template <int MAXT>
+template <int NT>
 __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_fwd_big_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                            const int *nvalid, int N, int G, float *out,
                                                                            long long ogstride, long long ldo) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
-    const BigSrc A = big_src(ya, G, g, c, true), B = big_src(yb, G, g, c, true);
+    const BigSrc A = big_src(ya, G, g, c), B = big_src(yb, G, g, c);
     const View vO = make_view(out, ogstride, ldo, G);
     const int o_off = g * vO.gs4 + c * vO.ld4;
     big_zero_fill(vO, o_off, N, 32 * ntv, tid);
     if (ntv == 0) return;
-    f32x16 acc[MAXT];
-    big_gemm<MAXT, true, false>(acc, A, B, big_lds, N, nv, ntv, tid);
+    f32x16 acc[BigCfg<NT>::MAXT];
+    big_gemm<NT, true, false>(acc, A, B, big_lds, N, nv, ntv, tid);
     float s1 = 0.f, s2 = 0.f;
-    big_store<MAXT, false>(acc, vO, o_off, A, N, nv, ntv, s1, s2, tid);
+    big_store<NT, false>(acc, vO, o_off, A, N, nv, ntv, s1, s2, tid);
 }
 
-template <int MAXT>
+template <int NT>
 __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                            const float *dm, long long dmg, long long ldm,
                                                                            const int *nvalid, int N, int G, float *da,
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
-    const BigSrc A = big_src(ya, G, g, c, true), B = big_src(yb, G, g, c, true);
+    const BigSrc A = big_src(ya, G, g, c), B = big_src(yb, G, g, c);
     const BigSrc D = big_src_plain(dm, dmg, ldm, G, g, c);
     const View vOA = make_view(da, ogstride, ldo, G), vOB = make_view(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs4 + c * vOA.ld4;
@@ -697,13 +698,13 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
     big_zero_fill(vOB, o_off, N, 32 * ntv, tid);
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     if (ntv > 0) {
-        f32x16 acc[MAXT];
-        big_gemm<MAXT, true, true>(acc, D, B, big_lds, N, nv, ntv, tid);          // dA = dM Yb^T
-        if (s12a) big_store<MAXT, true>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
-        else big_store<MAXT, false>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
-        big_gemm<MAXT, false, false>(acc, A, D, big_lds, N, nv, ntv, tid);        // dB = Ya^T dM
-        if (s12a) big_store<MAXT, true>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
-        else big_store<MAXT, false>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
+        f32x16 acc[BigCfg<NT>::MAXT];
+        big_gemm<NT, true, true>(acc, D, B, big_lds, N, nv, ntv, tid);          // dA = dM Yb^T
+        if (s12a) big_store<NT, true>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
+        else big_store<NT, false>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
+        big_gemm<NT, false, false>(acc, A, D, big_lds, N, nv, ntv, tid);        // dB = Ya^T dM
+        if (s12a) big_store<NT, true>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
+        else big_store<NT, false>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
     }
     if (s12a) {
         sa1 = wave_sum(sa1);
@@ -727,16 +728,7 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
     }
 }
 
-// dynamic LDS of the big kernels: two buffers of the largest panel pair (KC + KC)
-inline int big_lds_bytes(int N) {
-    const int X = 32 * ((N + 31) / 32);
-    return 2 * 2 * X * BIG_LDK * 4;
-}
 inline bool big_path(int N) { return N > TM && N <= 256; }
-inline int big_maxt(int N) {
-    const int nt = (N + 31) / 32, T = nt * nt;
-    return (T + BIG_NW - 1) / BIG_NW;
-}
 
 }  // namespace
 
@@ -760,20 +752,18 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
         FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
                    (long long)G * ogstride < 0x7fffffffll / 4,
                    "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
-        const int lds = big_lds_bytes(N), mt = big_maxt(N);
 #define FGNN_BIG_FWD(MT)                                                                                              \
     {                                                                                                                 \
         static bool attr = false;                                                                                     \
         if (!attr) {                                                                                                  \
             (void)hipFuncSetAttribute((const void *)chan_matmul_fwd_big_kernel<MT>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<MT>::LDS_BYTES);             \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL(chan_matmul_fwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), lds,                   \
+        hipLaunchKernelGGL(chan_matmul_fwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
                            (hipStream_t)stream, *ya, *yb, nvalid, N, G, out, ogstride, ldo);                          \
     }
-        if (mt <= 2) FGNN_BIG_FWD(2)
-        else if (mt <= 4) FGNN_BIG_FWD(4)
+        if (N <= 128) FGNN_BIG_FWD(4)
         else FGNN_BIG_FWD(8)
 #undef FGNN_BIG_FWD
         FGNN_LAUNCH_CHECK();
@@ -809,21 +799,19 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
         FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
                    (long long)G * dmgstride < 0x7fffffffll / 4 && (long long)G * ogstride < 0x7fffffffll / 4,
                    "fgnn_chan_matmul_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
-        const int lds = big_lds_bytes(N), mt = big_maxt(N);
 #define FGNN_BIG_BWD(MT)                                                                                              \
     {                                                                                                                 \
         static bool attr = false;                                                                                     \
         if (!attr) {                                                                                                  \
             (void)hipFuncSetAttribute((const void *)chan_matmul_bwd_big_kernel<MT>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<MT>::LDS_BYTES);             \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), lds,                   \
+        hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
                            (hipStream_t)stream, *ya, *yb, dm, dmgstride, ldm, nvalid, N, G, da, db, ogstride, ldo,    \
                            s12a, s12b);                                                                               \
     }
-        if (mt <= 2) FGNN_BIG_BWD(2)
-        else if (mt <= 4) FGNN_BIG_BWD(4)
+        if (N <= 128) FGNN_BIG_BWD(4)
         else FGNN_BIG_BWD(8)
 #undef FGNN_BIG_BWD
         FGNN_LAUNCH_CHECK();

@@ -58,7 +58,32 @@ void run(int waves_per_simd) {
     hipFree(out); hipFree(cyc);
 }
 
+// effective shader clock under a sustained pure-MFMA load: wall time of N dependent MFMAs at 64 cycles each
+void clock_probe(int waves_per_simd) {
+    const int threads = 256 * waves_per_simd, blocks = 256, iters = 40000;
+    float *out; unsigned long long *cyc;
+    hipMalloc(&out, blocks * threads * 4); hipMalloc(&cyc, blocks * 8 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<1, 0, 0, 0><<<blocks, threads>>>(out, cyc, 1000);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k<1, 0, 0, 0><<<blocks, threads>>>(out, cyc, iters);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> h(blocks * threads / 64);
+    hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
+    double s = 0; for (auto v : h) s += v;
+    const double cycles = s / h.size();
+    const double mfma_per_simd = (double)iters * 16 * waves_per_simd;
+    printf("clock probe, %d waves/SIMD: %.2f ms wall, %.0f s_memtime ticks per wave -> %.3f GHz tick rate; %.1f ticks per MFMA; "
+           "fp32 MFMA rate %.1f TFLOP/s (256 CUs)\n", waves_per_simd, ms, cycles, cycles / (ms * 1e6), cycles / (iters * 16.0 * waves_per_simd),
+           mfma_per_simd * 1024 * 4096 / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(cyc);
+}
+
 int main() {
+    clock_probe(1); clock_probe(2);
     for (int w = 1; w <= 2; ++w) {
         run<1, 0, 0, 0>(w); run<1, 1, 0, 0>(w); run<1, 4, 0, 0>(w); run<1, 8, 0, 0>(w); run<1, 12, 0, 0>(w); run<1, 16, 0, 0>(w);
         run<2, 0, 0, 0>(w); run<2, 1, 0, 0>(w); run<2, 4, 0, 0>(w); run<2, 8, 0, 0>(w); run<2, 12, 0, 0>(w); run<2, 16, 0, 0>(w);
