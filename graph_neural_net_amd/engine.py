@@ -328,7 +328,10 @@ class FgnnEngine:
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
-        W['gscale'].fill_(grad_scale / self.total_nodes)
+        gs = grad_scale / self.total_nodes
+        if W.get('gscale_value') != gs:        # a 1-element fill kernel per step otherwise
+            W['gscale'].fill_(gs)
+            W['gscale_value'] = gs
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
