@@ -204,6 +204,48 @@ def test_cfg5_shape_ragged_30_120():
     assert (a - b).norm() / b.norm() < 2e-3
 
 
+@pytest.mark.parametrize('B,N', [(1, 1), (1, 2), (2, 3), (1, 31), (3, 33), (1, 64), (1, 65), (1, 97)])
+def test_degenerate_and_boundary_shapes(B, N):
+    """Smallest graphs (n = 1: zero variance everywhere), a single pair, and sizes straddling the tile (32),
+    single-tile matmul (64) and whole-matrix matmul (65+) boundaries: scores, loss and gradients vs the oracle."""
+    torch.manual_seed(100 + N)
+    sd = O.init_state_dict(num_blocks=2)
+    x1, x2 = synthetic.make_batch(9000 + N, B, N, 'ErdosRenyi', 0.5, 0.1)
+    s_ref, l_ref, g_ref = O.step_fwd_bwd(x1, x2, sd)
+    eng, params, lay, scores, loss, grads = _run_engine(sd, x1, x2, 2)
+    assert torch.isfinite(scores).all() and all(torch.isfinite(g).all() for g in grads.values())
+    assert rel(scores, s_ref) < 1e-4 or (scores - s_ref).abs().max() < 1e-6
+    assert abs(loss - l_ref.item()) <= 1e-5 * abs(l_ref.item()) + 1e-7
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
+    # (n = 2: the exact gradient is 0 by symmetry; ours is fp32 rounding noise of ~1e-7 per entry)
+    assert (a - b).norm() <= 5e-3 * b.norm() + 1e-4
+
+
+def test_ragged_with_single_vertex_and_full_size_graphs():
+    """A ragged batch mixing n = 1, n = 2 and n = Nmax graphs."""
+    torch.manual_seed(77)
+    sd = O.init_state_dict(num_blocks=2)
+    rng = np.random.default_rng(77)
+    xs, ys = [], []
+    for n in (1, 40, 2, 17, 40):
+        a, b = synthetic.make_pair(rng, n, 'ErdosRenyi', 0.5, 0.1)
+        xs.append(torch.from_numpy(a)); ys.append(torch.from_numpy(b))
+    s_ref, l_ref, g_ref = O.step_fwd_bwd_ragged(xs, ys, sd)
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    eng, params, lay, scores, loss, grads = _run_engine(sd, x1, x2, 2, nvalid=nv)
+    for i, n in enumerate(nv.tolist()):
+        assert rel(scores[i, :n, :n], s_ref[i]) < 1e-4 or (scores[i, :n, :n] - s_ref[i]).abs().max() < 1e-6
+        assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
+    assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
+    assert (a - b).norm() < 5e-3 * b.norm()
+
+
 def test_ragged_bucketed_step_equals_padded_batch_and_oracle():
     """Size-bucketed ragged step (one engine pass per size class) == per-graph dense oracle."""
     from graph_neural_net_amd.trainer import FgnnTrainer
