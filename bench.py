@@ -238,6 +238,7 @@ def main():
             out['cpu_baseline'] = None
         print(json.dumps(out))
     if world > 1:
+        dp.barrier()            # rank 0 is still in its roofline leg while the others are done
         torch.distributed.destroy_process_group()
 
 
