@@ -55,7 +55,7 @@ class MlpBwdArgs(C.Structure):
 
 class GradJob(C.Structure):
     _fields_ = [('wpart', C.c_void_p), ('count', C.c_int), ('out', C.c_void_p), ('s12', C.c_void_p),
-                ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p)]
+                ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p), ('rows', C.c_int), ('scale', C.c_float)]
 
 
 class PackJob(C.Structure):
@@ -83,6 +83,8 @@ _SIGNATURES = {
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_chan_matmul_fwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_chan_matmul_fwd_fin_supported': [_I],
+    'fgnn_chan_matmul_fwd_fin': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_colmax_fwd': [C.POINTER(Slab), _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_score_ce_fwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],

@@ -7,6 +7,7 @@
 //   forward : M  = Ya @ Yb
 //   backward: dA = dM @ Yb^T,   dB = Ya^T @ dM
 #include "fgnn_common.h"
+#include "fgnn_norm.h"
 
 namespace {
 
@@ -306,11 +307,23 @@ DEVI void finish_tile(float (&v)[16], float (&u)[16], const float (&x)[16], int 
 
 // One workgroup per (g,c) matrix.  (A persistent, software-pipelined variant was measured slower:
 // the kernel is instruction-issue bound, not load-latency bound, and the prefetch registers spilled.)
+// FIN: the GraphNorm records of both operands do not exist yet -- the workgroup finalizes them itself from
+// the tile statistics its producer (the mlp1 + mlp2 forward launch) left behind, while its tile loads are in
+// flight (wave 0: operand a, wave 1: operand b), and publishes them for every later consumer.  This is the
+// work of fgnn_gn_finalize2, without its launch.
+struct FinArgs {
+    const float *part_a, *part_b, *cnt, *gw_a, *gw_b;
+    float *nrm_a, *nrm_b;
+    float eps;
+    int tpg;
+};
+template <bool FIN>
 __global__ __launch_bounds__(256, 4) void chan_matmul_fwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                const int *nvalid, int N, int M, float *out,
-                                                               long long ogstride, long long ldo) {
+                                                               long long ogstride, long long ldo, const FinArgs F) {
     __shared__ float As[TM * LDS_LD];
     __shared__ float Bs[TM * LDS_LD];
+    __shared__ float4 fin_rec[2];
     const int C = ya.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qi = wave >> 1, qj = wave & 1;
@@ -323,9 +336,27 @@ __global__ __launch_bounds__(256, 4) void chan_matmul_fwd1_kernel(const fgnn_sla
     {
         const int g = gc / C, c = gc - g * C;
         const int nv = nvalid_of(nvalid, g, N);
+        TilePartials tp;
+        if (FIN && wave < 2) tp = finalize_load(wave ? F.part_b : F.part_a, F.cnt, g, c, C, F.tpg, lane);   // first in flight
         load_tile_raw(xa, vA, g * vA.gs4 + c * vA.ld4, N, nv, tid);
         load_tile_raw(xb, vB, g * vB.gs4 + c * vB.ld4, N, nv, tid);
-        const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+        NormRec na, nb;
+        if (FIN) {
+            if (wave < 2) {
+                const float4 r = finalize_reduce(tp, (float)nv, (wave ? F.gw_b : F.gw_a) ? (wave ? F.gw_b : F.gw_a)[c] : 1.f, F.eps);
+                if (lane == 0) {
+                    fin_rec[wave] = r;
+                    reinterpret_cast<float4 *>(wave ? F.nrm_b : F.nrm_a)[gc] = r;
+                }
+            }
+            __syncthreads();
+            const float4 ra = fin_rec[0], rb = fin_rec[1];
+            na.on = true; na.mean = ra.x; na.a = ra.y; na.beta = ya.beta ? ya.beta[c] : 0.f;
+            nb.on = true; nb.mean = rb.x; nb.a = rb.y; nb.beta = yb.beta ? yb.beta[c] : 0.f;
+        } else {
+            na = norm_of(ya, g, c);
+            nb = norm_of(yb, g, c);
+        }
         const int o_off = g * vO.gs4 + c * vO.ld4;
         {
             float va[16], vb[16];
@@ -743,8 +774,8 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
                    "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
         FGNN_CHECK((long long)G * ogstride < 0x7fffffffll / 4, "fgnn_chan_matmul_fwd: output exceeds 2 GiB");
         const int M = G * ya->C;
-        hipLaunchKernelGGL(chan_matmul_fwd1_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
-                           N, M, out, ogstride, ldo);
+        hipLaunchKernelGGL(chan_matmul_fwd1_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
+                           N, M, out, ogstride, ldo, FinArgs{});
         FGNN_LAUNCH_CHECK();
         return 0;
     }
@@ -771,6 +802,28 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
     }
     hipLaunchKernelGGL(chan_matmul_fwd_kernel, dim3(t, t, G * ya->C), dim3(256), 0, (hipStream_t)stream, *ya, *yb,
                        nvalid, N, out, ogstride, ldo);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_chan_matmul_fwd_fin_supported(int N) { return N <= TM ? 1 : 0; }
+
+extern "C" int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                                        const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                        const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
+                                        void *stream) {
+    FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr && part_a && part_b && cnt, "fgnn_chan_matmul_fwd_fin: null argument");
+    FGNN_CHECK(ya->nrm && yb->nrm, "fgnn_chan_matmul_fwd_fin: the slabs must carry the record buffers to fill");
+    FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_fwd_fin: bad shapes");
+    FGNN_CHECK(N <= TM, "fgnn_chan_matmul_fwd_fin: N=%d > %d (use fgnn_gn_finalize2 + fgnn_chan_matmul_fwd)", N, TM);
+    FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
+               (long long)G * ogstride < 0x7fffffffll / 4,
+               "fgnn_chan_matmul_fwd_fin: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
+    const int M = G * ya->C;
+    FinArgs F = {part_a, part_b, cnt, gn_weight_a, gn_weight_b, const_cast<float *>(ya->nrm), const_cast<float *>(yb->nrm), eps,
+                 fgnn_tiles_per_graph(N)};
+    hipLaunchKernelGGL(chan_matmul_fwd1_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid, N, M, out,
+                       ogstride, ldo, F);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
-    constexpr int CIN = CA + CB, SA = CA / 2, SB = CB / 2;
+    constexpr int SA = CA / 2, SB = CB / 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int P = A.N * A.N;

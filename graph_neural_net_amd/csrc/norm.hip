@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include "fgnn_common.h"
 #include "fgnn_pack.h"
+#include "fgnn_norm.h"
 
 static thread_local char g_err[512] = "";
 
@@ -21,15 +22,7 @@ extern "C" int fgnn_version(void) { return 1; }
 namespace {
 
 DEVI void write_nrm(float *nrm, long long idx, float mean, float m2, float m, float nv, float w, float eps) {
-    const float var = m > 0.f ? m2 / m : 0.f;
-    const float ve = var + eps;
-    const float q = 1.f / (2.f * sqrtf(nv * ve));
-    float4 o;
-    o.x = mean;
-    o.y = w * q;
-    o.z = q;
-    o.w = 1.f / ve;
-    reinterpret_cast<float4 *>(nrm)[idx] = o;
+    reinterpret_cast<float4 *>(nrm)[idx] = nrm_record(mean, m2, m, nv, w, eps);
 }
 
 // Chan's pairwise combination of (n, mean, M2) records.
@@ -61,34 +54,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, 
     if (idx >= G * C) return;
     const int lane = threadIdx.x & 63;
     const int g = idx / C, c = idx - g * C;
-    float nb[4], mb[4], qb[4];           // up to 256 tiles per graph in registers (N <= 90); else looped below
     float sn = 0.f, sm = 0.f;
     const int nt = (tpg + WAVE - 1) / WAVE;
-    if (nt <= 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = lane + WAVE * k;
-            const bool ok = t < tpg;
-            const int tc = ok ? t : 0;
-            const float n = cnt[(long long)g * tpg + tc];
-            const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + tc) * C + c];
-            nb[k] = ok ? n : 0.f;
-            mb[k] = pm.x;
-            qb[k] = ok ? pm.y : 0.f;
-            sn += nb[k];
-            sm += nb[k] * mb[k];
-        }
-        sn = wave_sum(sn);
-        sm = wave_sum(sm);
-        const float mean = sn > 0.f ? sm / sn : 0.f;
-        float m2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float d = mb[k] - mean;
-            m2 += qb[k] + nb[k] * d * d;
-        }
-        m2 = wave_sum(m2);
-        if (lane == 0) write_nrm(nrm, idx, mean, m2, sn, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
+    if (nt <= 4) {       // up to 256 tiles per graph (N <= 90) in registers; else looped below
+        const float4 r = finalize_wave(part, cnt, g, c, C, tpg, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps, lane);
+        if (lane == 0) reinterpret_cast<float4 *>(nrm)[idx] = r;
     } else {
         for (int t = lane; t < tpg; t += WAVE) {
             const float n = cnt[(long long)g * tpg + t];
@@ -324,7 +294,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J, in
     const fgnn_grad_job &jb = J.job[blockIdx.y];
     const int nblk = (jb.count + 63) / 64;
     if ((int)blockIdx.x < nblk) {
-        reduce_cols(jb.wpart, num_wg, jb.count, 1.f, jb.out, blockIdx.x, sm);
+        reduce_cols(jb.wpart, jb.rows > 0 ? jb.rows : num_wg, jb.count, jb.scale != 0.f ? jb.scale : 1.f, jb.out, blockIdx.x, sm);
     } else if ((int)blockIdx.x == gridDim.x - 1 && jb.s12) {
         affine_reduce(jb.s12, jb.nrm, G, C, jb.dgn_w, jb.dgn_b, sm);
     }

@@ -187,7 +187,9 @@ class FgnnEngine:
                 jobs[i].out = buf.data_ptr()
             _lib.call('fgnn_pack_operands', jobs, len(chunk), _lib.stream_ptr())
 
-    def _mlp_fwd(self, params, k, js, a, b):
+    def _mlp_fwd(self, params, k, js, a, b, finalize=True):
+        """finalize=False: leave the tile statistics of the two MLPs un-finalized (the matmul that consumes them
+        finalizes them in its own prologue, fgnn_chan_matmul_fwd_fin)."""
         L = self.layout
         args = _lib.MlpFwdArgs()
         args.G, args.N, args.depth, args.nmlp = self.G, self.N, L.depth, len(js)
@@ -207,6 +209,8 @@ class FgnnEngine:
         args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        if not finalize:
+            return
         if len(js) == 2:
             r0, r1 = L.mlp[(k, js[0])], L.mlp[(k, js[1])]
             _lib.call('fgnn_gn_finalize2', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
@@ -234,17 +238,27 @@ class FgnnEngine:
         self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
-            self._mlp_fwd(params, k, (1, 2), sin, None)
+            fin = bool(_lib.load().fgnn_chan_matmul_fwd_fin_supported(self.N))
+            self._mlp_fwd(params, k, (1, 2), sin, None, finalize=not fin)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
-            _lib.call('fgnn_chan_matmul_fwd', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
-                      _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st)
+            if fin:     # the matmul finalizes the GraphNorm records of mlp1 / mlp2 itself (one launch less)
+                r1, r2 = L.mlp[(k, 1)], L.mlp[(k, 2)]
+                _lib.call('fgnn_chan_matmul_fwd_fin', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
+                          _lib.ptr(self.cnt), C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r2['gn_w'])),
+                          EPS, self._nv(), self.G, self.N, _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st,
+                          tag='fgnn_chan_matmul_fwd')
+            else:
+                _lib.call('fgnn_chan_matmul_fwd', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
+                          _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st)
             self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
         out = self._slab_z(L.num_blocks, 3, params)
         _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
 
-    def forward(self, params, x, nvalid=None, total_nodes=None):
-        """Siamese forward on the stacked batch x = cat(x1, x2): returns (scores, loss)."""
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False):
+        """Siamese forward on the stacked batch x = cat(x1, x2): returns (scores, loss).
+        defer_loss: leave the final sum of the per-pair losses to the gradient-finalize launch of the
+        following backward() (one launch less per training step); `loss` is valid after that."""
         self.embed(params, x, nvalid)
         B, N = self.B, self.N
         st = _lib.stream_ptr()
@@ -254,8 +268,10 @@ class FgnnEngine:
         if total_nodes is None:
             total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
         self.total_nodes = float(total_nodes)
-        _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
-                  _lib.ptr(self.loss), st)
+        self._loss_pending = bool(defer_loss)
+        if not defer_loss:
+            _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
+                      _lib.ptr(self.loss), st)
         return self.scores, self.loss
 
     # ------------------------------------------------------------------ backward
@@ -373,10 +389,20 @@ class FgnnEngine:
             dy = din
         # ---- one launch: reduce the workgroup partials + GraphNorm affine gradients of all MLPs ----
         keys = [(k, j) for k in range(1, K + 1) for j in (1, 2, 3)]
+        if getattr(self, '_loss_pending', False):
+            keys.append('loss')
+            self._loss_pending = False
         for lo in range(0, len(keys), _lib.MAX_GRAD_JOBS):
             chunk = keys[lo:lo + _lib.MAX_GRAD_JOBS]
             jobs = (_lib.GradJob * len(chunk))()
             for i, kj in enumerate(chunk):
+                if kj == 'loss':        # loss = sum(pair_loss) / nodes rides along as one more reduction job
+                    jobs[i].wpart = self.pair_loss.data_ptr()
+                    jobs[i].count = 1
+                    jobs[i].out = self.loss.data_ptr()
+                    jobs[i].rows = self.B * _lib.FGNN_SCORE_SPLIT
+                    jobs[i].scale = 1.0 / self.total_nodes
+                    continue
                 rec = L.mlp[kj]
                 jobs[i].wpart = W['wpart'][kj].data_ptr()
                 jobs[i].count = rec['count']
@@ -390,7 +416,7 @@ class FgnnEngine:
 
     def step(self, params, grads, x, nvalid=None, total_nodes=None):
         """One training step's model work: forward + loss + backward."""
-        scores, loss = self.forward(params, x, nvalid, total_nodes)
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True)
         self.backward(params, grads)
         return scores, loss
 

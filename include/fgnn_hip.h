@@ -113,6 +113,14 @@ int fgnn_gn_apply(const float *z, long long zgstride, long long ldz, const float
  * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
 int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
                          float *out, long long ogstride, long long ldo, void *stream);
+/* The same product with the work of fgnn_gn_finalize2 folded into its prologue (single-tile matrices, N <= 64):
+ * each (g,c) workgroup finalizes the two GraphNorm records it needs from the tile statistics (part_a / part_b /
+ * cnt of the preceding two-MLP fgnn_mlp_fwd call) while its tile loads are in flight, normalises with them and
+ * writes them to ya->nrm / yb->nrm for the later consumers -- one launch less per block.                     */
+int fgnn_chan_matmul_fwd_fin_supported(int N);
+int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                             const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                             const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo, void *stream);
 
 /* ---- ColumnMaxPooling.forward (models/layers.py:202-203; masked: maskedtensor.py:213-228)
  * e[g,c,i] = max_j y[g,c,i,j] (first index on ties), idx int32; rows i >= nvalid -> 0.   */
@@ -204,6 +212,8 @@ int fgnn_reduce_partials(const float *wpart, int num_wg, int count, float *out, 
 typedef struct {
     const float *wpart; int count; float *out;
     const float *s12; const float *nrm; float *dgn_w; float *dgn_b;
+    int rows;      /* rows of wpart to sum; 0 = num_wg (the MLP backward partials) */
+    float scale;   /* factor applied to the sums; 0 = 1 (lets the loss = sum pair_loss / nodes ride along) */
 } fgnn_grad_job;
 int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream);
 
