@@ -93,7 +93,7 @@ DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const float *rec, bool on, bool 
 }
 
 // LDS operand sets of one MLP (units: k-steps; one float per lane per step)
-// waves per workgroup: 3 per SIMD where the kernel fits 168 VGPRs, else 2 per SIMD
+// waves per workgroup: 4 per SIMD (the forward kernels need <= 128 VGPRs); one workgroup per CU
 template <int CA, int CB>
 constexpr int fwd_waves() { return 16; }
 
@@ -111,7 +111,7 @@ struct FwdLayout {
     static constexpr int MLP_F = PK.floats;                        // floats per MLP image
     static constexpr int WEIGHT_F = NMLP * MLP_F;
     static constexpr int REC_F = 2 * 32 * 4;                       // per wave: records of slab a, slab b
-    static constexpr int LDS_F = WEIGHT_F + NW * (TILE_F + REC_F) + 4;
+    static constexpr int LDS_F = WEIGHT_F + NW * (TILE_F + REC_F);
 };
 
 template <int CNT>
@@ -153,19 +153,17 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     float *wl = smem;
     float *tl = smem + L::WEIGHT_F + wv * TILE_F;
     float *recA = smem + L::WEIGHT_F + NW * TILE_F + wv * L::REC_F, *recB = recA + 128;
-    int *ctr = reinterpret_cast<int *>(smem + L::WEIGHT_F + NW * (TILE_F + L::REC_F));
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
     View vz[NMLP];
 #pragma unroll
     for (int m = 0; m < NMLP; ++m) vz[m] = make_view(A.z[m], FGNN_H * A.ldz, A.ldz, A.G);
 
-    // contiguous tile range of this workgroup; waves pull tiles from the LDS counter
+    // contiguous tile range of this workgroup; wave w takes tiles T0 + w, T0 + w + NW, ... (static)
     const int nwg = gridDim.x;
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
     const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
     const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
-    (void)ctr;
 
     // The first tile's input slabs and per-graph records are requested BEFORE the operand image
     // is copied, so the three dependent round trips of the prologue overlap into one.

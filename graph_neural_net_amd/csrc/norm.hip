@@ -25,18 +25,6 @@ DEVI void write_nrm(float *nrm, long long idx, float mean, float m2, float m, fl
     reinterpret_cast<float4 *>(nrm)[idx] = nrm_record(mean, m2, m, nv, w, eps);
 }
 
-// Chan's pairwise combination of (n, mean, M2) records.
-DEVI void chan_combine(float &n, float &mean, float &m2, float nb, float mb, float m2b) {
-    const float nn = n + nb;
-    if (nb > 0.f) {
-        const float delta = mb - mean;
-        const float f = nb / nn;
-        mean += delta * f;
-        m2 += m2b + delta * delta * (n * f);
-        n = nn;
-    }
-}
-
 // one wave per (g, c, MLP): exact two-level decomposition with plain (fixed-tree) wave sums,
 //   mean = sum_t n_t mean_t / sum_t n_t,   M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
 // (no cancellation: the between-tile term is formed from differences of means).
