@@ -89,37 +89,55 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
     }
 }
 
-// one wave per (g,c): each lane writes whole rows of dy (zeros + one scattered value) and the
-// wave accumulates the GraphNorm-backward sums S1 = sum de, S2 = sum de * (z[i, idx] - mean).
-__global__ void colmax_bwd_kernel(const float *de, const int *idx, const int *nvalid, int G, int C, int N,
-                                  float *dy, long long gstride, long long ldp, const fgnn_slab y, float *s12) {
-    const int gc = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
-    if (gc >= G * C) return;
-    const int lane = threadIdx.x & 63;
+// one workgroup per (g,c): the rows' (argmax, d e) pairs are staged in LDS, then the workgroup walks the
+// matrix linearly (coalesced stores: zeros + one scattered value per row) and accumulates the GraphNorm-
+// backward sums S1 = sum de, S2 = sum de * (z[i, idx] - mean) (fixed-order reduction).
+constexpr int CMB_MAXN = 1024;    // rows staged per workgroup; larger N falls back to per-element global reads
+__global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const int *idx, const int *nvalid, int G, int C,
+                                                         int N, float *dy, long long gstride, long long ldp,
+                                                         const fgnn_slab y, float *s12) {
+    __shared__ int sidx[CMB_MAXN];
+    __shared__ float sde[CMB_MAXN];
+    __shared__ float red[4][2];
+    const int gc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = gc / C, c = gc - g * C;
     const int nv = nvalid_of(nvalid, g, N);
     float *mat = dy + (long long)g * gstride + (long long)c * ldp;
     const float *zm = s12 ? y.ptr + (long long)g * y.gstride + (long long)c * y.ldp : nullptr;
     const float mean = s12 ? y.nrm[(long long)gc * 4] : 0.f;
+    const bool staged = N <= CMB_MAXN;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = lane; i < N; i += WAVE) {
+    for (int i = tid; i < N; i += 256) {
         const long long t = (long long)gc * N + i;
         const int bi = idx[t];
         const float d = i < nv ? de[t] : 0.f;
-        float *row = mat + (long long)i * N;
-        for (int j = 0; j < N; ++j) row[j] = (j == bi) ? d : 0.f;
+        if (staged) {
+            sidx[i] = bi;
+            sde[i] = d;
+        }
         if (s12 && i < nv) {
             s1 += d;
             s2 += d * (zm[(long long)i * N + bi] - mean);
         }
     }
+    __syncthreads();
+    const float invN = 1.f / (float)N;
+    for (int p = tid; p < N * N; p += 256) {
+        const int i = (int)(((float)p + 0.5f) * invN);
+        const int j = p - i * N;
+        const int bi = staged ? sidx[i] : idx[(long long)gc * N + i];
+        const float d = staged ? sde[i] : (i < nv ? de[(long long)gc * N + i] : 0.f);
+        mat[p] = (j == bi) ? d : 0.f;
+    }
     if (s12) {
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) {
-            s12[(long long)gc * 2] = s1;
-            s12[(long long)gc * 2 + 1] = s2;
+            red[wave][0] = s1;
+            red[wave][1] = s2;
         }
+        __syncthreads();
+        if (tid < 2) s12[(long long)gc * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     }
 }
 
@@ -290,7 +308,7 @@ extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvali
     fgnn_slab ys = {};
     if (s12) ys = *y;
     const int tot = G * C;
-    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream, de,
+    hipLaunchKernelGGL(colmax_bwd_kernel, dim3((unsigned)tot), dim3(256), 0, (hipStream_t)stream, de,
                        idx, nvalid, G, C, N, dy, gstride, ldp, ys, s12);
     FGNN_LAUNCH_CHECK();
     return 0;
