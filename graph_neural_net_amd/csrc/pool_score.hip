@@ -6,11 +6,15 @@
 
 namespace {
 
-// generic: one thread per (g,c,i) row (used when a matrix does not fit the LDS staging below)
-__global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, int N, float *e, int *idx) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// generic (N > 64): one wave per (g,c,i) row, lanes stride the columns (coalesced); the arg-max keeps the
+// FIRST maximum (torch.max semantics): each lane scans its columns in ascending order, the wave reduction
+// prefers the larger value and, on equal values, the smaller column.
+__global__ __launch_bounds__(256) void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, int N, float *e,
+                                                         int *idx) {
+    const long long t = (long long)blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     const int C = y.C;
     if (t >= (long long)G * C * N) return;
+    const int lane = threadIdx.x & 63;
     const int i = (int)(t % N);
     const int gc = (int)(t / N);
     const int g = gc / C, c = gc - g * C;
@@ -27,7 +31,8 @@ __global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, i
             be = y.beta ? y.beta[c] : 0.f;
         }
         best = -FLT_MAX;
-        for (int j = 0; j < nv; ++j) {
+        bi = 0x7fffffff;
+        for (int j = lane; j < nv; j += WAVE) {
             float v = row[j];
             if (y.nrm) v = (v - mean) * a + be;
             if (v > best) {
@@ -35,9 +40,19 @@ __global__ void colmax_fwd_kernel(const fgnn_slab y, const int *nvalid, int G, i
                 bi = j;
             }
         }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
     }
-    e[t] = best;
-    idx[t] = bi;
+    if (lane == 0) {
+        e[t] = best;
+        idx[t] = bi;
+    }
 }
 
 // N <= 64: one wave per (g,c); the matrix is read with coalesced loads, normalised and staged in a
@@ -295,7 +310,7 @@ extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int
         FGNN_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(colmax_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *y,
+    hipLaunchKernelGGL(colmax_fwd_kernel, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y,
                        nvalid, G, N, e, idx);
     FGNN_LAUNCH_CHECK();
     return 0;
