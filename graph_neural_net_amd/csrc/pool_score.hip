@@ -259,6 +259,73 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
     }
 }
 
+// Large N (dS does not fit LDS): grid (B, CSPLIT, ceil(N / SB_BLK)).  Workgroup (b, cs, rb) stages the row block
+// dS[i0:i1, :] and produces de1 for those rows, then stages the column block dS[:, i0:i1] and produces de2 for
+// those columns -- no cross-workgroup reduction, nothing recomputed inside the inner loops.
+constexpr int SB_BLK = 64;
+template <bool CE>
+__global__ __launch_bounds__(256) void score_bwd_blocked_kernel(const float *e1, const float *e2, const float *scores,
+                                                                const float *lse, const float *dscores,
+                                                                const int *nvalid, const float *gscale, int C, int N,
+                                                                float *de1, float *de2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int cper = (C + CSPLIT - 1) / CSPLIT;
+    const int c0 = blockIdx.y * cper;
+    const int cn = (c0 + cper <= C ? cper : (C > c0 ? C - c0 : 0));
+    float *s1 = sm, *s2 = sm + (size_t)cper * N;
+    float *dS = s2 + (size_t)cper * N;         // phase 1: [SB_BLK][N + 1], phase 2: [N][SB_BLK + 1]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nv = nvalid_of(nvalid, b, N);
+    const int x0 = blockIdx.z * SB_BLK, x1 = (x0 + SB_BLK < N) ? x0 + SB_BLK : N, w = x1 - x0;
+    const float *p1 = e1 + ((long long)b * C + c0) * N, *p2 = e2 + ((long long)b * C + c0) * N;
+    for (int e = tid; e < cn * N; e += 256) {
+        s1[e] = p1[e];
+        s2[e] = p2[e];
+    }
+    const float gs = CE ? *gscale : 1.f;
+    const float *S = (CE ? scores : dscores) + (long long)b * N * N;
+    const float *Lr = CE ? lse + (long long)b * N : nullptr;
+    auto ds_at = [&](int i, int jj) -> float {
+        if (i >= nv || jj >= nv) return 0.f;
+        float d = S[(long long)i * N + jj];
+        if (CE) d = (expf(d - Lr[i]) - (i == jj ? 1.f : 0.f)) * gs;
+        return d;
+    };
+    // ---- phase 1: rows x0..x1 ----
+    {
+        const int ld = N + 1;
+        for (int e = tid; e < w * N; e += 256) {
+            const int r = e / N, jj = e - r * N;
+            dS[r * ld + jj] = ds_at(x0 + r, jj);
+        }
+        __syncthreads();
+        for (int e = tid; e < cn * w; e += 256) {
+            const int c = e / w, r = e - c * w;
+            float a1 = 0.f;
+            const float *r2 = s2 + c * N, *drow = dS + r * ld;
+            for (int jj = 0; jj < nv; ++jj) a1 = fmaf(r2[jj], drow[jj], a1);
+            de1[((long long)b * C + c0 + c) * N + x0 + r] = (x0 + r) < nv ? a1 : 0.f;
+        }
+        __syncthreads();
+    }
+    // ---- phase 2: columns x0..x1 ----
+    {
+        const int ld = SB_BLK + 1;
+        for (int e = tid; e < N * w; e += 256) {
+            const int i = e / w, r = e - i * w;
+            dS[i * ld + r] = ds_at(i, x0 + r);
+        }
+        __syncthreads();
+        for (int e = tid; e < cn * w; e += 256) {
+            const int c = e / w, r = e - c * w;
+            float a2 = 0.f;
+            const float *r1 = s1 + c * N;
+            for (int i = 0; i < nv; ++i) a2 = fmaf(r1[i], dS[i * ld + r], a2);
+            de2[((long long)b * C + c0 + c) * N + x0 + r] = (x0 + r) < nv ? a2 : 0.f;
+        }
+    }
+}
+
 // triplet_loss pieces on a given score tensor (module-level API): one workgroup per pair.
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float *scores, const int *nvalid, int N, float *lse,
                                                      float *pair_loss) {
@@ -347,10 +414,14 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
         hipLaunchKernelGGL((score_bwd_kernel<CE, true>), dim3(B, CSPLIT), dim3(256), lds, st, e1, e2, scores, lse, dscores,
                            nvalid, gscale, C, N, de1, de2);
     } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)score_bwd_kernel<CE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((score_bwd_kernel<CE, false>), dim3(B, CSPLIT), dim3(256), lds, st, e1, e2, scores, lse, dscores,
-                           nvalid, gscale, C, N, de1, de2);
+        const int cper = (C + CSPLIT - 1) / CSPLIT;
+        const int big = (N + 1) * SB_BLK > N * (SB_BLK + 1) ? (N + 1) * SB_BLK : N * (SB_BLK + 1);
+        const int lds2 = (2 * cper * N + big) * (int)sizeof(float);
+        FGNN_CHECK(lds2 <= 160 * 1024, "score backward: N=%d too large for the blocked LDS staging", N);
+        if (lds2 > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)score_bwd_blocked_kernel<CE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        hipLaunchKernelGGL((score_bwd_blocked_kernel<CE>), dim3(B, CSPLIT, (N + SB_BLK - 1) / SB_BLK), dim3(256), lds2, st, e1, e2,
+                           scores, lse, dscores, nvalid, gscale, C, N, de1, de2);
     }
     FGNN_LAUNCH_CHECK();
     return 0;
