@@ -50,7 +50,8 @@ class MlpBwdArgs(C.Structure):
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
-                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p)]
+                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p),
+                ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p)]
 
 
 class GradJob(C.Structure):
@@ -98,6 +99,7 @@ _SIGNATURES = {
     'fgnn_grad_finalize': [_VP, _I, _I, _I, _I, _VP],
     'fgnn_gn_bwd_apply': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_mlp_bwd': [C.POINTER(MlpBwdArgs), _VP],
+    'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
     'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],

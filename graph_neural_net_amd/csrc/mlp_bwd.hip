@@ -122,11 +122,7 @@ DEVI void norm_from_lds(float (&y)[S > 0 ? S : 1], const float (&x)[S > 0 ? S : 
 // dz coefficients {mean, ca, cb, cc} of channel `ch` of graph g: precomputed (A.coef) or derived here
 // from the GraphNorm-backward sums S1,S2 and the output's GraphNorm record:
 //   dz = a*dy - a*S2*r2/m * (z - mean) - a*S1/m
-DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch) {
-    if (A.coef) return reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + ch];
-    const float4 n = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + ch];
-    const float2 sv = reinterpret_cast<const float2 *>(A.s12)[(long long)g * FGNN_H + ch];
-    const float nv = (float)nvalid_of(A.nvalid, g, A.N);
+DEVI float4 coef_from_sums(const float4 n, const float2 sv, float nv) {
     const float m = nv * nv;
     float4 k;
     k.x = n.x;
@@ -134,6 +130,12 @@ DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch) {
     k.z = m > 0.f ? -n.y * sv.y * n.w / m : 0.f;
     k.w = m > 0.f ? -n.y * sv.x / m : 0.f;
     return k;
+}
+DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch) {
+    if (A.coef) return reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + ch];
+    const float4 n = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + ch];
+    const float2 sv = reinterpret_cast<const float2 *>(A.s12)[(long long)g * FGNN_H + ch];
+    return coef_from_sums(n, sv, (float)nvalid_of(A.nvalid, g, A.N));
 }
 
 // dW += Dt (rows = out channel) x In (rows = in channel), contraction over the 32 pixels.
@@ -188,7 +190,8 @@ struct BwdLayout {
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int TILE_F_ALL = NW * NSLOT * TILE_F;
     static constexpr int RED_F = NW * PCOUNT;                             // final reduction reuses the whole allocation
-    static constexpr int MAIN_F = WEIGHT_F + NW * REC_F + TILE_F_ALL;
+    static constexpr int WGK_F = FGNN_BWD_COEF_GRAPHS * 128;              // workgroup cache of dz coefficient records
+    static constexpr int MAIN_F = WEIGHT_F + NW * REC_F + TILE_F_ALL + WGK_F;
     static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
 };
 
@@ -266,6 +269,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
+    // dz coefficients from the per-tile sums its consumer left behind (the work of fgnn_gn_bwd_coef_tiles,
+    // done per workgroup for the <= FGNN_BWD_COEF_GRAPHS graphs its tile range touches)
+    const bool from_tiles = A.s12tiles != nullptr;
+    float *wgK = tiles + L::TILE_F_ALL;
+    const int g0 = T0 / tpg;
 
     // The first tile's input slabs and per-graph records are requested BEFORE the operand image
     // is copied, so the dependent round trips of the prologue overlap into one.
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         load_raw<SA>(xa, va, c, h);
         load_raw<SB>(xb, vb, c, h);
         if (t < T1 && lane < 32) {
-            rk = coef_record(A, c.g, lane);
+            if (!from_tiles) rk = coef_record(A, c.g, lane);
             if (normA && lane < CA) {
                 ra = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
                 ra.z = A.a.beta ? A.a.beta[lane] : 0.f;
@@ -292,6 +300,35 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             cached_g = c.g;
             cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
         }
+    }
+    if (from_tiles) {
+        const int g1 = T1 > T0 ? (T1 - 1) / tpg : g0 - 1;
+        float2 *scr = reinterpret_cast<float2 *>(tiles);          // [16 slices][32 channels]; tiles are free here
+        const int cc = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        for (int g = g0; g <= g1; ++g) {
+            float p1 = 0.f, p2 = 0.f;
+            for (int t = sl; t < tpg; t += (64 * NW) / 32) {
+                const float2 v = reinterpret_cast<const float2 *>(A.s12tiles)[((long long)g * tpg + t) * FGNN_H + cc];
+                p1 += v.x;
+                p2 += v.y;
+            }
+            scr[sl * 32 + cc] = make_float2(p1, p2);
+            __syncthreads();
+            if (threadIdx.x < 32) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < (64 * NW) / 32; ++k) {               // fixed order
+                    s1 += scr[k * 32 + cc].x;
+                    s2 += scr[k * 32 + cc].y;
+                }
+                const float2 sv = make_float2(s1, s2);
+                if (A.s12_out) reinterpret_cast<float2 *>(A.s12_out)[(long long)g * FGNN_H + cc] = sv;
+                const float4 n = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + cc];
+                reinterpret_cast<float4 *>(wgK)[(g - g0) * 32 + cc] = coef_from_sums(n, sv, (float)nvalid_of(A.nvalid, g, A.N));
+            }
+            __syncthreads();
+        }
+        if (cached_g >= 0 && lane < 32) rk = reinterpret_cast<const float4 *>(wgK)[(cached_g - g0) * 32 + lane];
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
@@ -322,7 +359,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the loads
             // below so that the in-order vmcnt wait does not drain them.
             if (lane < 32) {
-                const float4 k4 = coef_record(A, c.g, lane);
+                const float4 k4 = from_tiles ? reinterpret_cast<const float4 *>(wgK)[(c.g - g0) * 32 + lane]
+                                             : coef_record(A, c.g, lane);
                 reinterpret_cast<float4 *>(recK)[lane] = k4;
                 if (normA && lane < CA) {
                     float4 n = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
@@ -664,6 +702,13 @@ extern "C" int fgnn_debug_phase_buffer(void *p, int ca, int cb) {
 
 extern "C" int fgnn_mlp_bwd_num_workgroups(void) { return BWD_WG; }
 
+extern "C" int fgnn_mlp_bwd_coef_tiles_supported(int G, int N) {
+    const long long tpg = fgnn_tiles_per_graph(N), total = (long long)G * tpg;
+    const long long per_wg = (total + BWD_WG - 1) / BWD_WG;
+    // a range of per_wg consecutive tiles touches at most (per_wg + tpg - 2) / tpg + 1 graphs
+    return (per_wg + tpg - 2) / tpg + 1 <= FGNN_BWD_COEF_GRAPHS ? 1 : 0;
+}
+
 extern "C" int fgnn_mlp_param_count(int Cin, int depth) { return 32 * Cin + 32 + (depth - 1) * (32 * 32 + 32); }
 
 extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
@@ -673,7 +718,7 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a->a.ptr && a->a.C > 0, "fgnn_mlp_bwd: slab a missing");
     FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_bwd: slab b has channels but no pointer");
     FGNN_CHECK(a->dy && a->z && a->wpart, "fgnn_mlp_bwd: missing dy/z/wpart");
-    FGNN_CHECK(a->coef || (a->s12 && a->znrm), "fgnn_mlp_bwd: need coef, or s12 + znrm");
+    FGNN_CHECK(a->coef || (a->s12 && a->znrm) || (a->s12tiles && a->znrm), "fgnn_mlp_bwd: need coef, or s12 + znrm, or s12tiles + znrm");
     {
         const long long lim = 0x7fffffffll / 4, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&
@@ -684,6 +729,9 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     const int tpg = fgnn_tiles_per_graph(a->N);
     const long long total = (long long)a->G * tpg;
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_bwd: too many tiles");
+    FGNN_CHECK(!a->s12tiles || fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N),
+               "fgnn_mlp_bwd: s12tiles needs a workgroup's tile range to span <= %d graphs (G=%d N=%d); "
+               "use fgnn_gn_bwd_coef_tiles", FGNN_BWD_COEF_GRAPHS, a->G, a->N);
     hipStream_t st = (hipStream_t)stream;
     if (a->depth == 1) return dispatch_c<1>(a, tpg, (int)total, st);
     if (a->depth == 2) return dispatch_c<2>(a, tpg, (int)total, st);

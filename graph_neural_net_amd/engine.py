@@ -305,7 +305,8 @@ class FgnnEngine:
                   _lib.ptr(W['coef'][slot]), None, None, _lib.stream_ptr())
 
     def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
-        """coef: precomputed coefficient buffer, or None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)]."""
+        """coef: precomputed coefficient buffer; None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)];
+        'tiles' -> every workgroup sums the per-tile S1/S2 partials (s12part) of the graphs it touches itself."""
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
@@ -321,7 +322,11 @@ class FgnnEngine:
             args.bias[l] = self._w(params, rec['b'][l])
         args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
-        if coef is not None:
+        if isinstance(coef, str):
+            args.s12tiles = W['s12part'].data_ptr()
+            args.s12_out = W['s12'][(k, j)].data_ptr()
+            args.znrm = self.nrm[(k, j)].data_ptr()
+        elif coef is not None:
             args.coef = coef.data_ptr()
         else:
             args.s12 = W['s12'][(k, j)].data_ptr()
@@ -365,6 +370,9 @@ class FgnnEngine:
         st = _lib.stream_ptr()
         gs = 32 * self.ldp
         K = L.num_blocks
+        # dz coefficients of mlp3 (blocks < K): summed from the tile partials inside the consumer's prologue when a
+        # workgroup's tile range spans few graphs, else by a separate fgnn_gn_bwd_coef_tiles launch
+        in_prologue = bool(_lib.load().fgnn_mlp_bwd_coef_tiles_supported(self.G, self.N))
         dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
@@ -375,15 +383,15 @@ class FgnnEngine:
             din = None if first else W['dy'][(K - k + 1) % 2]
             # mlp3: inputs [mult ; in].  Last block: dz coefficients derived in-kernel from the pooling's
             # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
-            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, None if k == K else W['coef'][2],
-                          W['dmult'], din, False, False)
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
+                          None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
             self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False)
             self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first)
-            if not first:
+            if not first and not in_prologue:
                 _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
             dy = din

@@ -197,8 +197,15 @@ typedef struct {
                                                 the FINAL dxa values (needs a.C == 32, a.nrm and dxa) -- the GraphNorm
                                                 backward sums of the MLP that produced slab a */
     const float *packed;                     /* optional: operand image from fgnn_pack_operands (kind 1) */
+    const float *s12tiles;                   /* optional (G, tpg, 32, 2): per-tile sums for THIS MLP's output as emitted by its
+                                                consumer's s12part; with znrm they replace coef / s12 -- every workgroup sums
+                                                the tiles of the graphs it touches in its prologue (the work of
+                                                fgnn_gn_bwd_coef_tiles without its launch; see ..._coef_tiles_supported) */
+    float *s12_out;                          /* optional (G*32*2): the summed s12 is also written here (affine gradients) */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
+#define FGNN_BWD_COEF_GRAPHS 4
+int fgnn_mlp_bwd_coef_tiles_supported(int G, int N);   /* s12tiles usable: a workgroup spans <= FGNN_BWD_COEF_GRAPHS graphs */
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
  * layout [W0 (32*Cin) | b0 (32) | W1 (32*32) | b1 (32) | ...]                           */
 int fgnn_mlp_param_count(int Cin, int depth);
