@@ -238,7 +238,9 @@ class FgnnEngine:
         self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
-            fin = bool(_lib.load().fgnn_chan_matmul_fwd_fin_supported(self.N))
+            # finalize-in-prologue lengthens every matmul workgroup by ~2 us: it beats the separate finalize launch
+            # (~6 us) only while the matmul runs a few workgroup rounds (measured cross-over: B ~ 64-128 pairs at N = 50)
+            fin = bool(_lib.load().fgnn_chan_matmul_fwd_fin_supported(self.N)) and self.G * 32 <= 4096
             self._mlp_fwd(params, k, (1, 2), sin, None, finalize=not fin)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             if fin:     # the matmul finalizes the GraphNorm records of mlp1 / mlp2 itself (one launch less)
