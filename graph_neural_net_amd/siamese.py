@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import _lib
 from .blocks import block, block_emb, node_embedding
 from .losses import triplet_loss
+from .metrics import accuracy_max
 from .masked import MaskedTensor
 from .network import Network
 
@@ -68,6 +69,7 @@ class Siamese_Node_Exp(nn.Module):
         self.node_embedder_dic = {'input': (None, []), 'ne': node_emb_type(original_features_num, **node_emb)}
         self.node_embedder = Network(self.node_embedder_dic)
         self.loss = triplet_loss()
+        self.metric = accuracy_max      # the reference's default is the host-side Hungarian metric (trainers.py:52)
         self.lr, self.scheduler_decay, self.scheduler_step, self.lr_stop = lr, scheduler_decay, scheduler_step, lr_stop
 
     def forward(self, x1, x2):
@@ -89,6 +91,28 @@ class Siamese_Node_Exp(nn.Module):
         if ragged:
             return MaskedTensor(scores, nvalid, (1, 2), x1.base_name)
         return scores
+
+    # -- the step methods of the reference's LightningModule (models/trainers.py:70-90); `log` is a no-op
+    #    here and is overridden by whatever training shell wraps the module
+    def log(self, name, value, **kwargs):
+        pass
+
+    def _shared_step(self, batch, prefix):
+        raw_scores = self(batch[0], batch[1])
+        loss = self.loss(raw_scores)
+        self.log(prefix + '_loss', loss)
+        acc, n = self.metric(raw_scores)
+        self.log(prefix + '_acc', acc / n)
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self._shared_step(batch, 'train')
+
+    def validation_step(self, batch, batch_idx):
+        self._shared_step(batch, 'val')
+
+    def test_step(self, batch, batch_idx):
+        self._shared_step(batch, 'test')
 
     def configure_optimizers(self):
         optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, amsgrad=False)

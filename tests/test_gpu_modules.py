@@ -120,6 +120,34 @@ def test_siamese_fused_module_path():
             assert rel(p.grad.cpu(), d['grad64/' + k]) < 4 * yard + 1e-5, k
 
 
+def test_siamese_step_methods_mirror_the_lightning_module():
+    """training_step / validation_step as in models/trainers.py:70-83: loss returned, loss + accuracy logged;
+    an optimizer built by configure_optimizers() trains the module."""
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=1,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne, lr=1e-2).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    logged = {}
+    model.log = lambda name, value, **kw: logged.__setitem__(name, float(value.detach()) if torch.is_tensor(value) else float(value))
+    batch = ({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+    loss = model.training_step(batch, 0)
+    assert abs(loss.item() - d['loss'].item()) < 1e-5 * d['loss'].item()
+    assert abs(logged['train_loss'] - d['loss'].item()) < 1e-5 * d['loss'].item()
+    ref_acc = (d['scores'].argmax(-1) == torch.arange(d['scores'].shape[-1])).double().mean().item()
+    assert abs(logged['train_acc'] - ref_acc) < 1e-12
+    opt = model.configure_optimizers()['optimizer']
+    first = loss.item()
+    for _ in range(30):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+    assert loss.item() < 0.9 * first
+    model.validation_step(batch, 0)
+    assert 'val_loss' in logged and 'val_acc' in logged
+
+
 def test_siamese_ragged_module_path():
     """Variable-N pairs through MaskedTensors: the path that is broken in the reference (SURVEY section 0 row 4);
     expected values = per-graph dense oracle runs."""
