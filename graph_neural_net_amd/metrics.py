@@ -1,5 +1,8 @@
 """accuracy_max (toolbox/metrics.py:119-141) on the device: argmax over each score row compared with
-the identity matching.  The Hungarian metric of the reference (SciPy on the host) stays out of scope."""
+the identity matching, plus the Hungarian metric of the reference (toolbox/metrics.py:92-116) as a host-side
+evaluation metric: ONE device->host copy of the log-softmax scores per call, SciPy assignment per graph --
+meant for validation, not for the per-step path."""
+import numpy as np
 import torch
 
 from . import _lib
@@ -25,3 +28,26 @@ def accuracy_max(weights, aggregate_score=True):
     if aggregate_score:
         return int(correct.sum().item()), int(sizes.sum().item())
     return (correct.to(torch.float64) / sizes.to(torch.float64)).tolist()
+
+
+def accuracy_linear_assignment(rawscores, aggregate_score=True):
+    """rawscores: (bs, n, n) tensor or MaskedTensor.  Maximum-weight matching on log_softmax(scores) per graph,
+    counted against the identity matching: (n_correct, n_vertices) or the list of per-graph accuracies."""
+    from scipy.optimize import linear_sum_assignment
+    if isinstance(rawscores, MaskedTensor):
+        s, sizes = rawscores.tensor, rawscores.sizes()
+    else:
+        s, sizes = rawscores, [rawscores.shape[1]] * rawscores.shape[0]
+    s = s.detach()
+    if isinstance(rawscores, MaskedTensor):      # padding columns must not take part in the row softmax
+        col = torch.arange(s.shape[-1], device=s.device)[None, None, :] < rawscores.nvalid.to(s.device)[:, None, None]
+        s = s.masked_fill(~col, float('-inf'))
+    cost = (-torch.log_softmax(s, -1)).cpu().numpy()
+    acc, total, all_acc = 0, 0, []
+    for b, n in enumerate(sizes):
+        _, preds = linear_sum_assignment(cost[b, :n, :n])
+        hit = int(np.sum(preds == np.arange(n)))
+        acc += hit
+        total += n
+        all_acc.append(hit / n)
+    return (acc, total) if aggregate_score else all_acc
