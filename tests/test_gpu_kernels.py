@@ -16,7 +16,7 @@ def _slab(t, nrm=None, beta=None):
     return _lib.make_slab(t, Cc * N * N, N * N, Cc, nrm=nrm, beta=beta)
 
 
-@pytest.mark.parametrize('G,Cc,N', [(3, 4, 50), (2, 2, 7), (1, 3, 64), (2, 2, 65), (1, 2, 130)])
+@pytest.mark.parametrize('G,Cc,N', [(3, 4, 50), (2, 2, 7), (1, 3, 64), (2, 2, 65), (1, 2, 130), (1, 2, 256), (1, 1, 260)])
 def test_chan_matmul_fwd_bwd(G, Cc, N):
     g = torch.Generator().manual_seed(N)
     a = torch.randn(G, Cc, N, N, generator=g)
@@ -34,6 +34,55 @@ def test_chan_matmul_fwd_bwd(G, Cc, N):
               _lib.ptr(da), _lib.ptr(db), Cc * P, P, None, None, _lib.stream_ptr())
     assert rel(da.cpu(), torch.matmul(dm.double(), b.double().transpose(-1, -2))) < 2e-6
     assert rel(db.cpu(), torch.matmul(a.double().transpose(-1, -2), dm.double())) < 2e-6
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_chan_matmul_random_ragged_shapes(seed):
+    """Random (G, C, N, nvalid) across the three matmul paths (single tile, whole-matrix, generic), normalised
+    operands, with the S1/S2 by-products of the backward checked against their definition."""
+    rng = torch.Generator().manual_seed(1000 + seed)
+    N = int(torch.randint(2, 150, (1,), generator=rng))
+    G = int(torch.randint(1, 4, (1,), generator=rng))
+    Cc = int(torch.randint(1, 5, (1,), generator=rng))
+    nv = torch.randint(1, N + 1, (G,), generator=rng).to(torch.int32)
+    nv[0] = N
+    P = N * N
+    a = torch.randn(G, Cc, N, N, generator=rng)
+    b = torch.randn(G, Cc, N, N, generator=rng)
+    dm = torch.randn(G, Cc, N, N, generator=rng)
+    nrm_a = torch.rand(G, Cc, 4, generator=rng) + 0.5          # {mean, a, q, r2}
+    nrm_b = torch.rand(G, Cc, 4, generator=rng) + 0.5
+    beta_a, beta_b = torch.randn(Cc, generator=rng), torch.randn(Cc, generator=rng)
+    ad, bd, dmd = a.to(DEV), b.to(DEV), dm.to(DEV)
+    na, nb, ba, bb = nrm_a.to(DEV).contiguous(), nrm_b.to(DEV).contiguous(), beta_a.to(DEV), beta_b.to(DEV)
+    sa, sb = _slab(ad, nrm=na, beta=ba), _slab(bd, nrm=nb, beta=bb)
+    nvd = nv.to(DEV)
+    out = torch.full((G, Cc, N, N), 3.0, device=DEV)
+    _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), _lib.ptr(nvd), G, N, _lib.ptr(out), Cc * P, P, _lib.stream_ptr())
+    da = torch.full((G, Cc, N, N), 3.0, device=DEV)
+    db = torch.full((G, Cc, N, N), 3.0, device=DEV)
+    s12a = torch.empty(G * Cc * 2, device=DEV)
+    s12b = torch.empty(G * Cc * 2, device=DEV)
+    _lib.call('fgnn_chan_matmul_bwd', C.byref(sa), C.byref(sb), _lib.ptr(dmd), Cc * P, P, _lib.ptr(nvd), G, N,
+              _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.stream_ptr())
+    out, da, db = out.cpu(), da.cpu(), db.cpu()
+    s12a, s12b = s12a.cpu().view(G, Cc, 2), s12b.cpu().view(G, Cc, 2)
+    for g, n in enumerate(nv.tolist()):
+        ya = ((a[g, :, :n, :n].double() - nrm_a[g, :, 0, None, None]) * nrm_a[g, :, 1, None, None] + beta_a[:, None, None])
+        yb = ((b[g, :, :n, :n].double() - nrm_b[g, :, 0, None, None]) * nrm_b[g, :, 1, None, None] + beta_b[:, None, None])
+        d = dm[g, :, :n, :n].double()
+        assert rel(out[g, :, :n, :n], ya @ yb) < 5e-6
+        ra, rb = d @ yb.transpose(-1, -2), ya.transpose(-1, -2) @ d
+        assert rel(da[g, :, :n, :n], ra) < 5e-6 and rel(db[g, :, :n, :n], rb) < 5e-6
+        for t in (out, da, db):
+            assert t[g, :, n:, :].abs().sum() == 0 and t[g, :, :, n:].abs().sum() == 0
+        ua = a[g, :, :n, :n].double() - nrm_a[g, :, 0, None, None]
+        ub = b[g, :, :n, :n].double() - nrm_b[g, :, 0, None, None]
+        ref_a = torch.stack([ra.sum((-1, -2)), (ra * ua).sum((-1, -2))], -1)
+        ref_b = torch.stack([rb.sum((-1, -2)), (rb * ub).sum((-1, -2))], -1)
+        scale = max(ref_a.abs().max().item(), ref_b.abs().max().item(), 1.0)
+        assert (s12a[g].double() - ref_a).abs().max() < 2e-5 * scale
+        assert (s12b[g].double() - ref_b).abs().max() < 2e-5 * scale
 
 
 def test_chan_matmul_ragged_padding_is_zero():
