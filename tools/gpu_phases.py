@@ -1,5 +1,5 @@
 """Debug: per-phase cycle breakdown of one mlp_bwd variant (needs `make -C graph_neural_net_amd/csrc phases`).
-usage: python tests/gpu_phases.py [B] [ca] [cb]"""
+usage: python tools/gpu_phases.py [B] [ca] [cb]"""
 import ctypes as C, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

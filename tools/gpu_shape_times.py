@@ -1,4 +1,4 @@
-"""Per-kernel times of one engine step at an arbitrary shape: python tests/gpu_shape_times.py B N [ragged_lo]"""
+"""Per-kernel times of one engine step at an arbitrary shape: python tools/gpu_shape_times.py B N [ragged_lo]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,9 +15,11 @@ nv = None
 if lo is None:
     x1, x2 = synthetic.make_batch(1, B, N, 'ErdosRenyi', 0.5, 0.1)
 else:
-    from oracle import fgnn_oracle as O
     xs, ys = synthetic.make_ragged_batch(1, B, lo, N)
-    x1, n1 = O.pad_graph_list(xs); x2, _ = O.pad_graph_list(ys)
+    nmax = max(x.shape[-1] for x in xs)
+    pad = lambda t: torch.nn.functional.pad(t, (0, nmax - t.shape[-1], 0, nmax - t.shape[-1]))
+    x1, x2 = torch.stack([pad(x) for x in xs]), torch.stack([pad(y) for y in ys])
+    n1 = torch.tensor([x.shape[-1] for x in xs], dtype=torch.int32)
     N = x1.shape[-1]
     nv = torch.cat([n1, n1]).to(dev)
 x = torch.cat([x1, x2]).contiguous().to(dev)
