@@ -59,7 +59,7 @@ def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2):
     return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * 4 * N * N * by
 
 
-def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=8):
+def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
     """The oracle (pure PyTorch CPU, same ATen op sequence as the reference) on the host cores."""
     from oracle import fgnn_oracle as O
     try:
@@ -78,7 +78,7 @@ def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=8):
         if best is None or dt < best:
             best, cores = dt, c
     torch.set_num_threads(cores)
-    # bounded sample: a slice of the same batch sized for ~10-30 s of CPU work in total
+    # bounded sample: (a slice of) the same batch, repeated until ~10 s of CPU work have been timed
     pairs = x1.shape[0]
     est_full = best * pairs / 2.0
     if est_full > 10.0:
