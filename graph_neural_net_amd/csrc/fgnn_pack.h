@@ -88,6 +88,37 @@ HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, int
     return jj < cb ? W[0][pk_ch(u, hh) * cin + ca + jj] : 0.f;
 }
 
+// The same copy split in two halves, so that a prologue can put the image loads in flight FIRST and do its other
+// (dependent) loads and arithmetic before the values are needed: one memory round trip instead of two.
+template <int N4, int NTHREADS>
+struct PkRegs {
+    static constexpr int PER = (N4 + NTHREADS - 1) / NTHREADS;
+    float4 v[PER];
+};
+template <int N4, int NTHREADS>
+DEVI void pk_load_regs(PkRegs<N4, NTHREADS> &r, const float *packed) {
+    // buffer loads: unlike plain global loads the compiler neither re-materialises them at their use nor sinks
+    // them.  (Dword loads: with a constant descriptor this compiler folds raw_buffer_load_b128 into one dword.)
+    const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, N4 * 16, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < PkRegs<N4, NTHREADS>::PER; ++k) {
+        const int off = (threadIdx.x + k * NTHREADS) * 16;                                // past the end: returns 0
+        r.v[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+        r.v[k].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 4, 0));
+        r.v[k].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 8, 0));
+        r.v[k].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 12, 0));
+    }
+}
+template <int N4, int NTHREADS>
+DEVI void pk_store_regs(float *lds, const PkRegs<N4, NTHREADS> &r) {
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+#pragma unroll
+    for (int k = 0; k < PkRegs<N4, NTHREADS>::PER; ++k) {
+        const int e = threadIdx.x + k * NTHREADS;
+        if (e < N4) dst[e] = r.v[k];
+    }
+}
+
 // copy a packed image (n4 float4s) into LDS with all threads of the workgroup
 DEVI void pk_copy_to_lds(float *lds, const float *packed, int n4, int nthreads) {
     const float4 *src = reinterpret_cast<const float4 *>(packed);

@@ -28,9 +28,9 @@
 // tiles and written to a buffer set by fgnn_debug_phase_buffer().  Not part of the shipped library.
 __device__ unsigned long long *g_phase_buf = nullptr;
 __device__ int g_phase_sel = 0;       // CA * 100 + CB of the variant that records
-#define PH_DECL unsigned long long ph_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = __builtin_amdgcn_s_memtime();
+#define PH_DECL unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = __builtin_amdgcn_s_memtime();
 #define PH(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_last_; ph_last_ = t_; }
-#define PH_FLUSH if (g_phase_buf && g_phase_sel == CA * 100 + CB && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; ++k_) g_phase_buf[((long long)blockIdx.x * NW + wv) * 12 + k_] = ph_[k_]; }
+#define PH_FLUSH if (g_phase_buf && g_phase_sel == CA * 100 + CB && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; ++k_) g_phase_buf[((long long)blockIdx.x * NW + wv) * 16 + k_] = ph_[k_]; }
 #else
 #define PH_DECL
 #define PH(k)
@@ -275,8 +275,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     float *wgK = tiles + L::TILE_F_ALL;
     const int g0 = T0 / tpg;
 
-    // The first tile's input slabs and per-graph records are requested BEFORE the operand image
-    // is copied, so the dependent round trips of the prologue overlap into one.
+    // Prologue = ONE memory round trip: the operand image is requested first (into registers), then the first
+    // tile's input slabs and the per-graph records; only then come the loads whose values are needed at once
+    // (dz coefficients derived from s12 / znrm, nvalid) and the image's way into LDS.
+    PkRegs<L::WEIGHT_F / 4, 64 * NW> img;
+    if (A.packed) pk_load_regs(img, A.packed);
+    __builtin_amdgcn_sched_barrier(0);      // keep these loads first (the scheduler would sink them to their use)
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), ra = rk, rb = rk;
     int cached_g = -1, cur_nv = A.N;
@@ -301,6 +305,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, c.g, A.N));
         }
     }
+    PH(12)              // prologue a: kernel arguments, views, first tile's loads + records issued
     if (from_tiles) {
         const int g1 = T1 > T0 ? (T1 - 1) / tpg : g0 - 1;
         float2 *scr = reinterpret_cast<float2 *>(tiles);          // [16 slices][32 channels]; tiles are free here
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
-        pk_copy_to_lds(wl, A.packed, L::WEIGHT_F / 4, 64 * NW);
+        pk_store_regs(wl, img);
     } else {
         const float *Wp[FGNN_MAX_DEPTH] = {A.W[0], A.W[1], A.W[2]};
         const float *Bp[FGNN_MAX_DEPTH] = {A.bias[0], A.bias[1], A.bias[2]};
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
         }
     }
+    PH(13)              // prologue b: operand image loaded and written to LDS
     if (lane < 32) {
         reinterpret_cast<float4 *>(recK)[lane] = rk;
         reinterpret_cast<float4 *>(recA)[lane] = ra;

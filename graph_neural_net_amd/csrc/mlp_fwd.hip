@@ -168,6 +168,10 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     // The first tile's input slabs and per-graph records are requested BEFORE the operand image
     // is copied, so the three dependent round trips of the prologue overlap into one.
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
+    // the operand image is requested first (into registers): its round trip overlaps the first tile's
+    PkRegs<L::WEIGHT_F / 4, 64 * NW> img;
+    if (A.packed) pk_load_regs(img, A.packed);
+    __builtin_amdgcn_sched_barrier(0);      // keep these loads first (the scheduler would sink them to their use)
     int tile = T0 + wv;
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     }
     // ---- operand image -> LDS: straight copy of the pre-packed image, or build it here ----
     if (A.packed) {
-        pk_copy_to_lds(wl, A.packed, L::WEIGHT_F / 4, 64 * NW);
+        pk_store_regs(wl, img);
     } else {
         constexpr PkFwd pk = L::PK;
 #pragma unroll
