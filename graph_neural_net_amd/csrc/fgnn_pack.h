@@ -118,10 +118,3 @@ DEVI void pk_store_regs(float *lds, const PkRegs<N4, NTHREADS> &r) {
         if (e < N4) dst[e] = r.v[k];
     }
 }
-
-// copy a packed image (n4 float4s) into LDS with all threads of the workgroup
-DEVI void pk_copy_to_lds(float *lds, const float *packed, int n4, int nthreads) {
-    const float4 *src = reinterpret_cast<const float4 *>(packed);
-    float4 *dst = reinterpret_cast<float4 *>(lds);
-    for (int e = threadIdx.x; e < n4; e += nthreads) dst[e] = src[e];
-}
