@@ -655,11 +655,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     PH(10)              // waiting for the slowest wave of the workgroup
     put_partials(smem + wv * PCOUNT);      // the whole LDS allocation is free now
     __syncthreads();
-    float *out = A.wpart + (long long)blockIdx.x * PCOUNT;
-    for (int e = threadIdx.x; e < PCOUNT; e += 64 * NW) {
-        float a = 0.f;
+    static_assert(PCOUNT % 4 == 0, "partials are summed four at a time");
+    float4 *out = reinterpret_cast<float4 *>(A.wpart + (long long)blockIdx.x * PCOUNT);
+    const float4 *part4 = reinterpret_cast<const float4 *>(smem);
+    for (int e = threadIdx.x; e < PCOUNT / 4; e += 64 * NW) {
+        float4 a = part4[e];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) a += smem[w * PCOUNT + e];      // fixed order
+        for (int w = 1; w < NW; ++w) {                                  // fixed order
+            const float4 b = part4[w * (PCOUNT / 4) + e];
+            a.x += b.x;
+            a.y += b.y;
+            a.z += b.z;
+            a.w += b.w;
+        }
         out[e] = a;
     }
     PH(11)              // workgroup reduction + partial store
