@@ -87,6 +87,8 @@ _SIGNATURES = {
     'fgnn_chan_matmul_fwd_fin_supported': [_I],
     'fgnn_chan_matmul_fwd_fin': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_colmax_fwd': [C.POINTER(Slab), _VP, _I, _I, _VP, _VP, _VP],
+    'fgnn_colmax_fwd_fin_supported': [_I],
+    'fgnn_colmax_fwd_fin': [C.POINTER(Slab), _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_score_ce_fwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_score_bwd': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],

@@ -3,6 +3,7 @@
 // forward/backward for gfx950.  These are small (O(B*C*N^2)) next to the blocks.
 #include <float.h>
 #include "fgnn_common.h"
+#include "fgnn_norm.h"
 
 namespace {
 
@@ -57,8 +58,16 @@ __global__ __launch_bounds__(256) void colmax_fwd_kernel(const fgnn_slab y, cons
 
 // N <= 64: one wave per (g,c); the matrix is read with coalesced loads, normalised and staged in a
 // wave-private LDS tile (row stride N+1: conflict-free row scans), then lane i scans row i.
+// FIN: the record of the input does not exist yet; the wave finalizes it from the producer's tile statistics
+// (the work of fgnn_gn_finalize for this (g,c), without its launch) and publishes it in y.nrm.
+struct ColmaxFin {
+    const float *part, *cnt, *gw;
+    float eps;
+    int tpg;
+};
+template <bool FIN>
 __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, const int *nvalid, int G, int N,
-                                                             float *e, int *idx) {
+                                                             float *e, int *idx, const ColmaxFin F) {
     __shared__ float sm[4][64 * 65];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gc = blockIdx.x * 4 + wave;
@@ -68,7 +77,13 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
     const int nv = nvalid_of(nvalid, g, N);
     const float *mat = y.ptr + (long long)g * y.gstride + (long long)c * y.ldp;
     float mean = 0.f, a = 1.f, be = 0.f;
-    if (y.nrm) {
+    if (FIN) {
+        const float4 n = finalize_wave(F.part, F.cnt, g, c, C, F.tpg, (float)nv, F.gw ? F.gw[c] : 1.f, F.eps, lane);
+        if (lane == 0) reinterpret_cast<float4 *>(const_cast<float *>(y.nrm))[gc] = n;
+        mean = n.x;
+        a = n.y;
+        be = y.beta ? y.beta[c] : 0.f;
+    } else if (y.nrm) {
         const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
         mean = n.x;
         a = n.y;
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
         const int i = (int)(((float)p + 0.5f) * invN);
         const int jj = p - i * N;
         float v = mat[p];
-        if (y.nrm) v = (v - mean) * a + be;
+        if (FIN || y.nrm) v = (v - mean) * a + be;
         t[i * ld + jj] = v;
     }
     // same wave wrote and reads: LDS operations of a wave execute in order
@@ -372,13 +387,26 @@ extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int
     FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && y->C > 0, "fgnn_colmax_fwd: bad arguments");
     const long long tot = (long long)G * y->C * N;
     if (N <= 64) {
-        hipLaunchKernelGGL(colmax_fwd_lds_kernel, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           *y, nvalid, G, N, e, idx);
+        hipLaunchKernelGGL(colmax_fwd_lds_kernel<false>, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, *y, nvalid, G, N, e, idx, ColmaxFin{});
         FGNN_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(colmax_fwd_kernel, dim3((unsigned)((tot + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y,
                        nvalid, G, N, e, idx);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_colmax_fwd_fin_supported(int N) { return N <= 64 ? 1 : 0; }
+
+extern "C" int fgnn_colmax_fwd_fin(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
+                                   const int *nvalid, int G, int N, float *e, int *idx, void *stream) {
+    FGNN_CHECK(y && y->ptr && y->nrm && part && cnt && e && idx && G > 0 && N > 0 && y->C > 0, "fgnn_colmax_fwd_fin: bad arguments");
+    FGNN_CHECK(N <= 64, "fgnn_colmax_fwd_fin: N=%d > 64 (use fgnn_gn_finalize + fgnn_colmax_fwd)", N);
+    const ColmaxFin F = {part, cnt, gn_weight, eps, fgnn_tiles_per_graph(N)};
+    hipLaunchKernelGGL(colmax_fwd_lds_kernel<true>, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y,
+                       nvalid, G, N, e, idx, F);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -252,9 +252,17 @@ class FgnnEngine:
             else:
                 _lib.call('fgnn_chan_matmul_fwd', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
                           _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st)
-            self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
+            # the last block's statistics are finalized by the pooling kernel that consumes them
+            pool_fin = k == L.num_blocks and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
+            self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin, finalize=not pool_fin)
         out = self._slab_z(L.num_blocks, 3, params)
-        _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
+        if pool_fin:
+            rec = L.mlp[(L.num_blocks, 3)]
+            _lib.call('fgnn_colmax_fwd_fin', C.byref(out), _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, rec['gn_w'])), EPS, self._nv(), self.G, self.N, _lib.ptr(self.E),
+                      _lib.ptr(self.idx), st, tag='fgnn_colmax_fwd')
+        else:
+            _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
 
     def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False):

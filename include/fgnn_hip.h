@@ -126,6 +126,11 @@ int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb, const flo
  * e[g,c,i] = max_j y[g,c,i,j] (first index on ties), idx int32; rows i >= nvalid -> 0.   */
 int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *e /* (G,C,N) */,
                     int *idx /* (G,C,N) */, void *stream);
+/* the same with the GraphNorm finalize of its input folded in (N <= 64): every (g,c) wave combines the tile
+ * statistics (part, cnt of the fgnn_mlp_fwd call that produced y) itself and writes the record to y->nrm */
+int fgnn_colmax_fwd_fin_supported(int N);
+int fgnn_colmax_fwd_fin(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
+                        const int *nvalid, int G, int N, float *e, int *idx, void *stream);
 
 /* ---- Siamese scoring + triplet_loss (models/trainers.py:67, toolbox/losses.py:20-34) ---
  * e1,e2: (B, C, N).  scores[b] = e1[b]^T e2[b] (B,N,N); lse (B,N) row log-sum-exp;
