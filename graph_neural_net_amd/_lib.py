@@ -107,6 +107,7 @@ _SIGNATURES = {
     'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
     'fgnn_sum_scale': [_VP, _I, _I, _F, _VP, _VP],
     'fgnn_adam_step': [_VP, _VP, _VP, _VP, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, C.c_double, _VP],
+    'fgnn_adam_step_dev': [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP],
     'fgnn_expand_adjacency': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_accuracy_max': [_VP, _VP, _I, _I, _VP, _VP],
 }

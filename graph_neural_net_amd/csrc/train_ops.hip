@@ -20,6 +20,48 @@ __global__ void adam_kernel(float *p, const float *g, float *m, float *v, int n,
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// The same update with the step count and the hyper-parameters read from device memory, so that the launch can
+// sit in a captured HIP graph and be replayed: hp = {lr, beta1, beta2, eps, grad_scale} (doubles), state =
+// {step count, arrivals}.  Every workgroup reads the step count before it signs the arrival counter; the last one
+// to sign advances the count for the next replay.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float *p, const float *g, float *m, float *v, int n,
+                                                       const double *hp, int *state) {
+    __shared__ float sh[6];
+    __shared__ int s_step;
+    if (threadIdx.x == 0) {
+        const int step = state[0] + 1;
+        const double lr = hp[0], b1 = hp[1], b2 = hp[2];
+        const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+        sh[0] = (float)(lr / bc1);
+        sh[1] = (float)(1.0 - b1);
+        sh[2] = (float)b2;
+        sh[3] = (float)(1.0 - b2);
+        sh[4] = (float)(1.0 / sqrt(bc2));
+        sh[5] = (float)hp[3];
+        s_step = step;
+    }
+    __syncthreads();
+    const float step_size = sh[0], w1 = sh[1], beta2 = sh[2], w2 = sh[3], inv_sqrt_bc2 = sh[4], eps = sh[5];
+    const float grad_scale = (float)hp[4];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float gi = g[i] * grad_scale;
+        const float mi = m[i] + (gi - m[i]) * w1;
+        const float vi = v[i] * beta2 + gi * gi * w2;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&state[1], 1) == (int)gridDim.x - 1) {      // every workgroup has read state[0] by now
+            state[1] = 0;
+            state[0] = s_step;
+        }
+    }
+}
+
 // one workgroup per pair: rows i < nv with argmax_j scores[i][j] (first maximum) == i
 __global__ __launch_bounds__(256) void accuracy_max_kernel(const float *scores, const int *nvalid, int N, int *correct) {
     __shared__ int red[4];
@@ -65,6 +107,15 @@ extern "C" int fgnn_adam_step(float *params, const float *grads, float *exp_avg,
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                        exp_avg_sq, n, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
                        (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n,
+                                  const double *hp, int *state, void *stream) {
+    FGNN_CHECK(params && grads && exp_avg && exp_avg_sq && hp && state && n > 0, "fgnn_adam_step_dev: bad arguments");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, n, hp, state);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

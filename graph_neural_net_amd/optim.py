@@ -25,6 +25,30 @@ class FlatAdam:
                   float(self.betas[1]), float(self.eps), self.t, float(grad_scale), _lib.stream_ptr())
 
 
+    # -- graph-replayable form: step count and hyper-parameters live in device memory ---------------------
+    def _dev_state(self):
+        if getattr(self, '_hp', None) is None:
+            self._hp = torch.zeros(5, dtype=torch.float64, device=self.params.device)
+            self._state = torch.tensor([self.t, 0], dtype=torch.int32, device=self.params.device)
+            self._hp_host = None
+        return self._hp, self._state
+
+    def sync_hyper_parameters(self, grad_scale=1.0):
+        """Push lr / betas / eps / grad_scale to the device copy if they changed (outside any graph capture)."""
+        hp, _ = self._dev_state()
+        cur = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
+        if cur != self._hp_host:
+            hp.copy_(torch.tensor(cur, dtype=torch.float64))
+            self._hp_host = cur
+
+    def step_dev(self, grads_flat):
+        """One update whose launch can be captured in a HIP graph and replayed (call sync_hyper_parameters first)."""
+        hp, state = self._dev_state()
+        self.t += 1
+        _lib.call('fgnn_adam_step_dev', _lib.ptr(self.params), _lib.ptr(grads_flat), _lib.ptr(self.exp_avg),
+                  _lib.ptr(self.exp_avg_sq), self.params.numel(), _lib.ptr(hp), _lib.ptr(state), _lib.stream_ptr())
+
+
 class ReduceLROnPlateau:
     """mode='min', relative threshold 1e-4 -- the torch defaults the reference relies on."""
 

@@ -241,6 +241,10 @@ int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *
  * semantics (models/trainers.py:92-104); grads are multiplied by grad_scale first; step >= 1.      */
 int fgnn_adam_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n, double lr,
                    double beta1, double beta2, double eps, int step, double grad_scale, void *stream);
+/* the same update for a captured / replayed launch: hp (device, 5 doubles) = {lr, beta1, beta2, eps, grad_scale};
+ * state (device, 2 ints, zero-initialised) = {steps taken, internal arrival counter}; the kernel advances state[0] */
+int fgnn_adam_step_dev(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int n,
+                       const double *hp, int *state, void *stream);
 /* accuracy_max (toolbox/metrics.py:119-141): correct[b] = #{i < n_b : argmax_j scores[b,i,j] == i},
  * first maximum on ties (np.argmax); int32, bit-exact.                                              */
 int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int *correct, void *stream);

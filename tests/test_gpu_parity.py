@@ -273,6 +273,30 @@ def test_ragged_bucketed_step_equals_padded_batch_and_oracle():
     assert ours < 2 * theirs + 1e-6, (ours, theirs)
 
 
+def test_captured_training_step_equals_eager():
+    """HIP-graph-captured trainer step (model work + device-side Adam step count) == eager trainer step:
+    identical loss trajectory and parameters (the kernels are the same and deterministic)."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    p0 = lay.init_flat(3, DEV)
+    batches = [synthetic.make_batch(7000 + i, 4, 18, 'ErdosRenyi', 0.3, 0.05) for i in range(3)]
+    out = []
+    for capture in (False, True):
+        tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, capture=capture)
+        losses = []
+        for s in range(7):
+            x1, x2 = batches[s % 3]
+            loss, scores = tr.train_step(x1.to(DEV), x2.to(DEV))
+            losses.append(loss.item())
+            if s == 3:
+                tr.opt.lr = 1e-3                  # a scheduler step between replays must be picked up
+        out.append((losses, tr.params.clone(), tr.opt.t))
+    (l0, p_eager, t0), (l1, p_graph, t1) = out
+    assert t0 == t1 == 7
+    assert l0 == l1
+    assert torch.equal(p_eager, p_graph)
+
+
 def test_training_step_matches_oracle_plus_torch_adam():
     """engine step + fused Adam tracks oracle autograd + torch.optim.Adam on the CPU: the loss of steps 1..4
     (which depends on the previously updated parameters) agrees, and training makes progress.  (Parameters

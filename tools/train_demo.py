@@ -14,7 +14,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 dev = torch.device('cuda:0')
 lay = ParamLayout(2, 4, 32, 32, 3)
-tr = FgnnTrainer(lay, lay.init_flat(0, dev), lr=1e-3)
+capture = os.environ.get('FGNN_CAPTURE', '1') != '0'
+tr = FgnnTrainer(lay, lay.init_flat(0, dev), lr=1e-3, capture=capture)
 pool = [synthetic.make_batch(100 + i, B, N, 'Regular', 0.2, 0.05) for i in range(16)]    # host generation is slow
 pool = [(a.to(dev), b.to(dev)) for a, b in pool]
 t0 = time.time()
@@ -25,4 +26,4 @@ for s in range(steps):
         acc, n = accuracy_max(scores)
         print('step %4d  loss %.4f  acc_max %.3f' % (s, loss.item(), acc / n), flush=True)
 torch.cuda.synchronize()
-print('%.1f steps/s (eager, incl. Adam, metric syncs excluded)' % (steps / (time.time() - t0)))
+print('%.1f steps/s (%s, incl. Adam)' % (steps / (time.time() - t0), 'HIP graph replay' if capture else 'eager launches'))
