@@ -25,6 +25,12 @@
 #include "fgnn_common.h"
 #include "fgnn_pack.h"
 
+#ifdef FGNN_PHASES
+// debug build only: absolute s_memtime stamps per wave {start, prologue done, loop done, tiles}
+__device__ unsigned long long *g_fwd_stamp = nullptr;
+__device__ int g_fwd_sel = 0;
+#endif
+
 namespace {
 
 constexpr int TLD = 36;              // LDS tile row stride (floats)
@@ -146,6 +152,11 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
+#ifdef FGNN_PHASES
+    const unsigned long long st0_ = __builtin_amdgcn_s_memtime();
+    unsigned long long st1_ = 0;
+    int ntl_ = 0;
+#endif
     constexpr int SA = CA / 2, SB = CB / 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -219,8 +230,14 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         reinterpret_cast<float4 *>(recB)[lane] = rb;
     }
     __syncthreads();
+#ifdef FGNN_PHASES
+    st1_ = __builtin_amdgcn_s_memtime();
+#endif
 
     while (tile < T1) {
+#ifdef FGNN_PHASES
+        ++ntl_;
+#endif
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, j);
         if (c.g != cached_g) {        // wave-uniform; issued before the prefetch (vmcnt is in-order)
             if (lane < 32) {
@@ -332,6 +349,15 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         for (int s = 0; s < SB; ++s) xb[s] = nb[s];
         tile = next;
     }
+#ifdef FGNN_PHASES
+    if (g_fwd_stamp && g_fwd_sel == CA * 1000 + CB * 10 + NMLP && (threadIdx.x & 63) == 0) {
+        unsigned long long *o = g_fwd_stamp + ((long long)blockIdx.x * NW + wv) * 4;
+        o[0] = st0_;
+        o[1] = st1_;
+        o[2] = __builtin_amdgcn_s_memtime();
+        o[3] = ntl_;
+    }
+#endif
 }
 
 template <int CA, int CB, int NMLP, int DEPTH>
@@ -371,6 +397,14 @@ int dispatch_c(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef FGNN_PHASES
+extern "C" int fgnn_debug_fwd_stamps(void *p, int ca, int cb, int nmlp) {
+    const int sel = ca * 1000 + cb * 10 + nmlp;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_sel), &sel, sizeof(sel)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_stamp), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int fgnn_tiles_per_graph(int N) { return (N * N + FGNN_TILE - 1) / FGNN_TILE; }
 
