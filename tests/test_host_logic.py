@@ -185,3 +185,19 @@ def test_accuracy_linear_assignment_host_metric():
     mt = MaskedTensor(pad, torch.tensor([3, 5]), (1, 2))
     assert accuracy_linear_assignment(mt) == (8, 8)
     assert accuracy_linear_assignment(mt, aggregate_score=False) == [1.0, 1.0]
+
+
+def test_bench_algorithmic_model_matches_survey_figures():
+    """bench.py's per-pair and per-launch algorithmic figures."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fl, by = bench.algorithmic_per_pair(50, 4)
+    assert abs(fl / 1e9 - 1.3349) < 1e-3 and abs(by / 1e6 - 61.16) < 1e-2
+    fl20, by20 = bench.algorithmic_per_pair(20, 1)
+    assert abs(fl20 / 1e9 - 0.0385) < 1e-3 and abs(by20 / 1e6 - 1.80) < 5e-2      # cfg1
+    b, f = bench.kernel_model('mlp_bwd[cin=32,dx=32]', 64, 50)
+    assert b == 4.0 * 64 * 2500 * 128 == 81.92e6 and f == 4.0 * 64 * 2500 * 3072
+    b, f = bench.kernel_model('fgnn_chan_matmul_fwd', 64, 50)
+    assert b == 4.0 * 64 * 32 * 2500 * 3 and f == 2.0 * 64 * 32 * 50 ** 3
