@@ -252,6 +252,15 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     // (operand image copy moved below: the first tile's loads are issued first)
 
     // ---- persistent accumulators ----
+    // Two-channel input (block 1: adjacency + degree): the layer-0 weight gradient has 2 useful columns, so an MFMA
+    // over a zero-padded 32-channel tile (and its LDS staging) is replaced by 48 per-lane FMAs / adds per tile,
+    // reduced over the pixels once at the end of the kernel.
+    constexpr bool VW0 = (CA == 2 && CB == 0);
+    float w0v[VW0 ? 32 : 1], b0v[VW0 ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (VW0 ? 32 : 1); ++r) w0v[r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < (VW0 ? 16 : 1); ++r) b0v[r] = 0.f;
     f32x16 dW0a, dW0b, dWh[DEPTH > 1 ? DEPTH - 1 : 1];
     float db[DEPTH];
     zero16(dW0a);
@@ -490,9 +499,22 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         // ---- layer 0: D tile = (DEPTH == 1 ? S2 : (DEPTH == 2 ? S1 : S2)); x tiles re-staged now ----
         {
             float *Dt = (DEPTH == 2) ? S1 : S2;
+            if constexpr (VW0) {
+                float ya[1];
+                norm_from_lds<SA>(ya, xa, recA, normA, c_valid, h);      // channel h of this lane's pixel
+                const float other = __shfl_xor(ya[0], 32);
+                const float x0 = h ? other : ya[0], x1 = h ? ya[0] : other;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    w0v[2 * r] = fmaf(dpre[r], x0, w0v[2 * r]);
+                    w0v[2 * r + 1] = fmaf(dpre[r], x1, w0v[2 * r + 1]);
+                    b0v[r] += dpre[r];
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) Dt[ch_of(r, h) * TLD + j] = dpre[r];
-            {
+            }
+            if constexpr (!VW0) {
                 float ya[SA > 0 ? SA : 1];
                 norm_from_lds<SA>(ya, xa, recA, normA, c_valid, h);
                 if constexpr (CA < 32) {
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                     for (int r = 0; r < 16; ++r) dxb_acc = mfma32(wt[r], dpre[r], dxb_acc);
                 }
             }
-            dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
+            if constexpr (!VW0) dW0a = wgrad_tile<true>(Dt, XA, dW0a, db[0], lane);
             if constexpr (CB > 0) {
                 float dummy = 0.f;
                 dW0b = wgrad_tile<false>(Dt, XB, dW0b, dummy, lane);
@@ -632,12 +654,26 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     constexpr int PCOUNT = L::PCOUNT;
 #pragma unroll
     for (int l = 0; l < DEPTH; ++l) db[l] += __shfl_xor(db[l], 32);
+    if constexpr (VW0) {                    // sum the per-pixel partials over the 32 lanes of each half-wave
+#pragma unroll
+        for (int r = 0; r < 32; ++r) w0v[r] = half_sum(w0v[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) b0v[r] = half_sum(b0v[r]);
+    }
     auto put_partials = [&](float *red) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = ch_of(r, h);
-            if (j < CA) red[o * CIN + j] = dW0a[r];
-            if (CB > 0 && j < CB) red[o * CIN + CA + j] = dW0b[r];
+            if constexpr (VW0) {
+                if (j == 0) {
+                    red[o * CIN] = w0v[2 * r];
+                    red[o * CIN + 1] = w0v[2 * r + 1];
+                    red[32 * CIN + o] = b0v[r];
+                }
+            } else {
+                if (j < CA) red[o * CIN + j] = dW0a[r];
+                if (CB > 0 && j < CB) red[o * CIN + CA + j] = dW0b[r];
+            }
         }
         int off = 32 * CIN;
 #pragma unroll
@@ -647,7 +683,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 for (int r = 0; r < 16; ++r) red[off + ch_of(r, h) * 32 + j] = dWh[l - 1][r];
                 off += 1024;
             }
-            if (h == 0) red[off + j] = db[l];
+            if (h == 0 && !(VW0 && l == 0)) red[off + j] = db[l];
             off += 32;
         }
     };
