@@ -27,11 +27,24 @@ from graph_neural_net_amd.engine import FgnnEngine, ParamLayout  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def kernel_model(tag, G, N):
-    """Algorithmic (bytes, flops) of one launch of `tag` (interface reads + writes, fp32)."""
+    """Algorithmic (bytes, flops) of one launch of `tag` (interface reads + writes; fp32 slabs, bf16 for the *16 kernels)."""
     P = N * N
+    if tag.startswith('mlp_fwd16['):
+        cin, nmlp = [int(v.split('=')[1]) for v in tag[10:-1].split(',')]
+        return 2.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
+    if tag.startswith('mlp_bwd16['):
+        cin, dx = [int(v.split('=')[1]) for v in tag[10:-1].split(',')]
+        return 2.0 * G * P * (cin + 64 + dx), 4.0 * G * P * (cin * 32 + 2 * 1024)
+    if tag == 'fgnn_chan_matmul_fwd16':
+        return 2.0 * G * 32 * P * 3, 2.0 * G * 32 * N ** 3
+    if tag == 'fgnn_chan_matmul_bwd16':
+        return 2.0 * G * 32 * P * 5, 4.0 * G * 32 * N ** 3
+    if tag == 'fgnn_colmax_bwd16' or tag == 'fgnn_colmax_fwd16':
+        return 2.0 * G * 32 * P, 1.0 * G * 32 * P
     if tag.startswith('mlp_fwd['):
         cin, nmlp = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
         return 4.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
@@ -49,14 +62,14 @@ def kernel_model(tag, G, N):
     return 0.0, 0.0
 
 
-def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2):
-    """(flops fwd+bwd, bytes fwd+bwd) per pair."""
+def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2, elt=4):
+    """(flops fwd+bwd, bytes fwd+bwd) per pair; elt = bytes per stored activation."""
     fg, by, cin = 0, 0, c0
     for _ in range(num_blocks):
         fg += 2 * N * N * (3 * cin * C + 7 * C * C) + 2 * N ** 3 * C
         by += 9 * cin + 17 * C
         cin = C
-    return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * 4 * N * N * by
+    return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * elt * N * N * by
 
 
 def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
@@ -100,8 +113,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=32, help='pairs per GPU')
-    ap.add_argument('--n', type=int, default=50, help='vertices per graph')
+    ap.add_argument('--config', default='cfg2', choices=('cfg2', 'cfg4'),
+                    help='BASELINE.json configs[1] (N=50 regular pairs, batch 32, fp32; the headline line) or '
+                         'configs[3] (N=200 dense ER pairs, batch 8, bf16)')
+    ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
+    ap.add_argument('--n', type=int, default=None, help='vertices per graph (default: the config\'s)')
     ap.add_argument('--blocks', type=int, default=4)
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -119,13 +135,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    B, N = args.batch, args.n
+    bf16 = args.config == 'cfg4'
+    B = args.batch if args.batch is not None else (8 if bf16 else 32)
+    N = args.n if args.n is not None else (200 if bf16 else 50)
     layout = ParamLayout(2, args.blocks, 32, 32, 3)
     params = layout.init_flat(0, dev)
     grads = torch.zeros_like(params)
-    x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
+    if bf16:       # cfg4: dense Erdos-Renyi (edge density 0.5) pairs, ER edge noise 0.1
+        x1, x2 = synthetic.make_batch(4000 + rank, B, N, 'ErdosRenyi', 0.5, 0.1)
+        from graph_neural_net_amd.engine16 import FgnnEngineBF16
+        eng = FgnnEngineBF16(layout, 2 * B, N, dev)
+    else:
+        x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
+        eng = FgnnEngine(layout, 2 * B, N, dev)
     x = torch.cat([x1, x2]).contiguous().to(dev)
-    eng = FgnnEngine(layout, 2 * B, N, dev)
     total_nodes = float(B * N * world)            # loss normaliser of the concatenated global batch
 
     def model_work():
@@ -190,10 +213,11 @@ def main():
         dom = max(kernels, key=lambda t: kernels[t][1])
         by, fl = kernel_model(dom, 2 * B, N)
         dur = summary[dom]['avg_ms'] * 1e-3
-        if fl / (MFMA_F32_PEAK_TF * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
+        mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
+        if fl / (mfma_peak * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
             ach = fl / dur / 1e12
-            roofline = {'bound': 'mfma', 'achieved': ach, 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                        'frac': ach / MFMA_F32_PEAK_TF, 'traffic': None}
+            roofline = {'bound': 'mfma', 'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                        'frac': ach / mfma_peak, 'traffic': None}
         else:
             ach = by / dur / 1e9
             roofline = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -201,8 +225,13 @@ def main():
         try:   # HBM traffic of that kernel from the committed PMC passes (same workload), if present
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
                 tr = json.load(f)
-            if dom in tr and (B, N) == (32, 50):
-                roofline['traffic'] = tr[dom]['bytes']
+            key = dom if not bf16 else 'cfg4:' + dom
+            if key in tr and (B, N) == ((8, 200) if bf16 else (32, 50)):
+                dom_key = key
+            else:
+                dom_key = None
+            if dom_key is not None:
+                roofline['traffic'] = tr[dom_key]['bytes']
                 roofline['traffic_source'] = tr.get('_source')
         except (OSError, ValueError):
             pass
@@ -214,22 +243,29 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        fl_pair, by_pair = algorithmic_per_pair(N, args.blocks)
+        fl_pair, by_pair = algorithmic_per_pair(N, args.blocks, elt=2 if bf16 else 4)
+        if bf16:
+            workload = ('cfg4: N=%d dense Erdos-Renyi pairs (edge density 0.5, ER edge noise 0.1), %d pairs per GPU, '
+                        '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd, bf16 storage + bf16 MFMA, '
+                        'fp32 accumulation / statistics / gradients' % (N, B, args.blocks))
+        else:
+            workload = ('cfg2: N=%d random-regular pairs (d=%d, ER edge noise 0.1), %d pairs per GPU, '
+                        '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd'
+                        % (N, synthetic.regular_degree(N, 0.2), B, args.blocks))
         out = {
-            'metric': 'graph-pairs/sec FGNN fwd+bwd, N=%d regular pairs' % N,
+            'metric': ('graph-pairs/sec FGNN fwd+bwd, N=%d dense ER pairs, bf16' % N) if bf16
+                      else 'graph-pairs/sec FGNN fwd+bwd, N=%d regular pairs' % N,
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'cfg2: N=%d random-regular pairs (d=%d, ER edge noise 0.1), %d pairs per GPU, '
-                                   '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd'
-                                   % (N, synthetic.regular_degree(N, 0.2), B, args.blocks),
+            'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
                        'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
                        'grad_allreduce': 'rccl sum of %d fp32 per step' % layout.total if world > 1 else 'none'},
             'roofline': roofline,
             'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,
                            'hbm_frac_of_8TBs': value / world * by_pair / (HBM_PEAK_GBS * 1e9),
-                           'mfma_frac_of_157TF': value / world * fl_pair / (MFMA_F32_PEAK_TF * 1e12)},
+                           'mfma_frac_of_peak': value / world * fl_pair / ((MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12)},
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

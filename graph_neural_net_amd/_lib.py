@@ -54,6 +54,32 @@ class MlpBwdArgs(C.Structure):
                 ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p)]
 
 
+class Slab16(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('gstride', C.c_longlong), ('ldp', C.c_longlong), ('C', C.c_int),
+                ('nrm', C.c_void_p), ('beta', C.c_void_p)]
+
+
+class MlpFwd16Args(C.Structure):
+    _fields_ = [('G', C.c_int), ('N', C.c_int), ('ldr', C.c_int), ('depth', C.c_int), ('nmlp', C.c_int),
+                ('nvalid', C.c_void_p),
+                ('a', Slab16), ('b', Slab16),
+                ('z', C.c_void_p * 2), ('ldz', C.c_longlong),
+                ('part', C.c_void_p * 2), ('cnt', C.c_void_p), ('packed', C.c_void_p)]
+
+
+class MlpBwd16Args(C.Structure):
+    _fields_ = [('G', C.c_int), ('N', C.c_int), ('ldr', C.c_int), ('depth', C.c_int),
+                ('nvalid', C.c_void_p),
+                ('a', Slab16), ('b', Slab16),
+                ('dy', C.c_void_p), ('dgstride', C.c_longlong), ('ldd', C.c_longlong),
+                ('z', C.c_void_p), ('zgstride', C.c_longlong), ('ldz', C.c_longlong),
+                ('coef', C.c_void_p),
+                ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
+                ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
+                ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
+                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p)]
+
+
 class GradJob(C.Structure):
     _fields_ = [('wpart', C.c_void_p), ('count', C.c_int), ('out', C.c_void_p), ('s12', C.c_void_p),
                 ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p), ('rows', C.c_int), ('scale', C.c_float)]
@@ -110,6 +136,21 @@ _SIGNATURES = {
     'fgnn_adam_step_dev': [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP],
     'fgnn_expand_adjacency': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_accuracy_max': [_VP, _VP, _I, _I, _VP, _VP],
+    # ---- bf16 path ----
+    'fgnn_tiles_per_graph16': [_I, _I],
+    'fgnn_to_bf16': [_VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_from_bf16': [_VP, _LL, _LL, _I, _I, _I, _I, _VP, _VP],
+    'fgnn_pack16_floats': [_I, _I, _I, _I, _I],
+    'fgnn_pack16_operands': [_VP, _I, _VP],
+    'fgnn_mlp_fwd16': [C.POINTER(MlpFwd16Args), _VP],
+    'fgnn_gn_finalize_tpg': [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP],
+    'fgnn_gn_finalize2_tpg': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP],
+    'fgnn_gn_bwd_coef_tiles_tpg': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_chan_matmul_fwd16': [C.POINTER(Slab16), C.POINTER(Slab16), _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_chan_matmul_bwd16': [C.POINTER(Slab16), C.POINTER(Slab16), _VP, _LL, _LL, _VP, _I, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
+    'fgnn_colmax_fwd16': [C.POINTER(Slab16), _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_colmax_bwd16': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab16), _VP, _VP],
+    'fgnn_mlp_bwd16': [C.POINTER(MlpBwd16Args), _VP],
 }
 _RESTYPES = {'fgnn_last_error': C.c_char_p}
 EXPORTS = tuple(_SIGNATURES)
@@ -183,6 +224,17 @@ def make_slab(t, gstride, ldp, channels, nrm=None, beta=None):
     s.C = channels
     s.nrm = nrm.data_ptr() if nrm is not None else None
     s.beta = beta.data_ptr() if beta is not None else None
+    return s
+
+
+def make_slab16(t, gstride, ldp, channels, nrm=None, beta=None):
+    s = Slab16()
+    s.ptr = t.data_ptr() if t is not None else None
+    s.gstride = gstride
+    s.ldp = ldp
+    s.C = channels
+    s.nrm = nrm.data_ptr() if nrm is not None else None
+    s.beta = beta if isinstance(beta, int) else (beta.data_ptr() if beta is not None else None)
     return s
 
 

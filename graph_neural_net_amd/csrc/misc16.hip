@@ -1,0 +1,230 @@
+// Small kernels of the bf16 path (gfx950): operand-image packing, fp32 <-> bf16 slab conversion with the padded row
+// pitch, ColumnMaxPooling (models/layers.py:194-203) forward / backward on bf16 slabs.
+#include <float.h>
+#include "fgnn_bf16.h"
+
+namespace {
+
+struct Pack16Jobs {
+    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
+};
+
+// grid (blocks per job, njobs): one thread per (step, lane) writes the lane's 4 dwords; the tail is plain fp32
+__global__ __launch_bounds__(256) void pack16_kernel(const Pack16Jobs J) {
+    const fgnn_pack_job &jb = J.job[blockIdx.y];
+    const Pk16 p = pk16_layout(jb.kind, jb.ca, jb.cb, jb.depth);
+    const int nm = jb.kind == 0 ? jb.nmlp : 1;
+    unsigned *out = reinterpret_cast<unsigned *>(jb.out);
+    for (int m = 0; m < nm; ++m) {
+        unsigned *om = out + (long long)m * p.floats;
+        const float *const *W = jb.W[m];
+        const float *const *Bv = jb.bias[m];
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.steps * 64; e += gridDim.x * 256) {
+            const int step = e >> 6, l = e & 63;
+            uint4 v;
+            unsigned d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                d[q] = cvt_pk(pk16_value(jb.kind, p, jb.ca, jb.cb, jb.depth, W, step, l, 2 * q),
+                              pk16_value(jb.kind, p, jb.ca, jb.cb, jb.depth, W, step, l, 2 * q + 1));
+            v.x = d[0];
+            v.y = d[1];
+            v.z = d[2];
+            v.w = d[3];
+            reinterpret_cast<uint4 *>(om)[e] = v;
+        }
+        float *tail = reinterpret_cast<float *>(om + p.bias_f);
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < 32 * p.nbias; e += gridDim.x * 256) {
+            const int layer = e >> 5, r = e & 15, h = (e >> 4) & 1;
+            tail[e] = Bv[layer][pk16_ch(r, h)];                                   // compact [layer][h][16]
+            if (jb.kind == 0) tail[32 * p.nbias + e] = Bv[layer][e & 31];         // plain [layer][32]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *x, const int *nvalid, int C, int N, int ldr,
+                                                      unsigned short *y, long long gstride, long long ldp) {
+    const int gc = blockIdx.y, g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    const float *src = x + (long long)gc * N * N;
+    unsigned short *dst = y + (long long)g * gstride + (long long)c * ldp;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N * ldr; p += gridDim.x * 256) {
+        const int i = p / ldr, j = p - i * ldr;
+        const float v = (i < nv && j < nv) ? src[(long long)i * N + j] : 0.f;
+        dst[p] = (unsigned short)(cvt_pk(v, 0.f) & 0xffffu);
+    }
+}
+
+__global__ __launch_bounds__(256) void from_bf16_kernel(const unsigned short *y, long long gstride, long long ldp, int C, int N,
+                                                        int ldr, float *x) {
+    const int gc = blockIdx.y, g = gc / C, c = gc - g * C;
+    const unsigned short *src = y + (long long)g * gstride + (long long)c * ldp;
+    float *dst = x + (long long)gc * N * N;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < N * N; p += gridDim.x * 256) {
+        const int i = p / N, j = p - i * N;
+        dst[p] = __builtin_bit_cast(float, (unsigned)src[(long long)i * ldr + j] << 16);
+    }
+}
+
+// one wave per (g, c, i) row: lanes stride the pixel pairs of the row; first maximum (torch.max semantics)
+__global__ __launch_bounds__(256) void colmax_fwd16_kernel(const fgnn_slab16 y, const int *nvalid, int G, int N, int ldr,
+                                                           float *e, int *idx) {
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int C = y.C;
+    if (t >= (long long)G * C * N) return;
+    const int lane = threadIdx.x & 63;
+    const int i = (int)(t % N);
+    const int gc = (int)(t / N);
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    float best = 0.f;
+    int bi = 0;
+    if (i < nv) {
+        const unsigned *row = reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned short *>(y.ptr) +
+                                                                  (long long)g * y.gstride + (long long)c * y.ldp +
+                                                                  (long long)i * ldr);
+        float a = 1.f, b = 0.f;
+        if (y.nrm) {
+            const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
+            a = n.y;
+            b = (y.beta ? y.beta[c] : 0.f) - n.x * n.y;
+        }
+        best = -FLT_MAX;
+        bi = 0x7fffffff;
+        for (int jp = lane; 2 * jp < nv; jp += WAVE) {
+            const unsigned d = row[jp];
+            const float v0 = fmaf(bf_lo(d), a, b), v1 = fmaf(bf_hi(d), a, b);
+            if (v0 > best) {
+                best = v0;
+                bi = 2 * jp;
+            }
+            if (2 * jp + 1 < nv && v1 > best) {
+                best = v1;
+                bi = 2 * jp + 1;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+    }
+    if (lane == 0) {
+        e[t] = best;
+        idx[t] = bi;
+    }
+}
+
+// one workgroup per (g,c): stage the rows' (argmax, R(de)), then walk the channel linearly in pixel pairs
+constexpr int CMB16_MAXN = 1024;
+__global__ __launch_bounds__(256) void colmax_bwd16_kernel(const float *de, const int *idx, const int *nvalid, int G, int C,
+                                                           int N, int ldr, unsigned short *dy, long long gstride,
+                                                           long long ldp, const fgnn_slab16 y, float *s12) {
+    __shared__ int sidx[CMB16_MAXN];
+    __shared__ unsigned sde[CMB16_MAXN];
+    __shared__ float red[4][2];
+    const int gc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    unsigned *mat = reinterpret_cast<unsigned *>(dy + (long long)g * gstride + (long long)c * ldp);
+    const unsigned short *zm =
+        s12 ? reinterpret_cast<const unsigned short *>(y.ptr) + (long long)g * y.gstride + (long long)c * y.ldp : nullptr;
+    const float mean = s12 ? y.nrm[(long long)gc * 4] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = tid; i < N; i += 256) {
+        const long long t = (long long)gc * N + i;
+        const int bi = idx[t];
+        const unsigned db = i < nv ? (cvt_pk(de[t], 0.f) & 0xffffu) : 0u;        // R(de)
+        sidx[i] = bi;
+        sde[i] = db;
+        if (s12 && i < nv) {
+            const float d = bf_lo(db);
+            s1 += d;
+            s2 += d * (bf_lo(zm[(long long)i * ldr + bi]) - mean);
+        }
+    }
+    __syncthreads();
+    const int hp = ldr / 2;            // pixel pairs per row
+    for (int q = tid; q < N * hp; q += 256) {
+        const int i = q / hp, jp = q - i * hp;
+        const int bi = sidx[i];
+        const unsigned d = sde[i];
+        mat[q] = (bi == 2 * jp) ? d : ((bi == 2 * jp + 1) ? (d << 16) : 0u);
+    }
+    if (s12) {
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) {
+            red[wave][0] = s1;
+            red[wave][1] = s2;
+        }
+        __syncthreads();
+        if (tid < 2) s12[(long long)gc * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
+}  // namespace
+
+extern "C" int fgnn_pack16_floats(int kind, int ca, int cb, int depth, int nmlp) {
+    return pk16_layout(kind, ca, cb, depth).floats * (kind == 0 ? nmlp : 1);
+}
+
+extern "C" int fgnn_pack16_operands(const fgnn_pack_job *jobs, int njobs, void *stream) {
+    FGNN_CHECK(jobs && njobs > 0 && njobs <= FGNN_MAX_PACK_JOBS, "fgnn_pack16_operands: bad arguments (njobs=%d)", njobs);
+    Pack16Jobs J;
+    for (int i = 0; i < njobs; ++i) {
+        FGNN_CHECK(jobs[i].out && jobs[i].depth >= 2 && jobs[i].depth <= FGNN_MAX_DEPTH && (jobs[i].nmlp == 1 || jobs[i].nmlp == 2),
+                   "fgnn_pack16_operands: job %d malformed", i);
+        FGNN_CHECK((jobs[i].ca == 2 || jobs[i].ca == 32) && (jobs[i].cb == 0 || jobs[i].cb == 2 || jobs[i].cb == 32),
+                   "fgnn_pack16_operands: job %d: slab widths must be 2 or 32", i);
+        J.job[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(pack16_kernel, dim3(4, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_to_bf16(const float *x, const int *nvalid, int G, int C, int N, int ldr, void *y, long long gstride,
+                            long long ldp, void *stream) {
+    FGNN_CHECK(x && y && G > 0 && C > 0 && N > 0 && ldr >= N && ldp >= (long long)N * ldr, "fgnn_to_bf16: bad arguments");
+    const int nb = (N * ldr + 255) / 256;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(nb > 64 ? 64 : nb, G * C), dim3(256), 0, (hipStream_t)stream, x, nvalid, C, N, ldr,
+                       (unsigned short *)y, gstride, ldp);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_from_bf16(const void *y, long long gstride, long long ldp, int G, int C, int N, int ldr, float *x,
+                              void *stream) {
+    FGNN_CHECK(x && y && G > 0 && C > 0 && N > 0 && ldr >= N, "fgnn_from_bf16: bad arguments");
+    const int nb = (N * N + 255) / 256;
+    hipLaunchKernelGGL(from_bf16_kernel, dim3(nb > 64 ? 64 : nb, G * C), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short *)y, gstride, ldp, C, N, ldr, x);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G, int N, int ldr, float *e, int *idx,
+                                 void *stream) {
+    FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && ldr >= N && ldr % 2 == 0, "fgnn_colmax_fwd16: bad arguments");
+    const long long rows = (long long)G * y->C * N;
+    hipLaunchKernelGGL(colmax_fwd16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y, nvalid, G, N,
+                       ldr, e, idx);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_colmax_bwd16(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
+                                 long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, void *stream) {
+    FGNN_CHECK(de && idx && dy && G > 0 && C > 0 && N > 0 && ldr >= N && ldr % 2 == 0, "fgnn_colmax_bwd16: bad arguments");
+    FGNN_CHECK(N <= CMB16_MAXN, "fgnn_colmax_bwd16: N=%d > %d", N, CMB16_MAXN);
+    FGNN_CHECK(!s12 || (y && y->ptr && y->nrm), "fgnn_colmax_bwd16: s12 needs the normalised input slab");
+    fgnn_slab16 none = {};
+    hipLaunchKernelGGL(colmax_bwd16_kernel, dim3(G * C), dim3(256), 0, (hipStream_t)stream, de, idx, nvalid, G, C, N, ldr,
+                       (unsigned short *)dy, gstride, ldp, y ? *y : none, s12);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

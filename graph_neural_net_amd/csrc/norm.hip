@@ -339,27 +339,37 @@ extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *st
     return 0;
 }
 
-extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
-                                int G, int C, int N, float eps, float *nrm, void *stream) {
-    FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize: bad arguments");
+extern "C" int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
+                                    int G, int C, int N, int tpg, float eps, float *nrm, void *stream) {
+    FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part, nullptr}, {gn_weight, nullptr}, {nrm, nullptr}};
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
-                       nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
+                       nvalid, G, C, N, tpg, eps);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
+                                int G, int C, int N, float eps, float *nrm, void *stream) {
+    return fgnn_gn_finalize_tpg(part, cnt, gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm, stream);
+}
 
-extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
-                                 const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
-                                 float *nrm0, float *nrm1, void *stream) {
-    FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0, "fgnn_gn_finalize2: bad arguments");
+extern "C" int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                                     const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps,
+                                     float *nrm0, float *nrm1, void *stream) {
+    FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_finalize2: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part0, part1}, {gn_weight0, gn_weight1}, {nrm0, nrm1}};
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
-                       nvalid, G, C, N, fgnn_tiles_per_graph(N), eps);
+                       nvalid, G, C, N, tpg, eps);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                                 const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
+                                 float *nrm0, float *nrm1, void *stream) {
+    return fgnn_gn_finalize2_tpg(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps,
+                                 nrm0, nrm1, stream);
 }
 
 extern "C" int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float *gn_weight,
@@ -436,14 +446,18 @@ extern "C" int fgnn_sum_scale(const float *in, int rows, int cols, float scale, 
     return 0;
 }
 
-extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
-                                      float *s12, float *coef, void *stream) {
-    FGNN_CHECK(s12part && nrm && s12 && coef && G > 0 && C > 0 && N > 0, "fgnn_gn_bwd_coef_tiles: bad arguments");
+extern "C" int fgnn_gn_bwd_coef_tiles_tpg(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                          int tpg, float *s12, float *coef, void *stream) {
+    FGNN_CHECK(s12part && nrm && s12 && coef && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_bwd_coef_tiles: bad arguments");
     const int tot = G * C;
     hipLaunchKernelGGL(gn_bwd_coef_tiles_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, s12part, nrm,
-                       nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef);
+                       nvalid, G, C, N, tpg, s12, coef);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                      float *s12, float *coef, void *stream) {
+    return fgnn_gn_bwd_coef_tiles_tpg(s12part, nrm, nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef, stream);
 }
 
 extern "C" int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream) {

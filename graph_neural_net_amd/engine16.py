@@ -1,0 +1,312 @@
+"""bf16 execution of the 2-FGNN hot path on one MI355X (BASELINE config 4: N = 200 dense pairs in 16-bit).
+
+Same launch structure as ``engine.FgnnEngine`` -- what ``Siamese_Node_Exp.forward`` + ``triplet_loss`` + autograd do
+in the reference (models/trainers.py:60-68, models/blocks_emb.py:16-43, toolbox/losses.py:20-34), which trains
+under 16-bit AMP (commander_explore.py:120-122, ``Network.half`` models/utils.py:71-74) -- with every activation
+and gradient slab STORED as bf16 (half the HBM bytes of the regime SURVEY.md 8d calls purely HBM-bound), every
+channel contraction and per-channel N x N product on ``v_mfma_f32_32x32x16_bf16``, and fp32 accumulation,
+biases, GraphNorm statistics, embeddings, scores, loss and parameter gradients.  Parameters and gradients are the
+same flat fp32 buffers as in the fp32 engine (one all-reduce per step).
+
+Rounding points are spelled out in ``oracle/fgnn_oracle_bf16.py`` (test infrastructure; never imported here).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import EPS, ParamLayout, _round_up  # noqa: F401
+
+
+class FgnnEngineBF16:
+    """Workspace + launch sequence for a fixed (G, N) problem on the current device, bf16 storage."""
+
+    def __init__(self, layout, G, N, device, ragged=False):
+        lib = _lib.load()
+        if layout.depth != 3:
+            raise RuntimeError('the bf16 kernels are built for depth_of_mlp = 3 (got %d)' % layout.depth)
+        if layout.c0 != 2:
+            raise RuntimeError('the bf16 kernels are built for original_features_num = 2 (got %d)' % layout.c0)
+        if N > 256:
+            raise RuntimeError('the bf16 per-channel matmul handles N <= 256 (got %d)' % N)
+        self.layout = layout
+        self.G, self.N = G, N
+        self.B = G // 2
+        self.ldr = _round_up(N, 8)                       # row pitch of an N x N matrix inside a channel
+        self.ldp = _round_up(N * self.ldr, 64)           # channel stride
+        self.tpg = lib.fgnn_tiles_per_graph16(N, self.ldr)
+        self.device = device
+        K = layout.num_blocks
+        f32 = dict(dtype=torch.float32, device=device)
+        bf = dict(dtype=torch.bfloat16, device=device)
+        act = lambda: torch.empty(G * 32 * self.ldp, **bf)
+        self.x16 = torch.empty(G * 2 * self.ldp, **bf)
+        self.z = {(k, j): act() for k in range(1, K + 1) for j in (1, 2, 3)}
+        self.mult = {k: act() for k in range(1, K + 1)}
+        self.nrm = {(k, j): torch.empty(G * 32 * 4, **f32) for k in range(1, K + 1) for j in (1, 2, 3)}
+        self.part = [torch.empty(G * self.tpg * 32 * 2, **f32) for _ in range(2)]
+        self.cnt = torch.empty(G * self.tpg, **f32)
+        self.E = torch.empty(G, 32, N, **f32)
+        self.idx = torch.empty(G, 32, N, dtype=torch.int32, device=device)
+        self.scores = torch.empty(self.B, N, N, **f32)
+        self.lse = torch.empty(self.B, N, **f32)
+        self.pair_loss = torch.empty(self.B * _lib.FGNN_SCORE_SPLIT, **f32)
+        self.loss = torch.empty(1, **f32)
+        self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
+        self._bwd = None
+        self._packs = {}
+        for k in range(1, K + 1):
+            cin = layout.c0 if k == 1 else 32
+            self._packs[('f', k, 12)] = (0, cin, 0, 2, torch.empty(lib.fgnn_pack16_floats(0, cin, 0, 3, 2), **f32))
+            self._packs[('f', k, 3)] = (0, 32, cin, 1, torch.empty(lib.fgnn_pack16_floats(0, 32, cin, 3, 1), **f32))
+            for j in (1, 2):
+                self._packs[('b', k, j)] = (1, cin, 0, 1, torch.empty(lib.fgnn_pack16_floats(1, cin, 0, 3, 1), **f32))
+            self._packs[('b', k, 3)] = (1, 32, cin, 1, torch.empty(lib.fgnn_pack16_floats(1, 32, cin, 3, 1), **f32))
+
+    # ------------------------------------------------------------------ helpers
+    def _nv(self):
+        return _lib.ptr(self.nvalid) if self.nvalid is not None else None
+
+    def _w(self, params, off):
+        return params.data_ptr() + 4 * off
+
+    def _slab_in(self, k, params):
+        if k == 1:
+            return _lib.make_slab16(self.x16, 2 * self.ldp, self.ldp, 2)
+        rec = self.layout.mlp[(k - 1, 3)]
+        return _lib.make_slab16(self.z[(k - 1, 3)], 32 * self.ldp, self.ldp, 32, nrm=self.nrm[(k - 1, 3)],
+                                beta=self._w(params, rec['gn_b']))
+
+    def _slab_z(self, k, j, params):
+        rec = self.layout.mlp[(k, j)]
+        return _lib.make_slab16(self.z[(k, j)], 32 * self.ldp, self.ldp, 32, nrm=self.nrm[(k, j)],
+                                beta=self._w(params, rec['gn_b']))
+
+    def _slab_raw(self, t):
+        return _lib.make_slab16(t, 32 * self.ldp, self.ldp, 32)
+
+    def pack_operands(self, params):
+        L = self.layout
+        items = list(self._packs.items())
+        for lo in range(0, len(items), _lib.MAX_PACK_JOBS):
+            chunk = items[lo:lo + _lib.MAX_PACK_JOBS]
+            jobs = (_lib.PackJob * len(chunk))()
+            for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
+                jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
+                js = (1, 2) if which == 12 else (which,)
+                for m, j in enumerate(js):
+                    rec = L.mlp[(k, j)]
+                    for l in range(L.depth):
+                        jobs[i].W[m][l] = self._w(params, rec['w'][l])
+                        jobs[i].bias[m][l] = self._w(params, rec['b'][l])
+                jobs[i].out = buf.data_ptr()
+            _lib.call('fgnn_pack16_operands', jobs, len(chunk), _lib.stream_ptr())
+
+    def _mlp_fwd(self, params, k, js, a, b):
+        L = self.layout
+        args = _lib.MlpFwd16Args()
+        args.G, args.N, args.ldr, args.depth, args.nmlp = self.G, self.N, self.ldr, L.depth, len(js)
+        args.nvalid = self.nvalid.data_ptr() if self.nvalid is not None else None
+        args.a = a
+        if b is not None:
+            args.b = b
+        for m, j in enumerate(js):
+            args.z[m] = self.z[(k, j)].data_ptr()
+            args.part[m] = self.part[m].data_ptr()
+        args.ldz = self.ldp
+        args.cnt = self.cnt.data_ptr()
+        args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
+        st = _lib.stream_ptr()
+        _lib.call('fgnn_mlp_fwd16', C.byref(args), st,
+                  tag='mlp_fwd16[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        if len(js) == 2:
+            r0, r1 = L.mlp[(k, js[0])], L.mlp[(k, js[1])]
+            _lib.call('fgnn_gn_finalize2_tpg', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, r0['gn_w'])), C.c_void_p(self._w(params, r1['gn_w'])), self._nv(),
+                      self.G, 32, self.N, self.tpg, EPS, _lib.ptr(self.nrm[(k, js[0])]), _lib.ptr(self.nrm[(k, js[1])]), st)
+        else:
+            rec = L.mlp[(k, js[0])]
+            _lib.call('fgnn_gn_finalize_tpg', _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, self.tpg, EPS,
+                      _lib.ptr(self.nrm[(k, js[0])]), st)
+
+    # ------------------------------------------------------------------ forward
+    def embed(self, params, x, nvalid=None):
+        """x: (G, 2, N, N) contiguous fp32 device tensor (0/1 adjacency + degrees: exact in bf16 for N <= 256)."""
+        L = self.layout
+        if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
+            raise RuntimeError('FgnnEngineBF16.embed: expected contiguous fp32 %s, got %s %s'
+                               % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
+        if (nvalid is None) != (self.nvalid is None):
+            raise RuntimeError('FgnnEngineBF16: ragged flag and nvalid argument disagree')
+        if nvalid is not None:
+            self.nvalid.copy_(nvalid.to(torch.int32))
+        st = _lib.stream_ptr()
+        _lib.call('fgnn_to_bf16', _lib.ptr(x), self._nv(), self.G, 2, self.N, self.ldr, _lib.ptr(self.x16),
+                  2 * self.ldp, self.ldp, st)
+        self.pack_operands(params)
+        gs = 32 * self.ldp
+        for k in range(1, L.num_blocks + 1):
+            sin = self._slab_in(k, params)
+            self._mlp_fwd(params, k, (1, 2), sin, None)
+            ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
+            _lib.call('fgnn_chan_matmul_fwd16', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N, self.ldr,
+                      _lib.ptr(self.mult[k]), gs, self.ldp, st)
+            self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
+        out = self._slab_z(L.num_blocks, 3, params)
+        _lib.call('fgnn_colmax_fwd16', C.byref(out), self._nv(), self.G, self.N, self.ldr, _lib.ptr(self.E),
+                  _lib.ptr(self.idx), st)
+        return self.E
+
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False):
+        self.embed(params, x, nvalid)
+        B, N = self.B, self.N
+        st = _lib.stream_ptr()
+        e1, e2 = self.E[:B], self.E[B:]
+        _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N,
+                  _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), st)
+        if total_nodes is None:
+            total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
+        self.total_nodes = float(total_nodes)
+        self._loss_pending = bool(defer_loss)
+        if not defer_loss:
+            _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
+                      _lib.ptr(self.loss), st)
+        return self.scores, self.loss
+
+    # ------------------------------------------------------------------ backward
+    def _alloc_bwd(self):
+        if self._bwd is not None:
+            return self._bwd
+        f32 = dict(dtype=torch.float32, device=self.device)
+        bf = dict(dtype=torch.bfloat16, device=self.device)
+        act = lambda: torch.empty(self.G * 32 * self.ldp, **bf)
+        nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
+        L = self.layout
+        keys = [(k, j) for k in range(1, L.num_blocks + 1) for j in (1, 2, 3)]
+        self._bwd = {
+            'dE': torch.empty(self.G, 32, self.N, **f32),
+            'dy': [act(), act()],
+            'dmult': act(), 'dy1': act(), 'dy2': act(),
+            's12': {kj: torch.empty(self.G * 32 * 2, **f32) for kj in keys},
+            'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32) for kj in keys},
+            's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
+            'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
+            'nwg': nwg,
+            'gscale': torch.empty(1, **f32),
+        }
+        return self._bwd
+
+    def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
+        L = self.layout
+        W = self._bwd
+        gs = 32 * self.ldp
+        args = _lib.MlpBwd16Args()
+        args.G, args.N, args.ldr, args.depth = self.G, self.N, self.ldr, L.depth
+        args.nvalid = self.nvalid.data_ptr() if self.nvalid is not None else None
+        args.a = a
+        if b is not None:
+            args.b = b
+        args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
+        args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
+        args.coef = coef.data_ptr()
+        if dxa is not None:
+            args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), gs, self.ldp
+        if dxb is not None:
+            args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
+        args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
+        args.wpart = W['wpart'][(k, j)].data_ptr()
+        args.packed = self._packs[('b', k, j)][4].data_ptr()
+        if emit:
+            args.s12part = W['s12part'].data_ptr()
+        _lib.call('fgnn_mlp_bwd16', C.byref(args), _lib.stream_ptr(),
+                  tag='mlp_bwd16[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
+                                                  (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
+
+    def backward(self, params, grads, grad_scale=1.0):
+        W = self._alloc_bwd()
+        B, N = self.B, self.N
+        st = _lib.stream_ptr()
+        gs = grad_scale / self.total_nodes
+        if W.get('gscale_value') != gs:
+            W['gscale'].fill_(gs)
+            W['gscale_value'] = gs
+        e1, e2 = self.E[:B], self.E[B:]
+        _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
+                  self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
+        return self.backward_from_dE(params, grads, W['dE'])
+
+    def backward_from_dE(self, params, grads, dE):
+        L = self.layout
+        W = self._alloc_bwd()
+        st = _lib.stream_ptr()
+        gs = 32 * self.ldp
+        K = L.num_blocks
+
+        def coef_from_s12(kj, slot):
+            _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12'][kj]), _lib.ptr(self.nrm[kj]), self._nv(), self.G, 32, self.N,
+                      _lib.ptr(W['coef'][slot]), None, None, st)
+            return W['coef'][slot]
+
+        dy = W['dy'][0]
+        out = self._slab_z(K, 3, params)
+        _lib.call('fgnn_colmax_bwd16', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N, self.ldr,
+                  _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
+        coef3 = coef_from_s12((K, 3), 2)
+        for k in range(K, 0, -1):
+            sin = self._slab_in(k, params)
+            first = (k == 1)
+            din = None if first else W['dy'][(K - k + 1) % 2]
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False)
+            ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
+            _lib.call('fgnn_chan_matmul_bwd16', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
+                      self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
+                      _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
+            _lib.call('fgnn_gn_bwd_coef2', _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), _lib.ptr(self.nrm[(k, 1)]),
+                      _lib.ptr(self.nrm[(k, 2)]), self._nv(), self.G, 32, self.N, _lib.ptr(W['coef'][0]),
+                      _lib.ptr(W['coef'][1]), st)
+            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
+            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
+            if not first:
+                _lib.call('fgnn_gn_bwd_coef_tiles_tpg', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
+                          self.G, 32, self.N, self.tpg, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
+                coef3 = W['coef'][2]
+            dy = din
+        keys = [(k, j) for k in range(1, K + 1) for j in (1, 2, 3)]
+        if getattr(self, '_loss_pending', False):
+            keys.append('loss')
+            self._loss_pending = False
+        for lo in range(0, len(keys), _lib.MAX_GRAD_JOBS):
+            chunk = keys[lo:lo + _lib.MAX_GRAD_JOBS]
+            jobs = (_lib.GradJob * len(chunk))()
+            for i, kj in enumerate(chunk):
+                if kj == 'loss':
+                    jobs[i].wpart = self.pair_loss.data_ptr()
+                    jobs[i].count = 1
+                    jobs[i].out = self.loss.data_ptr()
+                    jobs[i].rows = self.B * _lib.FGNN_SCORE_SPLIT
+                    jobs[i].scale = 1.0 / self.total_nodes
+                    continue
+                rec = L.mlp[kj]
+                jobs[i].wpart = W['wpart'][kj].data_ptr()
+                jobs[i].count = rec['count']
+                jobs[i].out = grads.data_ptr() + 4 * rec['off']
+                jobs[i].s12 = W['s12'][kj].data_ptr()
+                jobs[i].nrm = self.nrm[kj].data_ptr()
+                jobs[i].dgn_w = grads.data_ptr() + 4 * rec['gn_w']
+                jobs[i].dgn_b = grads.data_ptr() + 4 * rec['gn_b']
+            _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
+        return grads
+
+    def step(self, params, grads, x, nvalid=None, total_nodes=None):
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True)
+        self.backward(params, grads)
+        return scores, loss
+
+    # ------------------------------------------------------------------ inspection (tests)
+    def dense(self, buf, channels=32):
+        """bf16 workspace slab -> (G, channels, N, N) fp32 tensor (copy)."""
+        y = torch.empty(self.G, channels, self.N, self.N, dtype=torch.float32, device=self.device)
+        _lib.call('fgnn_from_bf16', _lib.ptr(buf), channels * self.ldp, self.ldp, self.G, channels, self.N, self.ldr,
+                  _lib.ptr(y), _lib.stream_ptr())
+        return y

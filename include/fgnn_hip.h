@@ -256,6 +256,95 @@ int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N,
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);
 
+/* =====================================================================================================
+ * bf16 variant of the same path (BASELINE config 4: N = 200 dense pairs, 16-bit).  The reference trains under
+ * 16-bit AMP (commander_explore.py:120-122, Network.half models/utils.py:71-74); here activations and gradient
+ * slabs are STORED as bf16, every channel contraction / per-channel N x N product runs on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, and biases, GraphNorm statistics, embeddings, scores, loss
+ * and all parameter gradients stay fp32.  Rounding points: oracle/fgnn_oracle_bf16.py.
+ *
+ * Layout of a bf16 activation tensor (G, C, ldp): a channel holds N rows of `ldr` elements, ldr = N rounded up
+ * to a multiple of 8 (rows 16-byte aligned), element (i, j) at i*ldr + j; ldp >= N*ldr is a multiple of 64
+ * (channels 128-byte aligned).  Columns j >= N, like all padding of a ragged graph, are stored as exact zeros.
+ * A "tile" of the bf16 MLP kernels is 64 consecutive elements of a channel; tile statistics / per-tile sums
+ * (part, cnt, s12part) have fgnn_tiles_per_graph16(N, ldr) = ceil(N*ldr / 64) entries per graph. */
+typedef struct {
+    const void *ptr;         /* bf16 (G, C, ldp)                                        */
+    long long gstride;       /* elements between graphs                                 */
+    long long ldp;           /* elements between channels                               */
+    int C;                   /* channels: 2 or 32 (0 = slab unused)                     */
+    const float *nrm;        /* optional (G*C*4) fp32 {mean, a, q, r2}                  */
+    const float *beta;       /* optional (C) fp32                                       */
+} fgnn_slab16;
+int fgnn_tiles_per_graph16(int N, int ldr);
+
+/* fp32 (G, C, N, N) contiguous  ->  bf16 (G, C, ldp) with row pitch ldr (padding zero-filled), and back */
+int fgnn_to_bf16(const float *x, const int *nvalid, int G, int C, int N, int ldr, void *y, long long gstride, long long ldp,
+                 void *stream);
+int fgnn_from_bf16(const void *y, long long gstride, long long ldp, int G, int C, int N, int ldr, float *x, void *stream);
+
+/* operand images of the bf16 MLP kernels (weights rounded to bf16, biases fp32), packed once per step.
+ * kind 0 = forward image (nmlp MLPs back to back), kind 1 = backward image (one MLP, W[0] / bias[0]). */
+int fgnn_pack16_floats(int kind, int ca, int cb, int depth, int nmlp);   /* size in 4-byte units */
+int fgnn_pack16_operands(const fgnn_pack_job *jobs, int njobs, void *stream);
+
+/* MlpBlock_Real.forward minus the normalisation (models/layers.py:126-131), bf16 storage: see fgnn_mlp_fwd */
+typedef struct {
+    int G, N, ldr, depth, nmlp;
+    const int *nvalid;
+    fgnn_slab16 a, b;
+    void *z[2];                             /* out bf16 (G, 32, ldz)                      */
+    long long ldz;
+    float *part[2];                         /* out (G, tpg16, 32, 2) {mean, M2} of the fp32 z */
+    float *cnt;                             /* out (G, tpg16)                             */
+    const void *packed;                     /* operand image (kind 0) -- required          */
+} fgnn_mlp_fwd16_args;
+int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *args, void *stream);
+
+/* GraphNorm finalize / backward-coefficient helpers with an explicit tile count per graph (the fp32 entry points
+ * derive it from FGNN_TILE) */
+int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const float *gn_weight, const int *nvalid, int G, int C, int N,
+                         int tpg, float eps, float *nrm, void *stream);
+int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                          const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps, float *nrm0,
+                          float *nrm1, void *stream);
+int fgnn_gn_bwd_coef_tiles_tpg(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N, int tpg,
+                               float *s12, float *coef, void *stream);
+
+/* Matmul.forward / backward on bf16 slabs (models/layers.py:161-162), N <= 256: operands normalised on load and
+ * rounded to bf16, fp32 accumulation, outputs rounded to bf16; s12a / s12b as in fgnn_chan_matmul_bwd (sums of the
+ * ROUNDED outputs). */
+int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr,
+                           void *out, long long ogstride, long long ldo, void *stream);
+int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
+                           const int *nvalid, int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo,
+                           float *s12a, float *s12b, void *stream);
+
+/* ColumnMaxPooling on a bf16 slab: e (G,C,N) fp32 = max_j of the fp32-normalised values, idx int32 */
+int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G, int N, int ldr, float *e, int *idx, void *stream);
+/* its backward: dy (bf16) [g,c,i,idx] = R(de[g,c,i]); s12 = {sum dy, sum dy*(z-mean)} of the rounded values */
+int fgnn_colmax_bwd16(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
+                      long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, void *stream);
+
+/* MlpBlock_Real backward on bf16 slabs: see fgnn_mlp_bwd.  coef (G*32*4) is required (fgnn_gn_bwd_coef*).
+ * dx outputs are rounded to bf16; with accumulate the old bf16 value is added in fp32 before rounding. */
+typedef struct {
+    int G, N, ldr, depth;
+    const int *nvalid;
+    fgnn_slab16 a, b;
+    const void *dy;  long long dgstride, ldd;
+    const void *z;   long long zgstride, ldz;
+    const float *coef;
+    void *dxa; long long dxa_gstride, dxa_ld;
+    void *dxb; long long dxb_gstride, dxb_ld;
+    int accumulate_a, accumulate_b;
+    float *wpart;                            /* out (num_wg, fgnn_mlp_param_count) partial dW/db (fp32) */
+    float *s12part;                          /* optional out (G, tpg16, 32, 2): per-tile {sum dxa, sum dxa*(z_a-mean_a)} of the
+                                                FINAL (rounded) dxa values (needs a.C == 32, a.nrm, dxa, no slab b)        */
+    const void *packed;                      /* operand image (kind 1) -- required */
+} fgnn_mlp_bwd16_args;
+int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,177 @@
+"""CPU oracle for the bf16 variant of the 2-FGNN hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file; nothing under ``graph_neural_net_amd/`` does.
+
+What it restates: the reference's algorithm (same functions as ``oracle/fgnn_oracle.py``:
+models/layers.py:47-80,109-131,145-146,161-162,194-203, models/blocks_emb.py:16-43,
+models/trainers.py:60-68, toolbox/losses.py:20-34) evaluated the way the reference is trained -- in 16-bit
+(``pl.Trainer(precision=16)``, commander_explore.py:120-122; ``Network.half``, models/utils.py:71-74) --
+with the rounding points of the HIP bf16 kernels made explicit:
+
+  * activations travel between kernels as bf16: the pre-norm MLP output z, the matmul output, every
+    gradient slab (``R(.)`` below = round-to-nearest-even to bf16);
+  * every matrix-core operand is bf16: conv weights R(W), the normalised input R((z - mean) a + beta),
+    hidden activations R(relu(.)), back-propagated dz / dpre R(.);
+  * accumulation, biases, GraphNorm statistics, the pooled embedding, scores, loss and every parameter
+    gradient are fp32.
+
+The backward pass is written out by hand (autograd would place the gradient roundings elsewhere).  With
+``rounding=False`` every R(.) is the identity and the whole thing must agree with the fp32 oracle's autograd
+result (tests/test_oracle_bf16.py) -- that pins the hand-written backward; the bf16 behaviour itself is
+pinned against the imported reference run in bf16 / fp32 / fp64 by the fixtures of
+tests/golden/make_golden.py (see tests/golden/README.md).
+
+Parity status: PINNED (structure: fp32 oracle; bf16 error level: reference-generated fixtures).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import fgnn_oracle as O
+
+EPS = O.EPS
+
+
+def rbf(t):
+    """round to bf16 (RNE) and back to fp32"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _ident(t):
+    return t
+
+
+class _Mlp:
+    """One MlpBlock_Real: forward keeps what the backward needs."""
+
+    def __init__(self, ws, bs, gn_w, gn_b, R):
+        self.R = R
+        self.ws = [w.reshape(w.shape[0], w.shape[1]) for w in ws]       # (Cout, Cin)
+        self.wr = [R(w) for w in self.ws]
+        self.bs = list(bs)
+        self.gn_w = gn_w.reshape(-1)
+        self.gn_b = gn_b.reshape(-1)
+
+    def forward(self, y_in):
+        """y_in: (G, Cin, N, N) operand values (already rounded).  Returns z (fp32) and the record."""
+        R = self.R
+        self.y_in = y_in
+        self.hs = []
+        h = y_in
+        for l in range(len(self.wr) - 1):
+            pre = torch.einsum('oc,gcij->goij', self.wr[l], h) + self.bs[l].view(1, -1, 1, 1)
+            h = R(torch.relu(pre))
+            self.hs.append(h)
+        z = torch.einsum('oc,gcij->goij', self.wr[-1], h) + self.bs[-1].view(1, -1, 1, 1)
+        n = z.shape[-1]
+        self.n = n
+        self.mean = z.mean(dim=(-1, -2), keepdim=True)
+        var = z.var(dim=(-1, -2), unbiased=False, keepdim=True)
+        self.r2 = 1.0 / (var + EPS)
+        self.q = 1.0 / (2.0 * torch.sqrt(n * (var + EPS)))
+        self.a = self.gn_w.view(1, -1, 1, 1) * self.q
+        self.z_bf = R(z)
+        return self.z_bf
+
+    def normalized(self, rounded=True):
+        y = (self.z_bf - self.mean) * self.a + self.gn_b.view(1, -1, 1, 1)
+        return self.R(y) if rounded else y
+
+    def backward(self, dy, need_dx=True):
+        """dy: gradient w.r.t. the normalised output (bf16 values).  Returns dx (fp32, w.r.t. y_in) and fills
+        self.grads = {'w': [...], 'b': [...], 'gn_w', 'gn_b'}."""
+        R = self.R
+        m = float(self.n * self.n)
+        u = self.z_bf - self.mean
+        s1 = dy.sum(dim=(-1, -2), keepdim=True)
+        s2 = (dy * u).sum(dim=(-1, -2), keepdim=True)
+        self.s1, self.s2 = s1, s2
+        ca = self.a
+        cb = -self.a * s2 * self.r2 / m
+        cc = -self.a * s1 / m
+        dpre = R(ca * dy + cb * u + cc)
+        gw, gb = [None] * len(self.wr), [None] * len(self.wr)
+        for l in range(len(self.wr) - 1, -1, -1):
+            hin = self.hs[l - 1] if l > 0 else self.y_in
+            gw[l] = torch.einsum('goij,gcij->oc', dpre, hin)
+            gb[l] = dpre.sum(dim=(0, 2, 3))
+            if l > 0 or need_dx:
+                dh = torch.einsum('oc,goij->gcij', self.wr[l], dpre)
+            if l > 0:
+                dpre = R(dh * (hin > 0).to(dh.dtype))
+        self.grads = {'w': gw, 'b': gb,
+                      'gn_w': (self.q * s2).sum(dim=0).reshape(-1), 'gn_b': s1.sum(dim=0).reshape(-1)}
+        return dh if need_dx else None
+
+
+def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
+    """One step's model work in the bf16 scheme.  Returns (scores, loss, grads{name: tensor}) in fp32."""
+    R = rbf if rounding else _ident
+    sd = {k: v.detach().to(torch.float32) for k, v in O._strip(sd).items()}
+    K = O.num_blocks_of(sd)
+    B, N = x1.shape[0], x1.shape[-1]
+    x = R(torch.cat([x1, x2]).to(torch.float32))
+    mlps = {}
+    y_in = x
+    prev = None
+    for k in range(1, K + 1):
+        for j in (1, 2, 3):
+            mlps[(k, j)] = _Mlp(*O.mlp_params(sd, k, j), R)
+        m1, m2, m3 = mlps[(k, 1)], mlps[(k, 2)], mlps[(k, 3)]
+        m1.forward(y_in)
+        m2.forward(y_in)
+        y1, y2 = m1.normalized(), m2.normalized()
+        mult = R(torch.matmul(y1, y2))
+        m3.forward(torch.cat([mult, y_in], dim=1))
+        m3.y1, m3.y2, m3.mult = y1, y2, mult
+        if keep is not None:
+            keep[(k, 'z1')], keep[(k, 'z2')], keep[(k, 'mult')], keep[(k, 'z3')] = m1.z_bf, m2.z_bf, mult, m3.z_bf
+        prev = m3
+        y_in = m3.normalized()
+    out = prev.normalized(rounded=False)            # the pooling reads fp32-normalised values
+    E, idx = torch.max(out, -1)
+    e1, e2 = E[:B], E[B:]
+    scores = torch.matmul(e1.transpose(1, 2), e2)
+    if total_nodes is None:
+        total_nodes = B * N
+    lse = torch.logsumexp(scores, dim=-1)
+    loss = (lse - torch.diagonal(scores, dim1=1, dim2=2)).sum() / total_nodes
+    # ---- backward ----
+    ds = (torch.softmax(scores, dim=-1) - torch.eye(N).unsqueeze(0)) / total_nodes
+    de1 = torch.matmul(e2, ds.transpose(1, 2))
+    de2 = torch.matmul(e1, ds)
+    dE = R(torch.cat([de1, de2]))
+    dy = torch.zeros_like(out).scatter_(-1, idx.unsqueeze(-1), dE.unsqueeze(-1))
+    if keep is not None:
+        keep['E'], keep['idx'], keep['dE'] = E, idx, dE
+    grads = {}
+    for k in range(K, 0, -1):
+        m1, m2, m3 = mlps[(k, 1)], mlps[(k, 2)], mlps[(k, 3)]
+        first = k == 1
+        dx3 = m3.backward(dy, need_dx=True)
+        dmult = R(dx3[:, :32])
+        din = None if first else R(dx3[:, 32:])
+        dy1 = R(torch.matmul(dmult, m3.y2.transpose(-1, -2)))
+        dy2 = R(torch.matmul(m3.y1.transpose(-1, -2), dmult))
+        dx1 = m1.backward(dy1, need_dx=not first)
+        dx2 = m2.backward(dy2, need_dx=not first)
+        if keep is not None:
+            keep[(k, 'dmult')], keep[(k, 'dy1')], keep[(k, 'dy2')] = dmult, dy1, dy2
+        if not first:
+            din = R(din + dx1)
+            din = R(din + dx2)
+            if keep is not None:
+                keep[(k, 'din')] = din
+        for j, mm in ((1, m1), (2, m2), (3, m3)):
+            pfx = 'ne_bm_block%d_mlp%d.' % (k, j)
+            for l in range(len(mm.wr)):
+                grads[pfx + 'convs.%d.weight' % l] = mm.grads['w'][l].reshape(sd[pfx + 'convs.%d.weight' % l].shape)
+                grads[pfx + 'convs.%d.bias' % l] = mm.grads['b'][l]
+            grads[pfx + 'gn.weight'] = mm.grads['gn_w'].reshape(1, -1, 1, 1)
+            grads[pfx + 'gn.bias'] = mm.grads['gn_b'].reshape(1, -1, 1, 1)
+        dy = din
+    return scores, loss, grads
+
+
+def flat(grads, names):
+    return torch.cat([grads[n].reshape(-1) for n in names])
