@@ -7,7 +7,7 @@
 DEVI float4 nrm_record(float mean, float m2, float m, float nv, float w, float eps) {
     const float var = m > 0.f ? m2 / m : 0.f;
     const float ve = var + eps;
-    const float q = 1.f / (2.f * sqrtf(nv * ve));
+    const float q = nv > 0.f ? 1.f / (2.f * sqrtf(nv * ve)) : 0.f;      // an empty (filler) graph normalises to 0, not inf
     float4 o;
     o.x = mean;
     o.y = w * q;

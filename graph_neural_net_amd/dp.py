@@ -7,9 +7,13 @@ xGMI, so a single un-bucketed call is the right shape.
 
 ``triplet_loss('mean')`` divides by the number of nodes in the *whole* batch
 (toolbox/losses.py:27-34).  To reproduce a single-process run on the concatenated
-batch, every rank scales its loss by 1/(global node count) and the gradients are
-summed (not averaged); ``global_node_count`` does that bookkeeping, including the
-ragged case where ranks hold different node counts.
+batch without a second collective, every rank back-propagates the UN-normalised sum of
+its pair losses and appends two floats to the flat gradient buffer -- its loss sum and
+its node count -- so that ONE all-reduce delivers the gradient sum,
+the global loss sum and the global normaliser; the division happens afterwards on the
+device (``FlatAdam.set_grad_scale_reciprocal``), including the ragged case where ranks
+hold different node counts.  ``global_node_count`` (a collective of its own) remains for
+callers that need the normaliser on the host.
 """
 import os
 
@@ -47,6 +51,10 @@ def global_node_count(local_nodes, device=None):
     t = torch.tensor([float(local_nodes)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
 def allreduce_sum_(flat):

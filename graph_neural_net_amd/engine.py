@@ -265,7 +265,7 @@ class FgnnEngine:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
 
-    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False):
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None):
         """Siamese forward on the stacked batch x = cat(x1, x2): returns (scores, loss).
         defer_loss: leave the final sum of the per-pair losses to the gradient-finalize launch of the
         following backward() (one launch less per training step); `loss` is valid after that."""
@@ -279,10 +279,11 @@ class FgnnEngine:
             total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
         self.total_nodes = float(total_nodes)
         self._loss_pending = bool(defer_loss)
+        self._loss_target = self.loss if loss_out is None else loss_out     # 1-element fp32 device tensor
         if not defer_loss:
             _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
-                      _lib.ptr(self.loss), st)
-        return self.scores, self.loss
+                      _lib.ptr(self._loss_target), st)
+        return self.scores, self._loss_target
 
     # ------------------------------------------------------------------ backward
     def _alloc_bwd(self):
@@ -417,7 +418,7 @@ class FgnnEngine:
                 if kj == 'loss':        # loss = sum(pair_loss) / nodes rides along as one more reduction job
                     jobs[i].wpart = self.pair_loss.data_ptr()
                     jobs[i].count = 1
-                    jobs[i].out = self.loss.data_ptr()
+                    jobs[i].out = self._loss_target.data_ptr()
                     jobs[i].rows = self.B * _lib.FGNN_SCORE_SPLIT
                     jobs[i].scale = 1.0 / self.total_nodes
                     continue
@@ -432,9 +433,9 @@ class FgnnEngine:
             _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
         return grads
 
-    def step(self, params, grads, x, nvalid=None, total_nodes=None):
+    def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None):
         """One training step's model work: forward + loss + backward."""
-        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True)
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out)
         self.backward(params, grads)
         return scores, loss
 

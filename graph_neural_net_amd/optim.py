@@ -23,7 +23,10 @@ class FlatAdam:
         _lib.call('fgnn_adam_step', _lib.ptr(self.params), _lib.ptr(grads_flat), _lib.ptr(self.exp_avg),
                   _lib.ptr(self.exp_avg_sq), self.params.numel(), float(self.lr), float(self.betas[0]),
                   float(self.betas[1]), float(self.eps), self.t, float(grad_scale), _lib.stream_ptr())
-
+        # the replayable form keeps its own step count in device memory: keep the two counters equal, so that
+        # eager and captured / device-side steps can be mixed freely
+        if getattr(self, '_state', None) is not None:
+            self._state[0:1].fill_(self.t)
 
     # -- graph-replayable form: step count and hyper-parameters live in device memory ---------------------
     def _dev_state(self):
@@ -34,12 +37,24 @@ class FlatAdam:
         return self._hp, self._state
 
     def sync_hyper_parameters(self, grad_scale=1.0):
-        """Push lr / betas / eps / grad_scale to the device copy if they changed (outside any graph capture)."""
+        """Push lr / betas / eps (and, unless it is None, grad_scale) to the device copy if they changed (outside any
+        graph capture).  grad_scale=None leaves hp[4] alone: the caller writes it on the device
+        (set_grad_scale_reciprocal)."""
         hp, _ = self._dev_state()
-        cur = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(grad_scale))
+        cur = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+               None if grad_scale is None else float(grad_scale))
         if cur != self._hp_host:
-            hp.copy_(torch.tensor(cur, dtype=torch.float64))
+            n = 4 if grad_scale is None else 5
+            hp[:n].copy_(torch.tensor(cur[:n], dtype=torch.float64))
             self._hp_host = cur
+
+    def set_grad_scale_reciprocal(self, denom):
+        """grad_scale <- 1 / denom for the device-side step, `denom` a 1-element device tensor (no host sync):
+        the global loss normaliser that arrives with the all-reduced gradient buffer."""
+        hp, _ = self._dev_state()
+        torch.reciprocal(denom.to(torch.float64), out=hp[4:5])
+        if self._hp_host is not None:
+            self._hp_host = self._hp_host[:4] + (None,)
 
     def step_dev(self, grads_flat):
         """One update whose launch can be captured in a HIP graph and replayed (call sync_hyper_parameters first)."""

@@ -1,32 +1,78 @@
 """Minimal data-parallel training step around the fused engine (the Lightning shell of the reference,
-models/trainers.py:70-104, is out of scope): forward + loss + backward (HIP), ONE all-reduce of the flat
-gradient buffer (RCCL), fused Adam."""
+models/trainers.py:70-104, is out of scope): forward + loss + backward (HIP), ONE all-reduce (RCCL) of the flat
+gradient buffer with the loss sum and the node count riding in its last two floats, fused Adam.
+
+No step reads anything back to the host: the loss normaliser of the concatenated global batch
+(toolbox/losses.py:27-34) arrives with the all-reduce and is applied on the device as Adam's gradient scale.
+"""
+import collections
+
 import torch
 import torch.nn.functional as F
 
 from . import dp
-from .engine import FgnnEngine, ParamLayout
+from .engine import FgnnEngine
 from .optim import FlatAdam
 
 
 class FgnnTrainer:
+    ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU); 288 GB HBM leave room to raise it
+
     def __init__(self, layout, params_flat, lr=1e-3, capture=False):
         """capture=True: constant-shape steps are captured in a HIP graph (model work + fused Adam; the gradient
         all-reduce, when there is more than one rank, stays an eager RCCL call between two captured halves) and
         replayed -- the launch overhead of ~40 kernels per step disappears."""
         self.layout = layout
         self.params = params_flat
-        self.grads = torch.zeros_like(params_flat)
+        n = params_flat.numel()
+        # [gradients (n) | sum of the pair losses | node count]: the unit of the one all-reduce per step
+        self.comm = torch.zeros(n + 2, dtype=torch.float32, device=params_flat.device)
+        self.grads = self.comm[:n]
+        self._loss_sum = self.comm[n:n + 1]
+        self._nodes = self.comm[n + 1:n + 2]
         self.opt = FlatAdam(params_flat, lr=lr)
         self.capture = capture
-        self._engines = {}
+        self._engines = collections.OrderedDict()
         self._graphs = {}
 
+    # ------------------------------------------------------------------ engines: bounded cache keyed on padded shapes
+    @staticmethod
+    def _engine_bytes(G, N, num_blocks):
+        ldp = -(-N * N // 32) * 32
+        return (4 * num_blocks + 5) * G * 32 * ldp * 4          # forward + backward activation slabs dominate
+
     def _engine(self, G, N, ragged):
+        """Engine for (G, N).  Ragged engines are shared between nearby shapes: G is rounded up to a multiple of 4
+        graphs (the surplus graphs get nvalid = 0 and cost nothing but their padding tiles), so a stream of ragged
+        batches re-uses a handful of workspaces instead of allocating one per (count, nmax); least recently used
+        engines are dropped beyond ENGINE_CACHE_BYTES."""
         key = (G, N, ragged)
-        if key not in self._engines:
-            self._engines[key] = FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
-        return self._engines[key]
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
+            self._engines[key] = eng
+            used = sum(self._engine_bytes(g, n, self.layout.num_blocks) for (g, n, _) in self._engines)
+            while used > self.ENGINE_CACHE_BYTES and len(self._engines) > 1:
+                (g, n, r), _ = self._engines.popitem(last=False)
+                self._graphs = {k: v for k, v in self._graphs.items() if not (2 * k[0] == g and k[1] == n and not r)}
+                used -= self._engine_bytes(g, n, self.layout.num_blocks)
+        else:
+            self._engines.move_to_end(key)
+        return eng
+
+    # ------------------------------------------------------------------ the one collective + optimizer
+    def _reduce_and_update(self, opt_graph=None):
+        """all-reduce [grads | loss sum | nodes], then Adam with grad_scale = 1 / global nodes (device side).
+        Returns the loss of the global batch as a fresh device scalar."""
+        dp.allreduce_sum_(self.comm)
+        self.opt.sync_hyper_parameters(grad_scale=None)
+        self.opt.set_grad_scale_reciprocal(self._nodes)
+        if opt_graph is not None:
+            opt_graph.replay()
+            self.opt.t += 1
+        else:
+            self.opt.step_dev(self.grads)
+        return (self._loss_sum / self._nodes).reshape(())
 
     # ------------------------------------------------------------------ ragged batches, bucketed by size
     @staticmethod
@@ -39,81 +85,83 @@ class FgnnTrainer:
             buckets.setdefault(-(-int(n) // granule) * granule, []).append(i)
         return sorted(buckets.items())
 
-    def model_step_ragged(self, xs, ys, granule=16):
+    def model_step_ragged(self, xs, ys, granule=16, total_nodes=None):
         """Forward + loss + backward of a ragged list of pairs (xs[i], ys[i]: (c0, n_i, n_i) device tensors),
-        one fused-engine pass per size bucket; gradients and loss of the buckets are summed, both normalised
-        by the node count of the WHOLE (global) batch, so the result equals the single padded batch.
-        Returns (loss, [scores_i of shape (n_i, n_i)]); self.grads holds the local gradient sum."""
+        one fused-engine pass per size bucket, each padded to the bucket's granule (a multiple of `granule`, so that
+        engines are shared between batches); gradients and losses of the buckets are summed.
+        total_nodes=None: normalised by this list's own node count (the single-process result);
+        total_nodes=1.0: the UN-normalised sums (the data-parallel step normalises after its all-reduce).
+        Returns (loss, [scores_i of shape (n_i, n_i)]); self.grads holds the gradient sum."""
         sizes = [int(x.shape[-1]) for x in xs]
-        total = dp.global_node_count(sum(sizes), self.params.device)
-        loss = torch.zeros((), dtype=torch.float32, device=self.params.device)
+        total = float(sum(sizes)) if total_nodes is None else float(total_nodes)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.params.device)
         scores = [None] * len(xs)
         acc = torch.zeros_like(self.grads)
+        tmp = torch.empty_like(self.grads)
         for npad, idx in self.bucket_by_size(sizes, granule):
-            nmax = max(sizes[i] for i in idx)          # pad to the bucket's own maximum, not to the granule
-            pad = lambda t: F.pad(t, (0, nmax - t.shape[-1], 0, nmax - t.shape[-1]))
-            x = torch.stack([pad(xs[i]) for i in idx] + [pad(ys[i]) for i in idx]).contiguous()
-            nv = torch.tensor([sizes[i] for i in idx] * 2, dtype=torch.int32, device=x.device)
-            eng = self._engine(2 * len(idx), nmax, True)
-            sc, l = eng.step(self.params, self.grads, x, nvalid=nv, total_nodes=total)
-            acc += self.grads
+            cnt = -(-len(idx) // 2) * 2                     # pairs rounded up to a multiple of 2 (G to a multiple of 4)
+            pad = lambda t: F.pad(t, (0, npad - t.shape[-1], 0, npad - t.shape[-1]))
+            fill = [torch.zeros_like(pad(xs[idx[0]]))] * (cnt - len(idx))
+            x = torch.stack([pad(xs[i]) for i in idx] + fill + [pad(ys[i]) for i in idx] + fill).contiguous()
+            ns = [sizes[i] for i in idx] + [0] * (cnt - len(idx))
+            nv = torch.tensor(ns * 2, dtype=torch.int32, device=x.device)
+            eng = self._engine(2 * cnt, npad, True)
+            sc, l = eng.step(self.params, tmp, x, nvalid=nv, total_nodes=total)
+            acc += tmp
             loss = loss + l
             for k, i in enumerate(idx):
                 scores[i] = sc[k, :sizes[i], :sizes[i]].clone()
         self.grads.copy_(acc)
-        return loss, scores
+        return loss.reshape(()), scores
 
     def train_step_ragged(self, xs, ys, granule=16):
-        loss, scores = self.model_step_ragged(xs, ys, granule)
-        dp.allreduce_sum_(self.grads)
-        dp.allreduce_sum_(loss)
-        self.opt.step(self.grads)
-        return loss, scores
+        loss, scores = self.model_step_ragged(xs, ys, granule, total_nodes=1.0)
+        self._loss_sum.copy_(loss.reshape(1))
+        self._nodes.fill_(float(sum(int(x.shape[-1]) for x in xs)))
+        return self._reduce_and_update(), scores
 
     # ------------------------------------------------------------------ captured constant-shape step
     def _captured_step(self, x1, x2):
         B, _, N, _ = x1.shape
-        world = dp.env_rank()[2] if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        world = dp.world_size()
         key = (B, N)
         st = self._graphs.get(key)
         if st is None:
             eng = self._engine(2 * B, N, False)
-            total = dp.global_node_count(B * N, self.params.device)
             xs = torch.cat([x1, x2]).contiguous().clone()
-            self.opt.sync_hyper_parameters()
-            # two eager steps on a side stream (allocations, kernel attributes), with the optimizer state restored after
-            snap = [t.clone() for t in (self.params, self.opt.exp_avg, self.opt.exp_avg_sq)]
+            self.opt.sync_hyper_parameters(grad_scale=None)
+            # two eager steps on a side stream (allocations, kernel attributes); they do not touch the optimizer
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    eng.step(self.params, self.grads, xs, total_nodes=total)
+                    eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            for t, s0 in zip((self.params, self.opt.exp_avg, self.opt.exp_avg_sq), snap):
-                t.copy_(s0)
+            t0 = self.opt.t
             g_model, g_opt = torch.cuda.CUDAGraph(), None
             with torch.cuda.graph(g_model):
-                scores, loss = eng.step(self.params, self.grads, xs, total_nodes=total)
-                if world == 1:
+                scores, _ = eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
+                if world == 1:                            # nothing to exchange: the whole step is one graph
+                    self.opt.set_grad_scale_reciprocal(self._nodes)
                     self.opt.step_dev(self.grads)
             if world > 1:
                 g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_opt):
                     self.opt.step_dev(self.grads)
-            self.opt.t -= 1                              # the capture itself did not execute an update
-            st = self._graphs[key] = (xs, g_model, g_opt, scores, loss, B)
-        xs, g_model, g_opt, scores, loss, B = st
-        self.opt.sync_hyper_parameters()
+            self.opt.t = t0                               # a capture does not execute an update
+            st = self._graphs[key] = (xs, g_model, g_opt, scores, B)
+        xs, g_model, g_opt, scores, B = st
         xs[:B].copy_(x1)
         xs[B:].copy_(x2)
+        self._nodes.fill_(float(B * N))
+        if g_opt is None:
+            self.opt.sync_hyper_parameters(grad_scale=None)
+            g_model.replay()
+            self.opt.t += 1
+            return (self._loss_sum / self._nodes).reshape(()), scores
         g_model.replay()
-        if g_opt is not None:
-            dp.allreduce_sum_(self.grads)
-            dp.allreduce_sum_(loss)
-            g_opt.replay()
-        self.opt.t += 1
-        return loss, scores
+        return self._reduce_and_update(opt_graph=g_opt), scores
 
     def train_step(self, x1, x2, nvalid=None):
         """x1, x2: (B, c0, N, N) local shard on the GPU.  Returns (loss of the global batch as a device
@@ -122,13 +170,11 @@ class FgnnTrainer:
             return self._captured_step(x1, x2)
         B, _, N, _ = x1.shape
         eng = self._engine(2 * B, N, nvalid is not None)
-        local_nodes = B * N if nvalid is None else int(nvalid.sum().item())
-        total = dp.global_node_count(local_nodes, self.params.device)
         x = torch.cat([x1, x2]).contiguous()
         nv = None if nvalid is None else torch.cat([nvalid, nvalid])
-        scores, loss = eng.step(self.params, self.grads, x, nvalid=nv, total_nodes=total)
-        loss = loss.clone()
-        dp.allreduce_sum_(self.grads)          # gradients of the concatenated global batch
-        dp.allreduce_sum_(loss)
-        self.opt.step(self.grads)
-        return loss, scores
+        if nvalid is None:
+            self._nodes.fill_(float(B * N))
+        else:
+            self._nodes.copy_(nvalid.sum().to(torch.float32).reshape(1))     # device-side, no host sync
+        scores, _ = eng.step(self.params, self.grads, x, nvalid=nv, total_nodes=1.0, loss_out=self._loss_sum)
+        return self._reduce_and_update(), scores

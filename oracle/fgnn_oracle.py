@@ -25,7 +25,7 @@ Reference lines each function follows (paths under /root/reference):
   fgnn_block           models/blocks_emb.py:16-27, models/layers.py:145-146,161-162
   node_embedding       models/blocks_emb.py:29-43, models/layers.py:194-203
   siamese_scores       models/trainers.py:60-68
-  triplet_loss_mean    toolbox/losses.py:8-34
+  triplet_loss_mean    toolbox/losses.py:8-34 ('mean');  triplet_loss_mean_of_mean: the 'mean_of_mean' reduction (:14-15)
   pad_graph_list       maskedtensors/maskedtensor.py:8-48
 """
 import math
@@ -138,6 +138,18 @@ def triplet_loss_mean(raw_scores):
         target = torch.arange(n_vertices)
         loss += F.cross_entropy(out, target, reduction='sum')
         total += n_vertices
+    return loss / total
+
+
+def triplet_loss_mean_of_mean(raw_scores):
+    """toolbox/losses.py:14-15,20-34 with loss_reduction='mean_of_mean': average over graphs of the per-graph mean CE."""
+    loss = 0
+    total = 0
+    for out in raw_scores:
+        n_vertices = out.shape[0]
+        target = torch.arange(n_vertices)
+        loss += F.cross_entropy(out, target, reduction='sum') / n_vertices
+        total += 1
     return loss / total
 
 

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Worker of tests/test_00_gpu_two_ranks.py: one rank of a data-parallel FgnnTrainer run (gloo rendezvous on 127.0.0.1,
+all ranks share cuda:0), or the single-process run on the concatenated batch (WORLD_SIZE=1).  Writes the parameters after
+each mode's steps and the per-step losses to <out>.pt.   usage: dp_worker.py <out-prefix>"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graph_neural_net_amd import dp, synthetic                   # noqa: E402
+from graph_neural_net_amd.engine import ParamLayout              # noqa: E402
+from graph_neural_net_amd.trainer import FgnnTrainer             # noqa: E402
+
+STEPS = 3
+
+
+def main():
+    out = sys.argv[1]
+    rank, _, world = dp.init_process_group('gloo')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    p0 = lay.init_flat(11, dev)
+    res = {}
+    # ---- constant N: global batch of 8 pairs, N = 18; eager and captured ----
+    batches = [synthetic.make_batch(7100 + s, 8, 18, 'ErdosRenyi', 0.3, 0.05) for s in range(STEPS)]
+    for mode in ('eager', 'capture'):
+        tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, capture=(mode == 'capture'))
+        losses = []
+        for s in range(STEPS):
+            x1, x2 = batches[s]
+            lo, hi = dp.shard_range(8, rank, world)
+            loss, _ = tr.train_step(x1[lo:hi].to(dev), x2[lo:hi].to(dev))
+            losses.append(loss.item())
+        res[mode] = (tr.params.cpu().clone(), losses, tr.opt.t)
+    # ---- ragged: 6 pairs with different sizes, ranks hold different node counts ----
+    tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
+    losses = []
+    for s in range(STEPS):
+        xs, ys = synthetic.make_ragged_batch(7200 + s, 6, 9, 40)
+        lo, hi = dp.shard_range(6, rank, world)
+        loss, _ = tr.train_step_ragged([x.to(dev) for x in xs[lo:hi]], [y.to(dev) for y in ys[lo:hi]], granule=16)
+        losses.append(loss.item())
+    res['ragged'] = (tr.params.cpu().clone(), losses, tr.opt.t)
+    # ---- padded ragged batch through train_step(nvalid=...) ----
+    tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
+    losses = []
+    from oracle import fgnn_oracle as O                          # (only pad_graph_list: test-side batch assembly)
+    for s in range(STEPS):
+        xs, ys = synthetic.make_ragged_batch(7300 + s, 4, 10, 30)
+        lo, hi = dp.shard_range(4, rank, world)
+        nmax = max(x.shape[-1] for x in xs)
+        pad = lambda t: torch.nn.functional.pad(t, (0, nmax - t.shape[-1], 0, nmax - t.shape[-1]))
+        x1 = torch.stack([pad(x) for x in xs[lo:hi]]).to(dev)
+        x2 = torch.stack([pad(y) for y in ys[lo:hi]]).to(dev)
+        nv = torch.tensor([x.shape[-1] for x in xs[lo:hi]], dtype=torch.int32, device=dev)
+        loss, _ = tr.train_step(x1, x2, nvalid=nv)
+        losses.append(loss.item())
+    res['padded'] = (tr.params.cpu().clone(), losses, tr.opt.t)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save(res, out + '.pt')
+    if world > 1:
+        dp.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -237,5 +237,164 @@ def main():
     print(json.dumps(meta, indent=1, sort_keys=True))
 
 
+def _pack_pairs(synthetic, x1, x2):
+    """bit-packed adjacencies of both sides (channel 0 is the 0/1 adjacency, channel 1 = its row sums)"""
+    return synthetic.pack_adjacency(x1[:, 0].numpy()), synthetic.pack_adjacency(x2[:, 0].numpy())
+
+
+def ref_step_bf16(model, x1, x2):
+    """The reference run the way it is trained: parameters and activations in a 16-bit float (the Network.half
+    recipe of models/utils.py:71-74 / precision=16 of commander_explore.py:120-122, here bf16 because the CPU has no
+    fp16 conv).  Everything -- conv, normalize, matmul, max, scoring, loss -- runs in bf16 on ATen."""
+    import copy
+    m = copy.deepcopy(model).to(torch.bfloat16)
+    m.zero_grad()
+    scores = m({'input': x1.to(torch.bfloat16)}, {'input': x2.to(torch.bfloat16)})
+    loss = m.loss(scores)
+    loss.backward()
+    grads = {n[len('node_embedder.'):]: p.grad.detach().float() for n, p in m.named_parameters()}
+    return scores.detach().float(), loss.detach().float(), grads
+
+
+def main_round2():
+    """Round-2 fixtures: input contract, cfg2 at the benchmarked batch, the N=200 regime (fp32 / fp64 / bf16 reference
+    runs) and a ragged n in [30, 120] batch.  The 4-block weights are those of cfg2_reg_n50_b2_4blk.npz (same seeds)."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from graph_neural_net_amd import synthetic
+    from oracle import fgnn_oracle as O
+    torch.set_num_threads(8)
+    with open(os.path.join(OUT, 'golden_meta.json')) as f:
+        meta = json.load(f)
+
+    # ---------------- input contract (loaders/data_generator.py:79-87, 118-125) ----------------
+    import loaders.data_generator as DG
+    rng = np.random.default_rng(7000)
+    d = {}
+    cases = [('ErdosRenyi', 13, 0.3), ('Regular', 50, 0.2), ('ErdosRenyi', 7, 0.5), ('ErdosRenyi', 200, 0.5)]
+    for i, (fam, n, p) in enumerate(cases):
+        w = synthetic.random_regular(rng, n, synthetic.regular_degree(n, p)) if fam == 'Regular' else synthetic.erdos_renyi(rng, n, p)
+        ref = DG.adjacency_matrix_to_tensor_representation(torch.from_numpy(w))
+        mine = torch.from_numpy(synthetic.tensor_representation(w))
+        assert ref.dtype == torch.float32 and torch.equal(ref, mine), 'tensor representation differs from the reference'
+        # the reference's noise formula on GIVEN noise graphs (its generator is networkx's global RNG): patch the ER
+        # generator it calls, record the two probabilities it asks for
+        z1 = synthetic.erdos_renyi(rng, n, 0.1)
+        z2 = synthetic.erdos_renyi(rng, n, p * 0.1 / (1 - p))
+        asked, queue = [], [z1, z2]
+        orig = DG.generate_erdos_renyi_netx
+        DG.generate_erdos_renyi_netx = lambda pe, nn_: (asked.append((pe, nn_)), (None, torch.from_numpy(queue.pop(0))))[1]
+        try:
+            wn_ref = DG.noise_erdos_renyi(None, torch.from_numpy(w), 0.1, p)
+        finally:
+            DG.generate_erdos_renyi_netx = orig
+        assert asked[0] == (0.1, n) and abs(asked[1][0] - p * 0.1 / (1 - p)) < 1e-15 and asked[1][1] == n
+        wn_mine = w * (1.0 - z1) + (1.0 - w) * z2                      # synthetic.noise_erdos_renyi's arithmetic
+        assert torch.equal(wn_ref, torch.from_numpy(wn_mine.astype(np.float32)))
+        if n <= 50:
+            d['w/%d' % i] = w
+            d['repr/%d' % i] = ref.numpy()
+            d['z1/%d' % i], d['z2/%d' % i], d['w_noise/%d' % i] = z1, z2, wn_ref.numpy()
+            d['pe/%d' % i] = np.array([asked[0][0], asked[1][0], p])
+    np.savez_compressed(os.path.join(OUT, 'input_contract.npz'), **d)
+    meta['cases']['input_contract'] = {'tensor_representation_equal': True, 'noise_formula_equal': True}
+
+    # ---------------- cfg2 at the benchmarked batch: N=50 Regular, B=32, 4 blocks ----------------
+    model = build_reference_model(4, seed=0)
+    perturb_(model, 200)
+    old = np.load(os.path.join(OUT, 'cfg2_reg_n50_b2_4blk.npz'))
+    for k, v in model.state_dict().items():
+        assert np.array_equal(old['sd/' + k[len('node_embedder.'):]], v.numpy()), 'weights differ from the cfg2 B=2 fixture'
+    x1, x2 = synthetic.make_batch(2000, 32, 50, 'Regular', 0.2, 0.1)
+    worst = check_oracle_bit_equal(model, x1, x2, 'cfg2_b32')
+    s, l, g = ref_step(model, x1, x2)
+    s64, l64, g64 = ref_step(f64(model), x1.double(), x2.double())
+    b1, b2 = _pack_pairs(synthetic, x1, x2)
+    d = {'bits1': b1, 'bits2': b2, 'n': np.array(50), 'scores': s.numpy(), 'scores64_as_f32': s64.float().numpy(),
+         'loss': l.numpy(), 'loss64': l64.numpy()}
+    for k, v in g.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in g64.items():
+        d['grad64/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'cfg2_reg_n50_b32_4blk.npz'), **d)
+    meta['cases']['cfg2_reg_n50_b32_4blk'] = {'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst,
+                                              'weights': 'cfg2_reg_n50_b2_4blk.npz sd/*'}
+
+    # ---------------- N=200 regime: dense ER p=.5, B=1, 4 blocks; fp32, fp64 and bf16 reference runs ----------------
+    x1, x2 = synthetic.make_batch(4000, 1, 200, 'ErdosRenyi', 0.5, 0.1)
+    worst = check_oracle_bit_equal(model, x1, x2, 'cfg4_b1')
+    s, l, g = ref_step(model, x1, x2)
+    s64, l64, g64 = ref_step(f64(model), x1.double(), x2.double())
+    s16, l16, g16 = ref_step_bf16(model, x1, x2)
+    b1, b2 = _pack_pairs(synthetic, x1, x2)
+    d = {'bits1': b1, 'bits2': b2, 'n': np.array(200), 'scores': s.numpy(), 'scores64_as_f32': s64.float().numpy(),
+         'scores_refbf16': s16.numpy(), 'loss': l.numpy(), 'loss64': l64.numpy(), 'loss_refbf16': l16.numpy()}
+    for k, v in g.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in g64.items():
+        d['grad64/' + k] = v.numpy()
+    for k, v in g16.items():
+        d['grad_refbf16/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'cfg4_er_n200_b1_4blk.npz'), **d)
+    names = list(g.keys())
+    flat = lambda gg: torch.cat([gg[k].reshape(-1).double() for k in names])
+    meta['cases']['cfg4_er_n200_b1_4blk'] = {
+        'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst, 'weights': 'cfg2_reg_n50_b2_4blk.npz sd/*',
+        'ref_fp32_vs_fp64_scores': O.max_rel_err(s, s64), 'ref_bf16_vs_fp64_scores': O.max_rel_err(s16, s64),
+        'ref_fp32_vs_fp64_flatgrad_l2': float((flat(g) - flat(g64)).norm() / flat(g64).norm()),
+        'ref_bf16_vs_fp64_flatgrad_l2': float((flat(g16) - flat(g64)).norm() / flat(g64).norm())}
+
+    # ---------------- ragged n in [30, 120], 4 pairs, 4 blocks: per-graph dense runs, fp32 + fp64 ----------------
+    xs, ys = synthetic.make_ragged_batch(5000, 4, 30, 120, 'ErdosRenyi', 0.2, 0.1)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    s_or, l_or, g_or = O.step_fwd_bwd_ragged(xs, ys, sd)
+
+    def ref_ragged(m, cast):
+        m.zero_grad()
+        e1 = [m.node_embedder({'input': cast(x).unsqueeze(0)})['ne/suffix'].squeeze(0) for x in xs]
+        e2 = [m.node_embedder({'input': cast(y).unsqueeze(0)})['ne/suffix'].squeeze(0) for y in ys]
+        scores = [a.t() @ b for a, b in zip(e1, e2)]
+        loss, tot = 0, 0
+        for sc in scores:   # triplet_loss('mean') on a list (toolbox/losses.py:27-34)
+            loss = loss + torch.nn.functional.cross_entropy(sc, torch.arange(sc.shape[0]), reduction='sum')
+            tot += sc.shape[0]
+        loss = loss / tot
+        loss.backward()
+        return [sc.detach() for sc in scores], loss.detach(), {n[len('node_embedder.'):]: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    sr, lr_, gr = ref_ragged(model, lambda t: t)
+    for a, b in zip(s_or, sr):
+        assert torch.equal(a, b), 'ragged big: oracle scores differ'
+    assert torch.equal(l_or, lr_)
+    sr64, lr64, gr64 = ref_ragged(f64(model), lambda t: t.double())
+    d = {'ns': np.array([x.shape[-1] for x in xs]), 'loss': lr_.numpy(), 'loss64': lr64.numpy()}
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        d['bits1/%d' % i] = synthetic.pack_adjacency(x[None, 0].numpy())
+        d['bits2/%d' % i] = synthetic.pack_adjacency(y[None, 0].numpy())
+        d['scores/%d' % i] = sr[i].numpy()
+        d['scores64_as_f32/%d' % i] = sr64[i].float().numpy()
+    for k, v in gr.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in gr64.items():
+        d['grad64/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'ragged_er_n30_120_b4_4blk.npz'), **d)
+    meta['cases']['ragged_er_n30_120_b4_4blk'] = {'oracle_bit_equal_forward': True, 'weights': 'cfg2_reg_n50_b2_4blk.npz sd/*'}
+
+    # ---------------- triplet_loss('mean_of_mean') of the reference on the cfg1 scores (toolbox/losses.py:14-15) ------
+    from toolbox.losses import triplet_loss
+    c1 = np.load(os.path.join(OUT, 'cfg1_er_n20_b4_1blk.npz'))
+    sc = torch.from_numpy(c1['scores'])
+    np.savez_compressed(os.path.join(OUT, 'losses_cfg1.npz'), mean=triplet_loss('mean')(sc).numpy(),
+                        mean_of_mean=triplet_loss('mean_of_mean')(sc).numpy())
+    meta['cases']['losses_cfg1'] = {}
+
+    with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta, indent=1, sort_keys=True))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'round2':
+        main_round2()
+    else:
+        main()

@@ -207,6 +207,14 @@ def test_expand_adjacency_bit_exact():
     import numpy as np
     from graph_neural_net_amd import synthetic
     from graph_neural_net_amd.inputs import expand_adjacency
+    # the reference's own representation (fixture generated by calling its adjacency_matrix_to_tensor_representation)
+    from util import load_golden
+    d = load_golden('input_contract.npz')
+    for i in sorted({int(kk.split('/')[1]) for kk in d if kk.startswith('w/')}):
+        w = d['w/%d' % i].numpy()
+        n = w.shape[0]
+        bits = torch.from_numpy(synthetic.pack_adjacency(w[None]).view(np.int32)).to(DEV)
+        assert torch.equal(expand_adjacency(bits, n).cpu()[0], d['repr/%d' % i])
     rng = np.random.default_rng(0)
     for n in (50, 33, 7):
         ws = np.stack([synthetic.erdos_renyi(rng, n, 0.3) for _ in range(5)])

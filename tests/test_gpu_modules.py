@@ -236,3 +236,15 @@ def test_loss_masked_equals_stacked():
     stacked = torch.stack(lst).cpu()
     ref = O.triplet_loss_mean(stacked)
     assert abs(triplet_loss()(torch.stack(lst)).item() - ref.item()) < 1e-5
+    ref2 = O.triplet_loss_mean_of_mean(stacked)
+    assert abs(triplet_loss('mean_of_mean')(torch.stack(lst)).item() - ref2.item()) < 1e-5 * abs(ref2.item())
+    # ragged lists: both reductions against the oracle on per-graph score matrices (sizes differ -> they are not equal)
+    rag = [torch.empty((n, n)).normal_(generator=g) for n in (7, 19, 12, 30)]
+    mt = from_list([t.to(DEV) for t in rag], dims=(0, 1))
+    for red, fn in (('mean', O.triplet_loss_mean), ('mean_of_mean', O.triplet_loss_mean_of_mean)):
+        got, want = triplet_loss(red)(mt).item(), fn(rag).item()
+        assert abs(got - want) < 1e-5 * abs(want), (red, got, want)
+    # the reference's own values on the cfg1 scores (fixture generated by calling its triplet_loss)
+    d, v = load_golden('cfg1_er_n20_b4_1blk.npz'), load_golden('losses_cfg1.npz')
+    for red in ('mean', 'mean_of_mean'):
+        assert abs(triplet_loss(red)(d['scores'].to(DEV)).item() - v[red].item()) < 1e-5 * abs(v[red].item())

@@ -29,3 +29,31 @@ def is_zero_grad(name):
     """Last conv bias of every MlpBlock_Real: analytically zero gradient (GraphNorm removes the
     mean), pure rounding noise in fp32."""
     return name.endswith('convs.2.bias')
+
+
+def unpack_pairs(bits, n):
+    """(G, n, ceil(n/32)) uint32 bit-packed adjacencies (synthetic.pack_adjacency) -> (G, 2, n, n) fp32 inputs
+    (channel 0 = adjacency, channel 1 = diag(row sums): loaders/data_generator.py:118-125)."""
+    b = np.asarray(bits.numpy() if hasattr(bits, 'numpy') else bits).astype(np.uint32)
+    g = b.shape[0]
+    w = np.unpackbits(b.view(np.uint8).reshape(g, n, -1), axis=-1, bitorder='little')[:, :, :n].astype(np.float32)
+    x = np.zeros((g, 2, n, n), dtype=np.float32)
+    x[:, 0] = w
+    idx = np.arange(n)
+    x[:, 1, idx, idx] = w.sum(-1)
+    return torch.from_numpy(x)
+
+
+def flat_of(grads, keys):
+    return torch.cat([grads[k].reshape(-1).double() for k in keys])
+
+
+def l2rel(a, b):
+    """L2-relative distance |a-b| / |b|"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm()).item()
+
+
+# bf16 results are compared with the reference's own all-bf16 run as the yard-stick: same error class = within this
+# factor of the reference-bf16 distance to the fp64 truth (see tests/test_oracle_bf16.py for the measured spread)
+BF16_CLASS = 2.0
