@@ -72,22 +72,36 @@ def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2, elt=4):
     return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * elt * N * N * by
 
 
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
-    """The oracle (pure PyTorch CPU, same ATen op sequence as the reference) on the host cores."""
+    """The oracle (pure PyTorch CPU, same ATen op sequence as the reference) on the host cores: thread sweep from 1 to
+    all available cores on a 2-pair slice, then the best thread count timed on a bounded sample (~10 s of CPU work);
+    the single-thread rate is reported next to it."""
     from oracle import fgnn_oracle as O
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     sd = {k: v.clone() for k, v in layout.unflatten(params.cpu()).items()}
-    # pick the thread count on a small slice (oversubscribing a big host makes ATen much slower)
+    sweep = {}
     best, cores = None, 1
-    for c in sorted({min(avail, v) for v in (8, 16, 32, 64)}):
+    for c in sorted({min(avail, v) for v in (1, 4, 8, 16, 32, 64, 128, 256, avail)}):
         torch.set_num_threads(c)
         O.step_fwd_bwd(x1[:2], x2[:2], sd)
         t0 = time.time()
         O.step_fwd_bwd(x1[:2], x2[:2], sd)
         dt = time.time() - t0
+        sweep[c] = 2.0 / dt
         if best is None or dt < best:
             best, cores = dt, c
     torch.set_num_threads(cores)
@@ -104,8 +118,12 @@ def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
         n += 1
     dt = (time.time() - t0) / n
     return {'value': pairs / dt, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d steps on %d of the %d pairs of the same batch (N=%d), %.2f s/step, torch %s CPU, '
-                      '%d threads (of %d available)' % (n, pairs, x1.shape[0], x1.shape[-1], dt, torch.__version__, cores, avail)}
+            'single_thread_value': sweep.get(1), 'cores_available': avail, 'cpu_model': _cpu_model(),
+            'thread_sweep_pairs_per_s': {str(k): round(v, 2) for k, v in sweep.items()},
+            'sample': '%d steps on %d of the %d pairs of the same batch (N=%d), %.2f s/step, torch %s CPU, fp32, '
+                      '%d threads = best of the sweep %s (of %d available); single_thread_value and the sweep are rates on a '
+                      '2-pair slice' % (n, pairs, x1.shape[0], x1.shape[-1], dt, torch.__version__, cores,
+                                        sorted(sweep), avail)}
 
 
 def main():
@@ -119,6 +137,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
     ap.add_argument('--n', type=int, default=None, help='vertices per graph (default: the config\'s)')
     ap.add_argument('--blocks', type=int, default=4)
+    ap.add_argument('--path', default='engine', choices=('engine', 'module'),
+                    help="'engine': FgnnEngine.step (the fused launch sequence, the headline); 'module': the same batch through "
+                         'the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward() (eager launches)')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
@@ -154,6 +175,24 @@ def main():
     def model_work():
         eng.step(params, grads, x, total_nodes=total_nodes)
 
+    if args.path == 'module':
+        # the surface a user of the reference calls (models/trainers.py:60-76): same weights, same batch, eager launches
+        from graph_neural_net_amd.siamese import Siamese_Node_Exp
+        node_emb = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=args.blocks,
+                        in_features=32, out_features=32, depth_of_mlp=3)
+        model = Siamese_Node_Exp(2, node_emb, metric='max', precision='bf16' if bf16 else 'fp32').to(dev)
+        with torch.no_grad():
+            for (name, off, shape), (_, p) in zip(layout.entries, model.node_embedder.named_parameters()):
+                p.copy_(params[off:off + p.numel()].view(shape))
+        xa, xb = x[:B], x[B:]
+        args.no_graph = True
+
+        def model_work():                      # noqa: F811
+            for p in model.parameters():
+                p.grad = None
+            loss = model.loss(model({'input': xa}, {'input': xb})) * (B * N / total_nodes)
+            loss.backward()
+
     graph = None
     model_work()                                  # allocates the backward workspace, sets kernel attributes
     torch.cuda.synchronize()
@@ -179,7 +218,8 @@ def main():
             graph.replay()
         else:
             model_work()
-        dp.allreduce_sum_(grads)
+        if world > 1:
+            dp.allreduce_sum_(grads if args.path == 'engine' else model.node_embedder._flat_grad)
 
     for _ in range(args.warmup):
         step()
@@ -260,7 +300,7 @@ def main():
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
-                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
+                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'path': args.path,
                        'grad_allreduce': 'rccl sum of %d fp32 per step' % layout.total if world > 1 else 'none'},
             'roofline': roofline,
             'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,

@@ -32,10 +32,24 @@ def infer_layout(state_dict):
                        out_features=last[0], depth_of_mlp=depth)
 
 
-def load_checkpoint(path_or_obj, device, layout=None):
+def _load(path, allow_pickle):
+    """torch.load restricted to tensors / plain containers; Lightning checkpoints that carry pickled hyper-parameter
+    objects need allow_pickle=True (arbitrary code execution: only for files you trust)."""
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as exc:
+        if not allow_pickle:
+            raise RuntimeError('checkpoint %r cannot be read with weights_only=True (%s); pass allow_pickle=True for a '
+                               'trusted file' % (path, exc))
+        if hasattr(path, 'seek'):
+            path.seek(0)
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_checkpoint(path_or_obj, device, layout=None, allow_pickle=False):
     """-> (layout, flat fp32 parameter buffer on `device`) from a Lightning .ckpt / a plain state_dict file
     or an already loaded object.  Every tensor of the layout must be present with the reference's shape."""
-    obj = torch.load(path_or_obj, map_location='cpu', weights_only=False) if isinstance(path_or_obj, (str, bytes)) or hasattr(path_or_obj, 'read') else path_or_obj
+    obj = _load(path_or_obj, allow_pickle) if isinstance(path_or_obj, (str, bytes)) or hasattr(path_or_obj, 'read') else path_or_obj
     sd = _state_dict_of(obj)
     layout = layout or infer_layout(sd)
     for name, _, shape in layout.entries:
@@ -47,11 +61,32 @@ def load_checkpoint(path_or_obj, device, layout=None):
     return layout, layout.flatten(sd, device)
 
 
-def save_checkpoint(path, layout, flat, extra=None):
-    """Write the flat buffer in the reference's format ({'state_dict': {node_embedder.<name>: tensor}})."""
+def save_checkpoint(path, layout, flat, extra=None, epoch=0, global_step=0, optimizer=None):
+    """Write the flat buffer in the layout of a Lightning checkpoint: {'state_dict': {node_embedder.<name>: tensor},
+    'epoch', 'global_step', 'pytorch-lightning_version'} (the keys Lightning's load_from_checkpoint migration looks at;
+    models/__init__.py:19-24), plus -- optionally -- the fused Adam state so that a resumed run continues the optimizer
+    ('fgnn_adam': exp_avg, exp_avg_sq, step, lr).  Only tensors and plain scalars are written, so the file loads with
+    weights_only=True."""
     sd = {'node_embedder.' + k: v.detach().cpu().clone() for k, v in layout.unflatten(flat).items()}
-    obj = {'state_dict': sd}
+    obj = {'state_dict': sd, 'epoch': int(epoch), 'global_step': int(global_step), 'pytorch-lightning_version': '1.9.0'}
+    if optimizer is not None:
+        obj['fgnn_adam'] = {'exp_avg': optimizer.exp_avg.detach().cpu().clone(), 'exp_avg_sq': optimizer.exp_avg_sq.detach().cpu().clone(),
+                            'step': int(optimizer.t), 'lr': float(optimizer.lr)}
     if extra:
         obj.update(extra)
     torch.save(obj, path)
     return obj
+
+
+def restore_optimizer(obj, optimizer):
+    """Continue the fused Adam from a checkpoint written with save_checkpoint(..., optimizer=...)."""
+    st = obj.get('fgnn_adam') if isinstance(obj, dict) else None
+    if st is None:
+        return False
+    optimizer.exp_avg.copy_(st['exp_avg'])
+    optimizer.exp_avg_sq.copy_(st['exp_avg_sq'])
+    optimizer.t = int(st['step'])
+    optimizer.lr = float(st['lr'])
+    if getattr(optimizer, '_state', None) is not None:
+        optimizer._state[0:1].fill_(optimizer.t)
+    return True

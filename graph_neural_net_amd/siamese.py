@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import _lib
 from .blocks import block, block_emb, node_embedding
 from .losses import triplet_loss
-from .metrics import accuracy_max
+from .metrics import accuracy_linear_assignment, accuracy_max
 from .masked import MaskedTensor
 from .network import Network
 
@@ -50,7 +50,13 @@ def _unwrap_input(x):
 
 
 class Siamese_Node_Exp(nn.Module):
-    def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5):
+    def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
+                 metric=None, precision='fp32'):
+        """Same positional signature as the reference (models/trainers.py:21).  Two keyword-only extras:
+        metric: None -> the reference's default, the Hungarian matching accuracy (`accuracy_linear_assignment`, host-side
+                SciPy like the reference: trainers.py:52, metrics.py:92-116); 'max' -> the device-side arg-max accuracy
+                (`accuracy_max`, metrics.py:118-141: no device->host copy of the scores per step); or any callable.
+        precision: 'fp32' (default) or 'bf16' (the bf16 engine; what `node_embedder.half()` also selects)."""
         super().__init__()
         node_emb = dict(node_emb)
         try:
@@ -69,7 +75,18 @@ class Siamese_Node_Exp(nn.Module):
         self.node_embedder_dic = {'input': (None, []), 'ne': node_emb_type(original_features_num, **node_emb)}
         self.node_embedder = Network(self.node_embedder_dic)
         self.loss = triplet_loss()
-        self.metric = accuracy_max      # the reference's default is the host-side Hungarian metric (trainers.py:52)
+        if metric is None or metric == 'linear_assignment':
+            self.metric = accuracy_linear_assignment
+        elif metric == 'max':
+            self.metric = accuracy_max
+        elif callable(metric):
+            self.metric = metric
+        else:
+            raise ValueError('metric must be None, "linear_assignment", "max" or a callable (got %r)' % (metric,))
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be "fp32" or "bf16" (got %r)' % (precision,))
+        if precision == 'bf16':
+            self.node_embedder.half()
         self.lr, self.scheduler_decay, self.scheduler_step, self.lr_stop = lr, scheduler_decay, scheduler_step, lr_stop
 
     def forward(self, x1, x2):

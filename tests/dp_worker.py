@@ -34,6 +34,8 @@ def main():
             lo, hi = dp.shard_range(8, rank, world)
             loss, _ = tr.train_step(x1[lo:hi].to(dev), x2[lo:hi].to(dev))
             losses.append(loss.item())
+            if s == 0:
+                res[mode + '_comm'] = tr.comm.cpu().clone()      # [summed gradients | loss sum | node count] after the all-reduce
         res[mode] = (tr.params.cpu().clone(), losses, tr.opt.t)
     # ---- ragged: 6 pairs with different sizes, ranks hold different node counts ----
     tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
@@ -43,7 +45,10 @@ def main():
         lo, hi = dp.shard_range(6, rank, world)
         loss, _ = tr.train_step_ragged([x.to(dev) for x in xs[lo:hi]], [y.to(dev) for y in ys[lo:hi]], granule=16)
         losses.append(loss.item())
+        if s == 0:
+            res['ragged_comm'] = tr.comm.cpu().clone()
     res['ragged'] = (tr.params.cpu().clone(), losses, tr.opt.t)
+    res['p0'] = p0.cpu().clone()
     # ---- padded ragged batch through train_step(nvalid=...) ----
     tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
     losses = []
@@ -58,6 +63,8 @@ def main():
         nv = torch.tensor([x.shape[-1] for x in xs[lo:hi]], dtype=torch.int32, device=dev)
         loss, _ = tr.train_step(x1, x2, nvalid=nv)
         losses.append(loss.item())
+        if s == 0:
+            res['padded_comm'] = tr.comm.cpu().clone()
     res['padded'] = (tr.params.cpu().clone(), losses, tr.opt.t)
     torch.cuda.synchronize()
     if rank == 0:

@@ -54,18 +54,25 @@ def test_two_ranks_equal_single_process(tmp_path):
     _launch(2, os.path.join(tmp, 'double'), tmp)
     one = torch.load(os.path.join(tmp, 'single.pt'))
     two = torch.load(os.path.join(tmp, 'double.pt'))
+    p0 = one['p0']
     for mode in ('eager', 'capture', 'ragged', 'padded'):
+        # (1) the sharp check: after the FIRST step's all-reduce both world sizes hold the same buffer -- the gradient sum of
+        #     the global batch (shard sums differ from the full-batch sum only by summation order: <= 2.4e-6 relative,
+        #     SURVEY.md 8c), the global loss sum and the global node count
+        c1, c2 = one[mode + '_comm'], two[mode + '_comm']
+        assert c1[-1] == c2[-1] and c1[-1] > 0                                   # node count: exact
+        assert abs(c1[-2] - c2[-2]) < 1e-5 * abs(c1[-2])                         # loss sum
+        assert ((c1[:-2] - c2[:-2]).norm() / c1[:-2].norm()).item() < 1e-5, mode
         p1, l1, t1 = one[mode]
         p2, l2, t2 = two[mode]
         assert t1 == t2 == 3
-        for a, b in zip(l1, l2):          # the loss of the GLOBAL batch, identical on every rank
-            assert abs(a - b) < 2e-5 * abs(a), (mode, l1, l2)
-        # parameters after 3 Adam steps: the shard-sum of the gradients differs from the full-batch gradient only by
-        # summation order (<= 2.4e-6 relative); Adam turns noise-level gradient entries into +-lr moves in
-        # both runs, so compare in the L2 sense and bound the worst entry by the total movement
-        moved = (p1 - one['eager'][0]).abs().max().item() if mode != 'eager' else 0.0
-        del moved
-        assert (p1 - p2).norm() / p1.norm() < 2e-5, (mode, ((p1 - p2).norm() / p1.norm()).item())
+        assert abs(l1[0] - l2[0]) < 1e-5 * abs(l1[0])                            # the loss of the GLOBAL batch on every rank
+        # (2) after three Adam steps: Adam turns the noise-level entries of the gradient (the analytically zero last-conv
+        #     biases) into +-lr moves in a noise-determined direction in BOTH runs, so later
+        #     losses / parameters agree only to that level: compare the parameter MOVEMENT
+        for a, b in zip(l1, l2):
+            assert abs(a - b) < 1e-3 * abs(a), (mode, l1, l2)
+        assert ((p1 - p2).norm() / (p1 - p0).norm()).item() < 0.1, (mode, ((p1 - p2).norm() / (p1 - p0).norm()).item())
     # captured == eager (same kernels, same order): bit-identical parameters in both world sizes
     assert torch.equal(one['eager'][0], one['capture'][0])
     assert torch.equal(two['eager'][0], two['capture'][0])

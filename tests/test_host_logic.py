@@ -88,7 +88,7 @@ def test_from_list_padding_and_masks_bit_exact():
         assert torch.equal(t, u)
     masks = mt.mask_dict
     assert set(masks) == {'N', 'N_'}
-    assert torch.equal(masks['N'][0], torch.tensor([1., 1, 1, 1, 0, 0]))
+    assert torch.equal(masks['N'].rename(None)[0], torch.tensor([1., 1, 1, 1, 0, 0])) and masks['N'].names == ('B', 'N')
     pad = mt.tensor.clone()
     for i, n in enumerate(mt.sizes()):
         pad[i, :, :n, :n] = 0
@@ -201,3 +201,32 @@ def test_bench_algorithmic_model_matches_survey_figures():
     assert b == 4.0 * 64 * 2500 * 128 == 81.92e6 and f == 4.0 * 64 * 2500 * 3072
     b, f = bench.kernel_model('fgnn_chan_matmul_fwd', 64, 50)
     assert b == 4.0 * 64 * 32 * 2500 * 3 and f == 2.0 * 64 * 32 * 50 ** 3
+
+
+def test_reduce_lr_on_plateau_matches_torch():
+    """optim.ReduceLROnPlateau == torch.optim.lr_scheduler.ReduceLROnPlateau with the reference's settings
+    (models/trainers.py:92-104: factor 0.5, patience 3, min_lr 1e-5, mode 'min', torch's relative threshold 1e-4)."""
+    import torch
+    from graph_neural_net_amd.optim import ReduceLROnPlateau
+
+    class _Opt:
+        def __init__(self, lr):
+            self.lr = lr
+
+    rng = __import__('random').Random(0)
+    for trial in range(5):
+        series, v = [], 1.0
+        for _ in range(80):
+            v = v * (1.0 - 0.02 * rng.random()) if rng.random() < 0.35 else v * (1.0 + 0.01 * rng.random())
+            series.append(v)
+        series[10] = series[9] * (1 - 5e-5)          # an improvement below the relative threshold does not count
+        p = torch.nn.Parameter(torch.zeros(1))
+        topt = torch.optim.Adam([p], lr=1e-3)
+        tsch = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, factor=0.5, patience=3, min_lr=1e-5)
+        mine_opt = _Opt(1e-3)
+        mine = ReduceLROnPlateau(mine_opt, factor=0.5, patience=3, min_lr=1e-5)
+        for m in series:
+            tsch.step(m)
+            mine.step(m)
+            assert abs(mine_opt.lr - topt.param_groups[0]['lr']) < 1e-15, (trial, mine_opt.lr, topt.param_groups[0]['lr'])
+        assert mine_opt.lr < 1e-3        # the schedule did something
