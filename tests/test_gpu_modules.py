@@ -187,8 +187,24 @@ def test_siamese_step_methods_mirror_the_lightning_module():
     loss = model.training_step(batch, 0)
     assert abs(loss.item() - d['loss'].item()) < 1e-5 * d['loss'].item()
     assert abs(logged['train_loss'] - d['loss'].item()) < 1e-5 * d['loss'].item()
+    # default metric = the reference's: Hungarian matching on log_softmax(scores) (trainers.py:52, metrics.py:92-116),
+    # recomputed here with SciPy on the reference's own scores
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from graph_neural_net_amd.metrics import accuracy_linear_assignment, accuracy_max
+    assert model.metric is accuracy_linear_assignment
+    cost = -torch.log_softmax(d['scores'], -1).numpy()
+    hits = sum(int(np.sum(linear_sum_assignment(c)[1] == np.arange(c.shape[0]))) for c in cost)
+    assert abs(logged['train_acc'] - hits / (cost.shape[0] * cost.shape[1])) < 1e-12
+    # opt-in device metric: arg-max accuracy (metrics.py:118-141)
+    m2 = Siamese_Node_Exp(2, ne, lr=1e-2, metric='max').to(DEV)
+    m2.load_state_dict(model.state_dict())
+    assert m2.metric is accuracy_max
+    log2 = {}
+    m2.log = lambda name, value, **kw: log2.__setitem__(name, float(value.detach()) if torch.is_tensor(value) else float(value))
+    m2.training_step(batch, 0)
     ref_acc = (d['scores'].argmax(-1) == torch.arange(d['scores'].shape[-1])).double().mean().item()
-    assert abs(logged['train_acc'] - ref_acc) < 1e-12
+    assert abs(log2['train_acc'] - ref_acc) < 1e-12
     opt = model.configure_optimizers()['optimizer']
     first = loss.item()
     for _ in range(30):
