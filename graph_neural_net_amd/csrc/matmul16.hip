@@ -1,14 +1,20 @@
 // Per-channel N x N matrix products on bf16 slabs (Matmul, models/layers.py:161-162) and their backward for gfx950,
-// N <= 256.  One 512-thread workgroup owns one (g,c) matrix: every operand element is read from HBM once, normalised on
-// load ((z - mean) a + beta in fp32, padding -> 0), rounded to bf16 and streamed through double-buffered LDS panels in
-// 64-wide k chunks; all ceil(nv/32)^2 output tiles of 32x32 live in the fp32 accumulators of the eight waves and are
+// N <= 256.  One 512-thread workgroup owns one (g,c) matrix: every operand element is read from HBM once (16-byte loads),
+// normalised on load ((z - mean) a + beta in fp32, padding -> 0), rounded to bf16 and streamed through double-buffered LDS
+// panels in 64-wide k chunks; all ceil(nv/32)^2 output tiles of 32x32 live in the fp32 accumulators of the eight waves and are
 // multiplied with v_mfma_f32_32x32x16_bf16.
-//   Out[m][n] = sum_k OpA(m,k) OpB(k,n),  OpA(m,k) = A_KC ? MA[m][k] : MA[k][m],  OpB(k,n) = B_KC ? MB[n][k] : MB[k][n]
-//   forward M = Ya Yb: (KC, KR);   dA = dM Yb^T: (KC, KC);   dB = Ya^T dM: (KR, KR)
-// Every panel is stored [x][kk] (k contiguous, 68-element = 136-byte row stride: an MFMA operand of one k-step is two
-// conflict-free ds_read_b64).  A K-contiguous source is copied row by row (8-byte loads); a K-row source is transposed
-// on the way in: a lane loads the pixel pair (x, x+1) of four consecutive source rows and writes two 8-byte panel rows.
-// Matrix rows are `ldr` elements apart (ldr % 8 == 0), so all of these accesses are aligned.
+//   Out[m][n] = sum_k OpA(m,k) OpB(k,n)
+//   forward M = Ya Yb;   dA = dM Yb^T;   dB = Ya^T dM
+// An operand reaches LDS as a plain copy of 16-byte row pieces of its source -- never transposed by the staging code:
+//   * a source whose rows are the operand's NON-contracted index (Ya in the forward, dM and Yb in dA) fills an [x][k] panel
+//     (68-element rows); an MFMA operand of one k-step is two conflict-free ds_read_b64;
+//   * a source whose rows are the CONTRACTED index (Yb in the forward, Ya and dM in dB) fills a [k][x] panel; the MFMA operand
+//     (lane = x, eight consecutive k) is fetched with ds_read_b64_tr_b16, the gfx950 LDS transpose read: within 16 lanes, lane i
+//     supplies the address of row i>>2, 8-byte piece i&3 of a 4 x 16 block and lane l receives column l of it
+//     (semantics measured with tools/ubench_tr16.hip).
+// Matrix rows are `ldr` elements apart (ldr % 8 == 0), so every 16-byte access is aligned.
+// N > 128: wave w owns the tile ROW w (its A operand of a k-step is read once and reused for every tile column).
+#include <type_traits>
 #include "fgnn_bf16.h"
 
 #ifndef MM_ABLATE
@@ -17,7 +23,11 @@
 
 namespace {
 
-constexpr int MM_NW = 8, MM_THREADS = 64 * MM_NW, MM_KC = 64, MM_LDK = 68;   // panel row stride in elements
+constexpr int MM_NW = 8, MM_THREADS = 64 * MM_NW, MM_KC = 64;
+constexpr int XK_LD = 136;                 // bytes per row of an [x][k] panel (64 k's + 4 elements of padding)
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct Src16 {
     View16 v;
@@ -30,18 +40,17 @@ struct Src16 {
 template <int NT, int NCOL = NT>
 struct MMCfg {
     static constexpr int XM = 32 * NT;
-    // tile ownership: NT == 8 (N > 128): wave w owns the tile ROW w (all tile columns): its A-operand fragment of a k-step is
-    // read from LDS once and reused for every column (2.3 instead of 4 ds_read_b64 per MFMA) and no index arithmetic is
-    // left in the k loop; smaller matrices (few tile rows) keep the cyclic assignment tile = wave + 8 i
-    static constexpr bool STRIP = NT == 8;
-    static constexpr int MAXT = STRIP ? NCOL : (NT * NT + MM_NW - 1) / MM_NW;
-    static constexpr int PANEL_B = XM * MM_LDK * 2;                 // bytes of one panel
+    static constexpr int KX_LD = XM * 2 + 64;                       // bytes per row of a [k][x] panel: (KX_LD / 4) % 64 == 16, so
+                                                                    // the 4 rows x 64 bytes of a transpose read tile all 64 banks
+    static constexpr int XK_BYTES = XM * XK_LD, KX_BYTES = MM_KC * KX_LD;
+    static constexpr int PANEL_B = XK_BYTES > KX_BYTES ? XK_BYTES : KX_BYTES;
     static constexpr int BUF_B = 2 * PANEL_B;                       // A + B panel
     static constexpr int LDS_BYTES = 2 * BUF_B;                     // double buffered
-    static constexpr int KC_SWEEPS = XM / 32;                       // 8-byte pieces per thread per K-contiguous panel
-    static constexpr int KR_SWEEPS = (16 * (XM / 2)) / MM_THREADS;  // 4x2 micro-tiles per thread per K-row panel
+    // tile ownership: NT == 8 (N > 128): wave w owns the tile ROW w; smaller matrices keep the cyclic assignment
+    static constexpr bool STRIP = NT == 8;
+    static constexpr int MAXT = STRIP ? NCOL : (NT * NT + MM_NW - 1) / MM_NW;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
-
 template <int NT, int NCOL>
 using AccArray = f32x16[MMCfg<NT, NCOL>::MAXT];
 
@@ -73,234 +82,204 @@ DEVI Src16 mm_src_plain(const void *p, long long gs, long long ld, int G, int g,
     return o;
 }
 
-// ---- K-contiguous source: thread -> (row x = tid/16 + 32*sweep, 4 k's at k0 + 4*(tid%16)) ------------------------------
-template <int NT>
-DEVI void kc_load(uint2 (&x)[MMCfg<NT>::KC_SWEEPS], const Src16 &s, int ldr, int nv, int k0, int tid) {
-    const int kq = tid & 15, xr = tid >> 4;
-    const int kk = k0 + 4 * kq;
-    const int base = kk < nv ? (xr * ldr + kk) * 2 : OOB_OFF;
+// eight consecutive elements of a row (row `r`, first element `e0`): normalise, zero the padding, round
+DEVI u32x4 norm8(const u32x4 x, const Src16 &s, int nv, int r, int e0) {
+    u32x4 o;
+    if ((nv & 7) == 0) {                 // the piece is valid or padding as a whole: the mask folds into the affine pair
+        const bool ok = r < nv && e0 < nv;
+        const float a = ok ? s.a : 0.f, b = ok ? s.b : 0.f;
 #pragma unroll
-    for (int i = 0; i < MMCfg<NT>::KC_SWEEPS; ++i) {
-        const int off = (xr + 32 * i) < nv ? base : OOB_OFF;
-        const int so = s.off2 + 32 * i * ldr * 2;
-        x[i].x = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(s.v.r, off, so, 0);
-        x[i].y = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(s.v.r, off, so + 4, 0);
-    }
-}
-template <int NT>
-DEVI void kc_stage(char *P, const uint2 (&x)[MMCfg<NT>::KC_SWEEPS], const Src16 &s, int nv, int k0, int tid) {
-    const int kq = tid & 15, xr = tid >> 4;
-    const int kk = k0 + 4 * kq;
-    char *dst = P + xr * (MM_LDK * 2) + kq * 8;
-    if (s.norm && (nv & 3) == 0) {
-        // nv % 4 == 0: a thread's four k's are valid or padding together -> the mask folds into the affine pair
-        const bool kok = kk < nv;
+        for (int q = 0; q < 4; ++q) o[q] = cvt_pk(fmaf(bf_lo(x[q]), a, b), fmaf(bf_hi(x[q]), a, b));
+    } else {
+        const float rm = r < nv ? 1.f : 0.f;
 #pragma unroll
-        for (int i = 0; i < MMCfg<NT>::KC_SWEEPS; ++i) {
-            const bool ok = kok && (xr + 32 * i) < nv;
-            const float a = ok ? s.a : 0.f, b = ok ? s.b : 0.f;
-            uint2 o;
-            o.x = cvt_pk(fmaf(bf_lo(x[i].x), a, b), fmaf(bf_hi(x[i].x), a, b));
-            o.y = cvt_pk(fmaf(bf_lo(x[i].y), a, b), fmaf(bf_hi(x[i].y), a, b));
-            *reinterpret_cast<uint2 *>(dst + 32 * i * (MM_LDK * 2)) = o;
+        for (int q = 0; q < 4; ++q) {
+            const float m0 = (e0 + 2 * q) < nv ? rm : 0.f, m1 = (e0 + 2 * q + 1) < nv ? rm : 0.f;
+            o[q] = cvt_pk(fmaf(bf_lo(x[q]), s.a, s.b) * m0, fmaf(bf_hi(x[q]), s.a, s.b) * m1);
         }
-        return;
     }
-    float m[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m[e] = (kk + e) < nv ? 1.f : 0.f;
-#pragma unroll
-    for (int i = 0; i < MMCfg<NT>::KC_SWEEPS; ++i) {
-        uint2 o = x[i];
-        if (s.norm) {
-            const float r = (xr + 32 * i) < nv ? 1.f : 0.f;
-            o.x = cvt_pk(fmaf(bf_lo(x[i].x), s.a, s.b) * (m[0] * r), fmaf(bf_hi(x[i].x), s.a, s.b) * (m[1] * r));
-            o.y = cvt_pk(fmaf(bf_lo(x[i].y), s.a, s.b) * (m[2] * r), fmaf(bf_hi(x[i].y), s.a, s.b) * (m[3] * r));
-        }
-        *reinterpret_cast<uint2 *>(dst + 32 * i * (MM_LDK * 2)) = o;
-    }
-}
-
-// ---- K-row source: thread -> (pixel pair xp = tid % (XM/2), k group kg = tid / (XM/2) + (MM_THREADS/(XM/2)) * sweep) -----
-template <int NT>
-DEVI void kr_load(unsigned (&x)[MMCfg<NT>::KR_SWEEPS][4], const Src16 &s, int ldr, int nv, int k0, int tid) {
-    constexpr int HX = MMCfg<NT>::XM / 2, KGS = MM_THREADS / HX;
-    const int xp = tid % HX, kg0 = tid / HX;
-    const int base = 2 * xp < nv ? 4 * xp : OOB_OFF;
-#pragma unroll
-    for (int i = 0; i < MMCfg<NT>::KR_SWEEPS; ++i) {
-        const int kr = k0 + 4 * (kg0 + KGS * i);                     // wave-uniform when HX >= 64
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            x[i][r] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(s.v.r, (kr + r) < nv ? base : OOB_OFF,
-                                                                      s.off2 + (kr + r) * ldr * 2, 0);
-    }
-}
-template <int NT>
-DEVI void kr_stage(char *P, const unsigned (&x)[MMCfg<NT>::KR_SWEEPS][4], const Src16 &s, int nv, int k0, int tid) {
-    constexpr int HX = MMCfg<NT>::XM / 2, KGS = MM_THREADS / HX;
-    const int xp = tid % HX, kg0 = tid / HX;
-    const float c0 = 2 * xp < nv ? 1.f : 0.f, c1 = (2 * xp + 1) < nv ? 1.f : 0.f;
-#pragma unroll
-    for (int i = 0; i < MMCfg<NT>::KR_SWEEPS; ++i) {
-        const int kg = kg0 + KGS * i;
-        const int kr = k0 + 4 * kg;
-        uint2 lo, hi;
-        if (s.norm && (nv & 3) == 0) {
-            // nv % 4 == 0: the 4 x 2 micro-tile is valid or padding as a whole
-            const bool ok = kr < nv && 2 * xp < nv;
-            const float a = ok ? s.a : 0.f, b = ok ? s.b : 0.f;
-            lo.x = cvt_pk(fmaf(bf_lo(x[i][0]), a, b), fmaf(bf_lo(x[i][1]), a, b));
-            lo.y = cvt_pk(fmaf(bf_lo(x[i][2]), a, b), fmaf(bf_lo(x[i][3]), a, b));
-            hi.x = cvt_pk(fmaf(bf_hi(x[i][0]), a, b), fmaf(bf_hi(x[i][1]), a, b));
-            hi.y = cvt_pk(fmaf(bf_hi(x[i][2]), a, b), fmaf(bf_hi(x[i][3]), a, b));
-        } else if (s.norm) {
-            float f0[4], f1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m = (kr + r) < nv ? 1.f : 0.f;
-                f0[r] = fmaf(bf_lo(x[i][r]), s.a, s.b) * (m * c0);
-                f1[r] = fmaf(bf_hi(x[i][r]), s.a, s.b) * (m * c1);
-            }
-            lo.x = cvt_pk(f0[0], f0[1]);
-            lo.y = cvt_pk(f0[2], f0[3]);
-            hi.x = cvt_pk(f1[0], f1[1]);
-            hi.y = cvt_pk(f1[2], f1[3]);
-        } else {
-            lo.x = pack_lo(x[i][0], x[i][1]);
-            lo.y = pack_lo(x[i][2], x[i][3]);
-            hi.x = pack_hi(x[i][0], x[i][1]);
-            hi.y = pack_hi(x[i][2], x[i][3]);
-        }
-        char *dst = P + (2 * xp) * (MM_LDK * 2) + kg * 8;
-        *reinterpret_cast<uint2 *>(dst) = lo;
-        *reinterpret_cast<uint2 *>(dst + MM_LDK * 2) = hi;
-    }
-}
-
-template <int NT, bool KC>
-struct Stage {
-    uint2 c[KC ? MMCfg<NT>::KC_SWEEPS : 1];
-    unsigned r[KC ? 1 : MMCfg<NT>::KR_SWEEPS][4];
-    DEVI void load(const Src16 &s, int ldr, int nv, int k0, int tid) {
-        if (MM_ABLATE == 4) {
-            for (auto &v : c) v = make_uint2(tid, k0);
-            for (auto &v : r) v[0] = v[1] = v[2] = v[3] = tid;
-            return;
-        }
-        if constexpr (KC) kc_load<NT>(c, s, ldr, nv, k0, tid);
-        else kr_load<NT>(r, s, ldr, nv, k0, tid);
-    }
-    DEVI void stage(char *P, const Src16 &s, int nv, int k0, int tid) {
-        if (MM_ABLATE == 3) {
-            for (auto &v : c) asm volatile("" ::"v"(v.x), "v"(v.y));
-            for (auto &v : r) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-            return;
-        }
-        if constexpr (KC) kc_stage<NT>(P, c, s, nv, k0, tid);
-        else kr_stage<NT>(P, r, s, nv, k0, tid);
-    }
-};
-
-// one k-step (16 k's) of the 32-row strip `t` of a panel for lane (j, h): k = 16*step + 8h .. +7
-DEVI i32x4 panel_operand(const char *P, int t, int step, int j, int h) {
-    const uint2 *p = reinterpret_cast<const uint2 *>(P + (32 * t + j) * (MM_LDK * 2) + (16 * step + 8 * h) * 2);
-    const uint2 a = p[0], b = p[1];
-    i32x4 o;
-    o[0] = (int)a.x;
-    o[1] = (int)a.y;
-    o[2] = (int)b.x;
-    o[3] = (int)b.y;
     return o;
 }
 
-// acc[ti] (tile wv + 8*ti of the ntv x ntv valid tiles) += OpA OpB over all k chunks
-template <int NT, int NCOL, bool A_KC, bool B_KC>
-DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv,
-                  int tid) {
+// ---- rows = non-contracted index -> [x][k] panel: thread -> (x = tid/8 + 64*sweep, 8 k's at k0 + 8*(tid%8)) --------------
+template <int NT>
+struct StageXK {
+    static constexpr int SW = MMCfg<NT>::XM / 64;
+    u32x4 r[SW];
+    DEVI void load(const Src16 &s, int ldr, int nv, int k0, int tid) {
+        const int pc = tid & 7, x = tid >> 3;
+        const int kk = k0 + 8 * pc;
+        const int base = kk < nv ? (x * ldr + kk) * 2 : OOB_OFF;
+#pragma unroll
+        for (int i = 0; i < SW; ++i) {
+            if (MM_ABLATE == 4) {
+                r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+                continue;
+            }
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (x + 64 * i) < nv ? base : OOB_OFF, s.off2 + 64 * i * ldr * 2, 0);
+        }
+    }
+    DEVI void stage(char *P, const Src16 &s, int nv, int k0, int tid) const {
+        const int pc = tid & 7, x = tid >> 3;
+        char *dst = P + x * XK_LD + pc * 16;
+#pragma unroll
+        for (int i = 0; i < SW; ++i) {
+            if (MM_ABLATE == 3) {
+                asm volatile("" ::"v"(r[i][0]), "v"(r[i][1]), "v"(r[i][2]), "v"(r[i][3]));
+                continue;
+            }
+            const u32x4 o = s.norm ? norm8(r[i], s, nv, x + 64 * i, k0 + 8 * pc) : r[i];
+            uint2 *d = reinterpret_cast<uint2 *>(dst + 64 * i * XK_LD);       // rows are 8-byte (not 16-byte) aligned
+            d[0] = make_uint2(o[0], o[1]);
+            d[1] = make_uint2(o[2], o[3]);
+        }
+    }
+};
+// ---- rows = contracted index -> [k][x] panel: thread -> (k = tid/PPR + RPS*sweep, 8 x's at 8*(tid%PPR)) ------------------
+template <int NT>
+struct StageKX {
+    static constexpr int PPR = MMCfg<NT>::XM / 8, RPS = MM_THREADS / PPR, SW = MM_KC / RPS;
+    u32x4 r[SW];
+    DEVI void load(const Src16 &s, int ldr, int nv, int k0, int tid) {
+        const int pc = tid % PPR, kr = tid / PPR;
+        const int base = 8 * pc < nv ? 16 * pc : OOB_OFF;
+#pragma unroll
+        for (int i = 0; i < SW; ++i) {
+            if (MM_ABLATE == 4) {
+                r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+                continue;
+            }
+            const int k = k0 + kr + RPS * i;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, k < nv ? base : OOB_OFF, s.off2 + k * ldr * 2, 0);
+        }
+    }
+    DEVI void stage(char *P, const Src16 &s, int nv, int k0, int tid) const {
+        const int pc = tid % PPR, kr = tid / PPR;
+        char *dst = P + kr * MMCfg<NT>::KX_LD + pc * 16;
+#pragma unroll
+        for (int i = 0; i < SW; ++i) {
+            if (MM_ABLATE == 3) {
+                asm volatile("" ::"v"(r[i][0]), "v"(r[i][1]), "v"(r[i][2]), "v"(r[i][3]));
+                continue;
+            }
+            const u32x4 o = s.norm ? norm8(r[i], s, nv, k0 + kr + RPS * i, 8 * pc) : r[i];
+            *reinterpret_cast<u32x4 *>(dst + RPS * i * MMCfg<NT>::KX_LD) = o;
+        }
+    }
+};
+template <int NT, bool XK>
+struct Stage : std::conditional<XK, StageXK<NT>, StageKX<NT>>::type {};
+
+// MFMA operand of k-step `step` for the 32 x-indices of strip t of a panel, lane = x
+struct OperandAddr {
+    int xk, kx;        // per-lane byte offsets inside an [x][k] / [k][x] panel
+};
+template <int NT>
+DEVI OperandAddr operand_addr(int lane) {
+    const int j = lane & 31, h = lane >> 5, i = lane & 15, cg = (lane >> 4) & 1;
+    OperandAddr o;
+    o.xk = j * XK_LD + 16 * h;
+    o.kx = (8 * h + (i >> 2)) * MMCfg<NT>::KX_LD + (16 * cg + 4 * (i & 3)) * 2;
+    return o;
+}
+template <int NT, bool XK>
+DEVI i32x4 read_operand(const char *P, const OperandAddr &oa, int t, int step) {
+    i32x4 o;
+    if constexpr (XK) {
+        const uint2 *p = reinterpret_cast<const uint2 *>(P + oa.xk + t * (32 * XK_LD) + step * 32);
+        const uint2 a = p[0], b = p[1];
+        o[0] = (int)a.x;
+        o[1] = (int)a.y;
+        o[2] = (int)b.x;
+        o[3] = (int)b.y;
+    } else {
+        typedef __attribute__((address_space(3))) s16x4 *lds_p;
+        constexpr int LD = MMCfg<NT>::KX_LD;
+        const char *q = P + oa.kx + step * (16 * LD) + t * 64;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)q);
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(q + 4 * LD));
+        const uint2 a = __builtin_bit_cast(uint2, v0), b = __builtin_bit_cast(uint2, v1);
+        o[0] = (int)a.x;
+        o[1] = (int)a.y;
+        o[2] = (int)b.x;
+        o[3] = (int)b.y;
+    }
+    return o;
+}
+
+// acc (the wave's tiles of the ntv x ntv valid tiles) = (OpA OpB)^T over all k chunks: the MFMA takes OpB^T as its first and
+// OpA^T as its second operand, so a lane ends up with one ROW of the product tile (what mm_store wants)
+template <int NT, int NCOL, bool A_XK, bool B_XK>
+DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid) {
     using Cf = MMCfg<NT, NCOL>;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
     const int T = ntv * ntv;
+    const OperandAddr oa = operand_addr<NT>(lane);
 #pragma unroll
     for (int ti = 0; ti < Cf::MAXT; ++ti) zero16f(acc[ti]);
     const int nkc = (nv + MM_KC - 1) / MM_KC;
-    // Two register sets per operand: the loads of chunk c + 2 are issued as soon as the set that held chunk c has been staged,
-    // so two chunks (2 x 50 KB per CU at N = 200) are in flight while one is multiplied -- with a single set every CU of the
-    // chip alternated in lockstep between "everyone waits for its chunk" and "everyone multiplies with HBM idle".
-    Stage<NT, A_KC> sa[2];
-    Stage<NT, B_KC> sb[2];
-    auto compute = [&](const char *pa) {
-        if (MM_ABLATE == 2) return;
-        const char *pb = pa + Cf::PANEL_B;
-        if constexpr (Cf::STRIP) {
-            if (wv < ntv) {
-#pragma unroll
-                for (int s = 0; s < MM_KC / 16; ++s) {
-                    const i32x4 a = panel_operand(pa, wv, s, j, h);
-#pragma unroll
-                    for (int tn = 0; tn < NCOL; ++tn)
-                        if (tn < ntv) acc[tn] = mfma16(a, panel_operand(pb, tn, s, j, h), acc[tn]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ti = 0; ti < Cf::MAXT; ++ti) {
-                const int t = wv + MM_NW * ti;
-                if (t < T) {
-                    const int tm = t / ntv, tn = t - tm * ntv;
-#pragma unroll
-                    for (int s = 0; s < MM_KC / 16; ++s)
-                        acc[ti] = mfma16(panel_operand(pa, tm, s, j, h), panel_operand(pb, tn, s, j, h), acc[ti]);
-                }
-            }
-        }
-    };
-    sa[0].load(A, ldr, nv, 0, tid);
-    sb[0].load(B, ldr, nv, 0, tid);
-    if (nkc > 1) {
-        sa[1].load(A, ldr, nv, MM_KC, tid);
-        sb[1].load(B, ldr, nv, MM_KC, tid);
-    }
-    sa[0].stage(lds, A, nv, 0, tid);
-    sb[0].stage(lds + Cf::PANEL_B, B, nv, 0, tid);
-    if (nkc > 2) {
-        sa[0].load(A, ldr, nv, 2 * MM_KC, tid);
-        sb[0].load(B, ldr, nv, 2 * MM_KC, tid);
-    }
+    Stage<NT, A_XK> sa;
+    Stage<NT, B_XK> sb;
+    sa.load(A, ldr, nv, 0, tid);
+    sb.load(B, ldr, nv, 0, tid);
+    sa.stage(lds, A, nv, 0, tid);
+    sb.stage(lds + Cf::PANEL_B, B, nv, 0, tid);
     __syncthreads();
-    for (int c = 0; c < nkc; c += 2) {
-        // even chunk c in buffer 0; chunk c + 1 (register set 1) goes to buffer 1 first, then its set is re-loaded with c + 3
-        if (c + 1 < nkc) {
-            sa[1].stage(lds + Cf::BUF_B, A, nv, (c + 1) * MM_KC, tid);
-            sb[1].stage(lds + Cf::BUF_B + Cf::PANEL_B, B, nv, (c + 1) * MM_KC, tid);
-            if (c + 3 < nkc) {
-                sa[1].load(A, ldr, nv, (c + 3) * MM_KC, tid);
-                sb[1].load(B, ldr, nv, (c + 3) * MM_KC, tid);
-            }
+    for (int c = 0; c < nkc; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nkc;
+        if (more) {
+            sa.load(A, ldr, nv, (c + 1) * MM_KC, tid);
+            sb.load(B, ldr, nv, (c + 1) * MM_KC, tid);
         }
-        compute(lds);
-        __syncthreads();
-        if (c + 1 < nkc) {
-            if (c + 2 < nkc) {
-                sa[0].stage(lds, A, nv, (c + 2) * MM_KC, tid);
-                sb[0].stage(lds + Cf::PANEL_B, B, nv, (c + 2) * MM_KC, tid);
-                if (c + 4 < nkc) {
-                    sa[0].load(A, ldr, nv, (c + 4) * MM_KC, tid);
-                    sb[0].load(B, ldr, nv, (c + 4) * MM_KC, tid);
+        const char *pa = lds + cur * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
+        if (MM_ABLATE != 2) {
+            if constexpr (Cf::STRIP) {
+                if (wv < ntv) {
+#pragma unroll
+                    for (int s = 0; s < MM_KC / 16; ++s) {
+                        const i32x4 a = read_operand<NT, A_XK>(pa, oa, wv, s);
+#pragma unroll
+                        for (int tn = 0; tn < NCOL; ++tn)
+                            if (tn < ntv) acc[tn] = mfma16(read_operand<NT, B_XK>(pb, oa, tn, s), a, acc[tn]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ti = 0; ti < Cf::MAXT; ++ti) {
+                    const int t = wv + MM_NW * ti;
+                    if (t < T) {
+                        const int tm = t / ntv, tn = t - tm * ntv;
+#pragma unroll
+                        for (int s = 0; s < MM_KC / 16; ++s)
+                            acc[ti] = mfma16(read_operand<NT, B_XK>(pb, oa, tn, s), read_operand<NT, A_XK>(pa, oa, tm, s), acc[ti]);
+                    }
                 }
             }
-            compute(lds + Cf::BUF_B);
-            __syncthreads();
         }
+        if (more) {
+            char *nx = lds + (cur ^ 1) * Cf::BUF_B;
+            sa.stage(nx, A, nv, (c + 1) * MM_KC, tid);
+            sb.stage(nx + Cf::PANEL_B, B, nv, (c + 1) * MM_KC, tid);
+        }
+        __syncthreads();
     }
 }
 
-// accumulators -> global as bf16 (rows >= N / columns >= ldr dropped), optionally S1 = sum t, S2 = sum t * (raw - mean)
-// of the ROUNDED values over the valid entries, `raw` re-read from the un-normalised slab
+// accumulators -> global as bf16 through LDS.  The accumulators hold Out^T tiles (mm_gemm swaps the MFMA operands), so a lane
+// owns one output ROW of a tile and four runs of four consecutive columns: it drops them into an [row][col] LDS image of the
+// matrix with four ds_write_b64, and the workgroup then copies the image out in 16-byte row pieces (a matrix with ldr == N is
+// one contiguous run).  Pieces outside the 32*ntv computed rows / columns are written as zeros, so the whole N x ldr output is
+// defined.  Optionally S1 = sum t, S2 = sum t * (raw - mean) of the ROUNDED values over the valid entries, `raw` re-read from
+// the un-normalised slab with the same 16-byte pieces.
+template <int NT>
+constexpr int out_pitch() { return MMCfg<NT>::XM * 2 + 16; }      // bytes; (pitch / 4) % 64 == 4: conflict-free 16-byte row reads
+
 template <int NT, int NCOL, bool WANT_S>
-DEVI void mm_store(const AccArray<NT, NCOL> &acc, const View16 &ov, int o_off2, const Src16 &raw, int N, int ldr,
+DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, int o_off2, const Src16 &raw, int N, int ldr,
                    int nv, int ntv, float &s1, float &s2, int tid) {
+    constexpr int OP = out_pitch<NT>();
+    static_assert(MMCfg<NT>::XM * OP <= MMCfg<NT>::LDS_BYTES, "output image must fit the staging panels");
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int T = ntv * ntv;
@@ -309,48 +288,47 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, const View16 &ov, int o_off2, 
         const int t = MMCfg<NT, NCOL>::STRIP ? (wv < ntv && ti < ntv ? wv * ntv + ti : T) : wv + MM_NW * ti;
         if (t < T) {
             const int tm = MMCfg<NT, NCOL>::STRIP ? wv : t / ntv, tn = MMCfg<NT, NCOL>::STRIP ? ti : t - tm * ntv;
-            const int col = 32 * tn + j;
-            const int rowb = 32 * tm + 4 * h;
-            const int base = col < ldr ? (rowb * ldr + col) * 2 : OOB_OFF;
-            const int vbase = col < nv ? (rowb * ldr + col) * 2 : OOB_OFF;
-            unsigned u[16];
+            char *p = lds + (32 * tm + j) * OP + (32 * tn + 4 * h) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                                       // columns 32 tn + 8 q + 4 h + {0..3}
+                *reinterpret_cast<uint2 *>(p + 16 * q) =
+                    make_uint2(cvt_pk(acc[ti][4 * q], acc[ti][4 * q + 1]), cvt_pk(acc[ti][4 * q + 2], acc[ti][4 * q + 3]));
+        }
+    }
+    __syncthreads();
+    const int piece = tid & 31, rs = tid >> 5, X = 32 * ntv;
+    if (8 * piece < ldr) {
+        const bool col_in = 8 * piece < X;
+        const bool whole = (nv & 7) == 0;
+        const int cbase = piece * 16;
+        const int rawc = (!whole || 8 * piece < nv) ? cbase : OOB_OFF;
+#pragma unroll 2
+        for (int r = rs; r < N; r += MM_THREADS / 32) {
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (col_in && r < X) v = *reinterpret_cast<const u32x4 *>(lds + r * OP + cbase);
+            u32x4 u;
+            if (WANT_S) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + r * ldr * 2, 0);
+            if (MM_ABLATE == 1) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ov.r, cbase, o_off2 + r * ldr * 2, 0);
             if (WANT_S) {
+                // outputs outside the valid nv x nv block are exact zeros (masked operands); `raw` there is replaced by 0 so
+                // that stale padding bits cannot turn 0 * x into NaN
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int dr = (r & 3) + 8 * (r >> 2);
-                    u[r] = (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(raw.v.r, (rowb + dr) < nv ? vbase : OOB_OFF,
-                                                                           raw.off2 + dr * ldr * 2, 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dr = (r & 3) + 8 * (r >> 2);
-                const unsigned d = cvt_pk(acc[ti][r], 0.f);
-                if (MM_ABLATE == 1) {
-                    asm volatile("" ::"v"(d));
-                    continue;
-                }
-                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(d & 0xffffu), ov.r, (rowb + dr) < N ? base : OOB_OFF,
-                                                      o_off2 + dr * ldr * 2, 0);
-                if (WANT_S) {
-                    const float m = ((rowb + dr) < nv && col < nv) ? 1.f : 0.f;
-                    const float tv = bf_lo(d) * m;
-                    s1 += tv;
-                    s2 += tv * (bf_lo(u[r]) - raw.mean);
+                for (int q = 0; q < 4; ++q) {
+                    float x0 = bf_lo(u[q]), x1 = bf_hi(u[q]);
+                    if (!whole) {
+                        x0 = (8 * piece + 2 * q) < nv ? x0 : raw.mean;
+                        x1 = (8 * piece + 2 * q + 1) < nv ? x1 : raw.mean;
+                    }
+                    const float t0 = bf_lo(v[q]), t1 = bf_hi(v[q]);
+                    s1 += t0 + t1;
+                    s2 = fmaf(t0, x0 - raw.mean, s2);
+                    s2 = fmaf(t1, x1 - raw.mean, s2);
                 }
             }
         }
     }
-}
-
-// zero the part of an N x ldr output outside the first X = 32*ntv rows / columns (pixel pairs; X is even)
-DEVI void mm_zero_fill(const View16 &ov, int o_off2, int N, int ldr, int X, int tid) {
-    if (X >= N && X >= ldr) return;
-    const int hp = ldr / 2;
-    for (int q = tid; q < N * hp; q += MM_THREADS) {
-        const int r = q / hp, cp = q - r * hp;
-        if (r >= X || 2 * cp >= X) buf_store_u32(0u, ov, q * 4, o_off2);
-    }
+    __syncthreads();                      // the image is the next product's staging buffer
 }
 
 template <int NT, int NCOL>
@@ -363,12 +341,10 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
     const Src16 A = mm_src(ya, G, g, c), B = mm_src(yb, G, g, c);
     const View16 vO = make_view16(out, ogstride, ldo, G);
     const int o_off = g * vO.gs2 + c * vO.ld2;
-    mm_zero_fill(vO, o_off, N, ldr, 32 * ntv, tid);
-    if (ntv == 0) return;
     f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-    mm_gemm<NT, NCOL, true, false>(acc, A, B, mm_lds, ldr, nv, ntv, tid);
+    mm_gemm<NT, NCOL, true, false>(acc, A, B, mm_lds, ldr, nv, ntv, tid);            // M = Ya Yb: [x][k] x [k][x]
     float s1 = 0.f, s2 = 0.f;
-    mm_store<NT, NCOL, false>(acc, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
+    mm_store<NT, NCOL, false>(acc, mm_lds, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
 }
 
 template <int NT, int NCOL>
@@ -386,17 +362,15 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     const Src16 D = mm_src_plain(dm, dmg, ldm, G, g, c);
     const View16 vOA = make_view16(da, ogstride, ldo, G), vOB = make_view16(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs2 + c * vOA.ld2;
-    mm_zero_fill(vOA, o_off, N, ldr, 32 * ntv, tid);
-    mm_zero_fill(vOB, o_off, N, ldr, 32 * ntv, tid);
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
-    if (ntv > 0) {
+    {
         f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-        mm_gemm<NT, NCOL, true, true>(acc, D, B, mm_lds, ldr, nv, ntv, tid);          // dA = dM Yb^T
-        if (s12a) mm_store<NT, NCOL, true>(acc, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
-        else mm_store<NT, NCOL, false>(acc, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
-        mm_gemm<NT, NCOL, false, false>(acc, A, D, mm_lds, ldr, nv, ntv, tid);        // dB = Ya^T dM
-        if (s12a) mm_store<NT, NCOL, true>(acc, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
-        else mm_store<NT, NCOL, false>(acc, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
+        mm_gemm<NT, NCOL, true, true>(acc, D, B, mm_lds, ldr, nv, ntv, tid);          // dA = dM Yb^T: both [x][k]
+        if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
+        else mm_store<NT, NCOL, false>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
+        mm_gemm<NT, NCOL, false, false>(acc, A, D, mm_lds, ldr, nv, ntv, tid);        // dB = Ya^T dM: both [k][x]
+        if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
+        else mm_store<NT, NCOL, false>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
     }
     if (s12a) {
         sa1 = wave_sum(sa1);
@@ -457,6 +431,8 @@ extern "C" int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr, "fgnn_chan_matmul_fwd16: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0 && N <= 256, "fgnn_chan_matmul_fwd16: bad shapes (N <= 256)");
     FGNN_CHECK(ldr >= N && ldr % 8 == 0, "fgnn_chan_matmul_fwd16: ldr must be a multiple of 8 and >= N");
+    FGNN_CHECK(ya->ldp % 8 == 0 && yb->ldp % 8 == 0 && ya->gstride % 8 == 0 && yb->gstride % 8 == 0,
+               "fgnn_chan_matmul_fwd16: channel / graph strides must be multiples of 8 elements (16-byte loads)");
     FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 2 && (long long)G * yb->gstride < 0x7fffffffll / 2 &&
                (long long)G * ogstride < 0x7fffffffll / 2,
                "fgnn_chan_matmul_fwd16: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
@@ -473,6 +449,9 @@ extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd16: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0 && N <= 256, "fgnn_chan_matmul_bwd16: bad shapes (N <= 256)");
     FGNN_CHECK(ldr >= N && ldr % 8 == 0, "fgnn_chan_matmul_bwd16: ldr must be a multiple of 8 and >= N");
+    FGNN_CHECK(ya->ldp % 8 == 0 && yb->ldp % 8 == 0 && ya->gstride % 8 == 0 && yb->gstride % 8 == 0 && ldm % 8 == 0 &&
+               dmgstride % 8 == 0,
+               "fgnn_chan_matmul_bwd16: channel / graph strides must be multiples of 8 elements (16-byte loads)");
     FGNN_CHECK((s12a == nullptr) == (s12b == nullptr), "fgnn_chan_matmul_bwd16: s12a and s12b come together");
     FGNN_CHECK(!s12a || (ya->nrm && yb->nrm), "fgnn_chan_matmul_bwd16: s12 outputs need normalised slabs");
     FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 2 && (long long)G * yb->gstride < 0x7fffffffll / 2 &&
