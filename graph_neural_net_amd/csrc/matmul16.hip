@@ -142,15 +142,16 @@ struct StageKX {
     u32x4 r[SW];
     DEVI void load(const Src16 &s, int ldr, int nv, int k0, int tid) {
         const int pc = tid % PPR, kr = tid / PPR;
-        const int base = 8 * pc < nv ? 16 * pc : OOB_OFF;
+        // per-lane part in the vector offset, the sweep's row block in the (uniform) scalar offset
+        const int base = 8 * pc < nv ? 16 * pc + kr * ldr * 2 : OOB_OFF;
 #pragma unroll
         for (int i = 0; i < SW; ++i) {
             if (MM_ABLATE == 4) {
                 r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
                 continue;
             }
-            const int k = k0 + kr + RPS * i;
-            r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, k < nv ? base : OOB_OFF, s.off2 + k * ldr * 2, 0);
+            const int kb = k0 + RPS * i;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, kb + kr < nv ? base : OOB_OFF, s.off2 + kb * ldr * 2, 0);
         }
     }
     DEVI void stage(char *P, const Src16 &s, int nv, int k0, int tid) const {
@@ -235,13 +236,14 @@ DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char 
         const char *pa = lds + cur * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
         if (MM_ABLATE != 2) {
             if constexpr (Cf::STRIP) {
+                // straight-line over all NCOL tile columns so that the LDS reads run ahead of the MFMAs; columns past ntv
+                // multiply the zero rows the staging wrote there (bucketed batches keep ntv close to NCOL)
                 if (wv < ntv) {
 #pragma unroll
                     for (int s = 0; s < MM_KC / 16; ++s) {
                         const i32x4 a = read_operand<NT, A_XK>(pa, oa, wv, s);
 #pragma unroll
-                        for (int tn = 0; tn < NCOL; ++tn)
-                            if (tn < ntv) acc[tn] = mfma16(read_operand<NT, B_XK>(pb, oa, tn, s), a, acc[tn]);
+                        for (int tn = 0; tn < NCOL; ++tn) acc[tn] = mfma16(read_operand<NT, B_XK>(pb, oa, tn, s), a, acc[tn]);
                     }
                 }
             } else {
@@ -301,15 +303,19 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
         const bool col_in = 8 * piece < X;
         const bool whole = (nv & 7) == 0;
         const int cbase = piece * 16;
-        const int rawc = (!whole || 8 * piece < nv) ? cbase : OOB_OFF;
+        const int voff = cbase + rs * ldr * 2;                                  // per-lane part; the row block is uniform
+        const int rawc = (!whole || 8 * piece < nv) ? voff : OOB_OFF;
 #pragma unroll 2
-        for (int r = rs; r < N; r += MM_THREADS / 32) {
+        for (int rb = 0; rb < N; rb += MM_THREADS / 32) {
+            const int r = rb + rs;
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (col_in && r < X) v = *reinterpret_cast<const u32x4 *>(lds + r * OP + cbase);
             u32x4 u;
-            if (WANT_S) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + r * ldr * 2, 0);
+            if (WANT_S) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + rb * ldr * 2, 0);
             if (MM_ABLATE == 1) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-            else __builtin_amdgcn_raw_buffer_store_b128(v, ov.r, cbase, o_off2 + r * ldr * 2, 0);
+            // soffset stays a literal 0: with an SGPR there the compiler assumes a VALU write to the data registers may follow
+            // the 128-bit store immediately -- on gfx950 that corrupted dword 2 of some lanes (measured, tools/gpu_mm16_check.py)
+            else __builtin_amdgcn_raw_buffer_store_b128(v, ov.r, r < N ? voff + o_off2 + rb * ldr * 2 : OOB_OFF, 0, 0);
             if (WANT_S) {
                 // outputs outside the valid nv x nv block are exact zeros (masked operands); `raw` there is replaced by 0 so
                 // that stale padding bits cannot turn 0 * x into NaN
