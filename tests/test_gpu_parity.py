@@ -36,12 +36,19 @@ def _run_engine(sd, x1, x2, nblk, nvalid=None):
     return eng, params, lay, scores.cpu(), loss.item(), lay.unflatten(grads.cpu())
 
 
-def _check_grads(got, d, flat_factor=2.0, tensor_factor=4.0):
+def _check_grads(got, d, flat_factor=2.0, tensor_factor=4.0, second_sample=None):
+    """Gradients against the fp64 truth, in units of the reference's own fp32 error.  `second_sample`: another equally
+    valid fp32 evaluation of the reference's op sequence (the pinned oracle run with one thread = another summation
+    order).  After four blocks the fp32 error of a tensor is dominated by rare ReLU / arg-max flips, so it is a heavy-tailed
+    random variable: at N=200 the 8-thread and the 1-thread oracle runs differ by 20x on individual tensors
+    (tools/gpu_graderr_table.py).  Where a second sample is given the yard-stick is the larger of the two."""
     keys = [k for k in sub(d, 'grad/') if not is_zero_grad(k)]
     flat = lambda pick: torch.cat([pick(k).reshape(-1).double() for k in keys])
     g64 = flat(lambda k: d['grad64/' + k])
     ours = (flat(lambda k: got[k]) - g64).norm() / g64.norm()
     theirs = (flat(lambda k: d['grad/' + k]) - g64).norm() / g64.norm()
+    if second_sample is not None:
+        theirs = max(theirs, (flat(lambda k: second_sample[k]) - g64).norm() / g64.norm())
     assert ours < flat_factor * theirs + 1e-6, (ours, theirs)      # whole-gradient L2 error vs the fp64 truth
     for k, ref in sub(d, 'grad/').items():
         if is_zero_grad(k):
@@ -49,7 +56,20 @@ def _check_grads(got, d, flat_factor=2.0, tensor_factor=4.0):
             continue
         ref64 = d['grad64/' + k]
         yard = rel(ref, ref64)                    # the reference's own fp32 error
+        if second_sample is not None:
+            yard = max(yard, rel(second_sample[k], ref64))
         assert rel(got[k], ref64) < tensor_factor * yard + 1e-5, (k, rel(got[k], ref64), yard)
+
+
+def _one_thread_sample(x1, x2, sd, ragged=False):
+    """The oracle's fp32 gradients evaluated with a single thread (different GEMM blocking / summation order);
+    ragged: x1 / x2 are lists of per-graph tensors."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return (O.step_fwd_bwd_ragged if ragged else O.step_fwd_bwd)(x1, x2, sd)[2]
+    finally:
+        torch.set_num_threads(n)
 
 
 def test_cfg1_against_golden():
@@ -236,7 +256,7 @@ def test_cfg4_shape_n200_dense_er_fp32_golden():
     eng, params, lay, scores, loss, grads = _run_engine(sd, x1, x2, 4)
     _score_gate(scores, d['scores'], d['scores64_as_f32'])
     assert abs(loss - d['loss'].item()) < 1e-5 * abs(d['loss'].item())
-    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR)
+    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR, second_sample=_one_thread_sample(x1, x2, sd))
 
 
 def test_cfg4_shape_n200_batch8_fp32():
@@ -250,7 +270,7 @@ def test_cfg4_shape_n200_batch8_fp32():
     assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
     d = {'grad/' + k: v for k, v in g_ref.items()}
     d.update({'grad64/' + k: v for k, v in g64.items()})
-    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR)
+    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR, second_sample=_one_thread_sample(x1, x2, sd))
 
 
 def test_cfg5_shape_ragged_30_120_golden():
@@ -268,7 +288,7 @@ def test_cfg5_shape_ragged_30_120_golden():
         _score_gate(scores[i, :n, :n], d['scores/%d' % i], d['scores64_as_f32/%d' % i])
         assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
     assert abs(loss - d['loss'].item()) < 1e-5 * abs(d['loss'].item())
-    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR)
+    _check_grads(grads, d, BIG_FLAT, BIG_TENSOR, second_sample=_one_thread_sample(xs, ys, sd, ragged=True))
 
 
 def test_cfg5_shape_ragged_30_120_batch8():
