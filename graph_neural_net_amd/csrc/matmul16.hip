@@ -18,7 +18,17 @@
 #include "fgnn_bf16.h"
 
 #ifndef MM_ABLATE
-#define MM_ABLATE 0          // debug builds (tools/gpu_mm16_ablate.py): 1 no stores, 2 no MFMA, 3 no LDS staging, 4 no global loads
+#define MM_ABLATE 0          // debug builds (tools/gpu_mm16_ablate.py): 1 no stores, 2 no MFMA, 3 no LDS staging, 4 no global loads,
+#endif                       // 5 phase time stamps of the forward kernel (fgnn_debug_mm16_stamps)
+
+#if MM_ABLATE == 5
+__device__ unsigned long long mm_stamps[1024][16];
+#define MM_STAMP(k)                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) mm_stamps[blockIdx.x][k] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define MM_STAMP(k) do {} while (0)
 #endif
 
 namespace {
@@ -101,6 +111,32 @@ DEVI u32x4 norm8(const u32x4 x, const Src16 &s, int nv, int r, int e0) {
     return o;
 }
 
+// The same arithmetic one dword (two elements) at a time, for the pipelined kernels that slot the staging of the NEXT
+// k chunk between the MFMAs of the current one.  The piece's validity folds into the affine pair; when nv is not a multiple
+// of 8 the one piece per row that straddles nv is finished with an AND mask on the packed result.
+struct PieceCtx {
+    float a, b;
+    unsigned mk[4];
+};
+template <bool WHOLE>
+DEVI PieceCtx piece_ctx(const Src16 &s, int nv, int row, int e0) {
+    PieceCtx c;
+    const bool ok = row < nv && e0 < nv;
+    c.a = ok ? s.a : 0.f;
+    c.b = ok ? s.b : 0.f;
+    if (!WHOLE) {
+        const int lim = nv - e0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c.mk[q] = lim >= 2 * q + 2 ? 0xffffffffu : (lim == 2 * q + 1 ? 0x0000ffffu : 0u);
+    }
+    return c;
+}
+template <bool WHOLE>
+DEVI unsigned norm_dword(unsigned x, const PieceCtx &c, int q) {
+    const unsigned o = cvt_pk(fmaf(bf_lo(x), c.a, c.b), fmaf(bf_hi(x), c.a, c.b));
+    return WHOLE ? o : (o & c.mk[q]);
+}
+
 // ---- rows = non-contracted index -> [x][k] panel: thread -> (x = tid/8 + 64*sweep, 8 k's at k0 + 8*(tid%8)) --------------
 template <int NT>
 struct StageXK {
@@ -134,6 +170,21 @@ struct StageXK {
             d[1] = make_uint2(o[2], o[3]);
         }
     }
+    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
+        const int pc = tid & 7, x = tid >> 3, kk = k0 + 8 * pc;
+        if (MM_ABLATE == 4) r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+        else r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (kk < nv && (x + 64 * i) < nv) ? (x * ldr + kk) * 2 : OOB_OFF,
+                                                          s.off2 + 64 * i * ldr * 2, 0);
+    }
+    template <bool WHOLE>
+    DEVI PieceCtx ctx(const Src16 &s, int nv, int k0, int i, int tid) const {
+        return piece_ctx<WHOLE>(s, nv, (tid >> 3) + 64 * i, k0 + 8 * (tid & 7));
+    }
+    DEVI void write(char *P, int i, const u32x4 o, int tid) const {
+        uint2 *d = reinterpret_cast<uint2 *>(P + ((tid >> 3) + 64 * i) * XK_LD + (tid & 7) * 16);
+        d[0] = make_uint2(o[0], o[1]);
+        d[1] = make_uint2(o[2], o[3]);
+    }
 };
 // ---- rows = contracted index -> [k][x] panel: thread -> (k = tid/PPR + RPS*sweep, 8 x's at 8*(tid%PPR)) ------------------
 template <int NT>
@@ -166,6 +217,19 @@ struct StageKX {
             const u32x4 o = s.norm ? norm8(r[i], s, nv, k0 + kr + RPS * i, 8 * pc) : r[i];
             *reinterpret_cast<u32x4 *>(dst + RPS * i * MMCfg<NT>::KX_LD) = o;
         }
+    }
+    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
+        const int pc = tid % PPR, kr = tid / PPR, kb = k0 + RPS * i;
+        if (MM_ABLATE == 4) r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+        else r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (8 * pc < nv && kb + kr < nv) ? 16 * pc + kr * ldr * 2 : OOB_OFF,
+                                                          s.off2 + kb * ldr * 2, 0);
+    }
+    template <bool WHOLE>
+    DEVI PieceCtx ctx(const Src16 &s, int nv, int k0, int i, int tid) const {
+        return piece_ctx<WHOLE>(s, nv, k0 + tid / PPR + RPS * i, 8 * (tid % PPR));
+    }
+    DEVI void write(char *P, int i, const u32x4 o, int tid) const {
+        *reinterpret_cast<u32x4 *>(P + (tid / PPR + RPS * i) * MMCfg<NT>::KX_LD + (tid % PPR) * 16) = o;
     }
 };
 template <int NT, bool XK>
@@ -208,11 +272,118 @@ DEVI i32x4 read_operand(const char *P, const OperandAddr &oa, int t, int step) {
     return o;
 }
 
+// ---- N > 128: software-pipelined version --------------------------------------------------------------------------------
+// One register set holds the NEXT chunk.  While the MFMAs of chunk c run, the wave normalises chunk c+1 one dword per
+// MFMA (the VALU work hides under the 8-pass matrix instructions of its own and of the SIMD's other wave), drops it into
+// the other LDS buffer and refills the freed registers with the same piece of chunk c+2, which then has one whole chunk
+// of MFMAs to arrive.  One k-step of the chunk = one staging sweep of each operand (MM_KC / 16 == sweeps == 4).
+// Waves past the last tile row repeat the last one (their SIMD's matrix pipe would idle otherwise) and are skipped by
+// mm_store; the last chunk stages the all-zero chunk past nv into the idle buffer.  Both keep the chunk one branch-free
+// block with a single code path (a second path's join makes the register allocator ping-pong the accumulators).
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE>
+DEVI void strip_chunk(AccArray<NT, NCOL> &acc, const char *pa, const char *pb, const OperandAddr &oa, int strip,
+                      Stage<NT, A_XK> &sa, Stage<NT, B_XK> &sb, char *nxa, char *nxb, const Src16 &A, const Src16 &B, int ldr,
+                      int nv, int k0n, int tid) {
+    static_assert(Stage<NT, A_XK>::SW == MM_KC / 16 && Stage<NT, B_XK>::SW == MM_KC / 16, "one sweep per k-step");
+    static_assert(NCOL >= 4, "dword slots");
+    // B operands run one MFMA ahead of their use; the order below is pinned with scheduling barriers (left alone the
+    // scheduler clusters the MFMAs and spills the staging registers)
+    constexpr int STEPS = MM_KC / 16, TOT = STEPS * NCOL;
+    i32x4 bq[2];
+    bq[0] = read_operand<NT, B_XK>(pb, oa, 0, 0);
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const i32x4 a = read_operand<NT, A_XK>(pa, oa, strip, s);
+        PieceCtx cx;
+#pragma unroll
+        for (int tn = 0; tn < NCOL; ++tn) {
+            const int it = s * NCOL + tn;
+            if (it + 1 < TOT) bq[(it + 1) & 1] = read_operand<NT, B_XK>(pb, oa, (it + 1) % NCOL, (it + 1) / NCOL);
+            if (MM_ABLATE != 2) acc[tn] = mfma16(bq[it & 1], a, acc[tn]);
+            if (MM_ABLATE != 3) {
+                if (tn < 4) {
+                    if (!A_PLAIN) {
+                        if (tn == 0) cx = sa.template ctx<WHOLE>(A, nv, k0n, s, tid);
+                        sa.r[s][tn] = norm_dword<WHOLE>(sa.r[s][tn], cx, tn);
+                    }
+                    if (tn == 3) {
+                        sa.write(nxa, s, sa.r[s], tid);
+                        sa.load_one(s, A, ldr, nv, k0n + MM_KC, tid);
+                    }
+                } else if (!B_PLAIN) {
+                    if (tn == 4) cx = sb.template ctx<WHOLE>(B, nv, k0n, s, tid);
+                    sb.r[s][tn - 4] = norm_dword<WHOLE>(sb.r[s][tn - 4], cx, tn - 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MM_ABLATE != 3) {
+            if (!B_PLAIN) {
+#pragma unroll
+                for (int q = NCOL - 4; q < 4; ++q) sb.r[s][q] = norm_dword<WHOLE>(sb.r[s][q], cx, q);
+            }
+            sb.write(nxb, s, sb.r[s], tid);
+            sb.load_one(s, B, ldr, nv, k0n + MM_KC, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE>
+DEVI void mm_gemm_strip(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid) {
+    using Cf = MMCfg<NT, NCOL>;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int strip = wv < ntv ? wv : ntv - 1;
+    const OperandAddr oa = operand_addr<NT>(lane);
+#pragma unroll
+    for (int ti = 0; ti < Cf::MAXT; ++ti) zero16f(acc[ti]);
+    const int nkc = (nv + MM_KC - 1) / MM_KC;
+    Stage<NT, A_XK> sa;
+    Stage<NT, B_XK> sb;
+    MM_STAMP(0);
+    sa.load(A, ldr, nv, 0, tid);
+    sb.load(B, ldr, nv, 0, tid);
+    MM_STAMP(1);
+#pragma unroll
+    for (int i = 0; i < MM_KC / 16; ++i) {                 // chunk 0: nothing to hide it under
+        if (!A_PLAIN) {
+            const PieceCtx c = sa.template ctx<WHOLE>(A, nv, 0, i, tid);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sa.r[i][q] = norm_dword<WHOLE>(sa.r[i][q], c, q);
+        }
+        sa.write(lds, i, sa.r[i], tid);
+        sa.load_one(i, A, ldr, nv, MM_KC, tid);            // past nv: out-of-range offsets, no traffic
+        if (!B_PLAIN) {
+            const PieceCtx c = sb.template ctx<WHOLE>(B, nv, 0, i, tid);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sb.r[i][q] = norm_dword<WHOLE>(sb.r[i][q], c, q);
+        }
+        sb.write(lds + Cf::PANEL_B, i, sb.r[i], tid);
+        sb.load_one(i, B, ldr, nv, MM_KC, tid);
+    }
+    __syncthreads();
+    MM_STAMP(2);
+    for (int c = 0; c < nkc; ++c) {
+        const char *pa = lds + (c & 1) * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
+        char *nx = lds + ((c & 1) ^ 1) * Cf::BUF_B;
+        strip_chunk<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, WHOLE>(acc, pa, pb, oa, strip, sa, sb, nx, nx + Cf::PANEL_B, A, B, ldr, nv,
+                                                                 (c + 1) * MM_KC, tid);
+        if (c < 4) MM_STAMP(3 + 2 * c);
+        __syncthreads();
+        if (c < 4) MM_STAMP(4 + 2 * c);
+    }
+}
+
 // acc (the wave's tiles of the ntv x ntv valid tiles) = (OpA OpB)^T over all k chunks: the MFMA takes OpB^T as its first and
 // OpA^T as its second operand, so a lane ends up with one ROW of the product tile (what mm_store wants)
-template <int NT, int NCOL, bool A_XK, bool B_XK>
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN = false, bool B_PLAIN = false>
 DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid) {
     using Cf = MMCfg<NT, NCOL>;
+    if constexpr (Cf::STRIP) {
+        if ((nv & 7) == 0) mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, true>(acc, A, B, lds, ldr, nv, ntv, tid);
+        else mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, false>(acc, A, B, lds, ldr, nv, ntv, tid);
+        return;
+    }
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = ntv * ntv;
     const OperandAddr oa = operand_addr<NT>(lane);
@@ -221,11 +392,14 @@ DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char 
     const int nkc = (nv + MM_KC - 1) / MM_KC;
     Stage<NT, A_XK> sa;
     Stage<NT, B_XK> sb;
+    MM_STAMP(0);
     sa.load(A, ldr, nv, 0, tid);
     sb.load(B, ldr, nv, 0, tid);
+    MM_STAMP(1);
     sa.stage(lds, A, nv, 0, tid);
     sb.stage(lds + Cf::PANEL_B, B, nv, 0, tid);
     __syncthreads();
+    MM_STAMP(2);
     for (int c = 0; c < nkc; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < nkc;
@@ -235,18 +409,7 @@ DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char 
         }
         const char *pa = lds + cur * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
         if (MM_ABLATE != 2) {
-            if constexpr (Cf::STRIP) {
-                // straight-line over all NCOL tile columns so that the LDS reads run ahead of the MFMAs; columns past ntv
-                // multiply the zero rows the staging wrote there (bucketed batches keep ntv close to NCOL)
-                if (wv < ntv) {
-#pragma unroll
-                    for (int s = 0; s < MM_KC / 16; ++s) {
-                        const i32x4 a = read_operand<NT, A_XK>(pa, oa, wv, s);
-#pragma unroll
-                        for (int tn = 0; tn < NCOL; ++tn) acc[tn] = mfma16(read_operand<NT, B_XK>(pb, oa, tn, s), a, acc[tn]);
-                    }
-                }
-            } else {
+            {
 #pragma unroll
                 for (int ti = 0; ti < Cf::MAXT; ++ti) {
                     const int t = wv + MM_NW * ti;
@@ -259,12 +422,14 @@ DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char 
                 }
             }
         }
+        if (c < 4) MM_STAMP(3 + 2 * c);
         if (more) {
             char *nx = lds + (cur ^ 1) * Cf::BUF_B;
             sa.stage(nx, A, nv, (c + 1) * MM_KC, tid);
             sb.stage(nx + Cf::PANEL_B, B, nv, (c + 1) * MM_KC, tid);
         }
         __syncthreads();
+        if (c < 4) MM_STAMP(4 + 2 * c);
     }
 }
 
@@ -298,6 +463,7 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
         }
     }
     __syncthreads();
+    MM_STAMP(11);
     const int piece = tid & 31, rs = tid >> 5, X = 32 * ntv;
     if (8 * piece < ldr) {
         const bool col_in = 8 * piece < X;
@@ -334,7 +500,9 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
             }
         }
     }
+    MM_STAMP(12);
     __syncthreads();                      // the image is the next product's staging buffer
+    MM_STAMP(13);
 }
 
 template <int NT, int NCOL>
@@ -371,10 +539,10 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     {
         f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-        mm_gemm<NT, NCOL, true, true>(acc, D, B, mm_lds, ldr, nv, ntv, tid);          // dA = dM Yb^T: both [x][k]
+        mm_gemm<NT, NCOL, true, true, true, false>(acc, D, B, mm_lds, ldr, nv, ntv, tid);          // dA = dM Yb^T: both [x][k]
         if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
         else mm_store<NT, NCOL, false>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
-        mm_gemm<NT, NCOL, false, false>(acc, A, D, mm_lds, ldr, nv, ntv, tid);        // dB = Ya^T dM: both [k][x]
+        mm_gemm<NT, NCOL, false, false, false, true>(acc, A, D, mm_lds, ldr, nv, ntv, tid);        // dB = Ya^T dM: both [k][x]
         if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
         else mm_store<NT, NCOL, false>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
     }
@@ -431,6 +599,12 @@ int launch_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, l
 }
 
 }  // namespace
+
+#if MM_ABLATE == 5
+extern "C" int fgnn_debug_mm16_stamps(unsigned long long *host_dst) {
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(mm_stamps), sizeof(mm_stamps));
+}
+#endif
 
 extern "C" int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr,
                                       void *out, long long ogstride, long long ldo, void *stream) {
