@@ -116,6 +116,8 @@ _SIGNATURES = {
     'fgnn_colmax_fwd_fin_supported': [_I],
     'fgnn_colmax_fwd_fin': [C.POINTER(Slab), _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_score_ce_fwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
+    'fgnn_score_row_blocks': [_I, _I],
+    'fgnn_score_ce_fwd_blocks': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_score_bwd': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_ce_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP],

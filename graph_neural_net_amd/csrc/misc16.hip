@@ -66,55 +66,60 @@ __global__ __launch_bounds__(256) void from_bf16_kernel(const unsigned short *y,
     }
 }
 
-// one wave per (g, c, i) row: lanes stride the pixel pairs of the row; first maximum (torch.max semantics)
+// 16 lanes per (g, c, i) row (4 rows per wave, 16 per workgroup): a lane walks the row in 16-byte pieces of eight
+// elements; first maximum (torch.max semantics: ties -> lower index)
 __global__ __launch_bounds__(256) void colmax_fwd16_kernel(const fgnn_slab16 y, const int *nvalid, int G, int N, int ldr,
                                                            float *e, int *idx) {
-    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const long long t = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int C = y.C;
-    if (t >= (long long)G * C * N) return;
-    const int lane = threadIdx.x & 63;
-    const int i = (int)(t % N);
-    const int gc = (int)(t / N);
+    const int sub = threadIdx.x & 15;
+    const bool live = t < (long long)G * C * N;
+    const long long tt = live ? t : 0;
+    const int i = (int)(tt % N);
+    const int gc = (int)(tt / N);
     const int g = gc / C, c = gc - g * C;
     const int nv = nvalid_of(nvalid, g, N);
-    float best = 0.f;
-    int bi = 0;
-    if (i < nv) {
-        const unsigned *row = reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned short *>(y.ptr) +
-                                                                  (long long)g * y.gstride + (long long)c * y.ldp +
-                                                                  (long long)i * ldr);
+    float best = -FLT_MAX;
+    int bi = 0x7fffffff;
+    if (live && i < nv) {
+        const u32x4 *row = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned short *>(y.ptr) +
+                                                            (long long)g * y.gstride + (long long)c * y.ldp + (long long)i * ldr);
         float a = 1.f, b = 0.f;
         if (y.nrm) {
             const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
             a = n.y;
             b = (y.beta ? y.beta[c] : 0.f) - n.x * n.y;
         }
-        best = -FLT_MAX;
-        bi = 0x7fffffff;
-        for (int jp = lane; 2 * jp < nv; jp += WAVE) {
-            const unsigned d = row[jp];
-            const float v0 = fmaf(bf_lo(d), a, b), v1 = fmaf(bf_hi(d), a, b);
-            if (v0 > best) {
-                best = v0;
-                bi = 2 * jp;
-            }
-            if (2 * jp + 1 < nv && v1 > best) {
-                best = v1;
-                bi = 2 * jp + 1;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov > best || (ov == best && oi < bi)) {
-                best = ov;
-                bi = oi;
+        for (int p = sub; 8 * p < nv; p += 16) {
+            const u32x4 d = row[p];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = 8 * p + 2 * q;
+                const float v0 = fmaf(bf_lo(d[q]), a, b), v1 = fmaf(bf_hi(d[q]), a, b);
+                if (j < nv && v0 > best) {
+                    best = v0;
+                    bi = j;
+                }
+                if (j + 1 < nv && v1 > best) {
+                    best = v1;
+                    bi = j + 1;
+                }
             }
         }
     }
-    if (lane == 0) {
-        e[t] = best;
-        idx[t] = bi;
+    for (int o = 8; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    if (live && sub == 0) {
+        const bool ok = i < nv;
+        e[t] = ok ? best : 0.f;
+        idx[t] = ok ? bi : 0;
     }
 }
 
@@ -209,9 +214,10 @@ extern "C" int fgnn_from_bf16(const void *y, long long gstride, long long ldp, i
 
 extern "C" int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G, int N, int ldr, float *e, int *idx,
                                  void *stream) {
-    FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && ldr >= N && ldr % 2 == 0, "fgnn_colmax_fwd16: bad arguments");
+    FGNN_CHECK(y && y->ptr && e && idx && G > 0 && N > 0 && ldr >= N && ldr % 8 == 0 && y->ldp % 8 == 0 && y->gstride % 8 == 0,
+               "fgnn_colmax_fwd16: bad arguments (row pitch / strides must be multiples of 8 elements)");
     const long long rows = (long long)G * y->C * N;
-    hipLaunchKernelGGL(colmax_fwd16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y, nvalid, G, N,
+    hipLaunchKernelGGL(colmax_fwd16_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *y, nvalid, G, N,
                        ldr, e, idx);
     FGNN_LAUNCH_CHECK();
     return 0;

@@ -171,33 +171,35 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
     }
 }
 
-// grid (B, FGNN_SCORE_SPLIT): workgroup (b, rp) owns a contiguous block of rows of pair b.
+// grid (B, row_blocks): workgroup (b, rp) owns a contiguous block of rows of pair b.
 // e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j]; lse_i; partial loss of its rows.
+// LDS: e2 whole (C x N) and the workgroup's own rows of e1 (C x rows).
 __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, const float *e2, const int *nvalid,
-                                                           int C, int N, float *scores, float *lse,
+                                                           int C, int N, int rows, float *scores, float *lse,
                                                            float *pair_loss) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *s1 = sm, *s2 = sm + (size_t)C * N;
-    float *red = s2 + (size_t)C * N;     // 4 floats
+    float *s2 = sm, *s1 = sm + (size_t)C * N;
+    float *red = s1 + (size_t)C * rows;  // 4 floats
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = nvalid_of(nvalid, b, N);
-    const int rows = (N + FGNN_SCORE_SPLIT - 1) / FGNN_SCORE_SPLIT;
     const int i0 = blockIdx.y * rows;
     const int i1 = (i0 + rows < N) ? i0 + rows : N;
+    const int w = i1 > i0 ? i1 - i0 : 0;
     const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
-    for (int e = tid; e < C * N; e += 256) {
-        s1[e] = p1[e];
-        s2[e] = p2[e];
+    for (int e = tid; e < C * N; e += 256) s2[e] = p2[e];
+    for (int e = tid; e < C * w; e += 256) {
+        const int c = e / w, r = e - c * w;
+        s1[c * rows + r] = p1[c * N + i0 + r];
     }
     __syncthreads();
     float *S = scores + (long long)b * N * N;
     const float invN = 1.f / (float)N;
-    for (int e = i0 * N + tid; e < i1 * N; e += 256) {
-        const int i = (int)(((float)e + 0.5f) * invN), j = e - i * N;
+    for (int e = tid; e < w * N; e += 256) {
+        const int r = (int)(((float)e + 0.5f) * invN), j = e - r * N;
         float acc = 0.f;
-        if (i < nv && j < nv)
-            for (int c = 0; c < C; ++c) acc = fmaf(s1[c * N + i], s2[c * N + j], acc);
-        S[e] = acc;
+        if (i0 + r < nv && j < nv)
+            for (int c = 0; c < C; ++c) acc = fmaf(s1[c * rows + r], s2[c * N + j], acc);
+        S[(long long)i0 * N + e] = acc;
     }
     __syncthreads();   // workgroup-scope visibility of S for the row pass below
     float wl = 0.f;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     }
     if (lane == 0) red[wave] = wl;
     __syncthreads();
-    if (tid == 0 && pair_loss) pair_loss[b * FGNN_SCORE_SPLIT + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0 && pair_loss) pair_loss[b * gridDim.y + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
@@ -277,12 +279,11 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
 // Large N (dS does not fit LDS): grid (B, CSPLIT, ceil(N / SB_BLK)).  Workgroup (b, cs, rb) stages the row block
 // dS[i0:i1, :] and produces de1 for those rows, then stages the column block dS[:, i0:i1] and produces de2 for
 // those columns -- no cross-workgroup reduction, nothing recomputed inside the inner loops.
-constexpr int SB_BLK = 64;
 template <bool CE>
 __global__ __launch_bounds__(256) void score_bwd_blocked_kernel(const float *e1, const float *e2, const float *scores,
                                                                 const float *lse, const float *dscores,
                                                                 const int *nvalid, const float *gscale, int C, int N,
-                                                                float *de1, float *de2) {
+                                                                int SB_BLK, float *de1, float *de2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int cper = (C + CSPLIT - 1) / CSPLIT;
     const int c0 = blockIdx.y * cper;
@@ -443,29 +444,43 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
                            nvalid, gscale, C, N, de1, de2);
     } else {
         const int cper = (C + CSPLIT - 1) / CSPLIT;
+        // 16-wide blocks when the batch is small (N = 200, B = 8: 8 x 4 x 13 workgroups instead of 8 x 4 x 4)
+        const int SB_BLK = (long long)B * CSPLIT * ((N + 63) / 64) >= 512 ? 64 : 16;
         const int big = (N + 1) * SB_BLK > N * (SB_BLK + 1) ? (N + 1) * SB_BLK : N * (SB_BLK + 1);
         const int lds2 = (2 * cper * N + big) * (int)sizeof(float);
         FGNN_CHECK(lds2 <= 160 * 1024, "score backward: N=%d too large for the blocked LDS staging", N);
         if (lds2 > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)score_bwd_blocked_kernel<CE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         hipLaunchKernelGGL((score_bwd_blocked_kernel<CE>), dim3(B, CSPLIT, (N + SB_BLK - 1) / SB_BLK), dim3(256), lds2, st, e1, e2,
-                           scores, lse, dscores, nvalid, gscale, C, N, de1, de2);
+                           scores, lse, dscores, nvalid, gscale, C, N, SB_BLK, de1, de2);
     }
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_score_row_blocks(int B, int N) {
+    // few large pairs: more row blocks than FGNN_SCORE_SPLIT so that the launch fills the chip (8 rows per workgroup)
+    if (N <= 64 || B * FGNN_SCORE_SPLIT >= 512) return FGNN_SCORE_SPLIT;
+    return (N + 7) / 8;
+}
+
+extern "C" int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
+                                        int row_blocks, float *scores, float *lse, float *pair_loss, void *stream) {
+    FGNN_CHECK(e1 && e2 && scores && B > 0 && C > 0 && N > 0 && row_blocks > 0, "fgnn_score_ce_fwd: bad arguments");
+    const int rows = (N + row_blocks - 1) / row_blocks;
+    const int lds = (C * N + C * rows + 4) * (int)sizeof(float);
+    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_fwd: C*N=%d too large for LDS staging", C * N);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)score_ce_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B, row_blocks), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, C, N, rows,
+                       scores, lse, pair_loss);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
                                  float *scores, float *lse, float *pair_loss, void *stream) {
-    FGNN_CHECK(e1 && e2 && scores && B > 0 && C > 0 && N > 0, "fgnn_score_ce_fwd: bad arguments");
-    const int lds = score_lds_bytes(C, N);
-    FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_fwd: C*N=%d too large for LDS staging", C * N);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)score_ce_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B, FGNN_SCORE_SPLIT), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, C, N, scores,
-                       lse, pair_loss);
-    FGNN_LAUNCH_CHECK();
-    return 0;
+    return fgnn_score_ce_fwd_blocks(e1, e2, nvalid, B, C, N, FGNN_SCORE_SPLIT, scores, lse, pair_loss, stream);
 }
 
 extern "C" int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,

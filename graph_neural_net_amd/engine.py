@@ -128,7 +128,8 @@ class FgnnEngine:
         self.B = G // 2
         self.scores = torch.empty(self.B, N, N, **f32)
         self.lse = torch.empty(self.B, N, **f32)
-        self.pair_loss = torch.empty(self.B * _lib.FGNN_SCORE_SPLIT, **f32)
+        self.score_blocks = _lib.load().fgnn_score_row_blocks(self.B, N)      # row blocks per pair of the scoring kernel
+        self.pair_loss = torch.empty(self.B * self.score_blocks, **f32)
         self.loss = torch.empty(1, **f32)
         self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
         # backward workspace (allocated lazily)
@@ -273,7 +274,7 @@ class FgnnEngine:
         B, N = self.B, self.N
         st = _lib.stream_ptr()
         e1, e2 = self.E[:B], self.E[B:]
-        _lib.call('fgnn_score_ce_fwd', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N,
+        _lib.call('fgnn_score_ce_fwd_blocks', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N, self.score_blocks,
                   _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), st)
         if total_nodes is None:
             total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
@@ -281,7 +282,7 @@ class FgnnEngine:
         self._loss_pending = bool(defer_loss)
         self._loss_target = self.loss if loss_out is None else loss_out     # 1-element fp32 device tensor
         if not defer_loss:
-            _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * _lib.FGNN_SCORE_SPLIT, 1, 1.0 / self.total_nodes,
+            _lib.call('fgnn_sum_scale', _lib.ptr(self.pair_loss), B * self.score_blocks, 1, 1.0 / self.total_nodes,
                       _lib.ptr(self._loss_target), st)
         return self.scores, self._loss_target
 
@@ -419,7 +420,7 @@ class FgnnEngine:
                     jobs[i].wpart = self.pair_loss.data_ptr()
                     jobs[i].count = 1
                     jobs[i].out = self._loss_target.data_ptr()
-                    jobs[i].rows = self.B * _lib.FGNN_SCORE_SPLIT
+                    jobs[i].rows = self.B * self.score_blocks
                     jobs[i].scale = 1.0 / self.total_nodes
                     continue
                 rec = L.mlp[kj]

@@ -139,6 +139,11 @@ int fgnn_colmax_fwd_fin(const fgnn_slab *y, const float *part, const float *cnt,
 #define FGNN_SCORE_SPLIT 4
 int fgnn_score_ce_fwd(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
                       float *scores, float *lse, float *pair_loss, void *stream);
+/* the same with `row_blocks` row blocks per pair instead of FGNN_SCORE_SPLIT (pair_loss: B * row_blocks partial sums);
+ * fgnn_score_row_blocks(B, N) is the count that fills the chip for a batch of B pairs of N vertices */
+int fgnn_score_row_blocks(int B, int N);
+int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const int *nvalid, int B, int C, int N, int row_blocks,
+                             float *scores, float *lse, float *pair_loss, void *stream);
 /* d e1, d e2 of loss = sum_b pair_loss[b] * (*gscale)   (gscale: device scalar = grad / sum n) */
 int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
                       const int *nvalid, const float *gscale, int B, int C, int N,
