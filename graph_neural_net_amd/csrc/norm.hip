@@ -48,20 +48,43 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, 
         const float4 r = finalize_wave(part, cnt, g, c, C, tpg, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps, lane);
         if (lane == 0) reinterpret_cast<float4 *>(nrm)[idx] = r;
     } else {
-        for (int t = lane; t < tpg; t += WAVE) {
-            const float n = cnt[(long long)g * tpg + t];
-            sn += n;
-            sm += n * reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c].x;
+        // eight loads in flight per lane and pass (a plain loop pays one memory round trip per 64 tiles)
+        constexpr int U = 8;
+        const float *cg = cnt + (long long)g * tpg;
+        const float2 *pg = reinterpret_cast<const float2 *>(part) + (long long)g * tpg * C + c;
+        for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
+            float n[U], x[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
+                n[k] = t < tpg ? cg[tc] : 0.f;
+                x[k] = pg[(long long)tc * C].x;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                sn += n[k];
+                sm += n[k] * x[k];
+            }
         }
         sn = wave_sum(sn);
         sm = wave_sum(sm);
         const float mean = sn > 0.f ? sm / sn : 0.f;
         float m2 = 0.f;
-        for (int t = lane; t < tpg; t += WAVE) {
-            const float n = cnt[(long long)g * tpg + t];
-            const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + t) * C + c];
-            const float d = pm.x - mean;
-            m2 += pm.y + n * d * d;
+        for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
+            float n[U];
+            float2 pm[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
+                n[k] = t < tpg ? cg[tc] : 0.f;
+                pm[k] = pg[(long long)tc * C];
+                if (t >= tpg) pm[k].y = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float d = pm[k].x - mean;
+                m2 += pm[k].y + n[k] * d * d;
+            }
         }
         m2 = wave_sum(m2);
         if (lane == 0) write_nrm(nrm, idx, mean, m2, sn, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps);
@@ -209,10 +232,21 @@ __global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *nrm,
     const int lane = threadIdx.x & 63;
     const int g = idx / C, c = idx - g * C;
     float s1 = 0.f, s2 = 0.f;
-    for (int t = lane; t < tpg; t += WAVE) {
-        const float2 p = reinterpret_cast<const float2 *>(s12part)[((long long)g * tpg + t) * C + c];
-        s1 += p.x;
-        s2 += p.y;
+    constexpr int U = 8;       // loads in flight per lane
+    const float2 *pg = reinterpret_cast<const float2 *>(s12part) + (long long)g * tpg * C + c;
+    for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
+        float2 p[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int t = t0 + k * WAVE;
+            p[k] = pg[(long long)(t < tpg ? t : 0) * C];
+            if (t >= tpg) p[k] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            s1 += p[k].x;
+            s2 += p[k].y;
+        }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
