@@ -480,7 +480,7 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
             if (WANT_S) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + rb * ldr * 2, 0);
             if (MM_ABLATE == 1) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             // soffset stays a literal 0: with an SGPR there the compiler assumes a VALU write to the data registers may follow
-            // the 128-bit store immediately -- on gfx950 that corrupted dword 2 of some lanes (measured, tools/gpu_mm16_check.py)
+            // the 128-bit store immediately -- on gfx950 that corrupted dword 2 of some lanes (measured, tests/diag/gpu_mm16_check.py)
             else __builtin_amdgcn_raw_buffer_store_b128(v, ov.r, r < N ? voff + o_off2 + rb * ldr * 2 : OOB_OFF, 0, 0);
             if (WANT_S) {
                 // outputs outside the valid nv x nv block are exact zeros (masked operands); `raw` there is replaced by 0 so

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Stage-by-stage comparison of the bf16 HIP engine with oracle/fgnn_oracle_bf16.py (diagnostic; the oracle is only the
-checker here).  usage: python tools/gpu_bf16_diag.py [N] [B] [blocks]"""
+checker here).  usage: python tests/diag/gpu_bf16_diag.py [N] [B] [blocks]"""
 import os
 import sys
 import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from graph_neural_net_amd import synthetic                      # noqa: E402
 from graph_neural_net_amd.engine import ParamLayout             # noqa: E402

@@ -1,7 +1,7 @@
 """Per-tensor gradient error table (ours vs fp64, reference/oracle fp32 vs fp64) for the two large fp32 parity cases:
-python tools/gpu_graderr_table.py [n200|ragged]"""
+python tests/diag/gpu_graderr_table.py [n200|ragged]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from graph_neural_net_amd import synthetic

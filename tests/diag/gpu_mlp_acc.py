@@ -1,6 +1,7 @@
 """accuracy of the MlpBlock_Real HIP backward vs torch fp32 autograd, both against fp64 autograd"""
-import sys, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from graph_neural_net_amd.layers import MlpBlock_Real
 from oracle import fgnn_oracle as O
 DEV = 'cuda:0'

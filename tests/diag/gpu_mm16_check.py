@@ -1,6 +1,6 @@
-"""Where does the bf16 channel matmul differ from the same-point oracle?  python tools/gpu_mm16_check.py [N]"""
+"""Where does the bf16 channel matmul differ from the same-point oracle?  python tests/diag/gpu_mm16_check.py [N]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from graph_neural_net_amd import synthetic

@@ -41,7 +41,7 @@ def _check_grads(got, d, flat_factor=2.0, tensor_factor=4.0, second_sample=None)
     valid fp32 evaluation of the reference's op sequence (the pinned oracle run with one thread = another summation
     order).  After four blocks the fp32 error of a tensor is dominated by rare ReLU / arg-max flips, so it is a heavy-tailed
     random variable: at N=200 the 8-thread and the 1-thread oracle runs differ by 20x on individual tensors
-    (tools/gpu_graderr_table.py).  Where a second sample is given the yard-stick is the larger of the two."""
+    (tests/diag/gpu_graderr_table.py).  Where a second sample is given the yard-stick is the larger of the two."""
     keys = [k for k in sub(d, 'grad/') if not is_zero_grad(k)]
     flat = lambda pick: torch.cat([pick(k).reshape(-1).double() for k in keys])
     g64 = flat(lambda k: d['grad64/' + k])
