@@ -35,7 +35,7 @@ class MlpFwdArgs(C.Structure):
                 ('z', C.c_void_p * 2),
                 ('ldz', C.c_longlong),
                 ('part', C.c_void_p * 2),
-                ('cnt', C.c_void_p), ('packed', C.c_void_p)]
+                ('cnt', C.c_void_p), ('packed', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p)]
 
 
 class MlpBwdArgs(C.Structure):
@@ -51,7 +51,7 @@ class MlpBwdArgs(C.Structure):
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
                 ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p),
-                ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p)]
+                ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p)]
 
 
 class Slab16(C.Structure):
@@ -137,6 +137,7 @@ _SIGNATURES = {
     'fgnn_adam_step': [_VP, _VP, _VP, _VP, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, C.c_double, _VP],
     'fgnn_adam_step_dev': [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP],
     'fgnn_expand_adjacency': [_VP, _VP, _I, _I, _VP, _VP],
+    'fgnn_adjacency_degree': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_accuracy_max': [_VP, _VP, _I, _I, _VP, _VP],
     # ---- bf16 path ----
     'fgnn_tiles_per_graph16': [_I, _I],

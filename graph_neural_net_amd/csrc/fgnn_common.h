@@ -77,6 +77,31 @@ DEVI void buf_store(float x, const View &v, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), v.r, voff, soff, 0);
 }
 
+// A 2-channel slab expanded on the fly from the bit-packed adjacency (loaders/data_generator.py:118-125): half-wave 0 holds
+// channel 0 = W[i][jj] (bit jj of row i), half-wave 1 channel 1 = [i == jj] * deg[i].  Bits past the valid vertices are not
+// masked here: a padding pixel only feeds padding outputs, which every consumer masks (fgnn_adjacency_degree does mask).
+struct PackedSrc {
+    rsrc_t bits, deg;
+    int N, words;
+};
+DEVI PackedSrc make_packed_src(const unsigned *bits, const float *deg, int G, int N) {
+    PackedSrc ps;
+    ps.N = N;
+    ps.words = (N + 31) / 32;
+    long long nb = (long long)G * N * ps.words * 4, nd = (long long)G * N * 4;
+    if (nb > 0x7fffffffll) nb = 0x7fffffffll;
+    ps.bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(bits), 0, (int)nb, 0x00020000);
+    ps.deg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(deg), 0, (int)nd, 0x00020000);
+    return ps;
+}
+template <class Ctx>
+DEVI void load_packed(float (&x)[1], const PackedSrc &ps, const Ctx &c, int h) {
+    const int ob = (c.inb && h == 0) ? (c.i * ps.words + (c.jj >> 5)) * 4 : OOB_OFF;
+    const int od = (c.inb && h == 1 && c.i == c.jj) ? c.i * 4 : OOB_OFF;
+    const unsigned w = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(ps.bits, ob, c.g * ps.N * ps.words * 4, 0);
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ps.deg, od, c.g * ps.N * 4, 0));
+    x[0] = h == 0 ? (((w >> (c.jj & 31)) & 1u) ? 1.f : 0.f) : d;
+}
 // max(x, 0) as ONE instruction (v_max_i32 on the bit pattern: negative floats are negative ints).
 // fmaxf / a float compare-select both become TWO v_max_f32 (operand canonicalisation for sNaN first).
 DEVI float relu1(float x) {

@@ -89,6 +89,13 @@ DEVI void load_raw(float (&x)[S > 0 ? S : 1], const View &v, const TileCtx &c, i
     }
 }
 
+// slab load: from memory, or (PK, 2-channel slabs only) from the packed adjacency
+template <int S, bool PK>
+DEVI void load_slab(float (&x)[S > 0 ? S : 1], const View &v, const PackedSrc &ps, const TileCtx &c, int h) {
+    if constexpr (PK && S == 1) load_packed(x, ps, c, h);
+    else load_raw<S>(x, v, c, h);
+}
+
 // rows ch_of(r,h) of a (G,32,ld) tensor
 DEVI void load_rows16(float (&x)[16], const View &v, const TileCtx &c, int h) {
     const int voff = lane_off<4>(v, c, h);
@@ -222,7 +229,7 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
     }
 }
 
-template <int CA, int CB, int DEPTH>
+template <int CA, int CB, int DEPTH, bool PK = false>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
                                                               const int total_tiles) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
@@ -234,6 +241,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const int P = A.N * A.N;
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
+    PackedSrc ps = {};
+    if constexpr (PK) ps = make_packed_src(A.xbits, A.xdeg, A.G, A.N);
     const View vdy = make_view(A.dy, A.dgstride, A.ldd, A.G);
     const View vz = make_view(A.z, A.zgstride, A.ldz, A.G);
     const View vdxa = make_view(A.dxa, A.dxa_gstride, A.dxa_ld, A.G);
@@ -296,8 +305,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     {
         const int t = T0 + wv;
         const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, j);
-        load_raw<SA>(xa, va, c, h);
-        load_raw<SB>(xb, vb, c, h);
+        load_slab<SA, PK>(xa, va, ps, c, h);
+        load_slab<SB, PK>(xb, vb, ps, c, h);
         if (t < T1 && lane < 32) {
             if (!from_tiles) rk = coef_record(A, c.g, lane);
             if (normA && lane < CA) {
@@ -543,8 +552,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
                 if constexpr (CA == 32 && CB == 0) {
                     load_raw<SA>(nxa, va, cn, h);
                 } else {
-                    load_raw<SA>(xa, va, cn, h);
-                    load_raw<SB>(xb, vb, cn, h);
+                    load_slab<SA, PK>(xa, va, ps, cn, h);
+                    load_slab<SB, PK>(xb, vb, ps, cn, h);
                 }
             }
             PH(6)       // layer-0 staging, next x requested
@@ -710,17 +719,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     PH_FLUSH
 }
 
-template <int CA, int CB, int DEPTH>
+template <int CA, int CB, int DEPTH, bool PK = false>
 int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = BwdLayout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -728,6 +737,15 @@ int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
 template <int DEPTH>
 int dispatch_c(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     const int ca = a->a.C, cb = a->b.C;
+    if (a->xbits) {          // the 2-channel slab comes from the bit-packed adjacency (built for depth 3)
+        if constexpr (DEPTH == 3) {
+            if (ca == 2 && cb == 0) return launch_bwd<2, 0, DEPTH, true>(a, tpg, total, st);
+            if (ca == 32 && cb == 2) return launch_bwd<32, 2, DEPTH, true>(a, tpg, total, st);
+        }
+        fgnn_set_error("fgnn_mlp_bwd: xbits needs depth 3 and a 2-channel slab (2 or 32+2 input channels), got depth %d, %d + %d",
+                       DEPTH, ca, cb);
+        return 1;
+    }
 #define FGNN_CASE(A_, B_) \
     if (ca == A_ && cb == B_) return launch_bwd<A_, B_, DEPTH>(a, tpg, total, st);
     FGNN_CASE(2, 0)
@@ -765,8 +783,11 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a != nullptr, "fgnn_mlp_bwd: null args");
     FGNN_CHECK(a->G > 0 && a->N > 0, "fgnn_mlp_bwd: bad G=%d N=%d", a->G, a->N);
     FGNN_CHECK(a->depth >= 1 && a->depth <= FGNN_MAX_DEPTH, "fgnn_mlp_bwd: depth %d not in 1..%d", a->depth, FGNN_MAX_DEPTH);
-    FGNN_CHECK(a->a.ptr && a->a.C > 0, "fgnn_mlp_bwd: slab a missing");
-    FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_bwd: slab b has channels but no pointer");
+    const bool pk_a = a->xbits && a->a.C == 2, pk_b = a->xbits && a->b.C == 2;     // that slab's memory is never touched
+    FGNN_CHECK((a->a.ptr || pk_a) && a->a.C > 0, "fgnn_mlp_bwd: slab a missing");
+    FGNN_CHECK(a->b.C == 0 || a->b.ptr || pk_b, "fgnn_mlp_bwd: slab b has channels but no pointer");
+    FGNN_CHECK(!a->xbits || a->xdeg, "fgnn_mlp_bwd: xbits without xdeg (fgnn_adjacency_degree)");
+    FGNN_CHECK(!(pk_a && a->dxa) && !(pk_b && a->dxb), "fgnn_mlp_bwd: no gradient with respect to the packed adjacency");
     FGNN_CHECK(a->dy && a->z && a->wpart, "fgnn_mlp_bwd: missing dy/z/wpart");
     FGNN_CHECK(a->coef || (a->s12 && a->znrm) || (a->s12tiles && a->znrm), "fgnn_mlp_bwd: need coef, or s12 + znrm, or s12tiles + znrm");
     {

@@ -80,6 +80,13 @@ DEVI void load_raw(float (&x)[S > 0 ? S : 1], const View &v, const TileCtx &c, i
     }
 }
 
+// slab load: from memory, or (PK, 2-channel slabs only) from the packed adjacency
+template <int S, bool PK>
+DEVI void load_slab(float (&x)[S > 0 ? S : 1], const View &v, const PackedSrc &ps, const TileCtx &c, int h) {
+    if constexpr (PK && S == 1) load_packed(x, ps, c, h);
+    else load_raw<S>(x, v, c, h);
+}
+
 // y = (x - mean) * a + beta with the per-graph records {mean, a, beta, -} read from wave-private LDS
 template <int S>
 DEVI void apply_norm(float (&x)[S > 0 ? S : 1], const float *rec, bool on, bool valid, int h) {
@@ -146,7 +153,7 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
     }
 }
 
-template <int CA, int CB, int NMLP, int DEPTH>
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
 __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_kernel(
     const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -166,6 +173,8 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     float *recA = smem + L::WEIGHT_F + NW * TILE_F + wv * L::REC_F, *recB = recA + 128;
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
+    PackedSrc ps = {};
+    if constexpr (PK) ps = make_packed_src(A.xbits, A.xdeg, A.G, A.N);
     View vz[NMLP];
 #pragma unroll
     for (int m = 0; m < NMLP; ++m) vz[m] = make_view(A.z[m], FGNN_H * A.ldz, A.ldz, A.G);
@@ -189,8 +198,8 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     int cached_g = -1, cur_nv = A.N;
     {
         const TileCtx c = decode_tile(tile, tile < T1, tpg, A.N, P, j);
-        load_raw<SA>(xa, va, c, h);
-        load_raw<SB>(xb, vb, c, h);
+        load_slab<SA, PK>(xa, va, ps, c, h);
+        load_slab<SB, PK>(xb, vb, ps, c, h);
         if (tile < T1 && lane < 32) {
             if (normA && lane < CA) {
                 ra = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)c.g * A.a.C + lane];
@@ -261,8 +270,8 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
         {
             const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, j);
-            load_raw<SA>(na, va, cn, h);
-            load_raw<SB>(nb, vb, cn, h);
+            load_slab<SA, PK>(na, va, ps, cn, h);
+            load_slab<SB, PK>(nb, vb, ps, cn, h);
         }
         apply_norm<SA>(xa, recA, normA, c_valid, h);
         apply_norm<SB>(xb, recB, normB, c_valid, h);
@@ -360,7 +369,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
 #endif
 }
 
-template <int CA, int CB, int NMLP, int DEPTH>
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
 int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
@@ -368,13 +377,13 @@ int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH>,
+        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     int grid = (total + NW - 1) / NW;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
+    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -382,6 +391,17 @@ int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
 template <int NMLP, int DEPTH>
 int dispatch_c(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
     const int ca = a->a.C, cb = a->b.C;
+    if (a->xbits) {          // the 2-channel slab comes from the bit-packed adjacency (built for depth 3)
+        if constexpr (DEPTH == 3) {
+            if (ca == 2 && cb == 0) return launch_fwd<2, 0, NMLP, DEPTH, true>(a, tpg, total, st);
+            if constexpr (NMLP == 1) {
+                if (ca == 32 && cb == 2) return launch_fwd<32, 2, NMLP, DEPTH, true>(a, tpg, total, st);
+            }
+        }
+        fgnn_set_error("fgnn_mlp_fwd: xbits needs depth 3 and a 2-channel slab (2 or 32+2 input channels), got depth %d, %d + %d",
+                       DEPTH, ca, cb);
+        return 1;
+    }
 #define FGNN_CASE(A_, B_) \
     if (ca == A_ && cb == B_) return launch_fwd<A_, B_, NMLP, DEPTH>(a, tpg, total, st);
     FGNN_CASE(2, 0)
@@ -413,9 +433,11 @@ extern "C" int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *a, void *stream) {
     FGNN_CHECK(a->G > 0 && a->N > 0, "fgnn_mlp_fwd: bad G=%d N=%d", a->G, a->N);
     FGNN_CHECK(a->nmlp == 1 || a->nmlp == 2, "fgnn_mlp_fwd: nmlp must be 1 or 2 (got %d)", a->nmlp);
     FGNN_CHECK(a->depth >= 1 && a->depth <= FGNN_MAX_DEPTH, "fgnn_mlp_fwd: depth %d not in 1..%d", a->depth, FGNN_MAX_DEPTH);
-    FGNN_CHECK(a->a.ptr && a->a.C > 0, "fgnn_mlp_fwd: slab a missing");
-    FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_fwd: slab b has channels but no pointer");
-    FGNN_CHECK((long long)a->N * a->N <= a->ldz && (long long)a->N * a->N <= a->a.ldp, "fgnn_mlp_fwd: channel stride < N*N");
+    const bool pk_a = a->xbits && a->a.C == 2, pk_b = a->xbits && a->b.C == 2;     // that slab's memory is never touched
+    FGNN_CHECK((a->a.ptr || pk_a) && a->a.C > 0, "fgnn_mlp_fwd: slab a missing");
+    FGNN_CHECK(a->b.C == 0 || a->b.ptr || pk_b, "fgnn_mlp_fwd: slab b has channels but no pointer");
+    FGNN_CHECK(!a->xbits || a->xdeg, "fgnn_mlp_fwd: xbits without xdeg (fgnn_adjacency_degree)");
+    FGNN_CHECK((long long)a->N * a->N <= a->ldz && (pk_a || (long long)a->N * a->N <= a->a.ldp), "fgnn_mlp_fwd: channel stride < N*N");
     for (int m = 0; m < a->nmlp; ++m) {
         FGNN_CHECK(a->z[m] && a->part[m], "fgnn_mlp_fwd: missing output %d", m);
         for (int l = 0; l < a->depth; ++l) FGNN_CHECK(a->W[m][l] && a->bias[m][l], "fgnn_mlp_fwd: missing weights mlp %d layer %d", m, l);

@@ -157,7 +157,32 @@ __global__ void expand_adjacency_kernel(const unsigned *bits, const int *nvalid,
     xg[p] = on ? 1.f : 0.f;
     xg[P + p] = deg;
 }
+__global__ void adjacency_degree_kernel(const unsigned *bits, const int *nvalid, int G, int N, int words, float *deg) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)G * N) return;
+    const int g = (int)(t / N), i = (int)(t - (long long)g * N);
+    const int nv = nvalid_of(nvalid, g, N);
+    const unsigned *row = bits + t * words;
+    int d = 0;
+    if (i < nv) {
+        for (int k = 0; k < words; ++k) {
+            const int left = nv - 32 * k;
+            const unsigned m = left >= 32 ? 0xffffffffu : (left <= 0 ? 0u : ((1u << left) - 1u));
+            d += __popc(row[k] & m);
+        }
+    }
+    deg[t] = (float)d;
+}
 }  // namespace
+
+extern "C" int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream) {
+    FGNN_CHECK(bits && deg && G > 0 && N > 0, "fgnn_adjacency_degree: bad arguments");
+    const long long tot = (long long)G * N;
+    hipLaunchKernelGGL(adjacency_degree_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits,
+                       nvalid, G, N, (N + 31) / 32, deg);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N, float *x, void *stream) {
     FGNN_CHECK(bits && x && G > 0 && N > 0, "fgnn_expand_adjacency: bad arguments");

@@ -135,6 +135,8 @@ class FgnnEngine:
         # backward workspace (allocated lazily)
         self._bwd = None
         self.x = None
+        self.xbits = None         # bit-packed adjacency input (embed(..., bits=...)) and its row sums
+        self.xdeg = None
         # LDS operand images of every MLP launch, re-packed once per step (fgnn_pack_operands)
         self._packs = {}
         for k in range(1, K + 1):
@@ -155,6 +157,10 @@ class FgnnEngine:
     def _slab_in(self, k, params):
         """Input slab of block k: raw x for k == 1, else block k-1's mlp3 output (normalise on load)."""
         if k == 1:
+            if self.xbits is not None:      # never materialised: block 1's kernels expand the packed adjacency themselves
+                s = _lib.Slab()
+                s.gstride, s.ldp, s.C = self.layout.c0 * self.P, self.P, self.layout.c0
+                return s
             return _lib.make_slab(self.x, self.layout.c0 * self.P, self.P, self.layout.c0)
         rec = self.layout.mlp[(k - 1, 3)]
         s = _lib.make_slab(self.z[(k - 1, 3)], 32 * self.ldp, self.ldp, 32, nrm=self.nrm[(k - 1, 3)])
@@ -208,6 +214,7 @@ class FgnnEngine:
         args.ldz = self.ldp
         args.cnt = self.cnt.data_ptr()
         args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
+        self._packed_input(args, k)
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         if not finalize:
@@ -223,19 +230,41 @@ class FgnnEngine:
                       C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, EPS,
                       _lib.ptr(self.nrm[(k, js[0])]), st)
 
+    def _packed_input(self, args, k):
+        """Block 1 with a bit-packed input: its 2-channel slab is expanded inside the kernel."""
+        if k == 1 and self.xbits is not None:
+            args.xbits = self.xbits.data_ptr()
+            args.xdeg = self.xdeg.data_ptr()
+
     # ------------------------------------------------------------------ forward
-    def embed(self, params, x, nvalid=None):
-        """x: (G, c0, N, N) contiguous device tensor.  Fills self.E / self.idx."""
+    def embed(self, params, x, nvalid=None, bits=None):
+        """x: (G, c0, N, N) contiguous device tensor -- or bits: (G, N, ceil(N/32)) int32 words of the bit-packed
+        adjacency (bit j of row i = W[i][j], the format of inputs.expand_adjacency / synthetic.pack_adjacency): the
+        (2, N, N) representation of loaders/data_generator.py:118-125 is then built inside block 1's kernels and never
+        exists in HBM.  Fills self.E / self.idx."""
         L = self.layout
-        if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
-            raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
-                               % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
         if (nvalid is None) != (self.nvalid is None):
             raise RuntimeError('FgnnEngine: ragged flag and nvalid argument disagree')
         if nvalid is not None:
             self.nvalid.copy_(nvalid.to(torch.int32))
-        self.x = x
         st = _lib.stream_ptr()
+        if bits is not None:
+            words = (self.N + 31) // 32
+            if x is not None or L.c0 != 2 or L.depth != 3:
+                raise RuntimeError('FgnnEngine.embed: bits= replaces x and needs original_features_num = 2, depth_of_mlp = 3')
+            if tuple(bits.shape) != (self.G, self.N, words) or bits.dtype not in (torch.int32, torch.uint32) \
+                    or not bits.is_contiguous() or bits.device.type != 'cuda':
+                raise RuntimeError('FgnnEngine.embed: expected contiguous 32-bit words %s on the GPU, got %s %s'
+                                   % ((self.G, self.N, words), tuple(bits.shape), bits.dtype))
+            if self.xdeg is None:
+                self.xdeg = torch.empty(self.G * self.N, dtype=torch.float32, device=self.device)
+            self.x, self.xbits = None, bits
+            _lib.call('fgnn_adjacency_degree', _lib.ptr(bits), self._nv(), self.G, self.N, _lib.ptr(self.xdeg), st)
+        else:
+            if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
+                raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
+                                   % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
+            self.x, self.xbits = x, None
         self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
@@ -266,11 +295,12 @@ class FgnnEngine:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
 
-    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None):
-        """Siamese forward on the stacked batch x = cat(x1, x2): returns (scores, loss).
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None):
+        """Siamese forward on the stacked batch x = cat(x1, x2) (or its bit-packed adjacency, see embed): returns
+        (scores, loss).
         defer_loss: leave the final sum of the per-pair losses to the gradient-finalize launch of the
         following backward() (one launch less per training step); `loss` is valid after that."""
-        self.embed(params, x, nvalid)
+        self.embed(params, x, nvalid, bits=bits)
         B, N = self.B, self.N
         st = _lib.stream_ptr()
         e1, e2 = self.E[:B], self.E[B:]
@@ -350,6 +380,7 @@ class FgnnEngine:
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'][(k, j)].data_ptr()
         args.packed = self._packs[('b', k, j)][4].data_ptr()
+        self._packed_input(args, k)
         if emit:
             args.s12part = W['s12part'].data_ptr()
         _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
@@ -434,9 +465,9 @@ class FgnnEngine:
             _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
         return grads
 
-    def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None):
+    def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):
         """One training step's model work: forward + loss + backward."""
-        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out)
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits)
         self.backward(params, grads)
         return scores, loss
 

@@ -88,6 +88,11 @@ typedef struct {
     const float *packed;                    /* optional: operand image from fgnn_pack_operands
                                                (kind 0) for exactly these weights; NULL = the kernel
                                                builds it itself (slower prologue)              */
+    const unsigned *xbits;                  /* optional: the 2-channel slab (a when a.C == 2, else b when b.C == 2) is not read
+                                               from its ptr but expanded on the fly from the bit-packed adjacency
+                                               (G, N, ceil(N/32)) words, bit j of row i = W[i][j]: channel 0 = W, channel 1 =
+                                               diag(xdeg) (loaders/data_generator.py:118-125); the slab need not exist */
+    const float *xdeg;                      /* (G, N) row sums over the valid columns, from fgnn_adjacency_degree */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
 
@@ -212,6 +217,8 @@ typedef struct {
                                                 the tiles of the graphs it touches in its prologue (the work of
                                                 fgnn_gn_bwd_coef_tiles without its launch; see ..._coef_tiles_supported) */
     float *s12_out;                          /* optional (G*32*2): the summed s12 is also written here (affine gradients) */
+    const unsigned *xbits;                   /* optional: 2-channel slab expanded from the bit-packed adjacency, as in  */
+    const float *xdeg;                       /*   fgnn_mlp_fwd_args                                                      */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
@@ -257,6 +264,9 @@ int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int 
 /* Input expansion (loaders/data_generator.py:118-125): bits (G, N, ceil(N/32)) uint32, bit j of row i =
  * W[i][j]  ->  x (G, 2, N, N) fp32 with x[g,0] = W, x[g,1] = diag(row sums); exact 0/1/integer values. */
 int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N, float *x, void *stream);
+/* deg[g][i] = number of set bits j < nvalid[g] in row i (0 for rows >= nvalid[g]): the diagonal of channel 1, for the
+ * kernels that expand the adjacency themselves (fgnn_mlp_fwd_args.xbits / xdeg) */
+int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream);
 
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);

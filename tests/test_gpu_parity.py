@@ -428,3 +428,38 @@ def test_training_step_matches_oracle_plus_torch_adam():
     for _ in range(20):
         loss, _ = tr.train_step(x1.to(DEV), x2.to(DEV))
     assert loss.item() < losses[0]
+
+
+@pytest.mark.parametrize('N,B,ragged', [(50, 4, False), (33, 3, False), (41, 3, True)])
+def test_bit_packed_adjacency_input_is_bit_identical(N, B, ragged):
+    """block 1's kernels expand the bit-packed adjacency themselves (the (2, n, n) tensor of
+    loaders/data_generator.py:118-125 never exists in HBM).  Scores, loss and every gradient must equal the dense-input
+    step bit for bit; in the ragged case the padding bits are garbage (all ones)."""
+    import numpy as np
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    rng = np.random.default_rng(5)
+    G = 2 * B
+    ns = [N] * G if not ragged else [int(v) for v in rng.integers(9, N + 1, size=B)] * 2
+    ns[0] = N
+    ns[B] = N
+    ws = np.ones((G, N, N), dtype=np.float32) if ragged else np.zeros((G, N, N), dtype=np.float32)
+    x = np.zeros((G, 2, N, N), dtype=np.float32)
+    for g, n in enumerate(ns):
+        w = synthetic.erdos_renyi(rng, n, 0.3)
+        ws[g, :n, :n] = w
+        x[g, :, :n, :n] = synthetic.tensor_representation(w)
+    nv = torch.tensor(ns, dtype=torch.int32, device=DEV) if ragged else None
+    bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
+    out = []
+    for kw in (dict(x=torch.from_numpy(x).to(DEV)), dict(x=None, bits=bits)):
+        eng = FgnnEngine(lay, G, N, DEV, ragged=ragged)
+        grads = torch.zeros_like(params)
+        scores, loss = eng.step(params, grads, kw.pop('x'), nvalid=nv, **kw)
+        torch.cuda.synchronize()
+        out.append((scores.clone(), loss.clone(), grads))
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.equal(out[0][2], out[1][2])
+    assert out[0][2].abs().sum() > 0
