@@ -170,12 +170,13 @@ struct StageXK {
             d[1] = make_uint2(o[2], o[3]);
         }
     }
-    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
+    static DEVI u32x4 load_piece(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
         const int pc = tid & 7, x = tid >> 3, kk = k0 + 8 * pc;
-        if (MM_ABLATE == 4) r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
-        else r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (kk < nv && (x + 64 * i) < nv) ? (x * ldr + kk) * 2 : OOB_OFF,
-                                                          s.off2 + 64 * i * ldr * 2, 0);
+        if (MM_ABLATE == 4) return u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+        return __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (kk < nv && (x + 64 * i) < nv) ? (x * ldr + kk) * 2 : OOB_OFF,
+                                                     s.off2 + 64 * i * ldr * 2, 0);
     }
+    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) { r[i] = load_piece(i, s, ldr, nv, k0, tid); }
     template <bool WHOLE>
     DEVI PieceCtx ctx(const Src16 &s, int nv, int k0, int i, int tid) const {
         return piece_ctx<WHOLE>(s, nv, (tid >> 3) + 64 * i, k0 + 8 * (tid & 7));
@@ -218,12 +219,13 @@ struct StageKX {
             *reinterpret_cast<u32x4 *>(dst + RPS * i * MMCfg<NT>::KX_LD) = o;
         }
     }
-    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
+    static DEVI u32x4 load_piece(int i, const Src16 &s, int ldr, int nv, int k0, int tid) {
         const int pc = tid % PPR, kr = tid / PPR, kb = k0 + RPS * i;
-        if (MM_ABLATE == 4) r[i] = u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
-        else r[i] = __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (8 * pc < nv && kb + kr < nv) ? 16 * pc + kr * ldr * 2 : OOB_OFF,
-                                                          s.off2 + kb * ldr * 2, 0);
+        if (MM_ABLATE == 4) return u32x4{(unsigned)tid, (unsigned)k0, 1u, 2u};
+        return __builtin_amdgcn_raw_buffer_load_b128(s.v.r, (8 * pc < nv && kb + kr < nv) ? 16 * pc + kr * ldr * 2 : OOB_OFF,
+                                                     s.off2 + kb * ldr * 2, 0);
     }
+    DEVI void load_one(int i, const Src16 &s, int ldr, int nv, int k0, int tid) { r[i] = load_piece(i, s, ldr, nv, k0, tid); }
     template <bool WHOLE>
     DEVI PieceCtx ctx(const Src16 &s, int nv, int k0, int i, int tid) const {
         return piece_ctx<WHOLE>(s, nv, k0 + tid / PPR + RPS * i, 8 * (tid % PPR));
@@ -280,10 +282,20 @@ DEVI i32x4 read_operand(const char *P, const OperandAddr &oa, int t, int step) {
 // Waves past the last tile row repeat the last one (their SIMD's matrix pipe would idle otherwise) and are skipped by
 // mm_store; the last chunk stages the all-zero chunk past nv into the idle buffer.  Both keep the chunk one branch-free
 // block with a single code path (a second path's join makes the register allocator ping-pong the accumulators).
-template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE>
+// LAST: the product's final chunk stages nothing (the LDS buffers become the output image next); instead the registers
+// receive chunk 0 of the NEXT product through `next(i, a_piece, b_piece)`, so its first loads fly during this chunk's MFMAs
+// and the store epilogue.
+struct NoNext {
+    DEVI void operator()(int, u32x4 &, u32x4 &) const {}
+};
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE, bool LAST, class Next>
 DEVI void strip_chunk(AccArray<NT, NCOL> &acc, const char *pa, const char *pb, const OperandAddr &oa, int strip,
                       Stage<NT, A_XK> &sa, Stage<NT, B_XK> &sb, char *nxa, char *nxb, const Src16 &A, const Src16 &B, int ldr,
-                      int nv, int k0n, int tid) {
+                      int nv, int k0n, int tid, const Next &next) {
+    if constexpr (LAST) {
+#pragma unroll
+        for (int i = 0; i < MM_KC / 16; ++i) next(i, sa.r[i], sb.r[i]);
+    }
     static_assert(Stage<NT, A_XK>::SW == MM_KC / 16 && Stage<NT, B_XK>::SW == MM_KC / 16, "one sweep per k-step");
     static_assert(NCOL >= 4, "dword slots");
     // B operands run one MFMA ahead of their use; the order below is pinned with scheduling barriers (left alone the
@@ -300,7 +312,7 @@ DEVI void strip_chunk(AccArray<NT, NCOL> &acc, const char *pa, const char *pb, c
             const int it = s * NCOL + tn;
             if (it + 1 < TOT) bq[(it + 1) & 1] = read_operand<NT, B_XK>(pb, oa, (it + 1) % NCOL, (it + 1) / NCOL);
             if (MM_ABLATE != 2) acc[tn] = mfma16(bq[it & 1], a, acc[tn]);
-            if (MM_ABLATE != 3) {
+            if (MM_ABLATE != 3 && !LAST) {
                 if (tn < 4) {
                     if (!A_PLAIN) {
                         if (tn == 0) cx = sa.template ctx<WHOLE>(A, nv, k0n, s, tid);
@@ -317,7 +329,7 @@ DEVI void strip_chunk(AccArray<NT, NCOL> &acc, const char *pa, const char *pb, c
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (MM_ABLATE != 3) {
+        if (MM_ABLATE != 3 && !LAST) {
             if (!B_PLAIN) {
 #pragma unroll
                 for (int q = NCOL - 4; q < 4; ++q) sb.r[s][q] = norm_dword<WHOLE>(sb.r[s][q], cx, q);
@@ -329,8 +341,11 @@ DEVI void strip_chunk(AccArray<NT, NCOL> &acc, const char *pa, const char *pb, c
     }
 }
 
-template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE>
-DEVI void mm_gemm_strip(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid) {
+// pre_a / pre_b: chunk 0 of this product when PRELOADED (left there by the previous product's last chunk); on return they
+// hold whatever `next` loaded (chunk 0 of the following product).
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN, bool B_PLAIN, bool WHOLE, bool PRELOADED, class Next>
+DEVI void mm_gemm_strip(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid,
+                        u32x4 (&pre_a)[4], u32x4 (&pre_b)[4], const Next &next) {
     using Cf = MMCfg<NT, NCOL>;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int strip = wv < ntv ? wv : ntv - 1;
@@ -341,8 +356,16 @@ DEVI void mm_gemm_strip(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B,
     Stage<NT, A_XK> sa;
     Stage<NT, B_XK> sb;
     MM_STAMP(0);
-    sa.load(A, ldr, nv, 0, tid);
-    sb.load(B, ldr, nv, 0, tid);
+    if constexpr (PRELOADED) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sa.r[i] = pre_a[i];
+            sb.r[i] = pre_b[i];
+        }
+    } else {
+        sa.load(A, ldr, nv, 0, tid);
+        sb.load(B, ldr, nv, 0, tid);
+    }
     MM_STAMP(1);
 #pragma unroll
     for (int i = 0; i < MM_KC / 16; ++i) {                 // chunk 0: nothing to hide it under
@@ -363,25 +386,46 @@ DEVI void mm_gemm_strip(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B,
     }
     __syncthreads();
     MM_STAMP(2);
-    for (int c = 0; c < nkc; ++c) {
+    for (int c = 0; c + 1 < nkc; ++c) {
         const char *pa = lds + (c & 1) * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
         char *nx = lds + ((c & 1) ^ 1) * Cf::BUF_B;
-        strip_chunk<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, WHOLE>(acc, pa, pb, oa, strip, sa, sb, nx, nx + Cf::PANEL_B, A, B, ldr, nv,
-                                                                 (c + 1) * MM_KC, tid);
+        strip_chunk<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, WHOLE, false>(acc, pa, pb, oa, strip, sa, sb, nx, nx + Cf::PANEL_B, A, B,
+                                                                        ldr, nv, (c + 1) * MM_KC, tid, next);
         if (c < 4) MM_STAMP(3 + 2 * c);
         __syncthreads();
         if (c < 4) MM_STAMP(4 + 2 * c);
+    }
+    if (nkc > 0) {
+        const int c = nkc - 1;
+        const char *pa = lds + (c & 1) * Cf::BUF_B, *pb = pa + Cf::PANEL_B;
+        strip_chunk<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, WHOLE, true>(acc, pa, pb, oa, strip, sa, sb, nullptr, nullptr, A, B, ldr, nv,
+                                                                       0, tid, next);
+        if (c < 4) MM_STAMP(3 + 2 * c);
+        __syncthreads();
+        if (c < 4) MM_STAMP(4 + 2 * c);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) next(i, sa.r[i], sb.r[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pre_a[i] = sa.r[i];
+        pre_b[i] = sb.r[i];
     }
 }
 
 // acc (the wave's tiles of the ntv x ntv valid tiles) = (OpA OpB)^T over all k chunks: the MFMA takes OpB^T as its first and
 // OpA^T as its second operand, so a lane ends up with one ROW of the product tile (what mm_store wants)
-template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN = false, bool B_PLAIN = false>
-DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid) {
+template <int NT, int NCOL, bool A_XK, bool B_XK, bool A_PLAIN = false, bool B_PLAIN = false, bool PRELOADED = false,
+          class Next = NoNext>
+DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char *lds, int ldr, int nv, int ntv, int tid,
+                  u32x4 (&pre_a)[4], u32x4 (&pre_b)[4], const Next &next = Next()) {
     using Cf = MMCfg<NT, NCOL>;
     if constexpr (Cf::STRIP) {
-        if ((nv & 7) == 0) mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, true>(acc, A, B, lds, ldr, nv, ntv, tid);
-        else mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, false>(acc, A, B, lds, ldr, nv, ntv, tid);
+        if ((nv & 7) == 0)
+            mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, true, PRELOADED>(acc, A, B, lds, ldr, nv, ntv, tid, pre_a, pre_b, next);
+        else
+            mm_gemm_strip<NT, NCOL, A_XK, B_XK, A_PLAIN, B_PLAIN, false, PRELOADED>(acc, A, B, lds, ldr, nv, ntv, tid, pre_a, pre_b, next);
         return;
     }
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -516,7 +560,8 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
     const View16 vO = make_view16(out, ogstride, ldo, G);
     const int o_off = g * vO.gs2 + c * vO.ld2;
     f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-    mm_gemm<NT, NCOL, true, false>(acc, A, B, mm_lds, ldr, nv, ntv, tid);            // M = Ya Yb: [x][k] x [k][x]
+    u32x4 pre_a[4], pre_b[4];
+    mm_gemm<NT, NCOL, true, false>(acc, A, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);       // M = Ya Yb: [x][k] x [k][x]
     float s1 = 0.f, s2 = 0.f;
     mm_store<NT, NCOL, false>(acc, mm_lds, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
 }
@@ -539,10 +584,18 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     {
         f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-        mm_gemm<NT, NCOL, true, true, true, false>(acc, D, B, mm_lds, ldr, nv, ntv, tid);          // dA = dM Yb^T: both [x][k]
+        u32x4 pre_a[4], pre_b[4];
+        // the first product's last chunk already requests chunk 0 of the second one (both of its operands are [k][x] sources)
+        auto next = [&](int i, u32x4 &ra, u32x4 &rb) {
+            if constexpr (MMCfg<NT, NCOL>::STRIP) {
+                ra = StageKX<NT>::load_piece(i, A, ldr, nv, 0, tid);
+                rb = StageKX<NT>::load_piece(i, D, ldr, nv, 0, tid);
+            }
+        };
+        mm_gemm<NT, NCOL, true, true, true, false, false>(acc, D, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b, next);   // dA = dM Yb^T
         if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
         else mm_store<NT, NCOL, false>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
-        mm_gemm<NT, NCOL, false, false, false, true>(acc, A, D, mm_lds, ldr, nv, ntv, tid);        // dB = Ya^T dM: both [k][x]
+        mm_gemm<NT, NCOL, false, false, false, true, true>(acc, A, D, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);         // dB = Ya^T dM
         if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
         else mm_store<NT, NCOL, false>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
     }
