@@ -75,9 +75,11 @@ DEVI Src16 mm_src(const fgnn_slab16 &s, int G, int g, int c) {
     if (o.norm) {
         const float4 n = reinterpret_cast<const float4 *>(s.nrm)[(long long)g * s.C + c];
         const float be = s.beta ? s.beta[c] : 0.f;
-        o.a = n.y;
-        o.b = be - n.x * n.y;
-        o.mean = n.x;
+        // uniform values: keep them in scalar registers
+        auto sgpr = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+        o.a = sgpr(n.y);
+        o.b = sgpr(be - n.x * n.y);
+        o.mean = sgpr(n.x);
     }
     return o;
 }
@@ -508,6 +510,10 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
     }
     __syncthreads();
     MM_STAMP(11);
+    // The next product's first chunk was requested during the last MFMA chunk.  Let it land BEFORE the stores below are
+    // issued: vector memory operations of a wave retire in order, so waiting for those loads later (a runtime number of
+    // stores in between) would mean waiting for every store to reach memory.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
     const int piece = tid & 31, rs = tid >> 5, X = 32 * ntv;
     if (8 * piece < ldr) {
         const bool col_in = 8 * piece < X;
