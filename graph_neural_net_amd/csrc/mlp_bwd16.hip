@@ -32,9 +32,35 @@ struct Bwd16Layout {
     static constexpr int REC_F = 64 + 64 + 128;                     // per wave: {a, b'} slab a, slab b, {mean, ca, cb, cc}
     static constexpr int PCOUNT = 32 * (CA + CB) + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int MAIN_F = WEIGHT_F + NWB * REC_F;
+    // Weight-gradient accumulator tiles kept in LDS between the tiles of the loop ("parked") instead of in registers: the
+    // variants that would otherwise spill them to scratch (the 64-input-channel kernel needs four 32x32 fp32 accumulators on
+    // top of everything else).  A scratch reload retires in order with the prefetch loads in flight and stalls behind them;
+    // LDS does not, and ~130 KB of it are idle here.  Slots in order of use: dW_2, dW_1, dW_0 (slab a), dW_0 (slab b).
+    static constexpr int NPARK = (CA >= 32 && CB >= 32) ? 4 : (CA >= 32 && CB > 0) ? 2 : (CA >= 32 ? 1 : 0);
+    static constexpr int PARK_OFF = (MAIN_F + 3) & ~3;
+    static constexpr int PARK_F = NWB * NPARK * 1024;
     static constexpr int RED_F = NWB * PCOUNT;
-    static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
+    static constexpr int LDS_F = PARK_OFF + PARK_F > RED_F ? PARK_OFF + PARK_F : RED_F;
 };
+
+// a parked accumulator tile: [4][64 lanes][4 floats] -> conflict-free 16-byte accesses
+DEVI f32x16 park_get(const float *slot, int lane) {
+    f32x16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = reinterpret_cast<const float4 *>(slot)[q * 64 + lane];
+        v[4 * q] = t.x;
+        v[4 * q + 1] = t.y;
+        v[4 * q + 2] = t.z;
+        v[4 * q + 3] = t.w;
+    }
+    return v;
+}
+DEVI void park_put(float *slot, int lane, const f32x16 &v) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
 
 DEVI void fetch_rec2(float *rec, const fgnn_slab16 &s, int g, int lane) {
     if (lane < 32) {
@@ -127,6 +153,21 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     zero16f(dW0b);
 #pragma unroll
     for (int l = 0; l + 1 < DEPTH; ++l) zero16f(dWh[l]);
+    // slot s of this wave's parked accumulators (s < NPARK), zero-initialised; `accum(slot, reg, f)` applies f to the tile
+    constexpr int NPARK = L::NPARK;
+    float *park = smem + L::PARK_OFF + wv * (NPARK * 1024);
+#pragma unroll
+    for (int s = 0; s < NPARK; ++s) park_put(park + s * 1024, lane, dW0a);
+    auto accum = [&](auto slot, f32x16 &reg, auto &&f) {
+        constexpr int S = decltype(slot)::value;
+        if constexpr (S < NPARK) {
+            f32x16 a = park_get(park + S * 1024, lane);
+            f(a);
+            park_put(park + S * 1024, lane, a);
+        } else {
+            f(reg);
+        }
+    };
 #pragma unroll
     for (int l = 0; l < DEPTH; ++l) db[l] = 0.f;
 
@@ -305,8 +346,12 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
                     pack_acc(dT, t);
                     t = transpose16(in, ident);
                     pack_acc(hT, t);
-                    dWh[l - 1] = mfma16(step_of(dT, 0), step_of(hT, 0), dWh[l - 1]);
-                    dWh[l - 1] = mfma16(step_of(dT, 1), step_of(hT, 1), dWh[l - 1]);
+                    auto upd = [&](f32x16 &a) {
+                        a = mfma16(step_of(dT, 0), step_of(hT, 0), a);
+                        a = mfma16(step_of(dT, 1), step_of(hT, 1), a);
+                    };
+                    if (l == 2) accum(std::integral_constant<int, 0>(), dWh[l - 1], upd);
+                    else accum(std::integral_constant<int, 1>(), dWh[l - 1], upd);
                 }
                 {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -323,11 +368,15 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
                 db[0] += sum16(t);
                 F16 dT;
                 pack_acc(dT, t);
-                dW0a = mfma16(step_of(dT, 0), step_of(yTa, 0), dW0a);
-                dW0a = mfma16(step_of(dT, 1), step_of(yTa, 1), dW0a);
+                accum(std::integral_constant<int, 2>(), dW0a, [&](f32x16 &a) {
+                    a = mfma16(step_of(dT, 0), step_of(yTa, 0), a);
+                    a = mfma16(step_of(dT, 1), step_of(yTa, 1), a);
+                });
                 if constexpr (CB > 0) {
-                    dW0b = mfma16(step_of(dT, 0), step_of(yTb, 0), dW0b);
-                    dW0b = mfma16(step_of(dT, 1), step_of(yTb, 1), dW0b);
+                    accum(std::integral_constant<int, 3>(), dW0b, [&](f32x16 &a) {
+                        a = mfma16(step_of(dT, 0), step_of(yTb, 0), a);
+                        a = mfma16(step_of(dT, 1), step_of(yTb, 1), a);
+                    });
                 }
             }
 
@@ -415,7 +464,12 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     constexpr int PCOUNT = L::PCOUNT;
 #pragma unroll
     for (int l = 0; l < DEPTH; ++l) db[l] += __shfl_xor(db[l], 32);
-    __syncthreads();                       // everyone done with the operand image
+    // parked accumulators back into registers before the reduction buffer (which aliases them) is written
+    if constexpr (NPARK > 0) dWh[1] = park_get(park, lane);
+    if constexpr (NPARK > 1) dWh[0] = park_get(park + 1024, lane);
+    if constexpr (NPARK > 2) dW0a = park_get(park + 2 * 1024, lane);
+    if constexpr (NPARK > 3) dW0b = park_get(park + 3 * 1024, lane);
+    __syncthreads();                       // everyone done with the operand image and the parked tiles
     {
         float *red = smem + wv * PCOUNT;
 #pragma unroll
