@@ -16,6 +16,7 @@
 // N > 128: wave w owns the tile ROW w (its A operand of a k-step is read once and reused for every tile column).
 #include <type_traits>
 #include "fgnn_bf16.h"
+#include "fgnn_norm.h"
 
 #ifndef MM_ABLATE
 #define MM_ABLATE 0          // debug builds (tools/gpu_mm16_ablate.py): 1 no stores, 2 no MFMA, 3 no LDS staging, 4 no global loads,
@@ -555,19 +556,110 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
     MM_STAMP(13);
 }
 
-template <int NT, int NCOL>
+// GraphNorm finalize of the two operands folded into the forward product's prologue (the work of fgnn_gn_finalize2_tpg
+// without its launch): the workgroup of matrix (g, c) reduces the tile statistics {mean_t, M2_t, n_t} of channel c of
+// graph g for both operands -- the same exact two-level decomposition, two fixed-order workgroup sums -- while its first
+// operand chunk is in flight, writes the records for the backward pass and uses them at once.
+struct FinArgs16 {
+    const float *part_a, *part_b, *cnt;      // (G, tpg, C, 2) {mean, M2} per tile and (G, tpg) valid elements per tile
+    const float *gw_a, *gw_b;                // GraphNorm weights (C) or NULL = 1
+    float *nrm_a, *nrm_b;                    // out: records (G*C*4)
+    float eps;
+    int tpg;
+};
+template <int K>
+DEVI void wg_sum(float (&v)[K], float (*red)[4], int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[wv][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < MM_NW; ++w) t += red[w][k];                // fixed order
+        v[k] = t;
+    }
+}
+
+template <int NT, int NCOL, bool FIN>
 __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgnn_slab16 ya, const fgnn_slab16 yb,
                                                                        const int *nvalid, int N, int ldr, int G, void *out,
-                                                                       long long ogstride, long long ldo) {
+                                                                       long long ogstride, long long ldo, const FinArgs16 F) {
     extern __shared__ __attribute__((aligned(16))) char mm_lds[];
+    __shared__ float fin_red[MM_NW][4];
+    constexpr bool STRIP = MMCfg<NT, NCOL>::STRIP;
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
-    const Src16 A = mm_src(ya, G, g, c), B = mm_src(yb, G, g, c);
+    Src16 A, B;
+    u32x4 pre_a[4], pre_b[4];
+    if constexpr (FIN) {
+        A = mm_src_plain(ya.ptr, ya.gstride, ya.ldp, G, g, c);
+        B = mm_src_plain(yb.ptr, yb.gstride, yb.ldp, G, g, c);
+        A.norm = B.norm = true;
+        // the tile statistics first (small, needed first), then the first operand chunk behind them
+        constexpr int TPT = 1024 / MM_THREADS;                           // tpg <= 1024 (N <= 256)
+        float n[TPT];
+        float2 pa[TPT], pb[TPT];
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int t = tid + k * MM_THREADS, tc = t < F.tpg ? t : 0;
+            const long long row = (long long)g * F.tpg + tc;
+            n[k] = t < F.tpg ? F.cnt[row] : 0.f;
+            pa[k] = reinterpret_cast<const float2 *>(F.part_a)[row * C + c];
+            pb[k] = reinterpret_cast<const float2 *>(F.part_b)[row * C + c];
+            if (t >= F.tpg) pa[k].y = pb[k].y = 0.f;
+        }
+        if constexpr (STRIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pre_a[i] = StageXK<NT>::load_piece(i, A, ldr, nv, 0, tid);
+                pre_b[i] = StageKX<NT>::load_piece(i, B, ldr, nv, 0, tid);
+            }
+        }
+        float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            s[0] += n[k];
+            s[1] += n[k] * pa[k].x;
+            s[2] += n[k] * pb[k].x;
+        }
+        wg_sum<3>(s, fin_red, tid);
+        const float ma = s[0] > 0.f ? s[1] / s[0] : 0.f, mb = s[0] > 0.f ? s[2] / s[0] : 0.f;
+        float q[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const float da = pa[k].x - ma, db = pb[k].x - mb;
+            q[0] += pa[k].y + n[k] * da * da;
+            q[1] += pb[k].y + n[k] * db * db;
+        }
+        wg_sum<2>(q, fin_red, tid);
+        const float4 ra = nrm_record(ma, q[0], s[0], (float)nv, F.gw_a ? F.gw_a[c] : 1.f, F.eps);
+        const float4 rb = nrm_record(mb, q[1], s[0], (float)nv, F.gw_b ? F.gw_b[c] : 1.f, F.eps);
+        if (tid == 0) {
+            reinterpret_cast<float4 *>(F.nrm_a)[gc] = ra;
+            reinterpret_cast<float4 *>(F.nrm_b)[gc] = rb;
+        }
+        auto sgpr = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+        A.a = sgpr(ra.y);
+        A.mean = sgpr(ra.x);
+        A.b = sgpr((ya.beta ? ya.beta[c] : 0.f) - ra.x * ra.y);
+        B.a = sgpr(rb.y);
+        B.mean = sgpr(rb.x);
+        B.b = sgpr((yb.beta ? yb.beta[c] : 0.f) - rb.x * rb.y);
+    } else {
+        A = mm_src(ya, G, g, c);
+        B = mm_src(yb, G, g, c);
+    }
     const View16 vO = make_view16(out, ogstride, ldo, G);
     const int o_off = g * vO.gs2 + c * vO.ld2;
     f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-    u32x4 pre_a[4], pre_b[4];
-    mm_gemm<NT, NCOL, true, false>(acc, A, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);       // M = Ya Yb: [x][k] x [k][x]
+    mm_gemm<NT, NCOL, true, false, false, false, FIN && STRIP>(acc, A, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);   // M = Ya Yb
     float s1 = 0.f, s2 = 0.f;
     mm_store<NT, NCOL, false>(acc, mm_lds, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
 }
@@ -627,19 +719,25 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     }
 }
 
-template <int NT, int NCOL = NT>
-int launch_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr, void *out,
-                 long long ogstride, long long ldo, hipStream_t st) {
+template <int NT, int NCOL, bool FIN>
+int launch_fwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr, void *out,
+                      long long ogstride, long long ldo, const FinArgs16 &F, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)chan_matmul_fwd16_kernel<NT, NCOL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)chan_matmul_fwd16_kernel<NT, NCOL, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   MMCfg<NT>::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((chan_matmul_fwd16_kernel<NT, NCOL>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya, *yb,
-                       nvalid, N, ldr, G, out, ogstride, ldo);
+    hipLaunchKernelGGL((chan_matmul_fwd16_kernel<NT, NCOL, FIN>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya,
+                       *yb, nvalid, N, ldr, G, out, ogstride, ldo, F);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int NT, int NCOL = NT>
+int launch_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr, void *out,
+                 long long ogstride, long long ldo, const FinArgs16 *F, hipStream_t st) {
+    if (F) return launch_fwd16_impl<NT, NCOL, true>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, *F, st);
+    return launch_fwd16_impl<NT, NCOL, false>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, FinArgs16{}, st);
 }
 template <int NT, int NCOL = NT>
 int launch_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
@@ -665,8 +763,8 @@ extern "C" int fgnn_debug_mm16_stamps(unsigned long long *host_dst) {
 }
 #endif
 
-extern "C" int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr,
-                                      void *out, long long ogstride, long long ldo, void *stream) {
+static int matmul_fwd16_common(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr, void *out,
+                               long long ogstride, long long ldo, const FinArgs16 *F, void *stream) {
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr, "fgnn_chan_matmul_fwd16: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0 && N <= 256, "fgnn_chan_matmul_fwd16: bad shapes (N <= 256)");
     FGNN_CHECK(ldr >= N && ldr % 8 == 0, "fgnn_chan_matmul_fwd16: ldr must be a multiple of 8 and >= N");
@@ -676,10 +774,34 @@ extern "C" int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *
                (long long)G * ogstride < 0x7fffffffll / 2,
                "fgnn_chan_matmul_fwd16: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) return launch_fwd16<2>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, st);
-    if (N <= 128) return launch_fwd16<4>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, st);
-    if (N <= 224) return launch_fwd16<8, 7>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, st);   // 7 tile columns: 16 registers less
-    return launch_fwd16<8>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, st);
+    if (N <= 64) return launch_fwd16<2>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, F, st);
+    if (N <= 128) return launch_fwd16<4>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, F, st);
+    if (N <= 224) return launch_fwd16<8, 7>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, F, st);   // 7 tile columns: 16 registers less
+    return launch_fwd16<8>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, F, st);
+}
+
+extern "C" int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr,
+                                      void *out, long long ogstride, long long ldo, void *stream) {
+    return matmul_fwd16_common(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, nullptr, stream);
+}
+
+extern "C" int fgnn_chan_matmul_fwd16_fin(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const float *part_a, const float *part_b,
+                                          const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                          int tpg, const int *nvalid, int G, int N, int ldr, void *out, long long ogstride,
+                                          long long ldo, void *stream) {
+    FGNN_CHECK(ya && yb && part_a && part_b && cnt && ya->nrm && yb->nrm && tpg > 0 && tpg <= 1024,
+               "fgnn_chan_matmul_fwd16_fin: needs the tile statistics, the record buffers (slab.nrm) and tpg <= 1024");
+    FinArgs16 F;
+    F.part_a = part_a;
+    F.part_b = part_b;
+    F.cnt = cnt;
+    F.gw_a = gn_weight_a;
+    F.gw_b = gn_weight_b;
+    F.nrm_a = const_cast<float *>(ya->nrm);
+    F.nrm_b = const_cast<float *>(yb->nrm);
+    F.eps = eps;
+    F.tpg = tpg;
+    return matmul_fwd16_common(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, &F, stream);
 }
 
 extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,

@@ -103,7 +103,9 @@ class FgnnEngineBF16:
                 jobs[i].out = buf.data_ptr()
             _lib.call('fgnn_pack16_operands', jobs, len(chunk), _lib.stream_ptr())
 
-    def _mlp_fwd(self, params, k, js, a, b):
+    def _mlp_fwd(self, params, k, js, a, b, finalize=True):
+        """finalize=False: leave the tile statistics un-finalized (the matmul that consumes the two outputs finalizes them in
+        its own prologue, fgnn_chan_matmul_fwd16_fin)."""
         L = self.layout
         args = _lib.MlpFwd16Args()
         args.G, args.N, args.ldr, args.depth, args.nmlp = self.G, self.N, self.ldr, L.depth, len(js)
@@ -120,6 +122,8 @@ class FgnnEngineBF16:
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd16', C.byref(args), st,
                   tag='mlp_fwd16[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        if not finalize:
+            return
         if len(js) == 2:
             r0, r1 = L.mlp[(k, js[0])], L.mlp[(k, js[1])]
             _lib.call('fgnn_gn_finalize2_tpg', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
@@ -149,10 +153,14 @@ class FgnnEngineBF16:
         gs = 32 * self.ldp
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
-            self._mlp_fwd(params, k, (1, 2), sin, None)
+            # mlp1 / mlp2's GraphNorm records are finalized by the matmul that consumes them (one launch less per block)
+            self._mlp_fwd(params, k, (1, 2), sin, None, finalize=False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
-            _lib.call('fgnn_chan_matmul_fwd16', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N, self.ldr,
-                      _lib.ptr(self.mult[k]), gs, self.ldp, st)
+            r1, r2 = L.mlp[(k, 1)], L.mlp[(k, 2)]
+            _lib.call('fgnn_chan_matmul_fwd16_fin', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
+                      _lib.ptr(self.cnt), C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r2['gn_w'])), EPS,
+                      self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(self.mult[k]), gs, self.ldp, st,
+                      tag='fgnn_chan_matmul_fwd16')
             self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
         out = self._slab_z(L.num_blocks, 3, params)
         _lib.call('fgnn_colmax_fwd16', C.byref(out), self._nv(), self.G, self.N, self.ldr, _lib.ptr(self.E),

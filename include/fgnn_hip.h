@@ -331,6 +331,13 @@ int fgnn_gn_bwd_coef_tiles_tpg(const float *s12part, const float *nrm, const int
  * ROUNDED outputs). */
 int fgnn_chan_matmul_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr,
                            void *out, long long ogstride, long long ldo, void *stream);
+/* the forward product with the GraphNorm finalize of its two operands folded into the prologue (replaces a
+ * fgnn_gn_finalize2_tpg launch): part_a / part_b / cnt are the tile statistics of the fgnn_mlp_fwd16 call that produced the
+ * operands; the records are written to ya->nrm / yb->nrm (G*C*4 floats each, for the backward pass) and used at once */
+int fgnn_chan_matmul_fwd16_fin(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const float *part_a, const float *part_b,
+                               const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps, int tpg,
+                               const int *nvalid, int G, int N, int ldr, void *out, long long ogstride, long long ldo,
+                               void *stream);
 int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
                            const int *nvalid, int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo,
                            float *s12a, float *s12b, void *stream);
