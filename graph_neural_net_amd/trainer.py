@@ -18,10 +18,16 @@ from .optim import FlatAdam
 class FgnnTrainer:
     ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU); 288 GB HBM leave room to raise it
 
-    def __init__(self, layout, params_flat, lr=1e-3, capture=False):
+    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32'):
         """capture=True: constant-shape steps are captured in a HIP graph (model work + fused Adam; the gradient
         all-reduce, when there is more than one rank, stays an eager RCCL call between two captured halves) and
-        replayed -- the launch overhead of ~40 kernels per step disappears."""
+        replayed -- the launch overhead of ~40 kernels per step disappears.
+        precision='bf16': the model work runs on the bf16 kernel set (engine16; the reference's
+        pl.Trainer(precision=16), commander_explore.py:120-122); parameters, gradients, Adam state and the collective
+        stay fp32."""
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be "fp32" or "bf16" (got %r)' % (precision,))
+        self.precision = precision
         self.layout = layout
         self.params = params_flat
         n = params_flat.numel()
@@ -49,7 +55,11 @@ class FgnnTrainer:
         key = (G, N, ragged)
         eng = self._engines.get(key)
         if eng is None:
-            eng = FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
+            if self.precision == 'bf16':
+                from .engine16 import FgnnEngineBF16
+                eng = FgnnEngineBF16(self.layout, G, N, self.params.device, ragged=ragged)
+            else:
+                eng = FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
             self._engines[key] = eng
             used = sum(self._engine_bytes(g, n, self.layout.num_blocks) for (g, n, _) in self._engines)
             while used > self.ENGINE_CACHE_BYTES and len(self._engines) > 1:
