@@ -489,7 +489,7 @@ DEVI void mm_gemm(AccArray<NT, NCOL> &acc, const Src16 &A, const Src16 &B, char 
 template <int NT>
 constexpr int out_pitch() { return MMCfg<NT>::XM * 2 + 16; }      // bytes; (pitch / 4) % 64 == 4: conflict-free 16-byte row reads
 
-template <int NT, int NCOL, bool WANT_S>
+template <int NT, int NCOL, int STATS>
 DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, int o_off2, const Src16 &raw, int N, int ldr,
                    int nv, int ntv, float &s1, float &s2, int tid) {
     constexpr int OP = out_pitch<NT>();
@@ -528,12 +528,16 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
             u32x4 v = u32x4{0u, 0u, 0u, 0u};
             if (col_in && r < X) v = *reinterpret_cast<const u32x4 *>(lds + r * OP + cbase);
             u32x4 u;
-            if (WANT_S) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + rb * ldr * 2, 0);
+            if (STATS == 1) u = __builtin_amdgcn_raw_buffer_load_b128(raw.v.r, r < nv ? rawc : OOB_OFF, raw.off2 + rb * ldr * 2, 0);
             if (MM_ABLATE == 1) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
             // soffset stays a literal 0: with an SGPR there the compiler assumes a VALU write to the data registers may follow
             // the 128-bit store immediately -- on gfx950 that corrupted dword 2 of some lanes (measured, tests/diag/gpu_mm16_check.py)
             else __builtin_amdgcn_raw_buffer_store_b128(v, ov.r, r < N ? voff + o_off2 + rb * ldr * 2 : OOB_OFF, 0, 0);
-            if (WANT_S) {
+            if (STATS == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s1 += bf_lo(v[q]) + bf_hi(v[q]);
+            }
+            if (STATS == 1) {
                 // outputs outside the valid nv x nv block are exact zeros (masked operands); `raw` there is replaced by 0 so
                 // that stale padding bits cannot turn 0 * x into NaN
 #pragma unroll
@@ -661,17 +665,23 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
     f32x16 acc[MMCfg<NT, NCOL>::MAXT];
     mm_gemm<NT, NCOL, true, false, false, false, FIN && STRIP>(acc, A, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);   // M = Ya Yb
     float s1 = 0.f, s2 = 0.f;
-    mm_store<NT, NCOL, false>(acc, mm_lds, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
+    mm_store<NT, NCOL, 0>(acc, mm_lds, vO, o_off, A, N, ldr, nv, ntv, s1, s2, tid);
 }
 
-template <int NT, int NCOL>
+// STATS: 0 none; 1 S1/S2 of both outputs from the raw operand slabs (re-read in the store epilogue); 2 from the trace term:
+//   sum dA (z_a - mean_a) = (T - beta_a S1_a) / a_a   and   sum dB (z_b - mean_b) = (T - beta_b S1_b) / a_b,
+//   T = <dM, Ya Yb> = sum over the tiles of tpart[.].y  (emitted by the kernel that produced dM: fgnn_mlp_bwd16 of mlp3, whose
+//   first slab is the forward product M).  Both identities are exact for the un-rounded products; with the stored bf16 values
+//   they carry the same 2^-9 / sqrt(3) relative noise as the sums of mode 1, and the two raw slabs are not read again.
+template <int NT, int NCOL, int STATS>
 __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgnn_slab16 ya, const fgnn_slab16 yb,
                                                                        const void *dm, long long dmg, long long ldm,
                                                                        const int *nvalid, int N, int ldr, int G, void *da,
                                                                        void *db, long long ogstride, long long ldo,
-                                                                       float *s12a, float *s12b) {
+                                                                       float *s12a, float *s12b, const float *tpart, int tpg) {
     extern __shared__ __attribute__((aligned(16))) char mm_lds[];
     __shared__ float red[MM_NW][4];
+    constexpr bool STRIP = MMCfg<NT, NCOL>::STRIP;
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
@@ -680,24 +690,45 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     const View16 vOA = make_view16(da, ogstride, ldo, G), vOB = make_view16(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs2 + c * vOA.ld2;
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
+    float T = 0.f;
+    u32x4 pre_a[4], pre_b[4];
+    constexpr bool PRE = STATS == 2 && STRIP;
+    if constexpr (STATS == 2) {
+        // tile partials first, then the first operand chunk behind them, then the (barrier-bound) reduction
+        constexpr int TPT = 1024 / MM_THREADS;
+        float tp[1] = {0.f};
+#pragma unroll
+        for (int k = 0; k < TPT; ++k) {
+            const int t = tid + k * MM_THREADS;
+            const float2 p = reinterpret_cast<const float2 *>(tpart)[((long long)g * tpg + (t < tpg ? t : 0)) * C + c];
+            tp[0] += t < tpg ? p.y : 0.f;
+        }
+        if constexpr (STRIP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pre_a[i] = StageXK<NT>::load_piece(i, D, ldr, nv, 0, tid);
+                pre_b[i] = StageXK<NT>::load_piece(i, B, ldr, nv, 0, tid);
+            }
+        }
+        wg_sum<1>(tp, red, tid);
+        T = tp[0];
+        __syncthreads();                 // `red` is used again at the end
+    }
     {
         f32x16 acc[MMCfg<NT, NCOL>::MAXT];
-        u32x4 pre_a[4], pre_b[4];
         // the first product's last chunk already requests chunk 0 of the second one (both of its operands are [k][x] sources)
         auto next = [&](int i, u32x4 &ra, u32x4 &rb) {
-            if constexpr (MMCfg<NT, NCOL>::STRIP) {
+            if constexpr (STRIP) {
                 ra = StageKX<NT>::load_piece(i, A, ldr, nv, 0, tid);
                 rb = StageKX<NT>::load_piece(i, D, ldr, nv, 0, tid);
             }
         };
-        mm_gemm<NT, NCOL, true, true, true, false, false>(acc, D, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b, next);   // dA = dM Yb^T
-        if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
-        else mm_store<NT, NCOL, false>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
+        mm_gemm<NT, NCOL, true, true, true, false, PRE>(acc, D, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b, next);     // dA = dM Yb^T
+        mm_store<NT, NCOL, STATS>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
         mm_gemm<NT, NCOL, false, false, false, true, true>(acc, A, D, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);         // dB = Ya^T dM
-        if (s12a) mm_store<NT, NCOL, true>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
-        else mm_store<NT, NCOL, false>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
+        mm_store<NT, NCOL, STATS>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
     }
-    if (s12a) {
+    if constexpr (STATS != 0) {
         sa1 = wave_sum(sa1);
         sa2 = wave_sum(sa2);
         sb1 = wave_sum(sb1);
@@ -713,6 +744,13 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < MM_NW; ++w) v += red[w][tid];                      // fixed order
+            if constexpr (STATS == 2) {
+                // lanes 0 / 2 hold S1 of dA / dB; lanes 1 / 3 form S2 from T and the S1 of their neighbour
+                const float s1 = __shfl(v, tid & ~1);
+                const Src16 &O = tid < 2 ? A : B;
+                const float beta = O.b + O.mean * O.a;                              // b = beta - mean a
+                if (tid & 1) v = O.a != 0.f ? (T - beta * s1) / O.a : 0.f;
+            }
             float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
             *dst = v;
         }
@@ -739,20 +777,28 @@ int launch_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid
     if (F) return launch_fwd16_impl<NT, NCOL, true>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, *F, st);
     return launch_fwd16_impl<NT, NCOL, false>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, FinArgs16{}, st);
 }
-template <int NT, int NCOL = NT>
-int launch_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
-                 int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
-                 hipStream_t st) {
+template <int NT, int NCOL, int STATS>
+int launch_bwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
+                      int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
+                      const float *tpart, int tpg, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)chan_matmul_bwd16_kernel<NT, NCOL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void *)chan_matmul_bwd16_kernel<NT, NCOL, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   MMCfg<NT>::LDS_BYTES);
         attr = true;
     }
-    hipLaunchKernelGGL((chan_matmul_bwd16_kernel<NT, NCOL>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya, *yb, dm,
-                       dmg, ldm, nvalid, N, ldr, G, da, db, ogstride, ldo, s12a, s12b);
+    hipLaunchKernelGGL((chan_matmul_bwd16_kernel<NT, NCOL, STATS>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya,
+                       *yb, dm, dmg, ldm, nvalid, N, ldr, G, da, db, ogstride, ldo, s12a, s12b, tpart, tpg);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int NT, int NCOL = NT>
+int launch_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
+                 int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
+                 const float *tpart, int tpg, hipStream_t st) {
+    if (!s12a) return launch_bwd16_impl<NT, NCOL, 0>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    if (tpart) return launch_bwd16_impl<NT, NCOL, 2>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    return launch_bwd16_impl<NT, NCOL, 1>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
 }
 
 }  // namespace
@@ -804,9 +850,9 @@ extern "C" int fgnn_chan_matmul_fwd16_fin(const fgnn_slab16 *ya, const fgnn_slab
     return matmul_fwd16_common(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, &F, stream);
 }
 
-extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,
-                                      long long ldm, const int *nvalid, int G, int N, int ldr, void *da, void *db,
-                                      long long ogstride, long long ldo, float *s12a, float *s12b, void *stream) {
+static int matmul_bwd16_common(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
+                               const int *nvalid, int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo,
+                               float *s12a, float *s12b, const float *tpart, int tpg, void *stream) {
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd16: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0 && N <= 256, "fgnn_chan_matmul_bwd16: bad shapes (N <= 256)");
     FGNN_CHECK(ldr >= N && ldr % 8 == 0, "fgnn_chan_matmul_bwd16: ldr must be a multiple of 8 and >= N");
@@ -815,12 +861,28 @@ extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *
                "fgnn_chan_matmul_bwd16: channel / graph strides must be multiples of 8 elements (16-byte loads)");
     FGNN_CHECK((s12a == nullptr) == (s12b == nullptr), "fgnn_chan_matmul_bwd16: s12a and s12b come together");
     FGNN_CHECK(!s12a || (ya->nrm && yb->nrm), "fgnn_chan_matmul_bwd16: s12 outputs need normalised slabs");
+    FGNN_CHECK(!tpart || (s12a && tpg > 0 && tpg <= 1024), "fgnn_chan_matmul_bwd16_t: tile partials need the s12 outputs and tpg <= 1024");
     FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 2 && (long long)G * yb->gstride < 0x7fffffffll / 2 &&
                (long long)G * dmgstride < 0x7fffffffll / 2 && (long long)G * ogstride < 0x7fffffffll / 2,
                "fgnn_chan_matmul_bwd16: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) return launch_bwd16<2>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, st);
-    if (N <= 128) return launch_bwd16<4>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, st);
-    if (N <= 224) return launch_bwd16<8, 7>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, st);
-    return launch_bwd16<8>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, st);
+    if (N <= 64) return launch_bwd16<2>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    if (N <= 128) return launch_bwd16<4>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    if (N <= 224)
+        return launch_bwd16<8, 7>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    return launch_bwd16<8>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+}
+
+extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,
+                                      long long ldm, const int *nvalid, int G, int N, int ldr, void *da, void *db,
+                                      long long ogstride, long long ldo, float *s12a, float *s12b, void *stream) {
+    return matmul_bwd16_common(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, nullptr, 0, stream);
+}
+
+extern "C" int fgnn_chan_matmul_bwd16_t(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,
+                                        long long ldm, const float *tpart, int tpg, const int *nvalid, int G, int N, int ldr,
+                                        void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
+                                        void *stream) {
+    FGNN_CHECK(tpart != nullptr, "fgnn_chan_matmul_bwd16_t: missing tile partials");
+    return matmul_bwd16_common(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, stream);
 }

@@ -176,7 +176,10 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     const int T0 = blockIdx.x * q_ + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
     const int T1 = T0 + q_ + ((int)blockIdx.x < rem ? 1 : 0);
     const bool normA = (CA >= 32) && A.a.nrm != nullptr, normB = (CB >= 32) && A.b.nrm != nullptr;
-    const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
+    // per-tile sums of the slab-a gradient: for a normalised single slab {sum dx, sum dx (z_a - mean_a)} (the GraphNorm backward
+    // sums of its producer); for the raw first slab of a two-slab MLP (mlp3: slab a = mult) {sum dx, sum dx * x_a} =
+    // the trace term T = <dM, M> from which fgnn_chan_matmul_bwd16 derives the S2 sums of both its operands
+    const bool emit = (CA == 32) && (CB == 0 ? normA : !normA) && A.dxa != nullptr && A.s12part != nullptr;
 
     {
         const float4 *src = reinterpret_cast<const float4 *>(A.packed);
@@ -404,6 +407,17 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
                             }
                         }
                     }
+                    if constexpr (CB > 0) {
+                        if (emit) {          // un-normalised slab: yTa is the transposed raw input itself
+                            const f32x16 tv = transpose16(v, ident);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                es1 += tv[2 * q] + tv[2 * q + 1];
+                                es2 = fmaf(tv[2 * q], bf_lo(yTa.d[q]), es2);
+                                es2 = fmaf(tv[2 * q + 1], bf_hi(yTa.d[q]), es2);
+                            }
+                        }
+                    }
                     if constexpr (GRP == 0) {
                         keepA = v;
                     } else {
@@ -531,7 +545,8 @@ extern "C" int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *a, void *stream) {
     FGNN_CHECK(a->a.ptr && a->a.C > 0 && a->packed, "fgnn_mlp_bwd16: slab a / operand image missing");
     FGNN_CHECK(a->b.C == 0 || a->b.ptr, "fgnn_mlp_bwd16: slab b has channels but no pointer");
     FGNN_CHECK(a->dy && a->z && a->wpart && a->coef, "fgnn_mlp_bwd16: missing dy/z/wpart/coef");
-    FGNN_CHECK(!a->s12part || (a->a.C == 32 && a->b.C == 0 && a->a.nrm && a->dxa), "fgnn_mlp_bwd16: s12part needs a single normalised 32-channel slab with dxa");
+    FGNN_CHECK(!a->s12part || (a->a.C == 32 && a->dxa && ((a->b.C == 0 && a->a.nrm) || (a->b.C > 0 && !a->a.nrm))),
+               "fgnn_mlp_bwd16: s12part needs dxa and either a single normalised 32-channel slab or a raw first slab of a two-slab MLP");
     {
         const long long lim = 0x7fffffffll / 2, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&

@@ -267,11 +267,14 @@ class FgnnEngineBF16:
             sin = self._slab_in(k, params)
             first = (k == 1)
             din = None if first else W['dy'][(K - k + 1) % 2]
-            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False)
+            # mlp3's backward also emits the per-tile trace term <dmult, mult>; the matmul backward derives the S2 sums of both
+            # its outputs from it instead of re-reading the two raw operand slabs
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False, emit=True)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
-            _lib.call('fgnn_chan_matmul_bwd16', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
-                      self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
-                      _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
+            _lib.call('fgnn_chan_matmul_bwd16_t', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
+                      _lib.ptr(W['s12part']), self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']),
+                      _lib.ptr(W['dy2']), gs, self.ldp, _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st,
+                      tag='fgnn_chan_matmul_bwd16')
             _lib.call('fgnn_gn_bwd_coef2', _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), _lib.ptr(self.nrm[(k, 1)]),
                       _lib.ptr(self.nrm[(k, 2)]), self._nv(), self.G, 32, self.N, _lib.ptr(W['coef'][0]),
                       _lib.ptr(W['coef'][1]), st)

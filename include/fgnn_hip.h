@@ -342,6 +342,14 @@ int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const v
                            const int *nvalid, int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo,
                            float *s12a, float *s12b, void *stream);
 
+/* the same with S2 derived from the trace term T = <dM, M> instead of re-reading the two raw operand slabs:
+ * tpart (G, tpg, C, 2): per-tile {sum dM, sum dM * M} as emitted (s12part) by the fgnn_mlp_bwd16 call that produced dM
+ * from the MLP whose first input slab is M = the forward product (mlp3);
+ *   sum dA (z_a - mean_a) = (T - beta_a S1_a) / a_a,   sum dB (z_b - mean_b) = (T - beta_b S1_b) / a_b */
+int fgnn_chan_matmul_bwd16_t(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
+                             const float *tpart, int tpg, const int *nvalid, int G, int N, int ldr, void *da, void *db,
+                             long long ogstride, long long ldo, float *s12a, float *s12b, void *stream);
+
 /* ColumnMaxPooling on a bf16 slab: e (G,C,N) fp32 = max_j of the fp32-normalised values, idx int32 */
 int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G, int N, int ldr, float *e, int *idx, void *stream);
 /* its backward: dy (bf16) [g,c,i,idx] = R(de[g,c,i]); s12 = {sum dy, sum dy*(z-mean)} of the rounded values */
