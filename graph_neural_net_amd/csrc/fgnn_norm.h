@@ -23,15 +23,19 @@ DEVI float4 nrm_record(float mean, float m2, float m, float nv, float w, float e
 struct TilePartials {
     float nb[4], mb[4], qb[4];
 };
-DEVI TilePartials finalize_load(const float *part, const float *cnt, int g, int c, int C, int tpg, int lane) {
+// `tr`: the partials are stored (G, C, tpg, 2) -- contiguous over the tiles of one channel (the bf16 kernels write them that
+// way: every consumer walks one (g, c) column, and with the (G, tpg, C, 2) layout each 8-byte read pulls in a whole line) --
+// instead of (G, tpg, C, 2)
+DEVI TilePartials finalize_load(const float *part, const float *cnt, int g, int c, int C, int tpg, int lane, bool tr = false) {
     TilePartials p;
+    const int ts = tr ? 1 : C, cs = tr ? tpg : 1;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int t = lane + WAVE * k;
         const bool ok = t < tpg;
         const int tc = ok ? t : 0;
         const float n = cnt[(long long)g * tpg + tc];
-        const float2 pm = reinterpret_cast<const float2 *>(part)[((long long)g * tpg + tc) * C + c];
+        const float2 pm = reinterpret_cast<const float2 *>(part)[(long long)g * tpg * C + (long long)tc * ts + (long long)c * cs];
         p.nb[k] = ok ? n : 0.f;
         p.mb[k] = pm.x;
         p.qb[k] = ok ? pm.y : 0.f;
@@ -58,6 +62,6 @@ DEVI float4 finalize_reduce(const TilePartials &p, float nv, float w, float eps)
     return nrm_record(mean, m2, sn, nv, w, eps);
 }
 DEVI float4 finalize_wave(const float *part, const float *cnt, int g, int c, int C, int tpg, float nv, float w, float eps,
-                          int lane) {
-    return finalize_reduce(finalize_load(part, cnt, g, c, C, tpg, lane), nv, w, eps);
+                          int lane, bool tr = false) {
+    return finalize_reduce(finalize_load(part, cnt, g, c, C, tpg, lane, tr), nv, w, eps);
 }

@@ -565,7 +565,7 @@ DEVI void mm_store(const AccArray<NT, NCOL> &acc, char *lds, const View16 &ov, i
 // graph g for both operands -- the same exact two-level decomposition, two fixed-order workgroup sums -- while its first
 // operand chunk is in flight, writes the records for the backward pass and uses them at once.
 struct FinArgs16 {
-    const float *part_a, *part_b, *cnt;      // (G, tpg, C, 2) {mean, M2} per tile and (G, tpg) valid elements per tile
+    const float *part_a, *part_b, *cnt;      // (G, C, tpg, 2) {mean, M2} per tile and (G, tpg) valid elements per tile
     const float *gw_a, *gw_b;                // GraphNorm weights (C) or NULL = 1
     float *nrm_a, *nrm_b;                    // out: records (G*C*4)
     float eps;
@@ -613,10 +613,9 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int t = tid + k * MM_THREADS, tc = t < F.tpg ? t : 0;
-            const long long row = (long long)g * F.tpg + tc;
-            n[k] = t < F.tpg ? F.cnt[row] : 0.f;
-            pa[k] = reinterpret_cast<const float2 *>(F.part_a)[row * C + c];
-            pb[k] = reinterpret_cast<const float2 *>(F.part_b)[row * C + c];
+            n[k] = t < F.tpg ? F.cnt[(long long)g * F.tpg + tc] : 0.f;
+            pa[k] = reinterpret_cast<const float2 *>(F.part_a)[((long long)g * C + c) * F.tpg + tc];
+            pb[k] = reinterpret_cast<const float2 *>(F.part_b)[((long long)g * C + c) * F.tpg + tc];
             if (t >= F.tpg) pa[k].y = pb[k].y = 0.f;
         }
         if constexpr (STRIP) {
@@ -670,7 +669,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
 
 // STATS: 0 none; 1 S1/S2 of both outputs from the raw operand slabs (re-read in the store epilogue); 2 from the trace term:
 //   sum dA (z_a - mean_a) = (T - beta_a S1_a) / a_a   and   sum dB (z_b - mean_b) = (T - beta_b S1_b) / a_b,
-//   T = <dM, Ya Yb> = sum over the tiles of tpart[.].y  (emitted by the kernel that produced dM: fgnn_mlp_bwd16 of mlp3, whose
+//   T = <dM, Ya Yb> = sum over the tiles of tpart[g][c][.]  (emitted by the kernel that produced dM: fgnn_mlp_bwd16 of mlp3, whose
 //   first slab is the forward product M).  Both identities are exact for the un-rounded products; with the stored bf16 values
 //   they carry the same 2^-9 / sqrt(3) relative noise as the sums of mode 1, and the two raw slabs are not read again.
 template <int NT, int NCOL, int STATS>
@@ -700,8 +699,8 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
 #pragma unroll
         for (int k = 0; k < TPT; ++k) {
             const int t = tid + k * MM_THREADS;
-            const float2 p = reinterpret_cast<const float2 *>(tpart)[((long long)g * tpg + (t < tpg ? t : 0)) * C + c];
-            tp[0] += t < tpg ? p.y : 0.f;
+            const float p = tpart[((long long)g * C + c) * tpg + (t < tpg ? t : 0)];
+            tp[0] += t < tpg ? p : 0.f;
         }
         if constexpr (STRIP) {
 #pragma unroll

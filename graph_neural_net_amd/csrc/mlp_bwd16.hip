@@ -462,7 +462,12 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
         if (emit) {
             es1 += __shfl_xor(es1, 32);
             es2 += __shfl_xor(es2, 32);
-            if (h == 0) reinterpret_cast<float2 *>(A.s12part)[((long long)c.g * tpg + c.tt) * FGNN_H + j] = make_float2(es1, es2);
+            if constexpr (CB == 0) {
+                if (h == 0) reinterpret_cast<float2 *>(A.s12part)[((long long)c.g * FGNN_H + j) * tpg + c.tt] = make_float2(es1, es2);
+            } else {
+                // the trace term only, (G, 32, tpg): its one reader (the matmul workgroup of (g, c)) walks the tiles of one channel
+                if (h == 0) A.s12part[((long long)c.g * FGNN_H + j) * tpg + c.tt] = es2;
+            }
         }
         // the wave's next tile
         {

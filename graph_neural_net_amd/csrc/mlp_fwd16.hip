@@ -253,7 +253,8 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
                 s = mean;
             }
             m2 += __shfl_xor(m2, 32);
-            if (h == 0) reinterpret_cast<float2 *>(A.part[m])[((long long)c.g * tpg + c.tt) * FGNN_H + j] = make_float2(s, m2);
+            // (G, 32, tpg, 2): contiguous over the tiles of one channel -- every consumer walks a (g, c) column
+            if (h == 0) reinterpret_cast<float2 *>(A.part[m])[((long long)c.g * FGNN_H + j) * tpg + c.tt] = make_float2(s, m2);
         }
         if (lane == 0) A.cnt[(long long)c.g * tpg + c.tt] = cnt;
         tile = next;

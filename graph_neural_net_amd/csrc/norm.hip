@@ -34,7 +34,7 @@ struct FinalizeJobs {
     float *nrm[2];
 };
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, const float *cnt, const int *nvalid,
-                                                         int G, int C, int N, int tpg, float eps) {
+                                                         int G, int C, int N, int tpg, float eps, int tr) {
     const float *part = J.part[blockIdx.y];
     const float *gw = J.gw[blockIdx.y];
     float *nrm = J.nrm[blockIdx.y];
@@ -45,20 +45,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, 
     float sn = 0.f, sm = 0.f;
     const int nt = (tpg + WAVE - 1) / WAVE;
     if (nt <= 4) {       // up to 256 tiles per graph (N <= 90) in registers; else looped below
-        const float4 r = finalize_wave(part, cnt, g, c, C, tpg, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps, lane);
+        const float4 r = finalize_wave(part, cnt, g, c, C, tpg, (float)nvalid_of(nvalid, g, N), gw ? gw[c] : 1.f, eps, lane, tr != 0);
         if (lane == 0) reinterpret_cast<float4 *>(nrm)[idx] = r;
     } else {
         // eight loads in flight per lane and pass (a plain loop pays one memory round trip per 64 tiles)
         constexpr int U = 8;
         const float *cg = cnt + (long long)g * tpg;
-        const float2 *pg = reinterpret_cast<const float2 *>(part) + (long long)g * tpg * C + c;
+        const int ts = tr ? 1 : C;              // tile stride of the partials (float2 units), see fgnn_norm.h
+        const float2 *pg = reinterpret_cast<const float2 *>(part) + (long long)g * tpg * C + (long long)c * (tr ? tpg : 1);
         for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
             float n[U], x[U];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
                 const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
                 n[k] = t < tpg ? cg[tc] : 0.f;
-                x[k] = pg[(long long)tc * C].x;
+                x[k] = pg[(long long)tc * ts].x;
             }
 #pragma unroll
             for (int k = 0; k < U; ++k) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, 
             for (int k = 0; k < U; ++k) {
                 const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
                 n[k] = t < tpg ? cg[tc] : 0.f;
-                pm[k] = pg[(long long)tc * C];
+                pm[k] = pg[(long long)tc * ts];
                 if (t >= tpg) pm[k].y = 0.f;
             }
 #pragma unroll
@@ -226,20 +227,21 @@ __global__ __launch_bounds__(256) void gn_bwd_affine_kernel(const float *s12, co
 // sums per-tile {S1,S2} partials (G,tpg,C,2) over the tiles (one wave per (g,c), fixed tree),
 // writes s12 (G*C*2) and the dz coefficients.
 __global__ void gn_bwd_coef_tiles_kernel(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
-                                         int tpg, float *s12, float *coef) {
+                                         int tpg, float *s12, float *coef, int tr) {
     const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (idx >= G * C) return;
     const int lane = threadIdx.x & 63;
     const int g = idx / C, c = idx - g * C;
     float s1 = 0.f, s2 = 0.f;
     constexpr int U = 8;       // loads in flight per lane
-    const float2 *pg = reinterpret_cast<const float2 *>(s12part) + (long long)g * tpg * C + c;
+    const int ts = tr ? 1 : C;
+    const float2 *pg = reinterpret_cast<const float2 *>(s12part) + (long long)g * tpg * C + (long long)c * (tr ? tpg : 1);
     for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
         float2 p[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             const int t = t0 + k * WAVE;
-            p[k] = pg[(long long)(t < tpg ? t : 0) * C];
+            p[k] = pg[(long long)(t < tpg ? t : 0) * ts];
             if (t >= tpg) p[k] = make_float2(0.f, 0.f);
         }
 #pragma unroll
@@ -373,37 +375,47 @@ extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *st
     return 0;
 }
 
-extern "C" int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
-                                    int G, int C, int N, int tpg, float eps, float *nrm, void *stream) {
+// tr = 1: partials stored (G, C, tpg, 2) (the bf16 kernels), 0: (G, tpg, C, 2) (the fp32 kernels)
+static int gn_finalize_launch(const float *part, const float *cnt, const float *gn_weight, const int *nvalid, int G, int C, int N,
+                              int tpg, float eps, float *nrm, int tr, void *stream) {
     FGNN_CHECK(part && cnt && nrm && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_finalize: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part, nullptr}, {gn_weight, nullptr}, {nrm, nullptr}};
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 1), dim3(256), 0, (hipStream_t)stream, J, cnt,
-                       nvalid, G, C, N, tpg, eps);
+                       nvalid, G, C, N, tpg, eps, tr);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
+                                    int G, int C, int N, int tpg, float eps, float *nrm, void *stream) {
+    return gn_finalize_launch(part, cnt, gn_weight, nvalid, G, C, N, tpg, eps, nrm, 1, stream);
+}
 extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
                                 int G, int C, int N, float eps, float *nrm, void *stream) {
-    return fgnn_gn_finalize_tpg(part, cnt, gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm, stream);
+    return gn_finalize_launch(part, cnt, gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm, 0, stream);
 }
 
-extern "C" int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
-                                     const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps,
-                                     float *nrm0, float *nrm1, void *stream) {
+static int gn_finalize2_launch(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                               const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps, float *nrm0,
+                               float *nrm1, int tr, void *stream) {
     FGNN_CHECK(part0 && part1 && cnt && nrm0 && nrm1 && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_finalize2: bad arguments");
     const int tot = G * C;
     FinalizeJobs J = {{part0, part1}, {gn_weight0, gn_weight1}, {nrm0, nrm1}};
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((tot + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, J, cnt,
-                       nvalid, G, C, N, tpg, eps);
+                       nvalid, G, C, N, tpg, eps, tr);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                                     const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps,
+                                     float *nrm0, float *nrm1, void *stream) {
+    return gn_finalize2_launch(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, tpg, eps, nrm0, nrm1, 1, stream);
 }
 extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
                                  const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
                                  float *nrm0, float *nrm1, void *stream) {
-    return fgnn_gn_finalize2_tpg(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps,
-                                 nrm0, nrm1, stream);
+    return gn_finalize2_launch(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm0, nrm1,
+                               0, stream);
 }
 
 extern "C" int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float *gn_weight,
@@ -480,18 +492,22 @@ extern "C" int fgnn_sum_scale(const float *in, int rows, int cols, float scale, 
     return 0;
 }
 
-extern "C" int fgnn_gn_bwd_coef_tiles_tpg(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
-                                          int tpg, float *s12, float *coef, void *stream) {
+static int gn_bwd_coef_tiles_launch(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N, int tpg,
+                                    float *s12, float *coef, int tr, void *stream) {
     FGNN_CHECK(s12part && nrm && s12 && coef && G > 0 && C > 0 && N > 0 && tpg > 0, "fgnn_gn_bwd_coef_tiles: bad arguments");
     const int tot = G * C;
     hipLaunchKernelGGL(gn_bwd_coef_tiles_kernel, dim3((tot + 3) / 4), dim3(256), 0, (hipStream_t)stream, s12part, nrm,
-                       nvalid, G, C, N, tpg, s12, coef);
+                       nvalid, G, C, N, tpg, s12, coef, tr);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int fgnn_gn_bwd_coef_tiles_tpg(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
+                                          int tpg, float *s12, float *coef, void *stream) {
+    return gn_bwd_coef_tiles_launch(s12part, nrm, nvalid, G, C, N, tpg, s12, coef, 1, stream);
+}
 extern "C" int fgnn_gn_bwd_coef_tiles(const float *s12part, const float *nrm, const int *nvalid, int G, int C, int N,
                                       float *s12, float *coef, void *stream) {
-    return fgnn_gn_bwd_coef_tiles_tpg(s12part, nrm, nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef, stream);
+    return gn_bwd_coef_tiles_launch(s12part, nrm, nvalid, G, C, N, fgnn_tiles_per_graph(N), s12, coef, 0, stream);
 }
 
 extern "C" int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream) {

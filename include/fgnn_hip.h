@@ -310,14 +310,16 @@ typedef struct {
     fgnn_slab16 a, b;
     void *z[2];                             /* out bf16 (G, 32, ldz)                      */
     long long ldz;
-    float *part[2];                         /* out (G, tpg16, 32, 2) {mean, M2} of the fp32 z */
+    float *part[2];                         /* out (G, 32, tpg16, 2) {mean, M2} of the fp32 z (tile index fastest: the
+                                               *_tpg helpers and fgnn_chan_matmul_fwd16_fin walk one (g, c) column) */
     float *cnt;                             /* out (G, tpg16)                             */
     const void *packed;                     /* operand image (kind 0) -- required          */
 } fgnn_mlp_fwd16_args;
 int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *args, void *stream);
 
-/* GraphNorm finalize / backward-coefficient helpers with an explicit tile count per graph (the fp32 entry points
- * derive it from FGNN_TILE) */
+/* GraphNorm finalize / backward-coefficient helpers of the bf16 kernels: explicit tile count per graph (the fp32 entry
+ * points derive it from FGNN_TILE) and partials in the bf16 kernels' layout (G, C, tpg, 2) -- tile index fastest -- instead
+ * of the fp32 kernels' (G, tpg, C, 2) */
 int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const float *gn_weight, const int *nvalid, int G, int C, int N,
                          int tpg, float eps, float *nrm, void *stream);
 int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
@@ -343,7 +345,7 @@ int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const v
                            float *s12a, float *s12b, void *stream);
 
 /* the same with S2 derived from the trace term T = <dM, M> instead of re-reading the two raw operand slabs:
- * tpart (G, tpg, C, 2): per-tile {sum dM, sum dM * M} as emitted (s12part) by the fgnn_mlp_bwd16 call that produced dM
+ * tpart (G, C, tpg): per-tile sum dM * M as emitted (into s12part) by the fgnn_mlp_bwd16 call that produced dM
  * from the MLP whose first input slab is M = the forward product (mlp3);
  *   sum dA (z_a - mean_a) = (T - beta_a S1_a) / a_a,   sum dB (z_b - mean_b) = (T - beta_b S1_b) / a_b */
 int fgnn_chan_matmul_bwd16_t(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
@@ -369,8 +371,10 @@ typedef struct {
     void *dxb; long long dxb_gstride, dxb_ld;
     int accumulate_a, accumulate_b;
     float *wpart;                            /* out (num_wg, fgnn_mlp_param_count) partial dW/db (fp32) */
-    float *s12part;                          /* optional out (G, tpg16, 32, 2): per-tile {sum dxa, sum dxa*(z_a-mean_a)} of the
-                                                FINAL (rounded) dxa values (needs a.C == 32, a.nrm, dxa, no slab b)        */
+    float *s12part;                          /* optional out, needs a.C == 32 and dxa.  Single normalised slab (no slab b):
+                                                (G, 32, tpg16, 2) per-tile {sum dxa, sum dxa*(z_a-mean_a)} of the FINAL (rounded)
+                                                dxa values.  Raw first slab of a two-slab MLP (mlp3: a = mult): (G, 32, tpg16)
+                                                per-tile sum dxa * x_a, the trace term read by fgnn_chan_matmul_bwd16_t */
     const void *packed;                      /* operand image (kind 1) -- required */
 } fgnn_mlp_bwd16_args;
 int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *args, void *stream);
