@@ -16,7 +16,7 @@ TAGS16 = {
     'mlp_bwd16_kernel<2, 0, 3>': 'mlp_bwd16[cin=2,dx=0]', 'mlp_bwd16_kernel<32, 2, 3>': 'mlp_bwd16[cin=34,dx=32]',
     'mlp_fwd16_kernel<32, 0, 2, 3>': 'mlp_fwd16[cin=32,nmlp=2]', 'mlp_fwd16_kernel<32, 32, 1, 3>': 'mlp_fwd16[cin=64,nmlp=1]',
     'mlp_fwd16_kernel<2, 0, 2, 3>': 'mlp_fwd16[cin=2,nmlp=2]', 'mlp_fwd16_kernel<32, 2, 1, 3>': 'mlp_fwd16[cin=34,nmlp=1]',
-    'chan_matmul_bwd16_kernel<8, 7>': 'fgnn_chan_matmul_bwd16', 'chan_matmul_fwd16_kernel<8, 7>': 'fgnn_chan_matmul_fwd16',
+    'chan_matmul_bwd16_kernel<8, 7, 2>': 'fgnn_chan_matmul_bwd16', 'chan_matmul_fwd16_kernel<8, 7, true>': 'fgnn_chan_matmul_fwd16',
 }
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rel = lambda f: os.path.relpath(f, root)
