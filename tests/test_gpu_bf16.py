@@ -154,3 +154,70 @@ def test_bf16_trainer_captured_equals_eager_and_tracks_fp32():
         assert abs(a - b) < 5e-2 * abs(b), (runs['eager16'][0], runs['fp32'][0])
     assert abs(runs['eager16'][0][0] - runs['fp32'][0][0]) < 5e-3 * abs(runs['fp32'][0][0])
     assert runs['fp32'][0][-1] < runs['fp32'][0][0] and runs['eager16'][0][-1] < runs['eager16'][0][0]
+
+
+@pytest.mark.parametrize('N', [40, 72, 200])
+def test_matmul16_entry_points_agree(N):
+    """Kernel level, through the C ABI: fgnn_chan_matmul_fwd16 against a torch product of the rounded operands, and the two
+    backward entry points against each other -- the plain one re-reads the raw slabs for S2, the _t one derives S2 from the
+    trace term <dM, M> (given here as one tile partial per (g, c)).  Outputs and S1 must be bit-identical, S2 must agree to
+    bf16-noise level."""
+    import ctypes as C
+    from graph_neural_net_amd import _lib
+    _lib.load()
+    G, Cc = 2, 32
+    ldr = (N + 7) // 8 * 8
+    ldp = (N * ldr + 63) // 64 * 64
+    tpg = _lib.load().fgnn_tiles_per_graph16(N, ldr)
+    gen = torch.Generator().manual_seed(N)
+    def slab(scale, shift):
+        t = torch.zeros(G, Cc, ldp)
+        v = torch.randn(G, Cc, N, N, generator=gen) * scale + shift
+        t[:, :, :N * ldr].view(G, Cc, N, ldr)[..., :N] = v
+        return t.to(torch.bfloat16).to(DEV).contiguous()
+    za, zb, dm = slab(0.3, 1.5), slab(0.2, -0.7), slab(0.05, 0.0)
+    nrm_a = torch.zeros(G * Cc, 4); nrm_b = torch.zeros(G * Cc, 4)
+    nrm_a[:, 0], nrm_a[:, 1] = 1.5, 0.8
+    nrm_b[:, 0], nrm_b[:, 1] = -0.7, 1.3
+    nrm_a, nrm_b = nrm_a.to(DEV).contiguous(), nrm_b.to(DEV).contiguous()
+    beta_a = (0.1 * torch.randn(Cc, generator=gen)).to(DEV)
+    beta_b = (0.1 * torch.randn(Cc, generator=gen)).to(DEV)
+    sa = _lib.make_slab16(za, Cc * ldp, ldp, Cc, nrm=nrm_a, beta=beta_a)
+    sb = _lib.make_slab16(zb, Cc * ldp, ldp, Cc, nrm=nrm_b, beta=beta_b)
+    st = _lib.stream_ptr()
+    out = torch.zeros(G * Cc * ldp, dtype=torch.bfloat16, device=DEV)
+    _lib.call('fgnn_chan_matmul_fwd16', C.byref(sa), C.byref(sb), None, G, N, ldr, _lib.ptr(out), Cc * ldp, ldp, st)
+    def dense(t):
+        return t.view(G, Cc, ldp)[:, :, :N * ldr].reshape(G, Cc, N, ldr)[..., :N].float().cpu()
+    # the kernel normalises with one fma, y = R(z a + (beta - mean a)); torch rounds twice, so an operand may differ by one
+    # bf16 ulp here and there: the product is compared in L2 (the element-wise half-ulp check with exact operands is
+    # tests/diag/gpu_mm16_kernel_check.py)
+    ya = (dense(za) * 0.8 + (beta_a.cpu().view(1, Cc, 1, 1) - 1.5 * 0.8)).to(torch.bfloat16).float()
+    yb = (dense(zb) * 1.3 + (beta_b.cpu().view(1, Cc, 1, 1) + 0.7 * 1.3)).to(torch.bfloat16).float()
+    m_ref = torch.matmul(ya.double(), yb.double()).float()
+    m_got = dense(out)
+    assert (m_got - m_ref).norm() < 3e-3 * m_ref.norm()
+    # T per (g, c) from the stored product, handed over in tile 0
+    tpart = torch.zeros(G, Cc, tpg)
+    tpart[:, :, 0] = (dense(dm) * m_got).sum((-1, -2))
+    tpart = tpart.to(DEV).contiguous()
+    res = []
+    for with_t in (False, True):
+        da = torch.zeros_like(out); db = torch.zeros_like(out)
+        s12a = torch.zeros(G * Cc * 2, device=DEV); s12b = torch.zeros(G * Cc * 2, device=DEV)
+        if with_t:
+            _lib.call('fgnn_chan_matmul_bwd16_t', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * ldp, ldp, _lib.ptr(tpart), tpg, None,
+                      G, N, ldr, _lib.ptr(da), _lib.ptr(db), Cc * ldp, ldp, _lib.ptr(s12a), _lib.ptr(s12b), st)
+        else:
+            _lib.call('fgnn_chan_matmul_bwd16', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * ldp, ldp, None, G, N, ldr,
+                      _lib.ptr(da), _lib.ptr(db), Cc * ldp, ldp, _lib.ptr(s12a), _lib.ptr(s12b), st)
+        torch.cuda.synchronize()
+        res.append((da.cpu(), db.cpu(), s12a.cpu().view(-1, 2), s12b.cpu().view(-1, 2)))
+    (da0, db0, a0, b0), (da1, db1, a1, b1) = res
+    assert torch.equal(da0.view(torch.int16), da1.view(torch.int16)) and torch.equal(db0.view(torch.int16), db1.view(torch.int16))
+    da_ref = torch.matmul(dense(dm).double(), yb.double().transpose(-1, -2)).float()
+    assert (dense(da0.to(DEV)) - da_ref).norm() < 3e-3 * da_ref.norm()
+    assert torch.equal(a0[:, 0], a1[:, 0]) and torch.equal(b0[:, 0], b1[:, 0])                  # S1: same sums
+    for s_plain, s_t in ((a0[:, 1], a1[:, 1]), (b0[:, 1], b1[:, 1])):
+        scale = s_plain.abs().mean()
+        assert (s_plain - s_t).abs().max() < 3e-2 * scale, ((s_plain - s_t).abs().max().item(), scale.item())
