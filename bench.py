@@ -141,6 +141,9 @@ def main():
     ap.add_argument('--config', default='cfg2', choices=('cfg2', 'cfg4'),
                     help='BASELINE.json configs[1] (N=50 regular pairs, batch 32, fp32; the headline line) or '
                          'configs[3] (N=200 dense ER pairs, batch 8, bf16)')
+    ap.add_argument('--precision', default=None, choices=('fp32', 'bf16'),
+                    help="kernel set (default: the config's -- fp32 for cfg2, bf16 for cfg4); '--precision bf16' with cfg2 is the "
+                         "reference's 16-bit training mode on the headline workload, reported with dtype bf16")
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
     ap.add_argument('--n', type=int, default=None, help='vertices per graph (default: the config\'s)')
     ap.add_argument('--blocks', type=int, default=4)
@@ -163,18 +166,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    bf16 = args.config == 'cfg4'
-    B = args.batch if args.batch is not None else (8 if bf16 else 32)
-    N = args.n if args.n is not None else (200 if bf16 else 50)
+    dense_er = args.config == 'cfg4'              # the workload
+    bf16 = (args.precision == 'bf16') if args.precision else dense_er      # the kernel set
+    B = args.batch if args.batch is not None else (8 if dense_er else 32)
+    N = args.n if args.n is not None else (200 if dense_er else 50)
     layout = ParamLayout(2, args.blocks, 32, 32, 3)
     params = layout.init_flat(0, dev)
     grads = torch.zeros_like(params)
-    if bf16:       # cfg4: dense Erdos-Renyi (edge density 0.5) pairs, ER edge noise 0.1
+    if dense_er:   # cfg4: dense Erdos-Renyi (edge density 0.5) pairs, ER edge noise 0.1
         x1, x2 = synthetic.make_batch(4000 + rank, B, N, 'ErdosRenyi', 0.5, 0.1)
+    else:
+        x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
+    if bf16:
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
         eng = FgnnEngineBF16(layout, 2 * B, N, dev)
     else:
-        x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
         eng = FgnnEngine(layout, 2 * B, N, dev)
     x = torch.cat([x1, x2]).contiguous().to(dev)
     total_nodes = float(B * N * world)            # loss normaliser of the concatenated global batch
@@ -273,7 +279,7 @@ def main():
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
                 tr = json.load(f)
             key = dom if not bf16 else 'cfg4:' + dom
-            if key in tr and (B, N) == ((8, 200) if bf16 else (32, 50)):
+            if key in tr and (B, N) == ((8, 200) if bf16 else (32, 50)) and bf16 == dense_er:
                 dom_key = key
             else:
                 dom_key = None
@@ -291,17 +297,17 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fl_pair, by_pair = algorithmic_per_pair(N, args.blocks, elt=2 if bf16 else 4)
-        if bf16:
+        if dense_er:
             workload = ('cfg4: N=%d dense Erdos-Renyi pairs (edge density 0.5, ER edge noise 0.1), %d pairs per GPU, '
-                        '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd, bf16 storage + bf16 MFMA, '
-                        'fp32 accumulation / statistics / gradients' % (N, B, args.blocks))
+                        '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd' % (N, B, args.blocks))
         else:
             workload = ('cfg2: N=%d random-regular pairs (d=%d, ER edge noise 0.1), %d pairs per GPU, '
                         '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd'
                         % (N, synthetic.regular_degree(N, 0.2), B, args.blocks))
+        if bf16:
+            workload += ', bf16 storage + bf16 MFMA, fp32 accumulation / statistics / gradients'
         out = {
-            'metric': ('graph-pairs/sec FGNN fwd+bwd, N=%d dense ER pairs, bf16' % N) if bf16
-                      else 'graph-pairs/sec FGNN fwd+bwd, N=%d regular pairs' % N,
+            'metric': 'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',

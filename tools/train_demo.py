@@ -1,5 +1,6 @@
 """End-to-end sanity run: train the default model on fresh synthetic regular-graph pairs with the fused HIP
-step + fused Adam and print the loss / arg-max accuracy trend.  usage: python tools/train_demo.py [steps] [B] [N]"""
+step + fused Adam and print the loss / arg-max accuracy trend.  usage: python tools/train_demo.py [steps] [B] [N]
+(FGNN_CAPTURE=0: eager launches; FGNN_PRECISION=bf16: the 16-bit kernel set)"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,8 @@ N = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 dev = torch.device('cuda:0')
 lay = ParamLayout(2, 4, 32, 32, 3)
 capture = os.environ.get('FGNN_CAPTURE', '1') != '0'
-tr = FgnnTrainer(lay, lay.init_flat(0, dev), lr=1e-3, capture=capture)
+precision = os.environ.get('FGNN_PRECISION', 'fp32')
+tr = FgnnTrainer(lay, lay.init_flat(0, dev), lr=1e-3, capture=capture, precision=precision)
 pool = [synthetic.make_batch(100 + i, B, N, 'Regular', 0.2, 0.05) for i in range(16)]    # host generation is slow
 pool = [(a.to(dev), b.to(dev)) for a, b in pool]
 t0 = time.time()
@@ -26,4 +28,4 @@ for s in range(steps):
         acc, n = accuracy_max(scores)
         print('step %4d  loss %.4f  acc_max %.3f' % (s, loss.item(), acc / n), flush=True)
 torch.cuda.synchronize()
-print('%.1f steps/s (%s, incl. Adam)' % (steps / (time.time() - t0), 'HIP graph replay' if capture else 'eager launches'))
+print('%.1f steps/s (%s, %s, incl. Adam)' % (steps / (time.time() - t0), precision, 'HIP graph replay' if capture else 'eager launches'))
