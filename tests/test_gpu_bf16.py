@@ -221,3 +221,42 @@ def test_matmul16_entry_points_agree(N):
     for s_plain, s_t in ((a0[:, 1], a1[:, 1]), (b0[:, 1], b1[:, 1])):
         scale = s_plain.abs().mean()
         assert (s_plain - s_t).abs().max() < 3e-2 * scale, ((s_plain - s_t).abs().max().item(), scale.item())
+
+
+def test_ragged_bf16_against_per_pair_oracle():
+    """Ragged batch in 16 bit (Nmax = 120: the 64 < N <= 128 class of the matmul kernels, padding in every tensor) against the
+    same-point oracle run pair by pair on the un-padded graphs, gradients summed under the global node normaliser."""
+    import numpy as np
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    sd = {k: v for k, v in sub(d, 'sd/').items() if k.startswith('ne_bm_block1') or k.startswith('ne_bm_block2')}
+    rng = np.random.default_rng(11)
+    ns = [120, 75, 97]
+    B, N = len(ns), max(ns)
+    xs, ys = [], []
+    for i, n in enumerate(ns):
+        a, b = synthetic.make_batch(9000 + i, 1, n, 'ErdosRenyi', 0.3, 0.05)
+        xs.append(a[0]); ys.append(b[0])
+    total = float(sum(ns))
+    s16, g16, g32 = [], None, None
+    for a, b in zip(xs, ys):
+        s, _, g = OB.step_fwd_bwd(a[None], b[None], sd, total_nodes=total)
+        _, _, gf = OB.step_fwd_bwd(a[None], b[None], sd, rounding=False, total_nodes=total)
+        s16.append(s[0])
+        g16 = g if g16 is None else {k: g16[k] + g[k] for k in g}
+        g32 = gf if g32 is None else {k: g32[k] + gf[k] for k in gf}
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    grads = torch.zeros_like(params)
+    eng = FgnnEngineBF16(lay, 2 * B, N, DEV, ragged=True)
+    scores, loss = eng.step(params, grads, torch.cat([x1, x2]).contiguous().to(DEV), nvalid=torch.cat([nv, nv]).to(DEV))
+    torch.cuda.synchronize()
+    scores, got = scores.cpu(), lay.unflatten(grads.cpu())
+    for i, n in enumerate(ns):
+        assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0          # exact zeros in the padding
+        assert l2rel(scores[i, :n, :n], s16[i]) < 2e-2
+    keys = [k for k in g16 if not is_zero_grad(k)]
+    f = lambda g: flat_of(g, keys)
+    # same-point gate: well inside the bf16 scheme's own distance to the un-rounded evaluation
+    assert l2rel(f(got), f(g16)) <= SAME_POINT * l2rel(f(g16), f(g32)), (l2rel(f(got), f(g16)), l2rel(f(g16), f(g32)))
