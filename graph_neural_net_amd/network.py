@@ -66,7 +66,7 @@ class _EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, nvalid, anchor):
-        eng = net._engine_for(x, nvalid)
+        eng = net._engine_for(x, nvalid, True)
         eng.embed(net._flat, x, nvalid)
         eng.generation = getattr(eng, 'generation', 0) + 1
         ctx.net, ctx.eng, ctx.generation = net, eng, eng.generation
@@ -170,10 +170,11 @@ class Network(nn.Module):
         self._grad_views = [self._flat_grad[o:o + n].view(shape) for o, n, shape in spans]
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
 
-    def _engine_for(self, x, nvalid):
+    def _engine_for(self, x, nvalid, grad):
         # separate workspaces for grad / no-grad forwards: an evaluation forward between a training forward and its
-        # backward must not overwrite the saved activations
-        key = (x.shape[0], x.shape[-1], nvalid is not None, x.device, torch.is_grad_enabled())
+        # backward must not overwrite the saved activations.  `grad` is passed in by the caller: inside an
+        # autograd.Function's forward torch.is_grad_enabled() is always False.
+        key = (x.shape[0], x.shape[-1], nvalid is not None, x.device, bool(grad))
         if key not in self._engines:
             if getattr(self, 'precision', 'fp32') == 'bf16':
                 from .engine16 import FgnnEngineBF16
@@ -202,7 +203,7 @@ class Network(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list):
             e = _EmbedFn.apply(self, t.contiguous(), nvalid, self._anchor)
         else:
-            eng = self._engine_for(t, nvalid)
+            eng = self._engine_for(t, nvalid, False)
             eng.embed(self._flat, t.contiguous(), nvalid)
             e = eng.E.clone()
         if isinstance(x, MaskedTensor):

@@ -270,3 +270,33 @@ def test_loss_masked_equals_stacked():
     d, v = load_golden('cfg1_er_n20_b4_1blk.npz'), load_golden('losses_cfg1.npz')
     for red in ('mean', 'mean_of_mean'):
         assert abs(triplet_loss(red)(d['scores'].to(DEV)).item() - v[red].item()) < 1e-5 * abs(v[red].item())
+
+
+def test_stale_workspace_is_detected_and_no_grad_forward_is_allowed():
+    """The fused engine keeps one workspace per shape: a second grad-mode forward of the same shape before backward() of
+    the first would make that backward differentiate against the wrong activations -- it must raise, not return wrong
+    gradients; an evaluation forward under no_grad in between uses its own workspace and is fine."""
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=1,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    x1, x2 = d['x1'].to(DEV), d['x2'].to(DEV)
+    loss_a = model.loss(model(x1, x2))
+    with torch.no_grad():
+        model(x2, x1)                                   # evaluation pass in between: separate workspace
+    loss_a.backward()
+    g_ok = [p.grad.clone() for p in model.parameters()]
+    for p in model.parameters():
+        p.grad = None
+    loss_b = model.loss(model(x1, x2))
+    loss_c = model.loss(model(x2, x1))                  # overwrites the workspace of loss_b's forward
+    with pytest.raises(RuntimeError, match='overwritten'):
+        loss_b.backward()
+    for p in model.parameters():
+        p.grad = None
+    loss_c.backward()                                   # the latest forward is still valid
+    for p in model.parameters():
+        p.grad = None
+    model.loss(model(x1, x2)).backward()
+    assert all(torch.equal(a, p.grad) for a, p in zip(g_ok, model.parameters()))

@@ -463,3 +463,40 @@ def test_bit_packed_adjacency_input_is_bit_identical(N, B, ragged):
     assert torch.equal(out[0][1], out[1][1])
     assert torch.equal(out[0][2], out[1][2])
     assert out[0][2].abs().sum() > 0
+
+
+def test_engine_cache_is_bounded_and_mixed_eager_captured_adam_stays_in_step(monkeypatch):
+    """(a) the per-shape engine cache of the trainer is an LRU with a byte budget; (b) a trainer that mixes
+    captured (dense) and eager (ragged) steps keeps ONE Adam step count: it must end where an all-eager trainer ends."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    p0 = lay.init_flat(4, DEV)
+    dense = [synthetic.make_batch(7300 + i, 4, 16, 'ErdosRenyi', 0.3, 0.05) for i in range(2)]
+    rng = np.random.default_rng(3)
+    def ragged_batch(seed, sizes):
+        xs, ys = [], []
+        for i, n in enumerate(sizes):
+            a, b = synthetic.make_batch(seed + i, 1, n, 'ErdosRenyi', 0.3, 0.05)
+            xs.append(a[0].to(DEV)); ys.append(b[0].to(DEV))
+        return xs, ys
+    rag = [ragged_batch(7400, [9, 14, 12]), ragged_batch(7500, [11, 16, 10])]
+    out = []
+    for capture in (True, False):
+        tr = FgnnTrainer(lay, p0.clone(), lr=1e-3, capture=capture)
+        for s in range(6):
+            if s % 2 == 0:
+                x1, x2 = dense[(s // 2) % 2]
+                tr.train_step(x1.to(DEV), x2.to(DEV))
+            else:
+                xs, ys = rag[(s // 2) % 2]
+                tr.train_step_ragged(xs, ys)
+        out.append((tr.params.clone(), tr.opt.t))
+    assert out[0][1] == out[1][1] == 6
+    assert torch.equal(out[0][0], out[1][0])
+    # (a) a tiny budget keeps at most a couple of engines alive however many shapes go by
+    monkeypatch.setattr(FgnnTrainer, 'ENGINE_CACHE_BYTES', 1 << 20)
+    tr = FgnnTrainer(lay, p0.clone(), lr=1e-3)
+    for i, sizes in enumerate(([9, 30], [17, 40], [25, 52], [33, 61], [12, 70])):
+        xs, ys = ragged_batch(7600 + 10 * i, sizes)
+        tr.train_step_ragged(xs, ys)
+    assert len(tr._engines) <= 2, list(tr._engines)

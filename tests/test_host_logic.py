@@ -230,3 +230,28 @@ def test_reduce_lr_on_plateau_matches_torch():
             mine.step(m)
             assert abs(mine_opt.lr - topt.param_groups[0]['lr']) < 1e-15, (trial, mine_opt.lr, topt.param_groups[0]['lr'])
         assert mine_opt.lr < 1e-3        # the schedule did something
+
+
+def test_checkpoint_loads_without_pickle_and_refuses_code_by_default(tmp_path):
+    """save_checkpoint writes tensors and plain scalars only (loads with weights_only=True, carries the keys Lightning's
+    migration looks at and, optionally, the fused Adam state); a file that needs the pickle loader is refused unless the
+    caller opts in."""
+    from graph_neural_net_amd import checkpoint
+    from graph_neural_net_amd.engine import ParamLayout
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    flat = lay.init_flat(1, 'cpu')
+    f = tmp_path / 'a.ckpt'
+    checkpoint.save_checkpoint(str(f), lay, flat, epoch=3, global_step=77)
+    obj = torch.load(str(f), weights_only=True)
+    assert obj['epoch'] == 3 and obj['global_step'] == 77 and 'pytorch-lightning_version' in obj
+    _, back = checkpoint.load_checkpoint(str(f), 'cpu')
+    assert torch.equal(back, flat)
+
+    import argparse                     # an arbitrary pickled object, as Lightning's hyper-parameter containers are
+    g = tmp_path / 'b.ckpt'
+    torch.save({'state_dict': {'node_embedder.' + k: v for k, v in lay.unflatten(flat).items()},
+                'hparams': argparse.Namespace(lr=1e-3)}, str(g))
+    with pytest.raises(RuntimeError, match='allow_pickle'):
+        checkpoint.load_checkpoint(str(g), 'cpu')
+    _, back = checkpoint.load_checkpoint(str(g), 'cpu', allow_pickle=True)       # explicit opt-in for a trusted file
+    assert torch.equal(back, flat)
