@@ -260,3 +260,32 @@ def test_ragged_bf16_against_per_pair_oracle():
     f = lambda g: flat_of(g, keys)
     # same-point gate: well inside the bf16 scheme's own distance to the un-rounded evaluation
     assert l2rel(f(got), f(g16)) <= SAME_POINT * l2rel(f(g16), f(g32)), (l2rel(f(got), f(g16)), l2rel(f(g16), f(g32)))
+
+
+def test_module_half_switch_runs_the_bf16_engine():
+    """Network.half() (models/utils.py:71-74) / Siamese_Node_Exp(precision='bf16'): the module surface in 16 bit equals the
+    bf16 engine driven directly (same kernels, same flat parameters) and stays in the bf16 class around the fp32 module."""
+    from graph_neural_net_amd.siamese import Siamese_Node_Exp
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    sd = sub(d, 'sd/')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=4,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    x1, x2 = synthetic.make_batch(2000, 4, 50, 'Regular', 0.2, 0.1)
+    outs = {}
+    for name in ('fp32', 'ctor', 'half'):
+        model = Siamese_Node_Exp(2, ne, precision='bf16' if name == 'ctor' else 'fp32').to(DEV)
+        model.load_state_dict({'node_embedder.' + k: v for k, v in sd.items()})
+        if name == 'half':
+            assert model.node_embedder.half() is model.node_embedder
+        scores = model(x1.to(DEV), x2.to(DEV))
+        loss = model.loss(scores)
+        loss.backward()
+        outs[name] = (scores.detach().cpu(), loss.item(),
+                      torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu())
+        assert all(p.dtype == torch.float32 for p in model.parameters())           # master parameters stay fp32
+    assert torch.equal(outs['ctor'][0], outs['half'][0]) and torch.equal(outs['ctor'][2], outs['half'][2])
+    eng, lay, s_eng, l_eng, g_eng = _run(sd, x1, x2, 4)
+    assert torch.equal(outs['ctor'][0], s_eng)                                      # same kernels as the engine
+    assert abs(outs['ctor'][1] - l_eng) < 1e-6 * abs(l_eng)
+    assert l2rel(outs['ctor'][2], lay.flatten(g_eng, 'cpu')) < 1e-5
+    assert 1e-4 < l2rel(outs['ctor'][0], outs['fp32'][0]) < 0.2                     # really 16-bit, and in its class

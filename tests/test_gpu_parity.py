@@ -500,3 +500,29 @@ def test_engine_cache_is_bounded_and_mixed_eager_captured_adam_stays_in_step(mon
         xs, ys = ragged_batch(7600 + 10 * i, sizes)
         tr.train_step_ragged(xs, ys)
     assert len(tr._engines) <= 2, list(tr._engines)
+
+
+def test_checkpoint_resume_continues_the_optimizer(tmp_path):
+    """save_checkpoint(..., optimizer=) + restore_optimizer: a run resumed from the file takes the same steps as the
+    uninterrupted run (parameters bit-identical)."""
+    from graph_neural_net_amd import checkpoint
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    p0 = lay.init_flat(6, DEV)
+    batches = [synthetic.make_batch(7700 + i, 4, 16, 'ErdosRenyi', 0.3, 0.05) for i in range(3)]
+    step = lambda tr, s: tr.train_step(batches[s % 3][0].to(DEV), batches[s % 3][1].to(DEV))
+    ref = FgnnTrainer(lay, p0.clone(), lr=2e-3)
+    for s in range(6):
+        step(ref, s)
+    a = FgnnTrainer(lay, p0.clone(), lr=2e-3)
+    for s in range(3):
+        step(a, s)
+    f = tmp_path / 'mid.ckpt'
+    checkpoint.save_checkpoint(str(f), lay, a.params, epoch=0, global_step=3, optimizer=a.opt)
+    obj = torch.load(str(f), weights_only=True)
+    layout, flat = checkpoint.load_checkpoint(obj, DEV)
+    b = FgnnTrainer(layout, flat, lr=1.0)                  # lr comes back from the file
+    assert checkpoint.restore_optimizer(obj, b.opt) and b.opt.t == 3 and b.opt.lr == 2e-3
+    for s in range(3, 6):
+        step(b, s)
+    assert torch.equal(b.params, ref.params)
