@@ -289,3 +289,26 @@ def test_module_half_switch_runs_the_bf16_engine():
     assert abs(outs['ctor'][1] - l_eng) < 1e-6 * abs(l_eng)
     assert l2rel(outs['ctor'][2], lay.flatten(g_eng, 'cpu')) < 1e-5
     assert 1e-4 < l2rel(outs['ctor'][0], outs['fp32'][0]) < 0.2                     # really 16-bit, and in its class
+
+
+def test_bf16_ragged_trainer_step_with_filler_graphs():
+    """FgnnTrainer(precision='bf16').train_step_ragged: size-bucketed ragged batch (the engine is built for a rounded-up graph
+    count, the surplus graphs have zero vertices) -- first-step loss and update direction agree with the fp32 trainer."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    p0 = lay.init_flat(8, DEV)
+    xs, ys = [], []
+    for i, n in enumerate([9, 33, 14, 40, 21]):                # five pairs: graph counts are rounded up to multiples of 4
+        a, b = synthetic.make_batch(7800 + i, 1, n, 'ErdosRenyi', 0.3, 0.05)
+        xs.append(a[0].to(DEV)); ys.append(b[0].to(DEV))
+    res = {}
+    for prec in ('fp32', 'bf16'):
+        tr = FgnnTrainer(lay, p0.clone(), lr=1e-3, precision=prec)
+        loss, _ = tr.train_step_ragged(xs, ys)
+        torch.cuda.synchronize()
+        assert torch.isfinite(tr.params).all()
+        res[prec] = (loss.item(), (tr.params - p0).cpu())
+    assert abs(res['bf16'][0] - res['fp32'][0]) < 5e-3 * abs(res['fp32'][0])
+    d16, d32 = res['bf16'][1], res['fp32'][1]
+    cos = torch.dot(d16, d32) / (d16.norm() * d32.norm())
+    assert cos > 0.8, cos.item()                                    # Adam's first step is +-lr per parameter: signs must agree
