@@ -434,7 +434,8 @@ template <bool CE>
 static int launch_score_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
                             const float *dscores, const int *nvalid, const float *gscale, int B, int C, int N,
                             float *de1, float *de2, hipStream_t st) {
-    const bool stage = score_bwd_lds_bytes(C, N, true) <= 160 * 1024;
+    // whole-dS staging gives only B x CSPLIT workgroups: with few large pairs (N > 64) the blocked kernel fills the chip better
+    const bool stage = score_bwd_lds_bytes(C, N, true) <= 160 * 1024 && (N <= 64 || (long long)B * CSPLIT >= 256);
     const int lds = score_bwd_lds_bytes(C, N, stage);
     FGNN_CHECK(lds <= 160 * 1024, "score backward: C*N=%d too large for LDS staging", C * N);
     if (stage) {
