@@ -255,3 +255,27 @@ def test_checkpoint_loads_without_pickle_and_refuses_code_by_default(tmp_path):
         checkpoint.load_checkpoint(str(g), 'cpu')
     _, back = checkpoint.load_checkpoint(str(g), 'cpu', allow_pickle=True)       # explicit opt-in for a trusted file
     assert torch.equal(back, flat)
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The bench.py lines committed under profiles/ (what the round's numbers are quoted from) carry every field of the
+    driver contract, a consistent value / ms_per_step pair and the roofline / cpu_baseline objects."""
+    import glob, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r02_*_bench*.json')))
+    assert files
+    for f in files:
+        d = json.loads(open(f).read().strip().split('\n')[-1])
+        for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                  'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+            assert k in d, (f, k)
+        assert d['unit'] == 'pairs/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+        assert 'workload' in d['config'] and 'model' not in d['config']
+        pairs = d['config']['global_batch']
+        assert abs(d['value'] - pairs / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+        r = d['roofline']
+        assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+        assert d['dtype'] == ('bf16' if 'bf16' in d['metric'] else 'f32')
+        if d.get('cpu_baseline'):
+            c = d['cpu_baseline']
+            assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
