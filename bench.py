@@ -96,7 +96,7 @@ def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
     sweep = {}
     best, cores = None, 1
     big = x1.shape[-1] > 64          # N = 200: seconds per pair -- one un-warmed 1-pair run per thread count
-    sl = 1 if big else 2
+    sl = 1 if big else min(16, x1.shape[0])      # (a 2-pair slice under-rates the high thread counts: ATen parallelises over the batch)
     # thread counts beyond the point where the rate falls are not tried (measured on the 256-core box: 16 threads are the
     # best, 128 threads are 20x slower, 256 threads took 200 s for two pairs)
     for c in sorted({min(avail, v) for v in ((1, 8, 32) if big else (1, 4, 8, 16, 32, 64))}):
