@@ -317,15 +317,18 @@ def test_degenerate_and_boundary_shapes(B, N):
     sd = O.init_state_dict(num_blocks=2)
     x1, x2 = synthetic.make_batch(9000 + N, B, N, 'ErdosRenyi', 0.5, 0.1)
     s_ref, l_ref, g_ref = O.step_fwd_bwd(x1, x2, sd)
+    s64, l64, g64 = O.step_fwd_bwd(x1.double(), x2.double(), {k: v.double() for k, v in sd.items()})
     eng, params, lay, scores, loss, grads = _run_engine(sd, x1, x2, 2)
     assert torch.isfinite(scores).all() and all(torch.isfinite(g).all() for g in grads.values())
-    assert rel(scores, s_ref) < 1e-4 or (scores - s_ref).abs().max() < 1e-6
+    # fp64 yard-stick as for the golden cases: scores within max(3e-5, 2x the oracle's own fp32 error), the flat gradient
+    # within 4x the oracle's own fp32-vs-fp64 distance (absolute floors for n <= 2, where scores / gradients are 0 by symmetry)
+    assert (scores - s64.float()).abs().max() < 1e-6 or _score_gate(scores, s_ref, s64.float()) is None
     assert abs(loss - l_ref.item()) <= 1e-5 * abs(l_ref.item()) + 1e-7
     keys = [k for k in g_ref if not is_zero_grad(k)]
-    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
-    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
-    # (n = 2: the exact gradient is 0 by symmetry; ours is fp32 rounding noise of ~1e-7 per entry)
-    assert (a - b).norm() <= 5e-3 * b.norm() + 1e-4
+    flat = lambda g: torch.cat([g[k].reshape(-1).double() for k in keys])
+    a, b, t = flat(grads), flat(g_ref), flat(g64)
+    # (n = 2: the exact gradient is 0 by symmetry; ours is fp32 rounding noise of ~1e-7 per entry, 4e-5 in norm)
+    assert (a - t).norm() <= 4.0 * (b - t).norm() + 1e-6 * t.norm() + 1e-4, ((a - t).norm().item(), (b - t).norm().item(), t.norm().item())
 
 
 def test_ragged_with_single_vertex_and_full_size_graphs():
