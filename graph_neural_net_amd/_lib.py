@@ -109,6 +109,9 @@ _SIGNATURES = {
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_conv1x1_dw_chunks': [_I, _I],
+    'fgnn_conv1x1_dw': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _I, _I, _I, _VP, _VP],
     'fgnn_chan_matmul_fwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_chan_matmul_fwd_fin_supported': [_I],
     'fgnn_chan_matmul_fwd_fin': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP],

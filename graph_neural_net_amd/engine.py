@@ -28,12 +28,13 @@ class ParamLayout:
 
     def __init__(self, original_features_num=2, num_blocks=4, in_features=32, out_features=32, depth_of_mlp=3):
         if in_features != _lib.FGNN_H or out_features != _lib.FGNN_H:
-            raise RuntimeError('the HIP kernels are built for in_features = out_features = 32 (got %d, %d)'
-                               % (in_features, out_features))
+            raise RuntimeError('the fused engine is built for in_features = out_features = 32 (got %d, %d); other widths '
+                               'run through the per-layer modules (layers.MlpBlock_Real)' % (in_features, out_features))
         if not 1 <= depth_of_mlp <= _lib.FGNN_MAX_DEPTH:
             raise RuntimeError('depth_of_mlp must be in 1..%d' % _lib.FGNN_MAX_DEPTH)
-        if original_features_num % 2:
-            raise RuntimeError('original_features_num must be even')
+        if original_features_num not in (2, 32):
+            raise RuntimeError('the fused engine is built for original_features_num = 2 or 32 (got %d); other widths run '
+                               'through the per-layer modules (layers.MlpBlock_Real)' % original_features_num)
         self.c0 = original_features_num
         self.num_blocks = num_blocks
         self.depth = depth_of_mlp

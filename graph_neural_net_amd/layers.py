@@ -24,6 +24,7 @@ from . import _lib
 from .masked import MaskedTensor
 
 FGNN_H = _lib.FGNN_H
+FUSED_INPUT_WIDTHS = (2, 16, 32, 32 + 2, 32 + 32)      # fgnn_mlp_fwd / fgnn_mlp_bwd instantiations
 
 
 def _split(x):
@@ -171,6 +172,57 @@ class _MlpGnFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------
+# One 1x1 conv (+ ReLU) of any width: the building block of MlpBlock_Real outside the fused 32-wide kernels
+# --------------------------------------------------------------------------------------
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv1x1(x)) (models/layers.py:125-131, one loop iteration) as csrc/conv.hip launches."""
+
+    @staticmethod
+    def forward(ctx, x, nvalid, weight, bias, relu):
+        _check(x, 'MlpBlock_Real')
+        x = x.contiguous()
+        w = weight.contiguous()
+        G, K, N, _ = x.shape
+        M = w.shape[0]
+        if w.shape[1] != K:
+            raise RuntimeError('MlpBlock_Real: conv expects %d input channels, the tensor has %d' % (w.shape[1], K))
+        P = N * N
+        y = torch.empty(G, M, N, N, dtype=torch.float32, device=x.device)
+        _lib.call('fgnn_conv1x1', _lib.ptr(x), K * P, P, None, _lib.ptr(w), K, 1, _lib.ptr(bias), int(relu), _nv(nvalid),
+                  G, N, M, K, _lib.ptr(y), M * P, P, _lib.stream_ptr())
+        ctx.save_for_backward(x, y if relu else None, w, nvalid)
+        ctx.relu, ctx.has_bias = relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, w, nvalid = ctx.saved_tensors
+        dy = dy.contiguous()
+        G, K, N, _ = x.shape
+        M = w.shape[0]
+        P = N * N
+        st = _lib.stream_ptr()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.call('fgnn_conv1x1', _lib.ptr(dy), M * P, P, _lib.ptr(y), _lib.ptr(w), 1, K, None, 0, _nv(nvalid),
+                      G, N, K, M, _lib.ptr(dx), K * P, P, st)
+        dw = db = None
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
+            cnt = M * K + M
+            wpart = torch.empty(chunks * cnt, **f32)
+            flat = torch.empty(cnt, **f32)
+            _lib.call('fgnn_conv1x1_dw', _lib.ptr(dy), M * P, P, _lib.ptr(y), _lib.ptr(x), K * P, P, _nv(nvalid), G, N, M, K,
+                      _lib.ptr(wpart), st)
+            _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat), st)
+            dw = flat[:M * K].view(M, K, 1, 1)
+            db = flat[M * K:] if ctx.has_bias else None
+        return dx, None, dw, db, None
+
+
+# --------------------------------------------------------------------------------------
 # GraphNorm / normalize on an arbitrary (G, C, N, N) tensor
 # --------------------------------------------------------------------------------------
 class _GraphNormFn(torch.autograd.Function):
@@ -270,12 +322,25 @@ class MlpBlock_Real(nn.Module):
             in_features = out_features
         self.gn = GraphNorm(out_features, constant_n_vertices=constant_n_vertices)
 
+    def fused(self):
+        """True when the fused 32-wide kernels (mlp_fwd.hip / mlp_bwd.hip) are built for this block's widths."""
+        return (all(c.out_channels == FGNN_H and c.bias is not None for c in self.convs)
+                and self.convs[0].in_channels in FUSED_INPUT_WIDTHS and 1 <= len(self.convs) <= _lib.FGNN_MAX_DEPTH
+                and self.gn.features[1] == FGNN_H)
+
     def forward(self, inputs):
         x, nvalid = _split(inputs)
-        wb = []
-        for conv in self.convs:
-            wb += [conv.weight, conv.bias]
-        y = _MlpGnFn.apply(x, nvalid, self.gn.eps, self.gn.weight, self.gn.bias, *wb)
+        if self.fused():
+            wb = []
+            for conv in self.convs:
+                wb += [conv.weight, conv.bias]
+            y = _MlpGnFn.apply(x, nvalid, self.gn.eps, self.gn.weight, self.gn.bias, *wb)
+        else:       # any other widths: one conv.hip launch per layer, then GraphNorm on the (G, C, N, N) tensor
+            y = x
+            last = len(self.convs) - 1
+            for l, conv in enumerate(self.convs):
+                y = _ConvFn.apply(y, nvalid, conv.weight, conv.bias, l < last)
+            y = _GraphNormFn.apply(y, nvalid, self.gn.eps, self.gn.weight, self.gn.bias)
         return _wrap(y, inputs)
 
 

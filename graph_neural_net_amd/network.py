@@ -195,6 +195,9 @@ class Network(nn.Module):
         """x: (G, c0, N, N) tensor or MaskedTensor -> node embeddings (G, C, N)."""
         lay = self._standard_layout()
         if lay is None:
+            if getattr(self, 'precision', 'fp32') == 'bf16':
+                raise RuntimeError('Network: the bf16 path is the fused engine (original_features_num = 2, in_features = '
+                                   'out_features = 32); this graph runs through the per-layer fp32 modules')
             return self.forward({'input': x})['ne/suffix']
         t, nvalid = (x.tensor, x.nvalid) if isinstance(x, MaskedTensor) else (x, None)
         if not t.is_cuda:

@@ -114,6 +114,28 @@ int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float 
 int fgnn_gn_apply(const float *z, long long zgstride, long long ldz, const float *nrm, const float *beta /* (C) or NULL=0 */,
                   const int *nvalid, int G, int C, int N, float *y, long long ygstride, long long ldy, void *stream);
 
+/* ---- generic-width 1x1 convolution (conv.hip) ------------------------------------------
+ * One layer of MlpBlock_Real.forward, `out = activation(conv_layer(out))` (models/layers.py:125-131: nn.Conv2d(k=1, bias=True)
+ * + F.relu), for channel widths the fused 32-wide fgnn_mlp_fwd / fgnn_mlp_bwd are not built for (any Cin = K and Cout = M up
+ * to FGNN_CONV_MAX_CH).  fp32, exact fma chain over the input channels.
+ *   y[g][o][p] = act( bias[o] + sum_k W[o*w_ostride + k*w_kstride] * xm[g][k][p] ),  act = ReLU when `relu`, else identity;
+ *   xm = x where relu_mask > 0 (same strides as x) or x itself when relu_mask == NULL.  Pixels outside the valid n x n corner of
+ *   a ragged graph (nvalid) are written as 0.
+ * The same entry point gives the input gradient of a layer: x := dy, relu_mask := the layer's saved (post-ReLU) output,
+ * W strides swapped (W^T), bias NULL, relu 0.                                                                            */
+#define FGNN_CONV_MAX_CH 256
+int fgnn_conv1x1(const float *x, long long x_gstride, long long x_ld, const float *relu_mask, const float *W,
+                 long long w_ostride, long long w_kstride, const float *bias, int relu, const int *nvalid, int G, int N,
+                 int M, int K, float *y, long long y_gstride, long long y_ld, void *stream);
+/* Parameter gradients of one layer: with dz = dy where relu_mask > 0 (all of dy when NULL), restricted to valid pixels,
+ *   dW[o][c] = sum_{g,p} dz[g][o][p] * x[g][c][p],  db[o] = sum_{g,p} dz[g][o][p]
+ * as fgnn_conv1x1_dw_chunks(G, N) partial records of M*K + M floats ([dW (M,K) | db (M)]) in `wpart`; finish with
+ * fgnn_reduce_partials(wpart, chunks, M*K + M, out) (fixed order: bit-reproducible).                                    */
+int fgnn_conv1x1_dw_chunks(int G, int N);
+int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d_ld, const float *relu_mask, const float *x,
+                    long long x_gstride, long long x_ld, const int *nvalid, int G, int N, int M, int K, float *wpart,
+                    void *stream);
+
 /* ---- Matmul.forward: per (g,c) N x N product (models/layers.py:161-162) --------------
  * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
 int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,

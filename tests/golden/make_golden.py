@@ -393,8 +393,84 @@ def main_round2():
     print(json.dumps(meta, indent=1, sort_keys=True))
 
 
+def main_widths():
+    """Channel widths other than the default 32/32/2 (models/layers.py:113-123 takes any): original_features_num = 3,
+    in_features = 16, out_features = 48, depth_of_mlp = 2, 2 blocks -- so the convs are 3->16, 16->16, 19->16, 16->48,
+    48->48, 64->48 (odd and non-multiple-of-32 widths).  Constant-size batch (fp32 + fp64 reference runs) and a ragged
+    batch run graph by graph through the dense reference model."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from oracle import fgnn_oracle as O
+    from models.trainers import Siamese_Node_Exp
+    torch.set_num_threads(8)
+    with open(os.path.join(OUT, 'golden_meta.json')) as f:
+        meta = json.load(f)
+    torch.manual_seed(11)
+    ne = dict(NODE_EMB, num_blocks=2, in_features=16, out_features=48, depth_of_mlp=2)
+    model = Siamese_Node_Exp(3, ne)
+    perturb_(model, 400)
+    g = torch.Generator().manual_seed(401)
+    x1 = torch.randn(3, 3, 14, 14, generator=g)
+    x2 = torch.randn(3, 3, 14, 14, generator=g)
+    worst = check_oracle_bit_equal(model, x1, x2, 'widths')
+    s, l, gr = ref_step(model, x1, x2)
+    s64, l64, gr64 = ref_step(f64(model), x1.double(), x2.double())
+    inter = model.node_embedder({'input': x1})
+    d = {'x1': x1.numpy(), 'x2': x2.numpy(), 'scores': s.numpy(), 'loss': l.numpy(), 'scores64': s64.numpy(),
+         'loss64': l64.numpy(), 'config': np.array([3, 2, 16, 48, 2])}
+    for k, v in model.state_dict().items():
+        d['sd/' + k[len('node_embedder.'):]] = v.numpy()
+    for k, v in gr.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in gr64.items():
+        d['grad64/' + k] = v.numpy()
+    for k in ('ne/bm/block1/mlp1', 'ne/bm/block1/mlp3', 'ne/bm/block2/mlp3', 'ne/suffix'):
+        d['inter/' + k] = inter[k].detach().numpy()
+    # ragged: graph by graph through the dense model (the reference tests' definition of masked correctness)
+    xs = [torch.randn(3, n, n, generator=g) for n in (6, 11, 9)]
+    ys = [torch.randn(3, n, n, generator=g) for n in (6, 11, 9)]
+
+    def ref_ragged(m, cast):
+        m.zero_grad()
+        e1 = [m.node_embedder({'input': cast(x).unsqueeze(0)})['ne/suffix'].squeeze(0) for x in xs]
+        e2 = [m.node_embedder({'input': cast(y).unsqueeze(0)})['ne/suffix'].squeeze(0) for y in ys]
+        scores = [a.t() @ b for a, b in zip(e1, e2)]
+        loss, tot = 0, 0
+        for sc in scores:   # triplet_loss('mean') on a list (toolbox/losses.py:27-34)
+            loss = loss + torch.nn.functional.cross_entropy(sc, torch.arange(sc.shape[0]), reduction='sum')
+            tot += sc.shape[0]
+        loss = loss / tot
+        loss.backward()
+        return ([sc.detach() for sc in scores], loss.detach(),
+                {n[len('node_embedder.'):]: p.grad.detach().clone() for n, p in m.named_parameters()})
+
+    sr, lr_, grr = ref_ragged(model, lambda t: t)
+    sr64, lr64, grr64 = ref_ragged(f64(model), lambda t: t.double())
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    s_or, l_or, _ = O.step_fwd_bwd_ragged(xs, ys, sd)
+    for a, b in zip(s_or, sr):
+        assert torch.equal(a, b), 'widths ragged: oracle scores differ'
+    assert torch.equal(l_or, lr_)
+    d['ragged/ns'] = np.array([x.shape[-1] for x in xs])
+    d['ragged/loss'], d['ragged/loss64'] = lr_.numpy(), lr64.numpy()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        d['ragged/x1/%d' % i], d['ragged/x2/%d' % i] = x.numpy(), y.numpy()
+        d['ragged/scores/%d' % i], d['ragged/scores64/%d' % i] = sr[i].numpy(), sr64[i].numpy()
+    for k, v in grr.items():
+        d['ragged/grad/' + k] = v.numpy()
+    for k, v in grr64.items():
+        d['ragged/grad64/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'widths_c3_16_48_d2_2blk.npz'), **d)
+    meta['cases']['widths_c3_16_48_d2_2blk'] = {'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst}
+    with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps(meta['cases']['widths_c3_16_48_d2_2blk'], indent=1, sort_keys=True))
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'round2':
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'widths':
+        main_widths()
     else:
         main()

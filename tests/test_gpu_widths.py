@@ -1,0 +1,218 @@
+"""GPU: channel widths outside the fused 32-wide kernels (models/layers.py:113-123 takes any in/out features):
+the generic 1x1-conv kernels of csrc/conv.hip through the C ABI, and the module surface built on them against
+reference-generated goldens (tests/golden/make_golden.py widths) with the reference's own fp32-vs-fp64 error as
+the yard-stick."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from graph_neural_net_amd import _lib
+from graph_neural_net_amd.layers import MlpBlock_Real
+from graph_neural_net_amd.masked import from_list
+from graph_neural_net_amd.siamese import Siamese_Node_Exp
+from oracle import fgnn_oracle as O
+from util import is_zero_grad, load_golden, rel, sub
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+NE = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=16,
+          out_features=48, depth_of_mlp=2)
+
+
+def _valid_mask(G, N, nv):
+    m = torch.zeros(G, 1, N, N, dtype=torch.float64)
+    for g in range(G):
+        n = N if nv is None else int(nv[g])
+        m[g, :, :n, :n] = 1
+    return m
+
+
+@pytest.mark.parametrize('K,M', [(3, 16), (19, 16), (64, 48), (33, 70), (1, 1), (256, 40)])
+@pytest.mark.parametrize('N,ragged', [(7, False), (14, True), (45, True)])
+def test_conv1x1_entry_points(K, M, N, ragged):
+    """fgnn_conv1x1 (forward and input gradient) and fgnn_conv1x1_dw + fgnn_reduce_partials against an fp64 ATen
+    conv + ReLU and its autograd gradients; padding of ragged graphs is exact zero."""
+    G = 3
+    g = torch.Generator().manual_seed(K * 1000 + M * 10 + N)
+    nv = torch.tensor([N, max(1, N // 2), N - 1], dtype=torch.int32) if ragged else None
+    mask = _valid_mask(G, N, nv)
+    x = (torch.randn(G, K, N, N, generator=g).double() * mask).float()
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    b = 0.3 * torch.randn(M, generator=g)
+    dy = (torch.randn(G, M, N, N, generator=g).double() * mask).float()
+    # fp64 reference with the MaskedTensor semantics: conv, activation, re-mask
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.relu(F.conv2d(xr, wr[:, :, None, None], br)) * mask
+    yr.backward(dy.double())
+    # the same in fp32 on the CPU: the yard-stick for the fp32 rounding level
+    y32 = F.relu(F.conv2d(x, w[:, :, None, None], b)) * mask.float()
+
+    P = N * N
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    nvd = nv.to(DEV) if ragged else None
+    nvp = _lib.ptr(nvd) if ragged else None
+    st = _lib.stream_ptr()
+    y = torch.full((G, M, N, N), float('nan'), device=DEV)
+    _lib.call('fgnn_conv1x1', _lib.ptr(xd), K * P, P, None, _lib.ptr(wd), K, 1, _lib.ptr(bd), 1, nvp, G, N, M, K,
+              _lib.ptr(y), M * P, P, st)
+    assert torch.isfinite(y).all()
+    assert rel(y.cpu(), yr.detach()) < 4 * rel(y32, yr.detach()) + 1e-6
+    assert (y.cpu().double() * (1 - mask)).abs().max() == 0
+    dx = torch.full((G, K, N, N), float('nan'), device=DEV)
+    _lib.call('fgnn_conv1x1', _lib.ptr(dyd), M * P, P, _lib.ptr(y), _lib.ptr(wd), 1, K, None, 0, nvp, G, N, K, M,
+              _lib.ptr(dx), K * P, P, st)
+    assert rel(dx.cpu(), xr.grad) < 1e-5
+    assert (dx.cpu().double() * (1 - mask)).abs().max() == 0
+    chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
+    cnt = M * K + M
+    wpart = torch.full((chunks * cnt,), float('nan'), device=DEV)
+    flat = torch.empty(cnt, device=DEV)
+    _lib.call('fgnn_conv1x1_dw', _lib.ptr(dyd), M * P, P, _lib.ptr(y), _lib.ptr(xd), K * P, P, nvp, G, N, M, K,
+              _lib.ptr(wpart), st)
+    _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat), st)
+    assert rel(flat[:M * K].view(M, K).cpu(), wr.grad) < 1e-5
+    assert rel(flat[M * K:].cpu(), br.grad) < 1e-5
+    # bit-reproducible
+    flat2 = torch.empty(cnt, device=DEV)
+    _lib.call('fgnn_conv1x1_dw', _lib.ptr(dyd), M * P, P, _lib.ptr(y), _lib.ptr(xd), K * P, P, nvp, G, N, M, K,
+              _lib.ptr(wpart), st)
+    _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat2), st)
+    assert torch.equal(flat, flat2)
+
+
+def test_conv1x1_rejects_bad_arguments():
+    x = torch.zeros(1, 4, 5, 5, device=DEV)
+    w = torch.zeros(300, 4, device=DEV)
+    y = torch.zeros(1, 300, 5, 5, device=DEV)
+    with pytest.raises(RuntimeError, match='at most'):
+        _lib.call('fgnn_conv1x1', _lib.ptr(x), 100, 25, None, _lib.ptr(w), 4, 1, None, 0, None, 1, 5, 300, 4,
+                  _lib.ptr(y), 300 * 25, 25, _lib.stream_ptr())
+    with pytest.raises(RuntimeError, match='strides'):
+        _lib.call('fgnn_conv1x1', _lib.ptr(x), 100, 24, None, _lib.ptr(w), 4, 1, None, 0, None, 1, 5, 8, 4,
+                  _lib.ptr(y), 8 * 25, 25, _lib.stream_ptr())
+
+
+@pytest.mark.parametrize('cin,cout,depth', [(3, 16, 2), (19, 16, 2), (64, 48, 1), (48, 48, 3), (32, 64, 3), (5, 32, 3)])
+def test_mlp_block_any_width_matches_oracle(cin, cout, depth):
+    """MlpBlock_Real on widths the fused kernels are not built for: forward + every gradient against the oracle run
+    in fp64, with the fp32 oracle's own error as the yard-stick; masked batch == per-graph dense results."""
+    torch.manual_seed(cin * 100 + cout)
+    mlp = MlpBlock_Real(cin, cout, depth).to(DEV)
+    assert not mlp.fused()
+    with torch.no_grad():
+        mlp.gn.weight.mul_(1.2)
+        mlp.gn.bias.add_(0.1)
+        for c in mlp.convs:
+            c.bias.add_(0.1 * torch.randn_like(c.bias))
+    sizes = (9, 12, 10)
+    lst = [torch.randn(cin, n, n) for n in sizes]
+    douts = [torch.randn(cout, n, n) for n in sizes]
+    ws = [c.weight.detach().cpu() for c in mlp.convs]
+    bs = [c.bias.detach().cpu() for c in mlp.convs]
+    gw, gb = mlp.gn.weight.detach().cpu(), mlp.gn.bias.detach().cpu()
+
+    def run(dt):
+        ps = [t.to(dt).requires_grad_(True) for t in ws + bs + [gw, gb]]
+        xs = [t.to(dt).requires_grad_(True) for t in lst]
+        ys = [O.mlp_block_real(x.unsqueeze(0), ps[:depth], ps[depth:2 * depth], ps[-2], ps[-1]).squeeze(0) for x in xs]
+        sum((y * d.to(dt)).sum() for y, d in zip(ys, douts)).backward()
+        return ys, xs, ps
+
+    y64, x64, p64 = run(torch.float64)
+    y32, x32, p32 = run(torch.float32)
+    xm = from_list([t.to(DEV) for t in lst], dims=(1, 2), base_name='N')
+    xt = xm.tensor.detach().requires_grad_(True)
+    from graph_neural_net_amd.masked import MaskedTensor
+    out = mlp(MaskedTensor(xt, xm.nvalid, xm.masked_dims, xm.base_name))
+    dpad = torch.zeros_like(out.tensor)
+    for i, (d, n) in enumerate(zip(douts, sizes)):
+        dpad[i, :, :n, :n] = d.to(DEV)
+    (out.tensor * dpad).sum().backward()
+    for i, n in enumerate(sizes):
+        assert rel(out.tensor[i, :, :n, :n].cpu(), y64[i]) < 4 * rel(y32[i], y64[i]) + 1e-6
+        assert rel(xt.grad[i, :, :n, :n].cpu(), x64[i].grad) < 4 * rel(x32[i].grad, x64[i].grad) + 1e-5
+        pad = out.tensor[i].clone()
+        pad[:, :n, :n] = 0
+        assert pad.abs().max() == 0
+    mine = [c.weight.grad for c in mlp.convs] + [c.bias.grad for c in mlp.convs] + [mlp.gn.weight.grad, mlp.gn.bias.grad]
+    for j, (a, b64, b32) in enumerate(zip(mine, p64, p32)):
+        if j == 2 * depth - 1:          # last conv bias: analytically zero gradient (GraphNorm removes the mean)
+            assert a.abs().max() < 1e-4
+            continue
+        b64g, b32g = b64.grad.reshape(a.shape), b32.grad.reshape(a.shape)
+        assert rel(a.cpu(), b64g) < 4 * rel(b32g, b64g) + 1e-5, j
+
+
+def _load_model(d, **kw):
+    model = Siamese_Node_Exp(3, dict(NE, **kw)).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    return model
+
+
+def test_siamese_any_width_against_reference_golden():
+    """original_features_num 3, in_features 16, out_features 48, depth 2 (convs 3->16, 19->16, 16->48, 64->48): scores,
+    loss, intermediates and every gradient against the reference's own fp32 / fp64 runs."""
+    d = load_golden('widths_c3_16_48_d2_2blk.npz')
+    model = _load_model(d)
+    assert model.node_embedder._standard_layout() is None          # not the fused engine: the per-layer modules
+    out = model.node_embedder({'input': d['x1'].to(DEV)})
+    for k, v in sub(d, 'inter/').items():
+        assert rel(out[k].detach().cpu(), v) < 2e-5, k
+    scores = model({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+    loss = model.loss(scores)
+    loss.backward()
+    yard = rel(d['scores'], d['scores64'])
+    assert rel(scores.detach().cpu(), d['scores64']) < max(2 * yard, 1e-5)
+    assert abs(loss.item() - d['loss64'].item()) < 1e-5 * d['loss64'].item()
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if is_zero_grad(k, 2):
+            assert p.grad.abs().max() < 1e-4
+        else:
+            yard = rel(d['grad/' + k], d['grad64/' + k])
+            assert rel(p.grad.cpu(), d['grad64/' + k]) < 4 * yard + 1e-5, k
+    # a second step accumulates into .grad like any autograd module
+    model.loss(model({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})).backward()
+    k = 'ne_bm_block2_mlp3.convs.0.weight'
+    assert rel(getattr(model.node_embedder, 'ne_bm_block2_mlp3').convs[0].weight.grad.cpu(), 2 * d['grad64/' + k]) < 1e-4
+
+
+def test_siamese_any_width_ragged_against_reference_golden():
+    d = load_golden('widths_c3_16_48_d2_2blk.npz')
+    model = _load_model(d, constant_n_vertices=False)
+    n = len(d['ragged/ns'])
+    m1 = from_list([d['ragged/x1/%d' % i].to(DEV) for i in range(n)], dims=(1, 2), base_name='N')
+    m2 = from_list([d['ragged/x2/%d' % i].to(DEV) for i in range(n)], dims=(1, 2), base_name='M')
+    scores = model(m1, m2)
+    loss = model.loss(scores)
+    loss.backward()
+    for i, a in enumerate(list(scores)):
+        ref64 = d['ragged/scores64/%d' % i]
+        assert a.shape == ref64.shape
+        assert rel(a.detach().cpu(), ref64) < max(2 * rel(d['ragged/scores/%d' % i], ref64), 1e-5)
+    assert abs(loss.item() - d['ragged/loss64'].item()) < 1e-5 * d['ragged/loss64'].item()
+    for name, p in model.named_parameters():
+        k = name[len('node_embedder.'):]
+        if not is_zero_grad(k, 2):
+            yard = rel(d['ragged/grad/' + k], d['ragged/grad64/' + k])
+            assert rel(p.grad.cpu(), d['ragged/grad64/' + k]) < 4 * yard + 1e-5, k
+
+
+def test_any_width_trains_and_bf16_is_refused():
+    d = load_golden('widths_c3_16_48_d2_2blk.npz')
+    model = _load_model(d)
+    batch = ({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+    opt = model.configure_optimizers()['optimizer']
+    first = None
+    for _ in range(40):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        first = first if first is not None else loss.item()
+        loss.backward()
+        opt.step()
+    assert loss.item() < 0.8 * first
+    with pytest.raises(RuntimeError, match='bf16'):
+        Siamese_Node_Exp(3, NE, precision='bf16').to(DEV)({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})

@@ -25,10 +25,10 @@ def rel(a, b):
     return d / s if s > 0 else d
 
 
-def is_zero_grad(name):
+def is_zero_grad(name, depth=3):
     """Last conv bias of every MlpBlock_Real: analytically zero gradient (GraphNorm removes the
     mean), pure rounding noise in fp32."""
-    return name.endswith('convs.2.bias')
+    return name.endswith('convs.%d.bias' % (depth - 1))
 
 
 def unpack_pairs(bits, n):
