@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
 FGNN_H = 32
 FGNN_TILE = 32
 FGNN_MAX_DEPTH = 3
+FGNN_RANGE_WG = 256          # include/fgnn_hip.h
 FGNN_SCORE_SPLIT = 4
 
 c_float_p = C.c_void_p   # device pointers travel as integers
@@ -35,7 +36,8 @@ class MlpFwdArgs(C.Structure):
                 ('z', C.c_void_p * 2),
                 ('ldz', C.c_longlong),
                 ('part', C.c_void_p * 2),
-                ('cnt', C.c_void_p), ('packed', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p)]
+                ('cnt', C.c_void_p), ('packed', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p),
+                ('ranges', C.c_void_p)]
 
 
 class MlpBwdArgs(C.Structure):
@@ -51,7 +53,8 @@ class MlpBwdArgs(C.Structure):
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
                 ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p),
-                ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p)]
+                ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p),
+                ('ranges', C.c_void_p)]
 
 
 class Slab16(C.Structure):
@@ -109,6 +112,7 @@ _SIGNATURES = {
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_ragged_tile_ranges': [_VP, _I, _I, _VP, _VP],
     'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_conv1x1_dw_chunks': [_I, _I],
     'fgnn_conv1x1_dw': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _I, _I, _I, _VP, _VP],

@@ -111,6 +111,26 @@ DEVI float relu1(float x) {
 
 DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
 
+// ---- ragged batches: tiles (FGNN_TILE consecutive pixels of an N x N plane) inside the padding ----------------------
+// does tile tt hold a pixel of the valid nv x nv corner?
+DEVI bool tile_live(int tt, int N, int nv) {
+    const int P = N * N, p0 = tt * FGNN_TILE, p1 = min(p0 + FGNN_TILE - 1, P - 1);
+    const int i0 = p0 / N, j0 = p0 - i0 * N, i1 = p1 / N;
+    return (i0 < nv && j0 < nv) || (i1 > i0 && i0 + 1 < nv);
+}
+// first live tile among t, t + step, t + 2 step, ... below t_end (t_end if none); step is a power of two.
+// All operands are wave-uniform.  Rows >= nv are padding up to the end of the graph, so that tail is jumped over.
+DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *nvalid) {
+    while (t < t_end) {
+        const int g = t / tpg, tt = t - g * tpg;
+        const int nv = nvalid[g];
+        if (tile_live(tt, N, nv)) break;
+        if (tt * FGNN_TILE / N >= nv) t += ((g + 1) * tpg - t + step - 1) & ~(step - 1);
+        else t += step;
+    }
+    return t;
+}
+
 // error plumbing shared by the launchers
 void fgnn_set_error(const char *fmt, ...);
 #define FGNN_CHECK(cond, ...)                       \

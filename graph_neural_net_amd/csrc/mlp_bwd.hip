@@ -229,7 +229,10 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
     }
 }
 
-template <int CA, int CB, int DEPTH, bool PK = false>
+// SKIP (ragged batches with A.ranges): the workgroup's tile range comes from fgnn_ragged_tile_ranges (equal work), the
+// waves step over tiles without a single valid pixel (they contribute nothing to the parameter gradients); the only thing
+// such a tile still delivers is an empty S1/S2 record, stored after the main loop.
+template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
                                                               const int total_tiles) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
@@ -283,8 +286,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     // which a wave accumulates its weight gradients is fixed -> bit-reproducible results
     const int nwg = gridDim.x;
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
-    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    if constexpr (SKIP) {
+        T0 = A.ranges[blockIdx.x];
+        T1 = A.ranges[blockIdx.x + 1];
+    }
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
     // dz coefficients from the per-tile sums its consumer left behind (the work of fgnn_gn_bwd_coef_tiles,
@@ -302,8 +309,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), ra = rk, rb = rk;
     int cached_g = -1, cur_nv = A.N;
+    int first = T0 + wv;
+    if constexpr (SKIP) first = __builtin_amdgcn_readfirstlane(next_live_tile(first, T1, NW, tpg, A.N, A.nvalid));
     {
-        const int t = T0 + wv;
+        const int t = first;
         const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P, j);
         load_slab<SA, PK>(xa, va, ps, c, h);
         load_slab<SB, PK>(xb, vb, ps, c, h);
@@ -377,7 +386,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     }
     __syncthreads();
     PH(9)               // prologue: first loads issued, operand image copied, barrier
-    for (int tile = T0 + wv; tile < T1; tile += NW) {
+    int tnext = 0;
+    for (int tile = first; tile < T1; tile = tnext) {
+        tnext = tile + NW;
+        if constexpr (SKIP) tnext = __builtin_amdgcn_readfirstlane(next_live_tile(tnext, T1, NW, tpg, A.N, A.nvalid));
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P, j);
         if (c.g != cached_g) {
             // per-graph records -> wave-private LDS.  Issued (and waited for) BEFORE the loads
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             // is lowest here).  The S1/S2-emitting variant still needs xa for (z - mean).
             float nxa[(CA == 32 && CB == 0) ? 16 : 1];
             {
-                const int tn = tile + NW;
+                const int tn = tnext;
                 const TileCtx cn = decode_tile(tn, tn < T1, tpg, A.N, P, j);
                 if constexpr (CA == 32 && CB == 0) {
                     load_raw<SA>(nxa, va, cn, h);
@@ -658,6 +670,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         }
     }
 
+    if constexpr (SKIP) {
+        // padding-only tiles of this wave's share: empty S1/S2 sums.  dx is NOT written there: its consumers step over the
+        // same tiles (MLP kernels) or read the valid corner only (the matmul backward).
+        if (emit) {
+            for (int t = T0 + wv; t < T1; t += NW) {
+                const TileCtx c = decode_tile(t, true, tpg, A.N, P, j);
+                if (tile_live(c.tt, A.N, A.nvalid[c.g])) continue;
+                if (h == 0)
+                    reinterpret_cast<float2 *>(A.s12part)[((long long)c.g * tpg + c.tt) * FGNN_H + j] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+
     // ---- workgroup reduction of the parameter gradients (fixed order over the waves) ----
     // layout: [W0 (32*CIN) | b0 (32) | W1 (1024) | b1 (32) | ...]
     constexpr int PCOUNT = L::PCOUNT;
@@ -719,19 +744,25 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     PH_FLUSH
 }
 
-template <int CA, int CB, int DEPTH, bool PK = false>
-int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
+template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false>
+int launch_bwd_impl(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = BwdLayout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int CA, int CB, int DEPTH, bool PK = false>
+int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
+    static_assert(BWD_WG == FGNN_RANGE_WG, "fgnn_ragged_tile_ranges splits for the backward grid");
+    if (a->ranges) return launch_bwd_impl<CA, CB, DEPTH, PK, true>(a, tpg, total, st);
+    return launch_bwd_impl<CA, CB, DEPTH, PK, false>(a, tpg, total, st);
 }
 
 template <int DEPTH>
@@ -800,6 +831,7 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     const int tpg = fgnn_tiles_per_graph(a->N);
     const long long total = (long long)a->G * tpg;
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_bwd: too many tiles");
+    FGNN_CHECK(!a->ranges || (a->nvalid && !a->s12tiles), "fgnn_mlp_bwd: ranges need nvalid and exclude s12tiles");
     FGNN_CHECK(!a->s12tiles || fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N),
                "fgnn_mlp_bwd: s12tiles needs a workgroup's tile range to span <= %d graphs (G=%d N=%d); "
                "use fgnn_gn_bwd_coef_tiles", FGNN_BWD_COEF_GRAPHS, a->G, a->N);

@@ -153,7 +153,9 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
     }
 }
 
-template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
+// SKIP (ragged batches with A.ranges): the workgroup's tile range comes from fgnn_ragged_tile_ranges (equal work), the
+// waves step over tiles without a single valid pixel; those tiles only get empty statistics records after the main loop.
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false>
 __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_kernel(
     const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -182,8 +184,12 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     // contiguous tile range of this workgroup; wave w takes tiles T0 + w, T0 + w + NW, ... (static)
     const int nwg = gridDim.x;
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
-    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    if constexpr (SKIP) {
+        T0 = A.ranges[blockIdx.x];
+        T1 = A.ranges[blockIdx.x + 1];
+    }
 
     // The first tile's input slabs and per-graph records are requested BEFORE the operand image
     // is copied, so the three dependent round trips of the prologue overlap into one.
@@ -193,6 +199,7 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
     if (A.packed) pk_load_regs(img, A.packed);
     __builtin_amdgcn_sched_barrier(0);      // keep these loads first (the scheduler would sink them to their use)
     int tile = T0 + wv;
+    if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_live_tile(tile, T1, NW, tpg, A.N, A.nvalid));
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     int cached_g = -1, cur_nv = A.N;
@@ -266,7 +273,8 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         }
         const bool c_valid = tile_valid(c, cur_nv);
         // prefetch this wave's next tile (static strided assignment)
-        const int next = tile + NW;
+        int next = tile + NW;
+        if constexpr (SKIP) next = __builtin_amdgcn_readfirstlane(next_live_tile(next, T1, NW, tpg, A.N, A.nvalid));
         float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
         {
             const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, j);
@@ -358,6 +366,20 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
         for (int s = 0; s < SB; ++s) xb[s] = nb[s];
         tile = next;
     }
+    if constexpr (SKIP) {
+        // padding-only tiles of this wave's share: empty statistics.  Their z pixels are NOT written: every consumer of a
+        // ragged slab either steps over the same tiles (the MLP kernels) or reads the valid corner only (matmul, pooling).
+        for (int t = T0 + wv; t < T1; t += NW) {
+            const TileCtx c = decode_tile(t, true, tpg, A.N, P, j);
+            if (tile_live(c.tt, A.N, A.nvalid[c.g])) continue;
+#pragma unroll
+            for (int m = 0; m < NMLP; ++m) {
+                if (h == 0)
+                    reinterpret_cast<float2 *>(A.part[m])[((long long)c.g * tpg + c.tt) * FGNN_H + j] = make_float2(0.f, 0.f);
+            }
+            if (lane == 0) A.cnt[(long long)c.g * tpg + c.tt] = 0.f;
+        }
+    }
 #ifdef FGNN_PHASES
     if (g_fwd_stamp && g_fwd_sel == CA * 1000 + CB * 10 + NMLP && (threadIdx.x & 63) == 0) {
         unsigned long long *o = g_fwd_stamp + ((long long)blockIdx.x * NW + wv) * 4;
@@ -369,23 +391,29 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
 #endif
 }
 
-template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
-int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false>
+int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK>,
+        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     int grid = (total + NW - 1) / NW;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
+    if (SKIP) grid = FGNN_RANGE_WG;
+    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
+int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
+    if (a->ranges) return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, true>(a, tpg, total, st);
+    return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, false>(a, tpg, total, st);
 }
 
 template <int NMLP, int DEPTH>
@@ -443,6 +471,7 @@ extern "C" int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *a, void *stream) {
         for (int l = 0; l < a->depth; ++l) FGNN_CHECK(a->W[m][l] && a->bias[m][l], "fgnn_mlp_fwd: missing weights mlp %d layer %d", m, l);
     }
     FGNN_CHECK(a->cnt, "fgnn_mlp_fwd: missing cnt");
+    FGNN_CHECK(!a->ranges || a->nvalid, "fgnn_mlp_fwd: ranges (fgnn_ragged_tile_ranges) only make sense with nvalid");
     {
         const long long lim = 0x7fffffffll / 4, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * FGNN_H * a->ldz < lim,

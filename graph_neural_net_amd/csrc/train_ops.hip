@@ -192,3 +192,63 @@ extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, in
     FGNN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- ragged batches: work-balanced tile ranges for the persistent MLP kernels (fgnn_mlp_fwd_args.ranges) -------------
+namespace {
+constexpr int RANGE_THREADS = 1024;
+constexpr int COST_LIVE = 16, COST_DEAD = 1;      // a padding-only tile is a zero-fill, any other a full pass
+
+__device__ __forceinline__ int tile_cost(int t, int tpg, int N, const int *nvalid) {
+    const int g = t / tpg;
+    return tile_live(t - g * tpg, N, nvalid[g]) ? COST_LIVE : COST_DEAD;
+}
+
+__global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int *nvalid, int G, int N, int tpg, int *ranges) {
+    __shared__ long long incl[RANGE_THREADS];
+    const int tid = threadIdx.x, total = G * tpg;
+    const int chunk = (total + RANGE_THREADS - 1) / RANGE_THREADS;
+    const int t0 = min(total, tid * chunk), t1 = min(total, t0 + chunk);
+    long long c = 0;
+    for (int t = t0; t < t1; ++t) c += tile_cost(t, tpg, N, nvalid);
+    incl[tid] = c;
+    __syncthreads();
+    for (int o = 1; o < RANGE_THREADS; o <<= 1) {          // inclusive scan of the chunk costs
+        const long long add = tid >= o ? incl[tid - o] : 0;
+        __syncthreads();
+        incl[tid] += add;
+        __syncthreads();
+    }
+    const long long all = incl[RANGE_THREADS - 1];
+    for (int b = tid; b <= FGNN_RANGE_WG; b += RANGE_THREADS) {
+        if (b == FGNN_RANGE_WG) {
+            ranges[b] = total;
+            continue;
+        }
+        const long long target = all * b / FGNN_RANGE_WG;
+        int lo = 0, hi = RANGE_THREADS - 1;                // first chunk whose inclusive sum exceeds the target
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (incl[mid] > target) hi = mid;
+            else lo = mid + 1;
+        }
+        long long acc = lo > 0 ? incl[lo - 1] : 0;
+        int t = min(total, lo * chunk);
+        const int te = min(total, t + chunk);
+        for (; t < te; ++t) {
+            const int ct = tile_cost(t, tpg, N, nvalid);
+            if (acc + ct > target) break;
+            acc += ct;
+        }
+        ranges[b] = t;
+    }
+}
+}  // namespace
+
+extern "C" int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges, void *stream) {
+    FGNN_CHECK(nvalid && ranges && G > 0 && N > 0, "fgnn_ragged_tile_ranges: bad arguments");
+    const long long tpg = fgnn_tiles_per_graph(N);
+    FGNN_CHECK(G * tpg < (1ll << 30), "fgnn_ragged_tile_ranges: too many tiles");
+    hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, N, (int)tpg, ranges);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}

@@ -107,6 +107,7 @@ def _round_up(x, m):
 
 class FgnnEngine:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
+    SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
 
     def __init__(self, layout, G, N, device, ragged=False):
         _lib.load()
@@ -133,6 +134,9 @@ class FgnnEngine:
         self.pair_loss = torch.empty(self.B * self.score_blocks, **f32)
         self.loss = torch.empty(1, **f32)
         self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
+        # ragged batches: work-balanced tile ranges of the MLP kernels (padding-only tiles are stepped over)
+        self.ranges = (torch.empty(_lib.FGNN_RANGE_WG + 1, dtype=torch.int32, device=device)
+                       if ragged and self.SKIP_PADDING_TILES else None)
         # backward workspace (allocated lazily)
         self._bwd = None
         self.x = None
@@ -216,6 +220,8 @@ class FgnnEngine:
         args.cnt = self.cnt.data_ptr()
         args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
         self._packed_input(args, k)
+        if self.ranges is not None:
+            args.ranges = self.ranges.data_ptr()
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         if not finalize:
@@ -249,6 +255,8 @@ class FgnnEngine:
         if nvalid is not None:
             self.nvalid.copy_(nvalid.to(torch.int32))
         st = _lib.stream_ptr()
+        if self.ranges is not None:
+            _lib.call('fgnn_ragged_tile_ranges', _lib.ptr(self.nvalid), self.G, self.N, _lib.ptr(self.ranges), st)
         if bits is not None:
             words = (self.N + 31) // 32
             if x is not None or L.c0 != 2 or L.depth != 3:
@@ -382,6 +390,8 @@ class FgnnEngine:
         args.wpart = W['wpart'][(k, j)].data_ptr()
         args.packed = self._packs[('b', k, j)][4].data_ptr()
         self._packed_input(args, k)
+        if self.ranges is not None:
+            args.ranges = self.ranges.data_ptr()
         if emit:
             args.s12part = W['s12part'].data_ptr()
         _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
@@ -416,7 +426,7 @@ class FgnnEngine:
         K = L.num_blocks
         # dz coefficients of mlp3 (blocks < K): summed from the tile partials inside the consumer's prologue when a
         # workgroup's tile range spans few graphs, else by a separate fgnn_gn_bwd_coef_tiles launch
-        in_prologue = bool(_lib.load().fgnn_mlp_bwd_coef_tiles_supported(self.G, self.N))
+        in_prologue = bool(_lib.load().fgnn_mlp_bwd_coef_tiles_supported(self.G, self.N)) and self.ranges is None
         dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
         _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,

@@ -8,7 +8,6 @@ No step reads anything back to the host: the loss normaliser of the concatenated
 import collections
 
 import torch
-import torch.nn.functional as F
 
 from . import dp
 from .engine import FgnnEngine
@@ -95,34 +94,59 @@ class FgnnTrainer:
             buckets.setdefault(-(-int(n) // granule) * granule, []).append(i)
         return sorted(buckets.items())
 
-    def model_step_ragged(self, xs, ys, granule=16, total_nodes=None):
-        """Forward + loss + backward of a ragged list of pairs (xs[i], ys[i]: (c0, n_i, n_i) device tensors),
-        one fused-engine pass per size bucket, each padded to the bucket's granule (a multiple of `granule`, so that
-        engines are shared between batches); gradients and losses of the buckets are summed.
-        total_nodes=None: normalised by this list's own node count (the single-process result);
-        total_nodes=1.0: the UN-normalised sums (the data-parallel step normalises after its all-reduce).
-        Returns (loss, [scores_i of shape (n_i, n_i)]); self.grads holds the gradient sum."""
+    def prepare_ragged(self, xs, ys, granule=16):
+        """Stage a ragged list of pairs (xs[i], ys[i]: (c0, n_i, n_i) tensors) for the bucketed step: one stacked,
+        zero-padded (2 * pairs, c0, npad, npad) device tensor + vertex counts per size bucket.  This is loader work (pad /
+        stack / copy): done once per batch, off the step's critical path.  -> dict for model_step_prepared."""
+        dev = self.params.device
         sizes = [int(x.shape[-1]) for x in xs]
-        total = float(sum(sizes)) if total_nodes is None else float(total_nodes)
-        loss = torch.zeros(1, dtype=torch.float32, device=self.params.device)
-        scores = [None] * len(xs)
-        acc = torch.zeros_like(self.grads)
-        tmp = torch.empty_like(self.grads)
+        buckets = []
         for npad, idx in self.bucket_by_size(sizes, granule):
             cnt = -(-len(idx) // 2) * 2                     # pairs rounded up to a multiple of 2 (G to a multiple of 4)
-            pad = lambda t: F.pad(t, (0, npad - t.shape[-1], 0, npad - t.shape[-1]))
-            fill = [torch.zeros_like(pad(xs[idx[0]]))] * (cnt - len(idx))
-            x = torch.stack([pad(xs[i]) for i in idx] + fill + [pad(ys[i]) for i in idx] + fill).contiguous()
-            ns = [sizes[i] for i in idx] + [0] * (cnt - len(idx))
-            nv = torch.tensor(ns * 2, dtype=torch.int32, device=x.device)
-            eng = self._engine(2 * cnt, npad, True)
-            sc, l = eng.step(self.params, tmp, x, nvalid=nv, total_nodes=total)
-            acc += tmp
-            loss = loss + l
+            x = torch.zeros(2 * cnt, xs[0].shape[0], npad, npad, dtype=torch.float32, device=dev)
             for k, i in enumerate(idx):
-                scores[i] = sc[k, :sizes[i], :sizes[i]].clone()
-        self.grads.copy_(acc)
+                n = sizes[i]
+                x[k, :, :n, :n] = xs[i]
+                x[cnt + k, :, :n, :n] = ys[i]
+            ns = [sizes[i] for i in idx] + [0] * (cnt - len(idx))
+            nv = torch.tensor(ns * 2, dtype=torch.int32, device=dev)
+            buckets.append({'npad': npad, 'idx': idx, 'pairs': cnt, 'x': x, 'nvalid': nv})
+        return {'sizes': sizes, 'buckets': buckets}
+
+    def model_step_prepared(self, batch, total_nodes=None, want_scores=True):
+        """Forward + loss + backward of a batch staged by prepare_ragged: one fused-engine pass per size bucket;
+        gradients and losses of the buckets are summed.
+        total_nodes=None: normalised by this batch's own node count (the single-process result);
+        total_nodes=1.0: the UN-normalised sums (the data-parallel step normalises after its all-reduce).
+        Returns (loss, [scores_i of shape (n_i, n_i)] or None); self.grads holds the gradient sum."""
+        sizes = batch['sizes']
+        total = float(sum(sizes)) if total_nodes is None else float(total_nodes)
+        loss = torch.zeros(1, dtype=torch.float32, device=self.params.device)
+        scores = [None] * len(sizes) if want_scores else None
+        first = True
+        for b in batch['buckets']:
+            eng = self._engine(2 * b['pairs'], b['npad'], True)
+            # the first bucket writes self.grads, the others go through the scratch vector and are added
+            dst = self.grads if first else self._grad_tmp()
+            sc, l = eng.step(self.params, dst, b['x'], nvalid=b['nvalid'], total_nodes=total)
+            if not first:
+                self.grads += dst
+            first = False
+            loss = loss + l
+            if want_scores:
+                for k, i in enumerate(b['idx']):
+                    scores[i] = sc[k, :sizes[i], :sizes[i]].clone()
         return loss.reshape(()), scores
+
+    def _grad_tmp(self):
+        if getattr(self, '_gtmp', None) is None:
+            self._gtmp = torch.empty_like(self.grads)
+        return self._gtmp
+
+    def model_step_ragged(self, xs, ys, granule=16, total_nodes=None):
+        """prepare_ragged + model_step_prepared in one call (each padded to the bucket's granule -- a multiple of `granule`,
+        so that engines are shared between batches).  Returns (loss, [scores_i of shape (n_i, n_i)])."""
+        return self.model_step_prepared(self.prepare_ragged(xs, ys, granule), total_nodes)
 
     def train_step_ragged(self, xs, ys, granule=16):
         loss, scores = self.model_step_ragged(xs, ys, granule, total_nodes=1.0)

@@ -93,6 +93,12 @@ typedef struct {
                                                (G, N, ceil(N/32)) words, bit j of row i = W[i][j]: channel 0 = W, channel 1 =
                                                diag(xdeg) (loaders/data_generator.py:118-125); the slab need not exist */
     const float *xdeg;                      /* (G, N) row sums over the valid columns, from fgnn_adjacency_degree */
+    const int *ranges;                      /* optional, ragged batches (nvalid != NULL): FGNN_RANGE_WG + 1 tile bounds from
+                                               fgnn_ragged_tile_ranges.  Workgroup w then owns tiles [ranges[w], ranges[w+1])
+                                               (equal WORK instead of equal tile counts) and tiles that lie entirely in the
+                                               padding are stepped over: their statistics records are written as empty, their
+                                               z pixels are left untouched (consumers must do the same, or read the valid
+                                               n x n corner only -- all kernels of this library do) */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
 
@@ -241,6 +247,8 @@ typedef struct {
     float *s12_out;                          /* optional (G*32*2): the summed s12 is also written here (affine gradients) */
     const unsigned *xbits;                   /* optional: 2-channel slab expanded from the bit-packed adjacency, as in  */
     const float *xdeg;                       /*   fgnn_mlp_fwd_args                                                      */
+    const int *ranges;                       /* optional work-balanced tile bounds + padding-tile skipping, as in the forward
+                                                arguments; cannot be combined with s12tiles                                  */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
@@ -289,6 +297,14 @@ int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N,
 /* deg[g][i] = number of set bits j < nvalid[g] in row i (0 for rows >= nvalid[g]): the diagonal of channel 1, for the
  * kernels that expand the adjacency themselves (fgnn_mlp_fwd_args.xbits / xdeg) */
 int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream);
+
+/* Ragged batches: work-balanced tile ranges for the persistent MLP kernels.  A tile (32 consecutive pixels of one graph's
+ * N x N plane) that holds no pixel of the valid n x n corner costs a zero-fill, any other tile a full pass; ranges[w] ..
+ * ranges[w+1] (w < FGNN_RANGE_WG) split the G * tiles_per_graph tiles into pieces of equal cost.  One small launch per
+ * batch; the result depends on nvalid only (deterministic).  No reference counterpart: the reference computes the padded
+ * (Nmax x Nmax) tensors in full (maskedtensors/maskedtensor.py:98-112).                                                  */
+#define FGNN_RANGE_WG 256
+int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges /* FGNN_RANGE_WG + 1 */, void *stream);
 
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);

@@ -529,3 +529,82 @@ def test_checkpoint_resume_continues_the_optimizer(tmp_path):
     for s in range(3, 6):
         step(b, s)
     assert torch.equal(b.params, ref.params)
+
+
+def _tile_live_np(N, nv):
+    """liveness of the ceil(N*N/32) tiles of one graph: does a tile hold a pixel of the valid nv x nv corner?"""
+    P = N * N
+    p = np.arange(-(-P // 32) * 32)
+    ok = (p < P) & (p // N < nv) & (p % N < nv)
+    return ok.reshape(-1, 32).any(1)
+
+
+@pytest.mark.parametrize('N,ns', [(120, [70, 35, 67, 103, 95, 78, 56, 103] * 4), (50, [50, 1, 17, 33, 50, 2]), (7, [3, 7, 0, 5]),
+                                  (200, [200, 30])])
+def test_ragged_tile_ranges_balance_the_work(N, ns):
+    """fgnn_ragged_tile_ranges: 257 monotone bounds covering every tile, pieces of equal cost (a padding-only tile costs
+    1/16 of a live one), against a numpy restatement of the tile liveness rule."""
+    from graph_neural_net_amd import _lib
+    nv = torch.tensor(ns, dtype=torch.int32, device=DEV)
+    G = len(ns)
+    tpg = -(-N * N // 32)
+    ranges = torch.full((257,), -1, dtype=torch.int32, device=DEV)
+    _lib.call('fgnn_ragged_tile_ranges', _lib.ptr(nv), G, N, _lib.ptr(ranges), _lib.stream_ptr())
+    r = ranges.cpu().numpy().astype(np.int64)
+    assert r[0] == 0 and r[-1] == G * tpg and (np.diff(r) >= 0).all()
+    cost = np.concatenate([np.where(_tile_live_np(N, n), 16, 1) for n in ns])
+    csum = np.concatenate([[0], np.cumsum(cost)])
+    piece = csum[r[1:]] - csum[r[:-1]]
+    assert piece.sum() == cost.sum()
+    assert piece.max() <= cost.sum() / 256 + 16 and piece.min() >= cost.sum() / 256 - 16
+
+
+def test_ragged_padding_tiles_are_skipped_not_trusted():
+    """The ragged engine steps over padding-only tiles (work-balanced ranges, zero-fill).  (i) Forward results are
+    bit-identical to the engine that computes every tile, gradients agree to fp32 summation-order noise; (ii) workspaces
+    full of NaN / a previous batch with larger graphs do not leak into the result (bit-identical to a fresh engine)."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    xs, ys = synthetic.make_ragged_batch(5100, 6, 20, 90)
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nvd = torch.cat([nv, nv]).to(DEV)
+    N, G = x.shape[-1], x.shape[0]
+
+    def run(eng):
+        g = torch.zeros_like(params)
+        s, l = eng.step(params, g, x, nvalid=nvd)
+        torch.cuda.synchronize()
+        return s.clone(), l.clone(), g
+
+    skip = FgnnEngine(lay, G, N, DEV, ragged=True)
+    assert skip.ranges is not None
+    s1, l1, g1 = run(skip)
+    FgnnEngine.SKIP_PADDING_TILES = False
+    try:
+        full = FgnnEngine(lay, G, N, DEV, ragged=True)
+    finally:
+        FgnnEngine.SKIP_PADDING_TILES = True
+    assert full.ranges is None
+    s0, l0, g0 = run(full)
+    assert torch.equal(s1, s0)
+    assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item())
+    assert ((g1 - g0).norm() / g0.norm()).item() < 2e-6
+    # (ii) poison every workspace tensor, then a batch of full-size graphs, then the ragged batch again
+    def poison(eng):
+        W = eng._bwd
+        ts = (list(eng.z.values()) + list(eng.mult.values()) + list(eng.nrm.values()) + eng.part + [eng.cnt, eng.E, eng.scores, eng.lse]
+              + W['dy'] + [W['dmult'], W['dy1'], W['dy2'], W['s12part'], W['dE']] + list(W['s12'].values())
+              + list(W['wpart'].values()) + W['coef'])
+        for t in ts:
+            t.fill_(float('nan'))
+    poison(skip)
+    s2, l2, g2 = run(skip)
+    assert torch.equal(s2, s1) and torch.equal(l2, l1) and torch.equal(g2, g1)
+    xf1, xf2 = synthetic.make_batch(5200, G // 2, N, 'ErdosRenyi', 0.3, 0.1)
+    gtmp = torch.zeros_like(params)
+    skip.step(params, gtmp, torch.cat([xf1, xf2]).contiguous().to(DEV), nvalid=torch.full((G,), N, dtype=torch.int32, device=DEV))
+    s3, l3, g3 = run(skip)
+    assert torch.equal(s3, s1) and torch.equal(l3, l1) and torch.equal(g3, g1)
