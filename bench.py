@@ -30,9 +30,13 @@ MFMA_F32_PEAK_TF = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
-def kernel_model(tag, G, N):
-    """Algorithmic (bytes, flops) of one launch of `tag` (interface reads + writes; fp32 slabs, bf16 for the *16 kernels)."""
+def kernel_model(tag, G, N, pix=None, cube=None):
+    """Algorithmic (bytes, flops) of one launch of `tag` (interface reads + writes; fp32 slabs, bf16 for the *16 kernels).
+    Ragged batches: pix = sum of n_g^2 and cube = sum of n_g^3 over the G graphs (the valid corners) replace G*N^2, G*N^3."""
     P = N * N
+    if pix is not None:          # every formula below is linear in G*P and G*N^3
+        P = pix / G
+        N = (cube / G) ** (1.0 / 3.0)
     if tag.startswith('mlp_fwd16['):
         cin, nmlp = [int(v.split('=')[1]) for v in tag[10:-1].split(',')]
         return 2.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
@@ -133,12 +137,43 @@ def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
                                         sorted(sweep), avail, sl)}
 
 
+def cpu_baseline_ragged(layout, params, xs, ys, min_seconds=10.0, max_steps=100):
+    """cfg5: the oracle on the ragged list, graph by graph (the reference's MaskedTensor path computes the padded batch;
+    per-graph dense runs are its own tests' definition of the result and the cheaper CPU schedule)."""
+    from oracle import fgnn_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    sd = {k: v.clone() for k, v in layout.unflatten(params.cpu()).items()}
+    sweep = {}
+    for c in sorted({min(avail, v) for v in (1, 8, 16, 32)}):
+        torch.set_num_threads(c)
+        O.step_fwd_bwd_ragged(xs[:2], ys[:2], sd)
+        t0 = time.time()
+        O.step_fwd_bwd_ragged(xs[:2], ys[:2], sd)
+        sweep[c] = 2.0 / (time.time() - t0)
+    cores = max(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    n = 0
+    while n < max_steps and (n == 0 or time.time() - t0 < min_seconds):
+        O.step_fwd_bwd_ragged(xs, ys, sd)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {'value': len(xs) / dt, 'unit': 'pairs/s', 'cores': cores, 'kind': 'port',
+            'single_thread_value': sweep.get(1), 'cores_available': avail, 'cpu_model': _cpu_model(),
+            'thread_sweep_pairs_per_s': {str(k): round(v, 2) for k, v in sweep.items()},
+            'sample': '%d steps on the %d ragged pairs of the same batch, graph by graph, %.2f s/step, torch %s CPU, fp32, %d '
+                      'threads = best of the sweep %s on the first 2 pairs' % (n, len(xs), dt, torch.__version__, cores, sorted(sweep))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--config', default='cfg2', choices=('cfg2', 'cfg4'),
+    ap.add_argument('--config', default='cfg2', choices=('cfg2', 'cfg4', 'cfg5'),
                     help='BASELINE.json configs[1] (N=50 regular pairs, batch 32, fp32; the headline line) or '
                          'configs[3] (N=200 dense ER pairs, batch 8, bf16)')
     ap.add_argument('--precision', default=None, choices=('fp32', 'bf16'),
@@ -167,13 +202,25 @@ def main():
     dev = torch.device('cuda', local_rank)
 
     dense_er = args.config == 'cfg4'              # the workload
+    ragged = args.config == 'cfg5'                # variable-N pairs, n in [30, N], one batch padded to its largest graph
     bf16 = (args.precision == 'bf16') if args.precision else dense_er      # the kernel set
-    B = args.batch if args.batch is not None else (8 if dense_er else 32)
-    N = args.n if args.n is not None else (200 if dense_er else 50)
+    B = args.batch if args.batch is not None else (8 if (dense_er or ragged) else 32)
+    N = args.n if args.n is not None else (200 if dense_er else (120 if ragged else 50))
     layout = ParamLayout(2, args.blocks, 32, 32, 3)
     params = layout.init_flat(0, dev)
     grads = torch.zeros_like(params)
-    if dense_er:   # cfg4: dense Erdos-Renyi (edge density 0.5) pairs, ER edge noise 0.1
+    nvalid, pix, cube, sizes = None, None, None, None
+    if ragged:     # cfg5: Erdos-Renyi pairs (edge density 0.2, ER edge noise 0.1), n ~ U{30..N}
+        if bf16:
+            raise SystemExit('bench.py: --config cfg5 runs the fp32 kernel set')
+        xs, ys = synthetic.make_ragged_batch(5000 + rank, B, 30, N, 'ErdosRenyi', 0.2, 0.1)
+        sizes = [int(t.shape[-1]) for t in xs]
+        N = max(sizes)
+        pad = lambda lst: torch.stack([torch.nn.functional.pad(t, (0, N - t.shape[-1], 0, N - t.shape[-1])) for t in lst])
+        x1, x2 = pad(xs), pad(ys)
+        nvalid = torch.tensor(sizes * 2, dtype=torch.int32, device=dev)
+        pix, cube = 2.0 * sum(n * n for n in sizes), 2.0 * sum(n ** 3 for n in sizes)
+    elif dense_er:   # cfg4: dense Erdos-Renyi (edge density 0.5) pairs, ER edge noise 0.1
         x1, x2 = synthetic.make_batch(4000 + rank, B, N, 'ErdosRenyi', 0.5, 0.1)
     else:
         x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
@@ -181,29 +228,35 @@ def main():
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
         eng = FgnnEngineBF16(layout, 2 * B, N, dev)
     else:
-        eng = FgnnEngine(layout, 2 * B, N, dev)
+        eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged)
     x = torch.cat([x1, x2]).contiguous().to(dev)
-    total_nodes = float(B * N * world)            # loss normaliser of the concatenated global batch
+    total_nodes = float((sum(sizes) if ragged else B * N) * world)      # loss normaliser of the concatenated global batch
 
     def model_work():
-        eng.step(params, grads, x, total_nodes=total_nodes)
+        eng.step(params, grads, x, nvalid=nvalid, total_nodes=total_nodes)
 
     if args.path == 'module':
         # the surface a user of the reference calls (models/trainers.py:60-76): same weights, same batch, eager launches
         from graph_neural_net_amd.siamese import Siamese_Node_Exp
         node_emb = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=args.blocks,
                         in_features=32, out_features=32, depth_of_mlp=3)
+        if ragged:
+            node_emb['constant_n_vertices'] = False
         model = Siamese_Node_Exp(2, node_emb, metric='max', precision='bf16' if bf16 else 'fp32').to(dev)
         with torch.no_grad():
             for (name, off, shape), (_, p) in zip(layout.entries, model.node_embedder.named_parameters()):
                 p.copy_(params[off:off + p.numel()].view(shape))
         xa, xb = x[:B], x[B:]
+        if ragged:      # what a user of the reference builds: one MaskedTensor batch per side (maskedtensor.from_list)
+            from graph_neural_net_amd.masked import from_list
+            xa = from_list([t.to(dev) for t in xs], dims=(1, 2), base_name='N')
+            xb = from_list([t.to(dev) for t in ys], dims=(1, 2), base_name='M')
         args.no_graph = True
 
         def model_work():                      # noqa: F811
             for p in model.parameters():
                 p.grad = None
-            loss = model.loss(model({'input': xa}, {'input': xb})) * (B * N / total_nodes)
+            loss = model.loss(model({'input': xa}, {'input': xb})) * ((sum(sizes) if ragged else B * N) / total_nodes)
             loss.backward()
 
     graph = None
@@ -264,7 +317,7 @@ def main():
         summary = {t: {'launches_per_step': v[0] / args.profile_steps, 'avg_ms': v[1] / v[0],
                        'share': v[1] / tot} for t, v in kernels.items()}
         dom = max(kernels, key=lambda t: kernels[t][1])
-        by, fl = kernel_model(dom, 2 * B, N)
+        by, fl = kernel_model(dom, 2 * B, N, pix, cube)
         dur = summary[dom]['avg_ms'] * 1e-3
         mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
         if fl / (mfma_peak * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
@@ -297,7 +350,13 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fl_pair, by_pair = algorithmic_per_pair(N, args.blocks, elt=2 if bf16 else 4)
-        if dense_er:
+        if ragged:      # mean over the pairs of this batch, each at its own size
+            per = [algorithmic_per_pair(n, args.blocks) for n in sizes]
+            fl_pair, by_pair = sum(p[0] for p in per) / B, sum(p[1] for p in per) / B
+            workload = ('cfg5: variable-N Erdos-Renyi pairs (edge density 0.2, ER edge noise 0.1), n ~ U{30..%d} (this batch: %s), '
+                        '%d pairs per GPU in ONE batch padded to its largest graph, %d FGNN blocks x 32 features, depth 3, '
+                        'siamese fwd + triplet loss + bwd' % (args.n or 120, sizes, B, args.blocks))
+        elif dense_er:
             workload = ('cfg4: N=%d dense Erdos-Renyi pairs (edge density 0.5, ER edge noise 0.1), %d pairs per GPU, '
                         '%d FGNN blocks x 32 features, depth 3, siamese fwd + triplet loss + bwd' % (N, B, args.blocks))
         else:
@@ -307,7 +366,8 @@ def main():
         if bf16:
             workload += ', bf16 storage + bf16 MFMA, fp32 accumulation / statistics / gradients'
         out = {
-            'metric': 'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
+            'metric': ('graph-pairs/sec FGNN fwd+bwd, variable-N pairs (n in [30, %d])' % (args.n or 120)) if ragged else
+                      'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
@@ -322,7 +382,7 @@ def main():
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(layout, params, x1, x2)
+            out['cpu_baseline'] = cpu_baseline_ragged(layout, params, xs, ys) if ragged else cpu_baseline(layout, params, x1, x2)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out))

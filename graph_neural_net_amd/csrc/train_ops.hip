@@ -198,10 +198,35 @@ namespace {
 constexpr int RANGE_THREADS = 1024;
 constexpr int COST_LIVE = 16, COST_DEAD = 1;      // a padding-only tile is a zero-fill, any other a full pass
 
-__device__ __forceinline__ int tile_cost(int t, int tpg, int N, const int *nvalid) {
-    const int g = t / tpg;
-    return tile_live(t - g * tpg, N, nvalid[g]) ? COST_LIVE : COST_DEAD;
-}
+// walks consecutive tiles without a division per tile: (graph, tile in graph, first pixel's row / column)
+struct TileWalk {
+    int g, tt, i0, j0, nv;
+    __device__ void start(int t, int tpg, int N, const int *nvalid) {
+        g = t / tpg;
+        tt = t - g * tpg;
+        i0 = tt * FGNN_TILE / N;
+        j0 = tt * FGNN_TILE - i0 * N;
+        nv = nvalid[g];
+    }
+    __device__ int cost(int N) const {       // tile_live() of fgnn_common.h on the tracked coordinates
+        const int P = N * N, p1 = min(tt * FGNN_TILE + FGNN_TILE - 1, P - 1);
+        const bool multi = p1 >= (i0 + 1) * N;                 // the tile reaches into row i0 + 1
+        return ((i0 < nv && j0 < nv) || (multi && i0 + 1 < nv)) ? COST_LIVE : COST_DEAD;
+    }
+    __device__ void next(int tpg, int N, const int *nvalid, int G) {
+        if (++tt == tpg) {
+            tt = 0;
+            i0 = j0 = 0;
+            if (++g < G) nv = nvalid[g];
+            return;
+        }
+        j0 += FGNN_TILE;
+        while (j0 >= N) {
+            j0 -= N;
+            ++i0;
+        }
+    }
+};
 
 __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int *nvalid, int G, int N, int tpg, int *ranges) {
     __shared__ long long incl[RANGE_THREADS];
@@ -209,7 +234,14 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
     const int chunk = (total + RANGE_THREADS - 1) / RANGE_THREADS;
     const int t0 = min(total, tid * chunk), t1 = min(total, t0 + chunk);
     long long c = 0;
-    for (int t = t0; t < t1; ++t) c += tile_cost(t, tpg, N, nvalid);
+    if (t0 < t1) {
+        TileWalk w;
+        w.start(t0, tpg, N, nvalid);
+        for (int t = t0; t < t1; ++t) {
+            c += w.cost(N);
+            w.next(tpg, N, nvalid, G);
+        }
+    }
     incl[tid] = c;
     __syncthreads();
     for (int o = 1; o < RANGE_THREADS; o <<= 1) {          // inclusive scan of the chunk costs
@@ -234,10 +266,15 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
         long long acc = lo > 0 ? incl[lo - 1] : 0;
         int t = min(total, lo * chunk);
         const int te = min(total, t + chunk);
-        for (; t < te; ++t) {
-            const int ct = tile_cost(t, tpg, N, nvalid);
-            if (acc + ct > target) break;
-            acc += ct;
+        if (t < te) {
+            TileWalk w;
+            w.start(t, tpg, N, nvalid);
+            for (; t < te; ++t) {
+                const int ct = w.cost(N);
+                if (acc + ct > target) break;
+                acc += ct;
+                w.next(tpg, N, nvalid, G);
+            }
         }
         ranges[b] = t;
     }
