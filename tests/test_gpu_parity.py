@@ -608,3 +608,40 @@ def test_ragged_padding_tiles_are_skipped_not_trusted():
     skip.step(params, gtmp, torch.cat([xf1, xf2]).contiguous().to(DEV), nvalid=torch.full((G,), N, dtype=torch.int32, device=DEV))
     s3, l3, g3 = run(skip)
     assert torch.equal(s3, s1) and torch.equal(l3, l1) and torch.equal(g3, g1)
+
+
+@pytest.mark.parametrize('ns', [[3, 7, 1, 5], [33, 2, 17, 31], [64, 20, 64, 9], [65, 40, 1, 65], [130, 12], [1, 1]])
+def test_ragged_skipping_engine_equals_full_engine_on_boundary_shapes(ns):
+    """Padding-tile skipping against the engine that computes every tile, on shapes where a tile spans several rows
+    (N < 32), straddles the 32 / 64 boundaries, or where whole workgroups get empty ranges (few tiles): scores and loss
+    bit-identical, gradients equal up to the summation order of the per-workgroup partials."""
+    torch.manual_seed(sum(ns))
+    sd = O.init_state_dict(num_blocks=2)
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    rng = np.random.default_rng(sum(ns))
+    xs, ys = [], []
+    for n in ns:
+        a, b = synthetic.make_pair(rng, n, 'ErdosRenyi', 0.4, 0.1)
+        xs.append(torch.from_numpy(a)); ys.append(torch.from_numpy(b))
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nvd = torch.cat([nv, nv]).to(DEV)
+    out = []
+    for skip in (True, False):
+        FgnnEngine.SKIP_PADDING_TILES = skip
+        try:
+            eng = FgnnEngine(lay, x.shape[0], x.shape[-1], DEV, ragged=True)
+        finally:
+            FgnnEngine.SKIP_PADDING_TILES = True
+        assert (eng.ranges is not None) == skip
+        g = torch.zeros_like(params)
+        sc, l = eng.step(params, g, x, nvalid=nvd)
+        torch.cuda.synchronize()
+        out.append((sc.clone(), l.clone(), g))
+    (s1, l1, g1), (s0, l0, g0) = out
+    assert torch.isfinite(s1).all() and torch.isfinite(g1).all()
+    assert torch.equal(s1, s0)
+    assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item())
+    assert (g1 - g0).norm().item() <= 5e-6 * g0.norm().item() + 1e-7
