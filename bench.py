@@ -211,8 +211,6 @@ def main():
     grads = torch.zeros_like(params)
     nvalid, pix, cube, sizes = None, None, None, None
     if ragged:     # cfg5: Erdos-Renyi pairs (edge density 0.2, ER edge noise 0.1), n ~ U{30..N}
-        if bf16:
-            raise SystemExit('bench.py: --config cfg5 runs the fp32 kernel set')
         xs, ys = synthetic.make_ragged_batch(5000 + rank, B, 30, N, 'ErdosRenyi', 0.2, 0.1)
         sizes = [int(t.shape[-1]) for t in xs]
         N = max(sizes)
@@ -226,7 +224,7 @@ def main():
         x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
     if bf16:
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
-        eng = FgnnEngineBF16(layout, 2 * B, N, dev)
+        eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged)
     else:
         eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged)
     x = torch.cat([x1, x2]).contiguous().to(dev)

@@ -67,7 +67,7 @@ class MlpFwd16Args(C.Structure):
                 ('nvalid', C.c_void_p),
                 ('a', Slab16), ('b', Slab16),
                 ('z', C.c_void_p * 2), ('ldz', C.c_longlong),
-                ('part', C.c_void_p * 2), ('cnt', C.c_void_p), ('packed', C.c_void_p)]
+                ('part', C.c_void_p * 2), ('cnt', C.c_void_p), ('packed', C.c_void_p), ('ranges', C.c_void_p)]
 
 
 class MlpBwd16Args(C.Structure):
@@ -80,7 +80,7 @@ class MlpBwd16Args(C.Structure):
                 ('dxa', C.c_void_p), ('dxa_gstride', C.c_longlong), ('dxa_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
-                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p)]
+                ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p), ('ranges', C.c_void_p)]
 
 
 class GradJob(C.Structure):
@@ -113,6 +113,7 @@ _SIGNATURES = {
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_ragged_tile_ranges': [_VP, _I, _I, _VP, _VP],
+    'fgnn_ragged_tile_ranges16': [_VP, _I, _I, _I, _VP, _VP],
     'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_conv1x1_dw_chunks': [_I, _I],
     'fgnn_conv1x1_dw': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _I, _I, _I, _VP, _VP],

@@ -111,24 +111,29 @@ DEVI float relu1(float x) {
 
 DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
 
-// ---- ragged batches: tiles (FGNN_TILE consecutive pixels of an N x N plane) inside the padding ----------------------
-// does tile tt hold a pixel of the valid nv x nv corner?
-DEVI bool tile_live(int tt, int N, int nv) {
-    const int P = N * N, p0 = tt * FGNN_TILE, p1 = min(p0 + FGNN_TILE - 1, P - 1);
-    const int i0 = p0 / N, j0 = p0 - i0 * N, i1 = p1 / N;
+// ---- ragged batches: tiles inside the padding ------------------------------------------------------------------------
+// A tile = T consecutive elements of a plane stored with row pitch `pitch` (fp32 slabs: T = FGNN_TILE, pitch = N; bf16
+// slabs: T = 64, pitch = ldr).  Does tile tt hold an element of the valid nv x nv corner?
+DEVI bool tile_live_p(int tt, int T, int pitch, int nv) {
+    const int p0 = tt * T, p1 = p0 + T - 1;
+    const int i0 = p0 / pitch, j0 = p0 - i0 * pitch, i1 = p1 / pitch;
     return (i0 < nv && j0 < nv) || (i1 > i0 && i0 + 1 < nv);
 }
 // first live tile among t, t + step, t + 2 step, ... below t_end (t_end if none); step is a power of two.
 // All operands are wave-uniform.  Rows >= nv are padding up to the end of the graph, so that tail is jumped over.
-DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *nvalid) {
+DEVI int next_live_tile_p(int t, int t_end, int step, int tpg, int T, int pitch, const int *nvalid) {
     while (t < t_end) {
         const int g = t / tpg, tt = t - g * tpg;
         const int nv = nvalid[g];
-        if (tile_live(tt, N, nv)) break;
-        if (tt * FGNN_TILE / N >= nv) t += ((g + 1) * tpg - t + step - 1) & ~(step - 1);
+        if (tile_live_p(tt, T, pitch, nv)) break;
+        if (tt * T / pitch >= nv) t += ((g + 1) * tpg - t + step - 1) & ~(step - 1);
         else t += step;
     }
     return t;
+}
+DEVI bool tile_live(int tt, int N, int nv) { return tile_live_p(tt, FGNN_TILE, N, nv); }
+DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *nvalid) {
+    return next_live_tile_p(t, t_end, step, tpg, FGNN_TILE, N, nvalid);
 }
 
 // error plumbing shared by the launchers

@@ -122,7 +122,10 @@ DEVI float sum16(const f32x16 &t) {
     return s;
 }
 
-template <int CA, int CB, int DEPTH>
+// SKIP (ragged batches with A.ranges): work-balanced tile range from fgnn_ragged_tile_ranges16; the waves step over tiles
+// without a valid element (no contribution to the parameter gradients, dx not written there); such a tile only gets an empty
+// S1/S2 (or trace-term) record.
+template <int CA, int CB, int DEPTH, bool SKIP = false>
 __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn_mlp_bwd16_args A, const int tpg,
                                                                  const int total_tiles) {
     static_assert(DEPTH == 3, "built for depth_of_mlp = 3");
@@ -173,8 +176,12 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
 
     const int nwg = gridDim.x;
     const int q_ = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = blockIdx.x * q_ + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
-    const int T1 = T0 + q_ + ((int)blockIdx.x < rem ? 1 : 0);
+    int T0 = blockIdx.x * q_ + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int T1 = T0 + q_ + ((int)blockIdx.x < rem ? 1 : 0);
+    if constexpr (SKIP) {
+        T0 = A.ranges[blockIdx.x];
+        T1 = A.ranges[blockIdx.x + 1];
+    }
     const bool normA = (CA >= 32) && A.a.nrm != nullptr, normB = (CB >= 32) && A.b.nrm != nullptr;
     // per-tile sums of the slab-a gradient: for a normalised single slab {sum dx, sum dx (z_a - mean_a)} (the GraphNorm backward
     // sums of its producer); for the raw first slab of a two-slab MLP (mlp3: slab a = mult) {sum dx, sum dx * x_a} =
@@ -205,8 +212,10 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
         }
         if (normA) la_mean = A.a.nrm[((long long)g * A.a.C + j) * 4];
     };
+    int first = T0 + wv;
+    if constexpr (SKIP) first = __builtin_amdgcn_readfirstlane(next_live_tile_p(first, T1, NWB, tpg, 64, A.ldr, A.nvalid));
     {
-        const int t = T0 + wv;
+        const int t = first;
         const Tile16 c = decode16(t, t < T1, tpg, A.ldr, PP, j);
         load_slab16<CA>(xa, va, c, h);
         if constexpr (CB > 0) load_slab16<CB>(xb, vb, c, h);
@@ -218,7 +227,10 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     const int ld2 = va.ld2;
     auto roff = [&](int r) { return ((r & 3) + 8 * (r >> 2)) * ld2; };
 
-    for (int tile = T0 + wv; tile < T1; tile += NWB) {
+    int tnext = 0;
+    for (int tile = first; tile < T1; tile = tnext) {
+        tnext = tile + NWB;
+        if constexpr (SKIP) tnext = __builtin_amdgcn_readfirstlane(next_live_tile_p(tnext, T1, NWB, tpg, 64, A.ldr, A.nvalid));
         const Tile16 c = decode16(tile, true, tpg, A.ldr, PP, j);
         if (c.g != cached_g) graph_change(c.g);
         const bool v0 = c.inb && c.i < cur_nv && c.jj < cur_nv;
@@ -471,10 +483,23 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
         }
         // the wave's next tile
         {
-            const int tn = tile + NWB;
+            const int tn = tnext;
             const Tile16 cn = decode16(tn, tn < T1, tpg, A.ldr, PP, j);
             load_slab16<CA>(xa, va, cn, h);
             if constexpr (CB > 0) load_slab16<CB>(xb, vb, cn, h);
+        }
+    }
+
+    if constexpr (SKIP) {       // padding-only tiles of this wave's share: empty S1/S2 / trace-term records
+        if (emit) {
+            for (int t = T0 + wv; t < T1; t += NWB) {
+                const int g = __builtin_amdgcn_readfirstlane(t / tpg), tt = t - g * tpg;
+                if (tile_live_p(tt, 64, A.ldr, A.nvalid[g])) continue;
+                if (h == 0) {
+                    if constexpr (CB == 0) reinterpret_cast<float2 *>(A.s12part)[((long long)g * FGNN_H + j) * tpg + tt] = make_float2(0.f, 0.f);
+                    else A.s12part[((long long)g * FGNN_H + j) * tpg + tt] = 0.f;
+                }
+            }
         }
     }
 
@@ -527,18 +552,24 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     }
 }
 
-template <int CA, int CB, int DEPTH>
-int launch_bwd16(const fgnn_mlp_bwd16_args *a, int tpg, int total, hipStream_t st) {
+template <int CA, int CB, int DEPTH, bool SKIP>
+int launch_bwd16_impl(const fgnn_mlp_bwd16_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = Bwd16Layout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd16_kernel<CA, CB, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd16_kernel<CA, CB, DEPTH, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((mlp_bwd16_kernel<CA, CB, DEPTH>), dim3(BWD16_WG), dim3(64 * NWB), LDS, st, *a, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd16_kernel<CA, CB, DEPTH, SKIP>), dim3(BWD16_WG), dim3(64 * NWB), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int CA, int CB, int DEPTH>
+int launch_bwd16(const fgnn_mlp_bwd16_args *a, int tpg, int total, hipStream_t st) {
+    static_assert(BWD16_WG == FGNN_RANGE_WG, "fgnn_ragged_tile_ranges16 splits for the backward grid");
+    if (a->ranges) return launch_bwd16_impl<CA, CB, DEPTH, true>(a, tpg, total, st);
+    return launch_bwd16_impl<CA, CB, DEPTH, false>(a, tpg, total, st);
 }
 
 }  // namespace

@@ -68,7 +68,10 @@ DEVI void operands2(i32x4 &e, i32x4 &o, const unsigned (&x)[2]) {
     o[1] = o[2] = o[3] = 0;
 }
 
-template <int CA, int CB, int NMLP, int DEPTH>
+// SKIP (ragged batches with A.ranges): work-balanced tile range from fgnn_ragged_tile_ranges16, the waves step over tiles
+// without a valid element; those only get empty statistics records (their z elements are not written: consumers step over
+// the same tiles or read the valid corner only).
+template <int CA, int CB, int NMLP, int DEPTH, bool SKIP = false>
 __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_fwd16_args A, const int tpg,
                                                                  const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,8 +92,12 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
 
     const int nwg = gridDim.x;
     const int q_ = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = blockIdx.x * q_ + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
-    const int T1 = T0 + q_ + ((int)blockIdx.x < rem ? 1 : 0);
+    int T0 = blockIdx.x * q_ + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int T1 = T0 + q_ + ((int)blockIdx.x < rem ? 1 : 0);
+    if constexpr (SKIP) {
+        T0 = A.ranges[blockIdx.x];
+        T1 = A.ranges[blockIdx.x + 1];
+    }
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
 
     // operand image -> LDS (straight copy of the packed image)
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
         for (int e = threadIdx.x; e < L::WEIGHT_F / 4; e += 64 * NWF) dst[e] = src[e];
     }
     int tile = T0 + wv;
+    if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_live_tile_p(tile, T1, NWF, tpg, 64, A.ldr, A.nvalid));
     unsigned xa[XA], xb[CB > 0 ? XB : 1];
     int cached_g = -1, cur_nv = A.N;
     {
@@ -138,7 +146,8 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
         if constexpr (CB >= 32) operands32(ybE, ybO, xb, recB, normB, h);
         else if constexpr (CB > 0) operands2(yb2E, yb2O, xb);
         // prefetch the wave's next tile
-        const int next = tile + NWF;
+        int next = tile + NWF;
+        if constexpr (SKIP) next = __builtin_amdgcn_readfirstlane(next_live_tile_p(next, T1, NWF, tpg, 64, A.ldr, A.nvalid));
         {
             const Tile16 cn = decode16(next, next < T1, tpg, A.ldr, PP, j);
             load_slab16<CA>(xa, va, cn, h);
@@ -259,24 +268,41 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
         if (lane == 0) A.cnt[(long long)c.g * tpg + c.tt] = cnt;
         tile = next;
     }
+    if constexpr (SKIP) {       // padding-only tiles of this wave's share: empty statistics records
+        for (int t = T0 + wv; t < T1; t += NWF) {
+            const int g = __builtin_amdgcn_readfirstlane(t / tpg), tt = t - g * tpg;
+            if (tile_live_p(tt, 64, A.ldr, A.nvalid[g])) continue;
+#pragma unroll
+            for (int m = 0; m < NMLP; ++m) {
+                if (h == 0) reinterpret_cast<float2 *>(A.part[m])[((long long)g * FGNN_H + j) * tpg + tt] = make_float2(0.f, 0.f);
+            }
+            if (lane == 0) A.cnt[(long long)g * tpg + tt] = 0.f;
+        }
+    }
 }
 
-template <int CA, int CB, int NMLP, int DEPTH>
-int launch_fwd16(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t st) {
+template <int CA, int CB, int NMLP, int DEPTH, bool SKIP>
+int launch_fwd16_impl(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t st) {
     using L = Fwd16Layout<CA, CB, NMLP, DEPTH>;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd16_kernel<CA, CB, NMLP, DEPTH>,
+        (void)hipFuncSetAttribute((const void *)mlp_fwd16_kernel<CA, CB, NMLP, DEPTH, SKIP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     int grid = (total + NWF - 1) / NWF;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((mlp_fwd16_kernel<CA, CB, NMLP, DEPTH>), dim3(grid), dim3(64 * NWF), LDS, st, *a, tpg, total);
+    if (SKIP) grid = FGNN_RANGE_WG;
+    hipLaunchKernelGGL((mlp_fwd16_kernel<CA, CB, NMLP, DEPTH, SKIP>), dim3(grid), dim3(64 * NWF), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int CA, int CB, int NMLP, int DEPTH>
+int launch_fwd16(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t st) {
+    if (a->ranges) return launch_fwd16_impl<CA, CB, NMLP, DEPTH, true>(a, tpg, total, st);
+    return launch_fwd16_impl<CA, CB, NMLP, DEPTH, false>(a, tpg, total, st);
 }
 
 }  // namespace
@@ -295,6 +321,7 @@ extern "C" int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *a, void *stream) {
     FGNN_CHECK(PP <= a->ldz && PP <= a->a.ldp && a->ldz % 2 == 0 && a->a.ldp % 2 == 0, "fgnn_mlp_fwd16: channel stride < N*ldr or odd");
     for (int m = 0; m < a->nmlp; ++m) FGNN_CHECK(a->z[m] && a->part[m], "fgnn_mlp_fwd16: missing output %d", m);
     FGNN_CHECK(a->cnt, "fgnn_mlp_fwd16: missing cnt");
+    FGNN_CHECK(!a->ranges || a->nvalid, "fgnn_mlp_fwd16: ranges (fgnn_ragged_tile_ranges16) only make sense with nvalid");
     {
         const long long lim = 0x7fffffffll / 2, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * FGNN_H * a->ldz < lim,

@@ -198,37 +198,37 @@ namespace {
 constexpr int RANGE_THREADS = 1024;
 constexpr int COST_LIVE = 16, COST_DEAD = 1;      // a padding-only tile is a zero-fill, any other a full pass
 
-// walks consecutive tiles without a division per tile: (graph, tile in graph, first pixel's row / column)
+// walks consecutive tiles without a division per tile: (graph, tile in graph, first element's row / column)
 struct TileWalk {
     int g, tt, i0, j0, nv;
-    __device__ void start(int t, int tpg, int N, const int *nvalid) {
+    __device__ void start(int t, int tpg, int T, int pitch, const int *nvalid) {
         g = t / tpg;
         tt = t - g * tpg;
-        i0 = tt * FGNN_TILE / N;
-        j0 = tt * FGNN_TILE - i0 * N;
+        i0 = tt * T / pitch;
+        j0 = tt * T - i0 * pitch;
         nv = nvalid[g];
     }
-    __device__ int cost(int N) const {       // tile_live() of fgnn_common.h on the tracked coordinates
-        const int P = N * N, p1 = min(tt * FGNN_TILE + FGNN_TILE - 1, P - 1);
-        const bool multi = p1 >= (i0 + 1) * N;                 // the tile reaches into row i0 + 1
+    __device__ int cost(int T, int pitch) const {       // tile_live_p() of fgnn_common.h on the tracked coordinates
+        const bool multi = j0 + T > pitch;                     // the tile reaches into row i0 + 1
         return ((i0 < nv && j0 < nv) || (multi && i0 + 1 < nv)) ? COST_LIVE : COST_DEAD;
     }
-    __device__ void next(int tpg, int N, const int *nvalid, int G) {
+    __device__ void next(int tpg, int T, int pitch, const int *nvalid, int G) {
         if (++tt == tpg) {
             tt = 0;
             i0 = j0 = 0;
             if (++g < G) nv = nvalid[g];
             return;
         }
-        j0 += FGNN_TILE;
-        while (j0 >= N) {
-            j0 -= N;
+        j0 += T;
+        while (j0 >= pitch) {
+            j0 -= pitch;
             ++i0;
         }
     }
 };
 
-__global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int *nvalid, int G, int N, int tpg, int *ranges) {
+__global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int *nvalid, int G, int T, int pitch, int tpg,
+                                                                       int *ranges) {
     __shared__ long long incl[RANGE_THREADS];
     const int tid = threadIdx.x, total = G * tpg;
     const int chunk = (total + RANGE_THREADS - 1) / RANGE_THREADS;
@@ -236,10 +236,10 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
     long long c = 0;
     if (t0 < t1) {
         TileWalk w;
-        w.start(t0, tpg, N, nvalid);
+        w.start(t0, tpg, T, pitch, nvalid);
         for (int t = t0; t < t1; ++t) {
-            c += w.cost(N);
-            w.next(tpg, N, nvalid, G);
+            c += w.cost(T, pitch);
+            w.next(tpg, T, pitch, nvalid, G);
         }
     }
     incl[tid] = c;
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
         const int te = min(total, t + chunk);
         if (t < te) {
             TileWalk w;
-            w.start(t, tpg, N, nvalid);
+            w.start(t, tpg, T, pitch, nvalid);
             for (; t < te; ++t) {
-                const int ct = w.cost(N);
+                const int ct = w.cost(T, pitch);
                 if (acc + ct > target) break;
                 acc += ct;
-                w.next(tpg, N, nvalid, G);
+                w.next(tpg, T, pitch, nvalid, G);
             }
         }
         ranges[b] = t;
@@ -285,7 +285,18 @@ extern "C" int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ran
     FGNN_CHECK(nvalid && ranges && G > 0 && N > 0, "fgnn_ragged_tile_ranges: bad arguments");
     const long long tpg = fgnn_tiles_per_graph(N);
     FGNN_CHECK(G * tpg < (1ll << 30), "fgnn_ragged_tile_ranges: too many tiles");
-    hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, N, (int)tpg, ranges);
+    hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, FGNN_TILE, N,
+                       (int)tpg, ranges);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_ragged_tile_ranges16(const int *nvalid, int G, int N, int ldr, int *ranges, void *stream) {
+    FGNN_CHECK(nvalid && ranges && G > 0 && N > 0 && ldr >= N, "fgnn_ragged_tile_ranges16: bad arguments");
+    const long long tpg = fgnn_tiles_per_graph16(N, ldr);
+    FGNN_CHECK(G * tpg < (1ll << 30), "fgnn_ragged_tile_ranges16: too many tiles");
+    hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, 64, ldr, (int)tpg,
+                       ranges);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

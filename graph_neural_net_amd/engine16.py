@@ -20,6 +20,7 @@ from .engine import EPS, ParamLayout, _round_up  # noqa: F401
 
 class FgnnEngineBF16:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device, bf16 storage."""
+    SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges16 + tile skipping in fgnn_mlp_fwd16 / fgnn_mlp_bwd16
 
     def __init__(self, layout, G, N, device, ragged=False):
         lib = _lib.load()
@@ -54,6 +55,9 @@ class FgnnEngineBF16:
         self.pair_loss = torch.empty(self.B * self.score_blocks, **f32)
         self.loss = torch.empty(1, **f32)
         self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
+        # ragged batches: work-balanced tile ranges of the MLP kernels (padding-only tiles are stepped over)
+        self.ranges = (torch.empty(_lib.FGNN_RANGE_WG + 1, dtype=torch.int32, device=device)
+                       if ragged and self.SKIP_PADDING_TILES else None)
         self._bwd = None
         self._packs = {}
         for k in range(1, K + 1):
@@ -119,6 +123,8 @@ class FgnnEngineBF16:
         args.ldz = self.ldp
         args.cnt = self.cnt.data_ptr()
         args.packed = self._packs[('f', k, 12 if len(js) == 2 else 3)][4].data_ptr()
+        if self.ranges is not None:
+            args.ranges = self.ranges.data_ptr()
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd16', C.byref(args), st,
                   tag='mlp_fwd16[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
@@ -147,6 +153,8 @@ class FgnnEngineBF16:
         if nvalid is not None:
             self.nvalid.copy_(nvalid.to(torch.int32))
         st = _lib.stream_ptr()
+        if self.ranges is not None:
+            _lib.call('fgnn_ragged_tile_ranges16', _lib.ptr(self.nvalid), self.G, self.N, self.ldr, _lib.ptr(self.ranges), st)
         _lib.call('fgnn_to_bf16', _lib.ptr(x), self._nv(), self.G, 2, self.N, self.ldr, _lib.ptr(self.x16),
                   2 * self.ldp, self.ldp, st)
         self.pack_operands(params)
@@ -227,6 +235,8 @@ class FgnnEngineBF16:
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'][(k, j)].data_ptr()
         args.packed = self._packs[('b', k, j)][4].data_ptr()
+        if self.ranges is not None:
+            args.ranges = self.ranges.data_ptr()
         if emit:
             args.s12part = W['s12part'].data_ptr()
         _lib.call('fgnn_mlp_bwd16', C.byref(args), _lib.stream_ptr(),

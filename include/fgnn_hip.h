@@ -305,6 +305,8 @@ int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N,
  * (Nmax x Nmax) tensors in full (maskedtensors/maskedtensor.py:98-112).                                                  */
 #define FGNN_RANGE_WG 256
 int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges /* FGNN_RANGE_WG + 1 */, void *stream);
+/* the same for the bf16 slabs (tiles of 64 elements of the ldr-pitched planes) */
+int fgnn_ragged_tile_ranges16(const int *nvalid, int G, int N, int ldr, int *ranges /* FGNN_RANGE_WG + 1 */, void *stream);
 
 /* out[i] = sum_k in[k][i] * scale  (tiny fixed-order reduction used for the loss) */
 int fgnn_sum_scale(const float *in, int rows, int cols, float scale, float *out, void *stream);
@@ -352,6 +354,7 @@ typedef struct {
                                                *_tpg helpers and fgnn_chan_matmul_fwd16_fin walk one (g, c) column) */
     float *cnt;                             /* out (G, tpg16)                             */
     const void *packed;                     /* operand image (kind 0) -- required          */
+    const int *ranges;                      /* optional (ragged): tile bounds from fgnn_ragged_tile_ranges16, see fgnn_mlp_fwd_args.ranges */
 } fgnn_mlp_fwd16_args;
 int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *args, void *stream);
 
@@ -414,6 +417,7 @@ typedef struct {
                                                 dxa values.  Raw first slab of a two-slab MLP (mlp3: a = mult): (G, 32, tpg16)
                                                 per-tile sum dxa * x_a, the trace term read by fgnn_chan_matmul_bwd16_t */
     const void *packed;                      /* operand image (kind 1) -- required */
+    const int *ranges;                       /* optional (ragged): tile bounds from fgnn_ragged_tile_ranges16 */
 } fgnn_mlp_bwd16_args;
 int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *args, void *stream);
 

@@ -312,3 +312,71 @@ def test_bf16_ragged_trainer_step_with_filler_graphs():
     d16, d32 = res['bf16'][1], res['fp32'][1]
     cos = torch.dot(d16, d32) / (d16.norm() * d32.norm())
     assert cos > 0.8, cos.item()                                    # Adam's first step is +-lr per parameter: signs must agree
+
+
+@pytest.mark.parametrize('ns', [[120, 75, 97, 33], [50, 7, 1, 24], [200, 40], [64, 64, 30, 9]])
+def test_bf16_ragged_padding_tiles_are_skipped_not_trusted(ns):
+    """bf16 ragged engine: padding-only tiles (64 elements of the ldr-pitched planes) are stepped over.  Scores bit-identical
+    to the engine that computes every tile, gradients equal up to the summation order of the workgroup partials; workspaces
+    poisoned with NaN bit patterns / a previous full-size batch do not leak (bit-identical to the first run)."""
+    import numpy as np
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    sd = {k: v for k, v in sub(d, 'sd/').items() if k.startswith('ne_bm_block1') or k.startswith('ne_bm_block2')}
+    rng = np.random.default_rng(sum(ns))
+    xs, ys = [], []
+    for n in ns:
+        a, b = synthetic.make_pair(rng, n, 'ErdosRenyi', 0.3, 0.1)
+        xs.append(torch.from_numpy(a)); ys.append(torch.from_numpy(b))
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nvd = torch.cat([nv, nv]).to(DEV)
+    G, N = x.shape[0], x.shape[-1]
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+
+    def run(eng, xin=x, nvin=nvd):
+        g = torch.zeros_like(params)
+        s, l = eng.step(params, g, xin, nvalid=nvin)
+        torch.cuda.synchronize()
+        return s.clone(), l.clone(), g
+
+    skip = FgnnEngineBF16(lay, G, N, DEV, ragged=True)
+    assert skip.ranges is not None
+    s1, l1, g1 = run(skip)
+    FgnnEngineBF16.SKIP_PADDING_TILES = False
+    try:
+        full = FgnnEngineBF16(lay, G, N, DEV, ragged=True)
+    finally:
+        FgnnEngineBF16.SKIP_PADDING_TILES = True
+    assert full.ranges is None
+    s0, l0, g0 = run(full)
+    assert torch.isfinite(s1).all() and torch.isfinite(g1).all()
+    assert torch.equal(s1, s0)
+    assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item())
+    assert (g1 - g0).norm().item() <= 1e-5 * g0.norm().item() + 1e-7
+    # poison: every bf16 / fp32 workspace tensor of the engine
+    W = skip._bwd
+    ts = (list(skip.z.values()) + list(skip.mult.values()) + list(skip.nrm.values()) + list(skip.part) + [skip.cnt, skip.E, skip.scores, skip.lse, skip.x16])
+    for v in W.values():
+        if torch.is_tensor(v):
+            ts.append(v)
+        elif isinstance(v, dict):
+            ts += [t for t in v.values() if torch.is_tensor(t)]
+        elif isinstance(v, (list, tuple)):
+            ts += [t for t in v if torch.is_tensor(t)]
+    for t in ts:
+        if t is W.get('gscale'):
+            continue
+        if t.dtype in (torch.float32,):
+            t.fill_(float('nan'))
+        elif t.dtype in (torch.bfloat16,):
+            t.fill_(float('nan'))
+        elif t.dtype in (torch.int16, torch.uint16):
+            t.fill_(0x7fc0)
+    s2, l2, g2 = run(skip)
+    assert torch.equal(s2, s1) and torch.equal(l2, l1) and torch.equal(g2, g1)
+    xf1, xf2 = synthetic.make_batch(5300, G // 2, N, 'ErdosRenyi', 0.3, 0.1)
+    run(skip, torch.cat([xf1, xf2]).contiguous().to(DEV), torch.full((G,), N, dtype=torch.int32, device=DEV))
+    s3, l3, g3 = run(skip)
+    assert torch.equal(s3, s1) and torch.equal(l3, l1) and torch.equal(g3, g1)
