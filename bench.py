@@ -364,7 +364,7 @@ def main():
         if bf16:
             workload += ', bf16 storage + bf16 MFMA, fp32 accumulation / statistics / gradients'
         out = {
-            'metric': ('graph-pairs/sec FGNN fwd+bwd, variable-N pairs (n in [30, %d])' % (args.n or 120)) if ragged else
+            'metric': ('graph-pairs/sec FGNN fwd+bwd, variable-N pairs (n in [30, %d])%s' % (args.n or 120, ', bf16' if bf16 else '')) if ragged else
                       'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,

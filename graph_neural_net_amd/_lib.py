@@ -163,6 +163,9 @@ _SIGNATURES = {
     'fgnn_chan_matmul_bwd16': [C.POINTER(Slab16), C.POINTER(Slab16), _VP, _LL, _LL, _VP, _I, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
     'fgnn_chan_matmul_bwd16_t': [C.POINTER(Slab16), C.POINTER(Slab16), _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _LL, _LL,
                                  _VP, _VP, _VP],
+    'fgnn_chan_matmul_bwd16_tc': [C.POINTER(Slab16), C.POINTER(Slab16), _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _VP, _VP, _LL, _LL,
+                                  _VP, _VP, _VP, _VP, _VP],
+    'fgnn_colmax_bwd16_coef': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab16), _VP, _VP, _VP],
     'fgnn_colmax_fwd16': [C.POINTER(Slab16), _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_colmax_bwd16': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab16), _VP, _VP],
     'fgnn_mlp_bwd16': [C.POINTER(MlpBwd16Args), _VP],

@@ -677,7 +677,8 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
                                                                        const void *dm, long long dmg, long long ldm,
                                                                        const int *nvalid, int N, int ldr, int G, void *da,
                                                                        void *db, long long ogstride, long long ldo,
-                                                                       float *s12a, float *s12b, const float *tpart, int tpg) {
+                                                                       float *s12a, float *s12b, const float *tpart, int tpg,
+                                                                       float *coefa, float *coefb) {
     extern __shared__ __attribute__((aligned(16))) char mm_lds[];
     __shared__ float red[MM_NW][4];
     constexpr bool STRIP = MMCfg<NT, NCOL>::STRIP;
@@ -752,6 +753,19 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
             }
             float *dst = (tid < 2 ? s12a : s12b) + (long long)gc * 2 + (tid & 1);
             *dst = v;
+            // dz coefficients of the two producing MLPs (the arithmetic of gn_bwd_coef_kernel), saving that launch
+            const float v2 = __shfl(v, tid | 1);
+            float *cf = tid < 2 ? coefa : coefb;
+            if (cf && !(tid & 1)) {
+                const float4 n = reinterpret_cast<const float4 *>(tid < 2 ? ya.nrm : yb.nrm)[gc];
+                const float m = (float)nv * (float)nv;
+                float4 o;
+                o.x = n.x;
+                o.y = n.y;
+                o.z = m > 0.f ? -n.y * v2 * n.w / m : 0.f;
+                o.w = m > 0.f ? -n.y * v / m : 0.f;
+                reinterpret_cast<float4 *>(cf)[gc] = o;
+            }
         }
     }
 }
@@ -776,10 +790,13 @@ int launch_fwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid
     if (F) return launch_fwd16_impl<NT, NCOL, true>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, *F, st);
     return launch_fwd16_impl<NT, NCOL, false>(ya, yb, nvalid, G, N, ldr, out, ogstride, ldo, FinArgs16{}, st);
 }
+struct CoefOut {
+    float *a = nullptr, *b = nullptr;       // optional (G*C*4) dz-coefficient records of the two operand MLPs
+};
 template <int NT, int NCOL, int STATS>
 int launch_bwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
                       int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
-                      const float *tpart, int tpg, hipStream_t st) {
+                      const float *tpart, int tpg, hipStream_t st, CoefOut co) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)chan_matmul_bwd16_kernel<NT, NCOL, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -787,17 +804,17 @@ int launch_bwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *
         attr = true;
     }
     hipLaunchKernelGGL((chan_matmul_bwd16_kernel<NT, NCOL, STATS>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya,
-                       *yb, dm, dmg, ldm, nvalid, N, ldr, G, da, db, ogstride, ldo, s12a, s12b, tpart, tpg);
+                       *yb, dm, dmg, ldm, nvalid, N, ldr, G, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, co.a, co.b);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 template <int NT, int NCOL = NT>
 int launch_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
                  int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
-                 const float *tpart, int tpg, hipStream_t st) {
-    if (!s12a) return launch_bwd16_impl<NT, NCOL, 0>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
-    if (tpart) return launch_bwd16_impl<NT, NCOL, 2>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
-    return launch_bwd16_impl<NT, NCOL, 1>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+                 const float *tpart, int tpg, hipStream_t st, CoefOut co) {
+    if (!s12a) return launch_bwd16_impl<NT, NCOL, 0>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
+    if (tpart) return launch_bwd16_impl<NT, NCOL, 2>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
+    return launch_bwd16_impl<NT, NCOL, 1>(ya, yb, dm, dmg, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
 }
 
 }  // namespace
@@ -851,8 +868,13 @@ extern "C" int fgnn_chan_matmul_fwd16_fin(const fgnn_slab16 *ya, const fgnn_slab
 
 static int matmul_bwd16_common(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
                                const int *nvalid, int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo,
-                               float *s12a, float *s12b, const float *tpart, int tpg, void *stream) {
+                               float *s12a, float *s12b, const float *tpart, int tpg, void *stream, float *coefa = nullptr,
+                               float *coefb = nullptr) {
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd16: null argument");
+    FGNN_CHECK((!coefa && !coefb) || (s12a && coefa && coefb), "fgnn_chan_matmul_bwd16_tc: the coefficient records come with the s12 sums");
+    CoefOut co;
+    co.a = coefa;
+    co.b = coefb;
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0 && N <= 256, "fgnn_chan_matmul_bwd16: bad shapes (N <= 256)");
     FGNN_CHECK(ldr >= N && ldr % 8 == 0, "fgnn_chan_matmul_bwd16: ldr must be a multiple of 8 and >= N");
     FGNN_CHECK(ya->ldp % 8 == 0 && yb->ldp % 8 == 0 && ya->gstride % 8 == 0 && yb->gstride % 8 == 0 && ldm % 8 == 0 &&
@@ -865,11 +887,11 @@ static int matmul_bwd16_common(const fgnn_slab16 *ya, const fgnn_slab16 *yb, con
                (long long)G * dmgstride < 0x7fffffffll / 2 && (long long)G * ogstride < 0x7fffffffll / 2,
                "fgnn_chan_matmul_bwd16: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) return launch_bwd16<2>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
-    if (N <= 128) return launch_bwd16<4>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+    if (N <= 64) return launch_bwd16<2>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
+    if (N <= 128) return launch_bwd16<4>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
     if (N <= 224)
-        return launch_bwd16<8, 7>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
-    return launch_bwd16<8>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st);
+        return launch_bwd16<8, 7>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
+    return launch_bwd16<8>(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, st, co);
 }
 
 extern "C" int fgnn_chan_matmul_bwd16(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,
@@ -884,4 +906,13 @@ extern "C" int fgnn_chan_matmul_bwd16_t(const fgnn_slab16 *ya, const fgnn_slab16
                                         void *stream) {
     FGNN_CHECK(tpart != nullptr, "fgnn_chan_matmul_bwd16_t: missing tile partials");
     return matmul_bwd16_common(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, stream);
+}
+
+extern "C" int fgnn_chan_matmul_bwd16_tc(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride,
+                                         long long ldm, const float *tpart, int tpg, const int *nvalid, int G, int N, int ldr,
+                                         void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
+                                         float *coefa, float *coefb, void *stream) {
+    FGNN_CHECK(tpart != nullptr, "fgnn_chan_matmul_bwd16_tc: missing tile partials");
+    return matmul_bwd16_common(ya, yb, dm, dmgstride, ldm, nvalid, G, N, ldr, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, stream,
+                               coefa, coefb);
 }

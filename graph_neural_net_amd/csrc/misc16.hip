@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void colmax_fwd16_kernel(const fgnn_slab16 y, 
 constexpr int CMB16_MAXN = 1024;
 __global__ __launch_bounds__(256) void colmax_bwd16_kernel(const float *de, const int *idx, const int *nvalid, int G, int C,
                                                            int N, int ldr, unsigned short *dy, long long gstride,
-                                                           long long ldp, const fgnn_slab16 y, float *s12) {
+                                                           long long ldp, const fgnn_slab16 y, float *s12, float *coef) {
     __shared__ int sidx[CMB16_MAXN];
     __shared__ unsigned sde[CMB16_MAXN];
     __shared__ float red[4][2];
@@ -167,7 +167,22 @@ __global__ __launch_bounds__(256) void colmax_bwd16_kernel(const float *de, cons
             red[wave][1] = s2;
         }
         __syncthreads();
-        if (tid < 2) s12[(long long)gc * 2 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (tid < 2) {
+            const float v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            s12[(long long)gc * 2 + tid] = v;
+            // dz coefficients of the producing MLP (the arithmetic of gn_bwd_coef_kernel), saving that launch
+            const float v1 = __shfl(v, 0), v2 = __shfl(v, 1);
+            if (coef && tid == 0) {
+                const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
+                const float m = (float)nv * (float)nv;
+                float4 o;
+                o.x = n.x;
+                o.y = n.y;
+                o.z = m > 0.f ? -n.y * v2 * n.w / m : 0.f;
+                o.w = m > 0.f ? -n.y * v1 / m : 0.f;
+                reinterpret_cast<float4 *>(coef)[gc] = o;
+            }
+        }
     }
 }
 
@@ -223,14 +238,20 @@ extern "C" int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G,
     return 0;
 }
 
-extern "C" int fgnn_colmax_bwd16(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
-                                 long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, void *stream) {
+extern "C" int fgnn_colmax_bwd16_coef(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
+                                      long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, float *coef,
+                                      void *stream) {
     FGNN_CHECK(de && idx && dy && G > 0 && C > 0 && N > 0 && ldr >= N && ldr % 2 == 0, "fgnn_colmax_bwd16: bad arguments");
     FGNN_CHECK(N <= CMB16_MAXN, "fgnn_colmax_bwd16: N=%d > %d", N, CMB16_MAXN);
     FGNN_CHECK(!s12 || (y && y->ptr && y->nrm), "fgnn_colmax_bwd16: s12 needs the normalised input slab");
+    FGNN_CHECK(!coef || s12, "fgnn_colmax_bwd16_coef: the coefficients come with the s12 sums");
     fgnn_slab16 none = {};
     hipLaunchKernelGGL(colmax_bwd16_kernel, dim3(G * C), dim3(256), 0, (hipStream_t)stream, de, idx, nvalid, G, C, N, ldr,
-                       (unsigned short *)dy, gstride, ldp, y ? *y : none, s12);
+                       (unsigned short *)dy, gstride, ldp, y ? *y : none, s12, coef);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_colmax_bwd16(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
+                                 long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, void *stream) {
+    return fgnn_colmax_bwd16_coef(de, idx, nvalid, G, C, N, ldr, dy, gstride, ldp, y, s12, nullptr, stream);
 }

@@ -263,16 +263,14 @@ class FgnnEngineBF16:
         gs = 32 * self.ldp
         K = L.num_blocks
 
-        def coef_from_s12(kj, slot):
-            _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12'][kj]), _lib.ptr(self.nrm[kj]), self._nv(), self.G, 32, self.N,
-                      _lib.ptr(W['coef'][slot]), None, None, st)
-            return W['coef'][slot]
-
+        # the dz coefficients of an MLP are written by the kernel that forms its s12 sums (pooling backward for the last MLP,
+        # the matmul backward for mlp1 / mlp2): no separate fgnn_gn_bwd_coef launches
         dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
-        _lib.call('fgnn_colmax_bwd16', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N, self.ldr,
-                  _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
-        coef3 = coef_from_s12((K, 3), 2)
+        _lib.call('fgnn_colmax_bwd16_coef', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N, self.ldr,
+                  _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), _lib.ptr(W['coef'][2]), st,
+                  tag='fgnn_colmax_bwd16')
+        coef3 = W['coef'][2]
         for k in range(K, 0, -1):
             sin = self._slab_in(k, params)
             first = (k == 1)
@@ -281,13 +279,10 @@ class FgnnEngineBF16:
             # its outputs from it instead of re-reading the two raw operand slabs
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False, emit=True)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
-            _lib.call('fgnn_chan_matmul_bwd16_t', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
+            _lib.call('fgnn_chan_matmul_bwd16_tc', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       _lib.ptr(W['s12part']), self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']),
-                      _lib.ptr(W['dy2']), gs, self.ldp, _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st,
-                      tag='fgnn_chan_matmul_bwd16')
-            _lib.call('fgnn_gn_bwd_coef2', _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), _lib.ptr(self.nrm[(k, 1)]),
-                      _lib.ptr(self.nrm[(k, 2)]), self._nv(), self.G, 32, self.N, _lib.ptr(W['coef'][0]),
-                      _lib.ptr(W['coef'][1]), st)
+                      _lib.ptr(W['dy2']), gs, self.ldp, _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
+                      _lib.ptr(W['coef'][0]), _lib.ptr(W['coef'][1]), st, tag='fgnn_chan_matmul_bwd16')
             self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
             self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
             if not first:

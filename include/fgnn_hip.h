@@ -393,11 +393,20 @@ int fgnn_chan_matmul_bwd16_t(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const
                              const float *tpart, int tpg, const int *nvalid, int G, int N, int ldr, void *da, void *db,
                              long long ogstride, long long ldo, float *s12a, float *s12b, void *stream);
 
+/* fgnn_chan_matmul_bwd16_t that also writes the dz-coefficient records (G*C*4, the output of fgnn_gn_bwd_coef) of the two
+ * operand MLPs from the s12 sums it has just formed -- one tiny launch per block less */
+int fgnn_chan_matmul_bwd16_tc(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmgstride, long long ldm,
+                              const float *tpart, int tpg, const int *nvalid, int G, int N, int ldr, void *da, void *db,
+                              long long ogstride, long long ldo, float *s12a, float *s12b, float *coefa, float *coefb,
+                              void *stream);
 /* ColumnMaxPooling on a bf16 slab: e (G,C,N) fp32 = max_j of the fp32-normalised values, idx int32 */
 int fgnn_colmax_fwd16(const fgnn_slab16 *y, const int *nvalid, int G, int N, int ldr, float *e, int *idx, void *stream);
 /* its backward: dy (bf16) [g,c,i,idx] = R(de[g,c,i]); s12 = {sum dy, sum dy*(z-mean)} of the rounded values */
 int fgnn_colmax_bwd16(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
                       long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, void *stream);
+/* the same, also writing the dz-coefficient record (G*C*4) of the pooled MLP from its s12 sums */
+int fgnn_colmax_bwd16_coef(const float *de, const int *idx, const int *nvalid, int G, int C, int N, int ldr, void *dy,
+                           long long gstride, long long ldp, const fgnn_slab16 *y, float *s12, float *coef, void *stream);
 
 /* MlpBlock_Real backward on bf16 slabs: see fgnn_mlp_bwd.  coef (G*32*4) is required (fgnn_gn_bwd_coef*).
  * dx outputs are rounded to bf16; with accumulate the old bf16 value is added in fp32 before rounding. */
