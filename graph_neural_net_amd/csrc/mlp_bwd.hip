@@ -519,7 +519,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
 
         // ---- layer 0: D tile = (DEPTH == 1 ? S2 : (DEPTH == 2 ? S1 : S2)); x tiles re-staged now ----
         {
-            float *Dt = (DEPTH == 2) ? S1 : S2;
+            // depth 2: S1 is free in the single-slab kernels; with a second slab it is the x_b slot, so dpre_0 goes to S2 (its
+            // last readers, the layer-1 weight-gradient operands, were issued before: LDS is in order within a wave)
+            float *Dt = (DEPTH == 2 && CB == 0) ? S1 : S2;
             if constexpr (VW0) {
                 float ya[1];
                 norm_from_lds<SA>(ya, xa, recA, normA, c_valid, h);      // channel h of this lane's pixel

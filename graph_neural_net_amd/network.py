@@ -66,11 +66,12 @@ class _EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, x, nvalid, anchor):
-        eng = net._engine_for(x, nvalid, True)
-        eng.embed(net._flat, x, nvalid)
+        params, xin = net._engine_params(), net._pad_input(x)
+        eng = net._engine_for(xin, nvalid, True)
+        eng.embed(params, xin, nvalid)
         eng.generation = getattr(eng, 'generation', 0) + 1
         ctx.net, ctx.eng, ctx.generation = net, eng, eng.generation
-        return eng.E.clone()
+        return net._crop_embedding(eng.E)
 
     @staticmethod
     def backward(ctx, dE):
@@ -81,22 +82,26 @@ class _EmbedFn(torch.autograd.Function):
                                'backward() before the next forward, or run the other forward under torch.no_grad()')
         params = net._param_list
         views = net._grad_views
-        if all(p.grad is None for p in params):            # the usual case after zero_grad(set_to_none=True)
-            eng.backward_from_dE(net._flat, net._flat_grad, dE.contiguous())
+        fresh = all(p.grad is None for p in params)        # the usual case after zero_grad(set_to_none=True)
+        target = net._flat_grad if fresh else net._flat_grad_tmp
+        dE = net._pad_dE(dE.contiguous())
+        if net._pad is None:
+            eng.backward_from_dE(net._flat, target, dE)
+        else:                                              # padded engine: gather the real entries of its gradient
+            eng.backward_from_dE(net._pad['pflat'], net._pad['pgrad'], dE)
+            torch.index_select(net._pad['pgrad'], 0, net._pad['idx'], out=target)
+        if fresh:
             for p, v in zip(params, views):
                 p.grad = v
+        elif all(p.grad is v for p, v in zip(params, views)):
+            net._flat_grad.add_(target)
         else:                                              # accumulate into whatever .grad holds
-            tmp = net._flat_grad_tmp
-            eng.backward_from_dE(net._flat, tmp, dE.contiguous())
-            if all(p.grad is v for p, v in zip(params, views)):
-                net._flat_grad.add_(tmp)
-            else:
-                for p, (off, n, shape) in zip(params, net._param_spans):
-                    g = tmp[off:off + n].view(shape)
-                    if p.grad is None:
-                        p.grad = g.clone()
-                    else:
-                        p.grad.add_(g)
+            for p, (off, n, shape) in zip(params, net._param_spans):
+                g = target[off:off + n].view(shape)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.add_(g)
         return None, None, None, torch.zeros_like(net._anchor)
 
 
@@ -107,6 +112,7 @@ class Network(nn.Module):
         for path, (node, _) in self.graph.items():
             setattr(self, path.replace(SEP, '_'), node)
         self._layout = None
+        self._pad = None          # widths below 32 embedded in the 32-wide engine by zero padding (_padded_layout)
         self._engines = {}
         self._flat = None
 
@@ -139,8 +145,92 @@ class Network(nn.Module):
             assert names == [e[0] for e in lay.entries]
             self._layout = lay
         except (AssertionError, AttributeError, RuntimeError):
-            self._layout = False
+            self._layout = self._padded_layout() or False
         return self._layout or None
+
+    def _padded_layout(self):
+        """Channel widths below the engine's (original_features_num <= 32, in_features / out_features <= 32): the same graph is
+        run by the 32-wide fused engine on zero-padded parameters and inputs -- the extra channels carry exact zeros through
+        conv / ReLU / GraphNorm (weight 0, bias 0) / matmul / pooling, so the results are those of the narrow model.  Returns the
+        padded ParamLayout and fills self._pad = {idx: position of every real parameter element inside the padded flat buffer,
+        ...}, or None when the graph does not fit."""
+        from .layers import MlpBlock_Real
+        try:
+            k = 0
+            while hasattr(self, 'ne_bm_block%d_mlp1' % (k + 1)):
+                k += 1
+            assert k > 0 and 'ne/suffix' in self.graph
+            blocks = [[getattr(self, 'ne_bm_block%d_mlp%d' % (b, j)) for j in (1, 2, 3)] for b in range(1, k + 1)]
+            depth = len(blocks[0][0].convs)
+            c0 = blocks[0][0].convs[0].in_channels
+            assert 1 <= depth <= _lib.FGNN_MAX_DEPTH and c0 <= 32
+            widths, last = [], c0
+            for m1, m2, m3 in blocks:
+                w = m1.convs[-1].out_channels
+                assert w <= 32
+                for m, cin in ((m1, last), (m2, last), (m3, w + last)):
+                    assert isinstance(m, MlpBlock_Real) and len(m.convs) == depth and m.convs[0].in_channels == cin
+                    assert all(c.out_channels == w and c.bias is not None for c in m.convs) and m.gn.features[1] == w
+                    assert m.gn.weight is not None
+                widths.append(w)
+                last = w
+            c0p = 2 if c0 <= 2 else 32
+            lay = ParamLayout(c0p, k, 32, 32, depth)
+            named = list(self.named_parameters())
+            assert [n for n, _ in named] == [e[0] for e in lay.entries]
+            idx = []
+            for (name, off, shape), (_, p) in zip(lay.entries, named):
+                b = int(name.split('block')[1].split('_')[0])
+                w, lin = widths[b - 1], (c0 if b == 1 else widths[b - 2])
+                if p.dim() == 4 and p.shape[0] != 1:             # conv weight (o, ci, 1, 1) inside (32, cp, 1, 1)
+                    o, ci, cp = p.shape[0], p.shape[1], shape[1]
+                    cols = torch.arange(ci)
+                    if '_mlp3.convs.0.' in name:                  # [mult (w) ; block input (lin)] -> [32 ; padded input]
+                        cols = torch.where(cols < w, cols, 32 + cols - w)
+                    idx.append((off + torch.arange(o)[:, None] * cp + cols[None, :]).reshape(-1))
+                else:                                             # conv bias (o,), gn weight / bias (1, o, 1, 1)
+                    idx.append(off + torch.arange(p.numel()))
+            self._pad = {'idx': torch.cat(idx), 'c0': c0, 'c0p': c0p, 'cout': widths[-1], 'total': lay.total, 'xbuf': {}}
+            return lay
+        except (AssertionError, AttributeError, RuntimeError, IndexError, ValueError):
+            self._pad = None
+            return None
+
+    def _engine_params(self):
+        """The flat parameter buffer the engine reads: the bound one, or its zero-padded image."""
+        if self._pad is None:
+            return self._flat
+        P = self._pad
+        if P.get('pflat') is None or P['pflat'].device != self._flat.device:
+            P['idx'] = P['idx'].to(self._flat.device)
+            P['pflat'] = torch.zeros(P['total'], dtype=torch.float32, device=self._flat.device)
+            P['pgrad'] = torch.zeros_like(P['pflat'])
+        P['pflat'].index_copy_(0, P['idx'], self._flat)
+        return P['pflat']
+
+    def _pad_input(self, x):
+        P = self._pad
+        if P is None or P['c0p'] == P['c0']:
+            return x
+        key = (tuple(x.shape), x.device)
+        buf = P['xbuf'].get(key)
+        if buf is None:
+            P['xbuf'].clear()
+            buf = P['xbuf'][key] = torch.zeros(x.shape[0], P['c0p'], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+        buf[:, :P['c0']].copy_(x)
+        return buf
+
+    def _crop_embedding(self, E):
+        if self._pad is None or self._pad['cout'] == E.shape[1]:
+            return E.clone()
+        return E[:, :self._pad['cout']].contiguous()
+
+    def _pad_dE(self, dE):
+        if self._pad is None or self._pad['cout'] == 32:
+            return dE
+        full = torch.zeros(dE.shape[0], 32, dE.shape[2], dtype=dE.dtype, device=dE.device)
+        full[:, :dE.shape[1]].copy_(dE)
+        return full
 
     def _bind_flat(self):
         """Move every parameter of the standard layout into one flat fp32 buffer (the parameters become views of it, in
@@ -206,9 +296,10 @@ class Network(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list):
             e = _EmbedFn.apply(self, t.contiguous(), nvalid, self._anchor)
         else:
-            eng = self._engine_for(t, nvalid, False)
-            eng.embed(self._flat, t.contiguous(), nvalid)
-            e = eng.E.clone()
+            xin = self._pad_input(t.contiguous())
+            eng = self._engine_for(xin, nvalid, False)
+            eng.embed(self._engine_params(), xin, nvalid)
+            e = self._crop_embedding(eng.E)
         if isinstance(x, MaskedTensor):
             return MaskedTensor(e, nvalid, (2,), x.base_name)
         return e

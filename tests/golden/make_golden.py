@@ -462,9 +462,30 @@ def main_widths():
         d['ragged/grad64/' + k] = v.numpy()
     np.savez_compressed(os.path.join(OUT, 'widths_c3_16_48_d2_2blk.npz'), **d)
     meta['cases']['widths_c3_16_48_d2_2blk'] = {'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst}
+
+    # ---- widths that fit inside the 32-wide engine (zero-padded there): 3 -> 16 -> 24, depth 2, 3 blocks ----
+    torch.manual_seed(12)
+    model = Siamese_Node_Exp(3, dict(NODE_EMB, num_blocks=3, in_features=16, out_features=24, depth_of_mlp=2))
+    perturb_(model, 500)
+    g = torch.Generator().manual_seed(501)
+    x1 = torch.randn(4, 3, 21, 21, generator=g)
+    x2 = torch.randn(4, 3, 21, 21, generator=g)
+    worst = check_oracle_bit_equal(model, x1, x2, 'widths_narrow')
+    s, l, gr = ref_step(model, x1, x2)
+    s64, l64, gr64 = ref_step(f64(model), x1.double(), x2.double())
+    d = {'x1': x1.numpy(), 'x2': x2.numpy(), 'scores': s.numpy(), 'loss': l.numpy(), 'scores64': s64.numpy(),
+         'loss64': l64.numpy(), 'config': np.array([3, 3, 16, 24, 2])}
+    for k, v in model.state_dict().items():
+        d['sd/' + k[len('node_embedder.'):]] = v.numpy()
+    for k, v in gr.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in gr64.items():
+        d['grad64/' + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'widths_c3_16_24_d2_3blk.npz'), **d)
+    meta['cases']['widths_c3_16_24_d2_3blk'] = {'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst}
     with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
         json.dump(meta, f, indent=1, sort_keys=True)
-    print(json.dumps(meta['cases']['widths_c3_16_48_d2_2blk'], indent=1, sort_keys=True))
+    print(json.dumps({k: v for k, v in meta['cases'].items() if k.startswith('widths')}, indent=1, sort_keys=True))
 
 
 if __name__ == '__main__':

@@ -79,7 +79,11 @@ def test_layers_against_reference_golden():
 
 
 @pytest.mark.parametrize('cin,depth,sizes', [(2, 1, [5, 9]), (2, 3, [50]), (16, 2, [7, 12, 33]), (32, 3, [20, 20]),
-                                              (32, 1, [3]), (32, 2, [40, 17]), (16, 3, [64, 65])])
+                                              (32, 1, [3]), (32, 2, [40, 17]), (16, 3, [64, 65]),
+                                              # two-slab inputs (mlp3 = [mult ; in]) at every depth: depth 2 once shared an LDS
+                                              # slot between x_b and dpre_0 (found by the narrow-width goldens)
+                                              (34, 1, [9, 6]), (34, 2, [21, 8]), (34, 3, [12]), (64, 1, [10]), (64, 2, [33, 20]),
+                                              (64, 3, [18, 7])])
 def test_mlp_block_autograd_matches_oracle(cin, depth, sizes):
     """MlpBlock_Real forward + autograd (through fgnn_mlp_fwd / fgnn_mlp_bwd) for every supported single-slab
     input width and depth, dense and ragged, against the oracle's per-graph autograd on the CPU."""

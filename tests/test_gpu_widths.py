@@ -216,3 +216,84 @@ def test_any_width_trains_and_bf16_is_refused():
     assert loss.item() < 0.8 * first
     with pytest.raises(RuntimeError, match='bf16'):
         Siamese_Node_Exp(3, NE, precision='bf16').to(DEV)({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+
+
+def test_narrow_widths_run_zero_padded_on_the_fused_engine():
+    """original_features_num 3, in_features 16, out_features 24, depth 2, 3 blocks: every width <= 32, so Network embeds the
+    model in the 32-wide fused engine (zero-padded parameters / input).  Scores, loss and every gradient against the
+    reference's own fp32 / fp64 runs; .grad accumulation; agreement with the per-layer module path."""
+    d = load_golden('widths_c3_16_24_d2_3blk.npz')
+    ne = dict(NE, num_blocks=3, in_features=16, out_features=24, depth_of_mlp=2)
+    model = Siamese_Node_Exp(3, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    net = model.node_embedder
+    assert net._standard_layout() is not None and net._pad is not None and net._pad['c0p'] == 32
+    b1, b2 = {'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)}
+    scores = model(b1, b2)
+    assert scores.shape == d['scores'].shape
+    loss = model.loss(scores)
+    loss.backward()
+    assert rel(scores.detach().cpu(), d['scores64']) < max(2 * rel(d['scores'], d['scores64']), 1e-5)
+    assert abs(loss.item() - d['loss64'].item()) < 1e-5 * d['loss64'].item()
+    fused = {}
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        assert p.grad is not None and p.grad.shape == p.shape
+        fused[k] = p.grad.clone()
+        if is_zero_grad(k, 2):
+            assert p.grad.abs().max() < 1e-4
+        else:
+            yard = rel(d['grad/' + k], d['grad64/' + k])
+            assert rel(p.grad.cpu(), d['grad64/' + k]) < 4 * yard + 1e-5, k
+    model.loss(model(b1, b2)).backward()                       # accumulates
+    k = 'ne_bm_block3_mlp3.convs.0.weight'
+    assert rel(net.ne_bm_block3_mlp3.convs[0].weight.grad, 2 * fused[k]) < 1e-6
+    with torch.no_grad():                                       # evaluation forward
+        assert torch.equal(model(b1, b2), scores.detach())
+    # the per-layer module path (conv.hip) on the same weights
+    ref = Siamese_Node_Exp(3, ne).to(DEV)
+    ref.load_state_dict(model.state_dict())
+    ref.node_embedder._layout = False
+    s2 = ref(b1, b2)
+    ref.loss(s2).backward()
+    assert rel(s2.detach(), scores.detach()) < 2e-5
+    for (n, p), (_, q) in zip(ref.named_parameters(), model.named_parameters()):
+        if not is_zero_grad(n, 2):
+            assert rel(p.grad, fused[n[len('node_embedder.'):]]) < 2e-3, n
+
+
+@pytest.mark.parametrize('c0,width,depth,ragged', [(1, 8, 3, False), (2, 16, 3, True), (5, 32, 1, True), (32, 20, 2, False)])
+def test_padded_engine_matches_oracle(c0, width, depth, ragged):
+    """more narrow configurations (1- / 2-channel inputs keep the 2-channel first block, others pad the input to 32 channels),
+    constant-size and ragged (MaskedTensor) batches, against the oracle in fp64 with its fp32 run as the yard-stick"""
+    torch.manual_seed(c0 * 100 + width)
+    sd = O.init_state_dict(original_features_num=c0, num_blocks=2, in_features=width, out_features=width, depth_of_mlp=depth)
+    g = torch.Generator().manual_seed(c0)
+    sizes = (9, 14, 11) if ragged else (12, 12, 12)
+    xs = [torch.randn(c0, n, n, generator=g) for n in sizes]
+    ys = [torch.randn(c0, n, n, generator=g) for n in sizes]
+    s32, l32, g32 = O.step_fwd_bwd_ragged(xs, ys, sd)
+    s64, l64, g64 = O.step_fwd_bwd_ragged([t.double() for t in xs], [t.double() for t in ys], {k: v.double() for k, v in sd.items()})
+    ne = dict(NE, num_blocks=2, in_features=width, out_features=width, depth_of_mlp=depth, constant_n_vertices=not ragged)
+    model = Siamese_Node_Exp(c0, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sd.items()})
+    assert model.node_embedder._standard_layout() is not None
+    assert (model.node_embedder._pad is None) == (c0 in (2, 32) and width == 32)
+    if ragged:
+        scores = model(from_list([t.to(DEV) for t in xs], dims=(1, 2), base_name='N'),
+                       from_list([t.to(DEV) for t in ys], dims=(1, 2), base_name='M'))
+        got = list(scores)
+    else:
+        scores = model(torch.stack(xs).to(DEV), torch.stack(ys).to(DEV))
+        got = list(scores)
+    loss = model.loss(scores)
+    loss.backward()
+    for a, b32, b64 in zip(got, s32, s64):
+        assert a.shape == b64.shape and rel(a.detach().cpu(), b64) < max(4 * rel(b32, b64), 2e-5)
+    assert abs(loss.item() - l64.item()) < 1e-5 * abs(l64.item())
+    keys = [k for k in g64 if not is_zero_grad(k, depth)]
+    grads = {n[len('node_embedder.'):]: p.grad.cpu() for n, p in model.named_parameters()}
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g32[k].reshape(-1).double() for k in keys])
+    t = torch.cat([g64[k].reshape(-1) for k in keys])
+    assert (a - t).norm() <= 4.0 * (b - t).norm() + 1e-5 * t.norm()
