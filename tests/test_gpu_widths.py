@@ -262,7 +262,9 @@ def test_narrow_widths_run_zero_padded_on_the_fused_engine():
             assert rel(p.grad, fused[n[len('node_embedder.'):]]) < 2e-3, n
 
 
-@pytest.mark.parametrize('c0,width,depth,ragged', [(1, 8, 3, False), (2, 16, 3, True), (5, 32, 1, True), (32, 20, 2, False)])
+@pytest.mark.parametrize('c0,width,depth,ragged', [(1, 8, 3, False), (2, 16, 3, True), (5, 32, 1, True), (32, 20, 2, False),
+                                                   # the un-padded engine at depths 1 and 2 (the 2 / 32+2 channel kernels)
+                                                   (2, 32, 2, False), (2, 32, 1, True), (32, 32, 2, True)])
 def test_padded_engine_matches_oracle(c0, width, depth, ragged):
     """more narrow configurations (1- / 2-channel inputs keep the 2-channel first block, others pad the input to 32 channels),
     constant-size and ragged (MaskedTensor) batches, against the oracle in fp64 with its fp32 run as the yard-stick"""
