@@ -299,3 +299,29 @@ def test_padded_engine_matches_oracle(c0, width, depth, ragged):
     b = torch.cat([g32[k].reshape(-1).double() for k in keys])
     t = torch.cat([g64[k].reshape(-1) for k in keys])
     assert (a - t).norm() <= 4.0 * (b - t).norm() + 1e-5 * t.norm()
+
+
+def test_narrow_model_in_bf16_runs_on_the_padded_bf16_engine():
+    """precision='bf16' with in_features = out_features = 16 (2-channel input, depth 3): the bf16 engine on the zero-padded
+    layout; scores / gradient direction follow the fp32 run of the same model."""
+    torch.manual_seed(3)
+    ne = dict(NE, num_blocks=2, in_features=16, out_features=16, depth_of_mlp=3)
+    m32 = Siamese_Node_Exp(2, ne).to(DEV)
+    m16 = Siamese_Node_Exp(2, ne, precision='bf16').to(DEV)
+    m16.load_state_dict(m32.state_dict())
+    from graph_neural_net_amd import synthetic
+    x1, x2 = synthetic.make_batch(42, 4, 24, 'ErdosRenyi', 0.3, 0.1)
+    x1, x2 = x1.to(DEV), x2.to(DEV)
+    out = {}
+    for name, m in (('fp32', m32), ('bf16', m16)):
+        s = m(x1, x2)
+        m.loss(s).backward()
+        out[name] = (s.detach(), torch.cat([p.grad.reshape(-1) for p in m.parameters()]))
+    assert m16.node_embedder._pad is not None
+    from graph_neural_net_amd.engine16 import FgnnEngineBF16
+    assert all(isinstance(e, FgnnEngineBF16) for e in m16.node_embedder._engines.values())
+    s32, g32 = out['fp32']
+    s16, g16 = out['bf16']
+    assert torch.isfinite(s16).all() and torch.isfinite(g16).all()
+    assert ((s16 - s32).norm() / s32.norm()).item() < 5e-2
+    assert (torch.dot(g16, g32) / (g16.norm() * g32.norm())).item() > 0.95
