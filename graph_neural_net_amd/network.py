@@ -140,9 +140,12 @@ class Network(nn.Module):
             assert k > 0 and isinstance(m1, MlpBlock_Real) and 'ne/suffix' in self.graph
             c0 = m1.convs[0].in_channels
             depth = len(m1.convs)
-            lay = ParamLayout(c0, k, m1.convs[0].out_channels, m1.convs[-1].out_channels, depth)
-            names = [n for n, _ in self.named_parameters()]
-            assert names == [e[0] for e in lay.entries]
+            last = getattr(self, 'ne_bm_block%d_mlp3' % k)
+            lay = ParamLayout(c0, k, m1.convs[0].out_channels if k > 1 else 32, last.convs[-1].out_channels, depth)
+            named = list(self.named_parameters())
+            assert [n for n, _ in named] == [e[0] for e in lay.entries]
+            # every tensor must have the engine's shape (names alone do not tell a 32 -> 16 model from the 32 -> 32 one)
+            assert all(tuple(p.shape) == tuple(e[2]) for (_, p), e in zip(named, lay.entries))
             self._layout = lay
         except (AssertionError, AttributeError, RuntimeError):
             self._layout = self._padded_layout() or False

@@ -325,3 +325,28 @@ def test_narrow_model_in_bf16_runs_on_the_padded_bf16_engine():
     assert torch.isfinite(s16).all() and torch.isfinite(g16).all()
     assert ((s16 - s32).norm() / s32.norm()).item() < 5e-2
     assert (torch.dot(g16, g32) / (g16.norm() * g32.norm())).item() > 0.95
+
+
+@pytest.mark.parametrize('c0,win,wout,depth,nblk', [(2, 32, 16, 1, 3), (32, 32, 4, 3, 2), (2, 16, 32, 2, 2)])
+def test_mixed_in_out_widths_are_not_mistaken_for_the_standard_layout(c0, win, wout, depth, nblk):
+    """in_features = 32 with a narrower out_features has the standard parameter NAMES but not its shapes (it used to be taken
+    for the 32/32 layout: garbage scores, out-of-bounds reads); it must run zero-padded and agree with the oracle."""
+    torch.manual_seed(win + wout)
+    sd = O.init_state_dict(original_features_num=c0, num_blocks=nblk, in_features=win, out_features=wout, depth_of_mlp=depth)
+    g = torch.Generator().manual_seed(7)
+    x1, x2 = torch.randn(2, c0, 17, 17, generator=g), torch.randn(2, c0, 17, 17, generator=g)
+    s32, l32, g32 = O.step_fwd_bwd(x1, x2, sd)
+    s64, l64, g64 = O.step_fwd_bwd(x1.double(), x2.double(), {k: v.double() for k, v in sd.items()})
+    ne = dict(NE, num_blocks=nblk, in_features=win, out_features=wout, depth_of_mlp=depth)
+    model = Siamese_Node_Exp(c0, ne).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sd.items()})
+    assert model.node_embedder._standard_layout() is not None and model.node_embedder._pad is not None
+    scores = model(x1.to(DEV), x2.to(DEV))
+    model.loss(scores).backward()
+    assert rel(scores.detach().cpu(), s64) < max(4 * rel(s32, s64), 2e-5)
+    keys = [k for k in g64 if not is_zero_grad(k, depth)]
+    grads = {n[len('node_embedder.'):]: p.grad.cpu() for n, p in model.named_parameters()}
+    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
+    b = torch.cat([g32[k].reshape(-1).double() for k in keys])
+    t = torch.cat([g64[k].reshape(-1) for k in keys])
+    assert (a - t).norm() <= 4.0 * (b - t).norm() + 1e-5 * t.norm()
