@@ -350,3 +350,49 @@ def test_mixed_in_out_widths_are_not_mistaken_for_the_standard_layout(c0, win, w
     b = torch.cat([g32[k].reshape(-1).double() for k in keys])
     t = torch.cat([g64[k].reshape(-1) for k in keys])
     assert (a - t).norm() <= 4.0 * (b - t).norm() + 1e-5 * t.norm()
+
+
+def test_conv1x1_with_padded_strides():
+    """fgnn_conv1x1 / fgnn_conv1x1_dw on tensors whose channel / graph strides are larger than the data (ld > N*N, gstride >
+    C*ld): the values between the planes must be neither read into the result nor overwritten."""
+    G, K, M, N = 2, 5, 37, 9
+    P = N * N
+    ldx, ldy = P + 7, P + 3
+    gsx, gsy = K * ldx + 11, M * ldy + 5
+    g = torch.Generator().manual_seed(0)
+    xbuf = torch.full((G * gsx,), 1e30)
+    x = torch.randn(G, K, P, generator=g)
+    for gi in range(G):
+        for k in range(K):
+            xbuf[gi * gsx + k * ldx: gi * gsx + k * ldx + P] = x[gi, k]
+    w = torch.randn(M, K, generator=g)
+    b = torch.randn(M, generator=g)
+    ref = torch.relu(torch.einsum('mk,gkp->gmp', w.double(), x.double()) + b.double()[None, :, None])
+    xd, wd, bd = xbuf.to(DEV), w.to(DEV), b.to(DEV)
+    ybuf = torch.full((G * gsy,), -7.0, device=DEV)
+    _lib.call('fgnn_conv1x1', _lib.ptr(xd), gsx, ldx, None, _lib.ptr(wd), K, 1, _lib.ptr(bd), 1, None, G, N, M, K,
+              _lib.ptr(ybuf), gsy, ldy, _lib.stream_ptr())
+    yb = ybuf.cpu()
+    seen = torch.zeros(G * gsy, dtype=torch.bool)
+    for gi in range(G):
+        for m in range(M):
+            o = gi * gsy + m * ldy
+            assert rel(yb[o:o + P], ref[gi, m]) < 1e-5
+            seen[o:o + P] = True
+    assert (yb[~seen] == -7.0).all()                     # nothing written between the planes
+    # parameter gradients from the same strided tensors
+    dy = torch.randn(G, M, P, generator=g)
+    dbuf = torch.full((G * gsy,), 1e30)
+    for gi in range(G):
+        for m in range(M):
+            dbuf[gi * gsy + m * ldy: gi * gsy + m * ldy + P] = dy[gi, m]
+    chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
+    cnt = M * K + M
+    wpart = torch.empty(chunks * cnt, device=DEV)
+    flat = torch.empty(cnt, device=DEV)
+    _lib.call('fgnn_conv1x1_dw', _lib.ptr(dbuf.to(DEV)), gsy, ldy, None, _lib.ptr(xd), gsx, ldx, None, G, N, M, K,
+              _lib.ptr(wpart), _lib.stream_ptr())
+    _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat), _lib.stream_ptr())
+    dw_ref = torch.einsum('gmp,gkp->mk', dy.double(), x.double())
+    assert rel(flat[:M * K].view(M, K).cpu(), dw_ref) < 1e-5
+    assert rel(flat[M * K:].cpu(), dy.double().sum((0, 2))) < 1e-5
