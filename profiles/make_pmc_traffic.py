@@ -33,7 +33,7 @@ def collect(src, tags, prefix):
     for line in open(src):
         m = re.match(r'^(\S.*?)\s+\(avg', line)
         if m:
-            cur = tags.get(m.group(1).strip())
+            cur = tags.get(m.group(1).strip().replace(', false', ''))       # (PK / SKIP template flags of the dense kernels)
             if cur:
                 cur = prefix + cur
                 out[cur] = {}
