@@ -475,6 +475,178 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
 }
 
 
+// ---------------------------------------------------------------------------------------
+// One WAVE per (g,c) matrix (N <= 64): no workgroup barrier, every operand element is loaded and normalised by
+// exactly one lane, about a fifth of the instructions per matrix of the workgroup-per-matrix kernels above.
+//   k-step s of half-wave h contracts k = 2 s + h, s = 0 .. 4*KQ - 1 (the summation order of the kernels above)
+//   A operand (lane = output row): the matrix is loaded row by row (lane = column: coalesced), normalised and
+//       staged in a wave-private LDS tile with the even columns in floats 0..31 and the odd ones in 32..63 of a
+//       row (row stride 68 floats), so that four consecutive k-steps of a lane are one conflict-free ds_read_b128;
+//   B operand (lane = output column, row k): loaded from global memory straight into the fragment layout
+//       (a half-wave reads 32 consecutive floats of row k);
+//   output: the D fragments are stored directly (a half-wave writes 32 consecutive floats of one row).
+// Masking without per-element selects: a padding COLUMN gets the per-lane constants a_eff = beta_eff = 0 (its
+// load is out of range and returns 0), a padding ROW of B is out of range of the per-matrix buffer descriptor
+// (reads 0; its value only meets the zero columns of A), a padding row of A (ragged batches only) is selected to 0.
+// ---------------------------------------------------------------------------------------
+constexpr int WLD = 68;            // floats per row of the wave-private A tile
+constexpr int W_WAVES = 2;         // matrices (waves) per workgroup
+
+DEVI rsrc_t mat_rsrc(const float *p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+DEVI float rsrc_load(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+DEVI void rsrc_store(float x, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), r, voff, soff, 0);
+}
+
+// rows 0 .. 8*KQ-1 of one matrix, lane = column; rows >= N re-read row 0 (never used)
+template <int KQ>
+DEVI void wave_rows_load(float (&x)[8 * KQ], rsrc_t r, int N, int voff) {
+#pragma unroll
+    for (int i = 0; i < 8 * KQ; ++i) x[i] = rsrc_load(r, voff, i < N ? i * N * 4 : 0);
+}
+// normalise (a_eff, beta_eff are 0 in padding columns) and stage as [row][pos(col)]; ragged: rows >= nv become 0
+template <int KQ>
+DEVI void wave_rows_stage(float *T, const float (&x)[8 * KQ], float mean, float a_eff, float b_eff, int nv, int N, int lane) {
+    if (nv < N) {
+#pragma unroll
+        for (int i = 0; i < 8 * KQ; ++i) {
+            const float v = (x[i] - mean) * a_eff + b_eff;
+            T[i * WLD + lane] = i < nv ? v : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8 * KQ; ++i) T[i * WLD + lane] = (x[i] - mean) * a_eff + b_eff;
+    }
+}
+
+template <int KQ, bool FIN>
+__global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                                           const int *nvalid, int N, int M, float *out,
+                                                                           long long ogstride, long long ldo,
+                                                                           const FinArgs F) {
+    constexpr int KH = 4 * KQ;
+    constexpr bool TWO = KQ > 4;                       // N > 32: two row blocks x two column blocks
+    constexpr int NB = TWO ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float lds[W_WAVES * 32 * NB * WLD];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gc = blockIdx.x * W_WAVES + wv;
+    if (gc >= M) return;
+    const int C = ya.C;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = __builtin_amdgcn_readfirstlane(nvalid_of(nvalid, g, N));
+    const int j = lane & 31, h = lane >> 5;
+    float *As = lds + wv * (32 * NB * WLD);
+    const rsrc_t rA = mat_rsrc(ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp, nv * N * 4);
+    const rsrc_t rB = mat_rsrc(yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp, nv * N * 4);
+    const rsrc_t rO = mat_rsrc(out + (long long)g * ogstride + (long long)c * ldo, N * N * 4);
+
+    TilePartials ta, tb;
+    if (FIN) {
+        ta = finalize_load(F.part_a, F.cnt, g, c, C, F.tpg, lane);
+        tb = finalize_load(F.part_b, F.cnt, g, c, C, F.tpg, lane);
+    }
+    // ---- every load of the matrix pair goes out before anything waits ----
+    float xa[8 * KQ], xb[NB][KH];
+    wave_rows_load<KQ>(xa, rA, N, lane < nv ? lane * 4 : OOB_OFF);
+    int voffB[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        const int col = 32 * cb + j;
+        voffB[cb] = col < nv ? (h * N + col) * 4 : OOB_OFF;
+    }
+#pragma unroll
+    for (int s = 0; s < KH; ++s)         // in the order the k-steps consume them (vector memory returns in order)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) xb[cb][s] = rsrc_load(rB, voffB[cb] + s * 2 * N * 4, 0);
+    // ---- GraphNorm records ----
+    float meanA, aA, meanB, aB;
+    if (FIN) {
+        const float4 ra = finalize_reduce(ta, (float)nv, F.gw_a ? F.gw_a[c] : 1.f, F.eps);
+        const float4 rb = finalize_reduce(tb, (float)nv, F.gw_b ? F.gw_b[c] : 1.f, F.eps);
+        if (lane == 0) {
+            reinterpret_cast<float4 *>(F.nrm_a)[gc] = ra;
+            reinterpret_cast<float4 *>(F.nrm_b)[gc] = rb;
+        }
+        meanA = ra.x; aA = ra.y; meanB = rb.x; aB = rb.y;
+    } else {
+        const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+        meanA = na.mean; aA = na.a; meanB = nb.mean; aB = nb.a;
+    }
+    const bool onA = FIN || ya.nrm != nullptr, onB = FIN || yb.nrm != nullptr;
+    const float betaA = (onA && ya.beta) ? ya.beta[c] : 0.f, betaB = (onB && yb.beta) ? yb.beta[c] : 0.f;
+    // ---- A: normalise, stage ----
+    {
+        const bool okc = lane < nv;
+        wave_rows_stage<KQ>(As, xa, meanA, okc ? aA : 0.f, okc ? betaA : 0.f, nv, N, (lane & 1) * 32 + (lane >> 1));
+    }
+    // ---- B: normalised chunk by chunk right before its MFMAs (the later rows are still in flight) ----
+    float aeB[NB], beB[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        const bool okc = 32 * cb + j < nv;
+        aeB[cb] = okc ? aB : 0.f;
+        beB[cb] = okc ? betaB : 0.f;
+    }
+    // ---- products: NB x NB independent accumulator chains ----
+    f32x16 acc[NB][NB];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        float4 af[NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb)
+            af[rb] = *reinterpret_cast<const float4 *>(As + (32 * rb + j) * WLD + h * 32 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float bv[NB];
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) bv[cb] = (xb[cb][4 * q + t] - meanB) * aeB[cb] + beB[cb];
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb) {
+                const float a = t == 0 ? af[rb].x : (t == 1 ? af[rb].y : (t == 2 ? af[rb].z : af[rb].w));
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = mfma32(a, bv[cb], acc[rb][cb]);
+            }
+        }
+    }
+    // ---- output: row 32 rb + ch_of(r, h), column 32 cb + j; rows >= N are out of range of the descriptor ----
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        const int col = 32 * cb + j;
+        const int voffO = col < N ? (4 * h * N + col) * 4 : OOB_OFF;
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                rsrc_store(acc[rb][cb][r], rO, voffO + (32 * rb + (r & 3) + 8 * (r >> 2)) * N * 4, 0);
+    }
+}
+
+template <bool FIN>
+int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int N, int M, float *out, long long ogstride,
+                 long long ldo, const FinArgs &F, hipStream_t st) {
+    const int KQ = (N + 7) / 8, grid = (M + W_WAVES - 1) / W_WAVES;
+#define FGNN_W(K_)                                                                                                       \
+    case K_:                                                                                                             \
+        hipLaunchKernelGGL((chan_matmul_fwd_w_kernel<K_, FIN>), dim3(grid), dim3(64 * W_WAVES), 0, st, *ya, *yb, nvalid, N, \
+                           M, out, ogstride, ldo, F);                                                                    \
+        break;
+    switch (KQ) {
+        FGNN_W(1) FGNN_W(2) FGNN_W(3) FGNN_W(4) FGNN_W(5) FGNN_W(6) FGNN_W(7) FGNN_W(8)
+    }
+#undef FGNN_W
+    return 0;
+}
+
 // =======================================================================================
 // Whole matrix per workgroup, 64 < N <= 256 (cfg4 N = 200, ragged batches padded past 64).
 // One 512-thread workgroup owns one (g,c) matrix: every operand element is read from HBM once,
@@ -761,6 +933,11 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
 
 inline bool big_path(int N) { return N > TM && N <= 256; }
 
+// debug only (tests/diag/gpu_mm_variants_equal.py): 0 selects the workgroup-per-matrix forward kernel for N <= 64, whose
+// results the wave-per-matrix kernel reproduces bit for bit
+int g_mm_wave_variant = 1;
+inline bool mm_wave_variant() { return g_mm_wave_variant != 0; }
+
 }  // namespace
 
 extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
@@ -774,6 +951,11 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
                    "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
         FGNN_CHECK((long long)G * ogstride < 0x7fffffffll / 4, "fgnn_chan_matmul_fwd: output exceeds 2 GiB");
         const int M = G * ya->C;
+        if (mm_wave_variant()) {
+            launch_fwd_w<false>(ya, yb, nvalid, N, M, out, ogstride, ldo, FinArgs{}, (hipStream_t)stream);
+            FGNN_LAUNCH_CHECK();
+            return 0;
+        }
         hipLaunchKernelGGL(chan_matmul_fwd1_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid,
                            N, M, out, ogstride, ldo, FinArgs{});
         FGNN_LAUNCH_CHECK();
@@ -808,6 +990,11 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
 
 extern "C" int fgnn_chan_matmul_fwd_fin_supported(int N) { return N <= TM ? 1 : 0; }
 
+extern "C" int fgnn_debug_matmul_variant(int wave_per_matrix) {
+    g_mm_wave_variant = wave_per_matrix;
+    return 0;
+}
+
 extern "C" int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
                                         const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
                                         const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
@@ -822,6 +1009,11 @@ extern "C" int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb
     const int M = G * ya->C;
     FinArgs F = {part_a, part_b, cnt, gn_weight_a, gn_weight_b, const_cast<float *>(ya->nrm), const_cast<float *>(yb->nrm), eps,
                  fgnn_tiles_per_graph(N)};
+    if (mm_wave_variant()) {
+        launch_fwd_w<true>(ya, yb, nvalid, N, M, out, ogstride, ldo, F, (hipStream_t)stream);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(chan_matmul_fwd1_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, *ya, *yb, nvalid, N, M, out,
                        ogstride, ldo, F);
     FGNN_LAUNCH_CHECK();
