@@ -343,6 +343,25 @@ def main():
                          'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
                          'alt_hbm_gbs': by / dur / 1e9, 'alt_mfma_tflops': fl / dur / 1e12})
         kernels = summary
+        # context for the fractions above: what a cache-cold device copy moves on THIS box (the best case of a streaming
+        # kernel whose inputs another kernel wrote) -- 8 x (32 MiB -> 32 MiB), event-timed
+        try:
+            bufs = [(torch.empty(8 << 20, dtype=torch.float32, device=dev).normal_(), torch.empty(8 << 20, dtype=torch.float32, device=dev))
+                    for _ in range(8)]
+            for s_, d_ in bufs:
+                d_.copy_(s_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(4):
+                for s_, d_ in bufs:
+                    d_.copy_(s_)
+            e1.record()
+            torch.cuda.synchronize()
+            roofline['cold_copy_gbs'] = 4 * 8 * 2 * (32 << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del bufs
+        except RuntimeError:
+            pass
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
