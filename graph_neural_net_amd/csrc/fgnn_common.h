@@ -111,6 +111,16 @@ DEVI float relu1(float x) {
 
 DEVI int nvalid_of(const int *nvalid, int g, int N) { return nvalid ? nvalid[g] : N; }
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own L2.  Kernels whose consecutive logical
+// workgroups share per-graph data (the 32 channel matrices of one graph read the same rows of tile statistics) remap
+// blockIdx so that consecutive logical indices run on ONE XCD; otherwise all eight L2s fetch the same lines
+// (PMC: +20 MB per launch of the forward matmul with finalize at G = 64, N = 50).  A pure performance mapping: any
+// dispatch order gives the same results.
+DEVI int xcd_swizzle(int b, int n) {
+    const int n8 = n & ~7;
+    return b < n8 ? (b & 7) * (n8 >> 3) + (b >> 3) : b;
+}
+
 // ---- ragged batches: tiles inside the padding ------------------------------------------------------------------------
 // A tile = T consecutive elements of a plane stored with row pitch `pitch` (fp32 slabs: T = FGNN_TILE, pitch = N; bf16
 // slabs: T = 64, pitch = ldr).  Does tile tt hold an element of the valid nv x nv corner?

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(cons
     constexpr int NB = TWO ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float lds[W_WAVES * 32 * NB * WLD];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gc = blockIdx.x * W_WAVES + wv;
+    const int gc = xcd_swizzle(blockIdx.x, gridDim.x) * W_WAVES + wv;
     if (gc >= M) return;
     const int C = ya.C;
     const int g = gc / C, c = gc - g * C;

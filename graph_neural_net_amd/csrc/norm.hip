@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const FinalizeJobs J, 
     const float *part = J.part[blockIdx.y];
     const float *gw = J.gw[blockIdx.y];
     float *nrm = J.nrm[blockIdx.y];
-    const int idx = blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    const int idx = xcd_swizzle(blockIdx.x, gridDim.x) * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (idx >= G * C) return;
     const int lane = threadIdx.x & 63;
     const int g = idx / C, c = idx - g * C;

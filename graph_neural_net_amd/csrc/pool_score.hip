@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
                                                              float *e, int *idx, const ColmaxFin F) {
     __shared__ float sm[4][64 * 65];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gc = blockIdx.x * 4 + wave;
+    const int gc = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + wave;
     const int C = y.C;
     if (gc >= G * C) return;
     const int g = gc / C, c = gc - g * C;
