@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
 // dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
 // de1[c][i] = sum_j e2[c][j] dS[i][j];  de2[c][j] = sum_i e1[c][i] dS[i][j].
 // grid (B, CSPLIT): every workgroup stages dS (N x N) once in LDS and handles C/CSPLIT channels.
-constexpr int CSPLIT = 4;
+constexpr int CSPLIT = 8;
 template <bool CE, bool STAGE>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const float *e2, const float *scores,
                                                         const float *lse, const float *dscores, const int *nvalid,
@@ -461,7 +461,8 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
 
 extern "C" int fgnn_score_row_blocks(int B, int N) {
     // few large pairs: more row blocks than FGNN_SCORE_SPLIT so that the launch fills the chip (8 rows per workgroup)
-    if (N <= 64 || B * FGNN_SCORE_SPLIT >= 512) return FGNN_SCORE_SPLIT;
+    if (B * FGNN_SCORE_SPLIT >= 512) return FGNN_SCORE_SPLIT;
+    if (N <= 64) return (N + 3) / 4;       // small batch of small pairs: one row per wave, B * N / 4 workgroups
     return (N + 7) / 8;
 }
 
