@@ -224,14 +224,15 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
 
 // dS[i][j] = (exp(S-lse_i) - [i==j]) * gscale (CE mode) or the given dscores (plain mode);
 // de1[c][i] = sum_j e2[c][j] dS[i][j];  de2[c][j] = sum_i e1[c][i] dS[i][j].
-// grid (B, CSPLIT): every workgroup stages dS (N x N) once in LDS and handles C/CSPLIT channels.
-constexpr int CSPLIT = 8;
+// grid (B, splits): every workgroup stages dS (N x N) once in LDS and handles C / gridDim.y channels.
+constexpr int CSPLIT = 4;          // channel splits of the blocked kernel and of large batches
+constexpr int CSPLIT_SMALL = 8;    // whole-dS staging at small batch (B * 4 < 256 workgroups)
 template <bool CE, bool STAGE>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const float *e2, const float *scores,
                                                         const float *lse, const float *dscores, const int *nvalid,
                                                         const float *gscale, int C, int N, float *de1, float *de2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int cper = (C + CSPLIT - 1) / CSPLIT;
+    const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c0 = blockIdx.y * cper;
     const int cn = (c0 + cper <= C ? cper : (C > c0 ? C - c0 : 0));
     float *s1 = sm, *s2 = sm + (size_t)cper * N;
@@ -426,8 +427,8 @@ extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvali
 }
 
 static int score_lds_bytes(int C, int N) { return (2 * C * N + 4) * (int)sizeof(float); }
-static int score_bwd_lds_bytes(int C, int N, bool stage) {
-    const int cper = (C + CSPLIT - 1) / CSPLIT;
+static int score_bwd_lds_bytes(int C, int N, bool stage, int csplit = CSPLIT) {
+    const int cper = (C + csplit - 1) / csplit;
     return (2 * cper * N + (stage ? N * (N + 1) : 0)) * (int)sizeof(float);
 }
 template <bool CE>
@@ -436,12 +437,13 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
                             float *de1, float *de2, hipStream_t st) {
     // whole-dS staging gives only B x CSPLIT workgroups: with few large pairs (N > 64) the blocked kernel fills the chip better
     const bool stage = score_bwd_lds_bytes(C, N, true) <= 160 * 1024 && (N <= 64 || (long long)B * CSPLIT >= 256);
-    const int lds = score_bwd_lds_bytes(C, N, stage);
+    const int csplit = (long long)B * CSPLIT < 256 ? CSPLIT_SMALL : CSPLIT;
+    const int lds = score_bwd_lds_bytes(C, N, stage, stage ? csplit : CSPLIT);
     FGNN_CHECK(lds <= 160 * 1024, "score backward: C*N=%d too large for LDS staging", C * N);
     if (stage) {
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)score_bwd_kernel<CE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((score_bwd_kernel<CE, true>), dim3(B, CSPLIT), dim3(256), lds, st, e1, e2, scores, lse, dscores,
+        hipLaunchKernelGGL((score_bwd_kernel<CE, true>), dim3(B, csplit), dim3(256), lds, st, e1, e2, scores, lse, dscores,
                            nvalid, gscale, C, N, de1, de2);
     } else {
         const int cper = (C + CSPLIT - 1) / CSPLIT;
