@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
     const float mean = s12 ? y.nrm[(long long)gc * 4] : 0.f;
     const bool staged = N <= CMB_MAXN;
     float s1 = 0.f, s2 = 0.f;
+    // N <= 256 (one row per thread): the z value at the arg-max position -- a second, dependent memory round trip -- is
+    // only requested here and consumed after the store sweep below, which does not depend on it
+    const bool late = N <= 256;
+    float zlate = 0.f, dlate = 0.f;
     for (int i = tid; i < N; i += 256) {
         const long long t = (long long)gc * N + i;
         const int bi = idx[t];
@@ -146,8 +150,13 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
             sde[i] = d;
         }
         if (s12 && i < nv) {
-            s1 += d;
-            s2 += d * (zm[(long long)i * N + bi] - mean);
+            if (late) {
+                zlate = zm[(long long)i * N + bi];
+                dlate = d;
+            } else {
+                s1 += d;
+                s2 += d * (zm[(long long)i * N + bi] - mean);
+            }
         }
     }
     __syncthreads();
@@ -160,6 +169,10 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
         mat[p] = (j == bi) ? d : 0.f;
     }
     if (s12) {
+        if (late && tid < nv) {
+            s1 += dlate;
+            s2 += dlate * (zlate - mean);
+        }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) {
