@@ -77,8 +77,24 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
     const int nv = nvalid_of(nvalid, g, N);
     const float *mat = y.ptr + (long long)g * y.gstride + (long long)c * y.ldp;
     float mean = 0.f, a = 1.f, be = 0.f;
+    TilePartials tp;
+    if (FIN) tp = finalize_load(F.part, F.cnt, g, c, C, F.tpg, lane);
+    // the whole matrix is requested before anything waits (lane = column, one load per row): a rolled loop over the
+    // elements pays one memory round trip per eight loads (five for N = 50)
+    float x[64];
+    const int col = lane < N ? lane : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (8 * q < N) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = 8 * q + r;
+                x[i] = mat[(i < N ? i : 0) * N + col];
+            }
+        }
+    }
     if (FIN) {
-        const float4 n = finalize_wave(F.part, F.cnt, g, c, C, F.tpg, (float)nv, F.gw ? F.gw[c] : 1.f, F.eps, lane);
+        const float4 n = finalize_reduce(tp, (float)nv, F.gw ? F.gw[c] : 1.f, F.eps);
         if (lane == 0) reinterpret_cast<float4 *>(const_cast<float *>(y.nrm))[gc] = n;
         mean = n.x;
         a = n.y;
@@ -91,13 +107,18 @@ __global__ __launch_bounds__(256) void colmax_fwd_lds_kernel(const fgnn_slab y, 
     }
     float *t = sm[wave];
     const int ld = N + 1;
-    const float invN = 1.f / (float)N;
-    for (int p = lane; p < N * N; p += WAVE) {
-        const int i = (int)(((float)p + 0.5f) * invN);
-        const int jj = p - i * N;
-        float v = mat[p];
-        if (FIN || y.nrm) v = (v - mean) * a + be;
-        t[i * ld + jj] = v;
+    const bool norm = FIN || y.nrm;
+    if (lane < N) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (8 * q < N) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int i = 8 * q + r;
+                    if (i < N) t[i * ld + lane] = norm ? (x[i] - mean) * a + be : x[i];
+                }
+            }
+        }
     }
     // same wave wrote and reads: LDS operations of a wave execute in order
     float best = 0.f;
