@@ -213,14 +213,29 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
                                                            float *pair_loss) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *s2 = sm, *s1 = sm + (size_t)C * N;
-    float *red = s1 + (size_t)C * rows;  // 4 floats
+    float *sS = s1 + (size_t)C * rows;   // the workgroup's score rows, [r][j]
+    float *red = sS + (size_t)rows * N;  // 4 floats
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = nvalid_of(nvalid, b, N);
     const int i0 = blockIdx.y * rows;
     const int i1 = (i0 + rows < N) ? i0 + rows : N;
     const int w = i1 > i0 ? i1 - i0 : 0;
     const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
-    for (int e = tid; e < C * N; e += 256) s2[e] = p2[e];
+    // eight loads in flight per thread and pass (a rolled copy loop pays one memory round trip per element)
+    constexpr int U = 8;
+    for (int e0 = tid; e0 < C * N; e0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + 256 * k;
+            v[k] = p2[e < C * N ? e : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + 256 * k;
+            if (e < C * N) s2[e] = v[k];
+        }
+    }
     for (int e = tid; e < C * w; e += 256) {
         const int c = e / w, r = e - c * w;
         s1[c * rows + r] = p1[c * N + i0 + r];
@@ -234,20 +249,22 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
         if (i0 + r < nv && j < nv)
             for (int c = 0; c < C; ++c) acc = fmaf(s1[c * rows + r], s2[c * N + j], acc);
         S[(long long)i0 * N + e] = acc;
+        sS[e] = acc;
     }
-    __syncthreads();   // workgroup-scope visibility of S for the row pass below
+    __syncthreads();
     float wl = 0.f;
     for (int i = i0 + wave; i < i1; i += 4) {
         float l = 0.f;
+        const float *Sr = sS + (size_t)(i - i0) * N;      // the row pass reads the LDS copy, not the global one
         if (i < nv) {
             float mx = -FLT_MAX;
-            for (int j = lane; j < nv; j += WAVE) mx = fmaxf(mx, S[(long long)i * N + j]);
+            for (int j = lane; j < nv; j += WAVE) mx = fmaxf(mx, Sr[j]);
             mx = wave_max(mx);
             float se = 0.f;
-            for (int j = lane; j < nv; j += WAVE) se += expf(S[(long long)i * N + j] - mx);
+            for (int j = lane; j < nv; j += WAVE) se += expf(Sr[j] - mx);
             se = wave_sum(se);
             l = mx + logf(se);
-            wl += l - S[(long long)i * N + i];
+            wl += l - Sr[i];
         }
         if (lane == 0 && lse) lse[(long long)b * N + i] = l;
     }
@@ -289,10 +306,29 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
         return d;
     };
     if (STAGE) {
-        for (int e = tid; e < N * N; e += 256) {
-            const int i = (int)(((float)e + 0.5f) * invN);
-            const int jj = e - i * N;
-            dS[i * ld + jj] = (i < nv && jj < nv) ? ds_at(i, jj) : 0.f;
+        // eight score loads in flight per thread and pass (the row's lse comes from the L1 / L2 resident vector)
+        constexpr int U = 8;
+        for (int e0 = tid; e0 < N * N; e0 += 256 * U) {
+            float v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                v[k] = S[e < N * N ? e : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                if (e < N * N) {
+                    const int i = (int)(((float)e + 0.5f) * invN);
+                    const int jj = e - i * N;
+                    float d = 0.f;
+                    if (i < nv && jj < nv) {
+                        d = v[k];
+                        if (CE) d = (expf(d - Lr[i]) - (i == jj ? 1.f : 0.f)) * gs;
+                    }
+                    dS[i * ld + jj] = d;
+                }
+            }
         }
     }
     __syncthreads();
@@ -506,7 +542,7 @@ extern "C" int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const 
                                         int row_blocks, float *scores, float *lse, float *pair_loss, void *stream) {
     FGNN_CHECK(e1 && e2 && scores && B > 0 && C > 0 && N > 0 && row_blocks > 0, "fgnn_score_ce_fwd: bad arguments");
     const int rows = (N + row_blocks - 1) / row_blocks;
-    const int lds = (C * N + C * rows + 4) * (int)sizeof(float);
+    const int lds = (C * N + C * rows + rows * N + 4) * (int)sizeof(float);
     FGNN_CHECK(lds <= 160 * 1024, "fgnn_score_ce_fwd: C*N=%d too large for LDS staging", C * N);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)score_ce_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
