@@ -296,7 +296,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const bool emit = (CA == 32) && (CB == 0) && normA && A.dxa != nullptr && A.s12part != nullptr;
     // dz coefficients from the per-tile sums its consumer left behind (the work of fgnn_gn_bwd_coef_tiles,
     // done per workgroup for the <= FGNN_BWD_COEF_GRAPHS graphs its tile range touches)
-    const bool from_tiles = A.s12tiles != nullptr;
+    // compiled into the two-slab kernels only (its user is mlp3): in the single-slab variants the extra prologue code
+    // perturbs the register allocation of the tile loop (0 -> 40 spilled SGPRs in <32,0,3>)
+    const bool from_tiles = (CB > 0) && A.s12tiles != nullptr;
     float *wgK = tiles + L::TILE_F_ALL;
     const int g0 = T0 / tpg;
 
@@ -339,10 +341,23 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
         const int cc = threadIdx.x & 31, sl = threadIdx.x >> 5;
         for (int g = g0; g <= g1; ++g) {
             float p1 = 0.f, p2 = 0.f;
-            for (int t = sl; t < tpg; t += (64 * NW) / 32) {
-                const float2 v = reinterpret_cast<const float2 *>(A.s12tiles)[((long long)g * tpg + t) * FGNN_H + cc];
-                p1 += v.x;
-                p2 += v.y;
+            // eight tile records in flight per thread and pass: rolled, this loop pays one (cold) memory round trip per
+            // record -- five in a row for N = 50 -- at the very start of the kernel
+            constexpr int TS = (64 * NW) / 32, U = 8;
+            for (int t0 = sl; t0 < tpg; t0 += TS * U) {
+                float2 v[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int t = t0 + TS * k;
+                    v[k] = reinterpret_cast<const float2 *>(A.s12tiles)[((long long)g * tpg + (t < tpg ? t : 0)) * FGNN_H + cc];
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    if (t0 + TS * k < tpg) {
+                        p1 += v[k].x;
+                        p2 += v[k].y;
+                    }
+                }
             }
             scr[sl * 32 + cc] = make_float2(p1, p2);
             __syncthreads();
@@ -834,6 +849,7 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     const long long total = (long long)a->G * tpg;
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_bwd: too many tiles");
     FGNN_CHECK(!a->ranges || (a->nvalid && !a->s12tiles), "fgnn_mlp_bwd: ranges need nvalid and exclude s12tiles");
+    FGNN_CHECK(!a->s12tiles || a->b.C > 0, "fgnn_mlp_bwd: s12tiles is built into the two-slab kernels only; use fgnn_gn_bwd_coef_tiles");
     FGNN_CHECK(!a->s12tiles || fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N),
                "fgnn_mlp_bwd: s12tiles needs a workgroup's tile range to span <= %d graphs (G=%d N=%d); "
                "use fgnn_gn_bwd_coef_tiles", FGNN_BWD_COEF_GRAPHS, a->G, a->N);

@@ -243,7 +243,8 @@ typedef struct {
     const float *s12tiles;                   /* optional (G, tpg, 32, 2): per-tile sums for THIS MLP's output as emitted by its
                                                 consumer's s12part; with znrm they replace coef / s12 -- every workgroup sums
                                                 the tiles of the graphs it touches in its prologue (the work of
-                                                fgnn_gn_bwd_coef_tiles without its launch; see ..._coef_tiles_supported) */
+                                                fgnn_gn_bwd_coef_tiles without its launch; see ..._coef_tiles_supported).
+                                                Two-slab MLPs (b.C > 0, i.e. mlp3) only                                 */
     float *s12_out;                          /* optional (G*32*2): the summed s12 is also written here (affine gradients) */
     const unsigned *xbits;                   /* optional: 2-channel slab expanded from the bit-packed adjacency, as in  */
     const float *xdeg;                       /*   fgnn_mlp_fwd_args                                                      */
