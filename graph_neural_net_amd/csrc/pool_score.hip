@@ -205,6 +205,45 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
     }
 }
 
+// Contiguous global -> LDS copy by a 256-thread workgroup with up to eight 16-byte loads in flight per thread (a rolled
+// element loop pays one memory round trip per element).
+DEVI void copy_to_lds256(float *dst, const float *src, int n, int tid) {
+    constexpr int U = 8;
+    int done = 0;
+    if (((reinterpret_cast<unsigned long long>(src) | reinterpret_cast<unsigned long long>(dst)) & 15ull) == 0) {
+        const int n4 = n >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int e0 = tid; e0 < n4; e0 += 256 * U) {
+            float4 v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                v[k] = s4[e < n4 ? e : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                if (e < n4) d4[e] = v[k];
+            }
+        }
+        done = n4 << 2;
+    }
+    for (int e0 = done + tid; e0 < n; e0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + 256 * k;
+            v[k] = src[e < n ? e : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int e = e0 + 256 * k;
+            if (e < n) dst[e] = v[k];
+        }
+    }
+}
+
 // grid (B, row_blocks): workgroup (b, rp) owns a contiguous block of rows of pair b.
 // e1,e2: (C, N) each.  scores[i][j] = sum_c e1[c][i] e2[c][j]; lse_i; partial loss of its rows.
 // LDS: e2 whole (C x N) and the workgroup's own rows of e1 (C x rows).
@@ -221,21 +260,7 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
     const int i1 = (i0 + rows < N) ? i0 + rows : N;
     const int w = i1 > i0 ? i1 - i0 : 0;
     const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
-    // eight loads in flight per thread and pass (a rolled copy loop pays one memory round trip per element)
-    constexpr int U = 8;
-    for (int e0 = tid; e0 < C * N; e0 += 256 * U) {
-        float v[U];
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const int e = e0 + 256 * k;
-            v[k] = p2[e < C * N ? e : 0];
-        }
-#pragma unroll
-        for (int k = 0; k < U; ++k) {
-            const int e = e0 + 256 * k;
-            if (e < C * N) s2[e] = v[k];
-        }
-    }
+    copy_to_lds256(s2, p2, C * N, tid);
     for (int e = tid; e < C * w; e += 256) {
         const int c = e / w, r = e - c * w;
         s1[c * rows + r] = p1[c * N + i0 + r];
@@ -365,25 +390,39 @@ __global__ __launch_bounds__(256) void score_bwd_blocked_kernel(const float *e1,
     const int nv = nvalid_of(nvalid, b, N);
     const int x0 = blockIdx.z * SB_BLK, x1 = (x0 + SB_BLK < N) ? x0 + SB_BLK : N, w = x1 - x0;
     const float *p1 = e1 + ((long long)b * C + c0) * N, *p2 = e2 + ((long long)b * C + c0) * N;
-    for (int e = tid; e < cn * N; e += 256) {
-        s1[e] = p1[e];
-        s2[e] = p2[e];
-    }
+    // every staging loop below keeps U loads in flight per thread: rolled, each element pays its own memory round trip
+    // (N = 200, B = 8: about thirty in a row per workgroup, the whole 20 us of the launch)
+    constexpr int U = 8;
+    copy_to_lds256(s1, p1, cn * N, tid);
+    copy_to_lds256(s2, p2, cn * N, tid);
     const float gs = CE ? *gscale : 1.f;
     const float *S = (CE ? scores : dscores) + (long long)b * N * N;
     const float *Lr = CE ? lse + (long long)b * N : nullptr;
-    auto ds_at = [&](int i, int jj) -> float {
+    // dS[i][jj] from the loaded score (and the row's lse); i, jj < N
+    auto ds_of = [&](float sv, float lv, int i, int jj) -> float {
         if (i >= nv || jj >= nv) return 0.f;
-        float d = S[(long long)i * N + jj];
-        if (CE) d = (expf(d - Lr[i]) - (i == jj ? 1.f : 0.f)) * gs;
-        return d;
+        return CE ? (expf(sv - lv) - (i == jj ? 1.f : 0.f)) * gs : sv;
     };
     // ---- phase 1: rows x0..x1 ----
     {
         const int ld = N + 1;
-        for (int e = tid; e < w * N; e += 256) {
-            const int r = e / N, jj = e - r * N;
-            dS[r * ld + jj] = ds_at(x0 + r, jj);
+        for (int e0 = tid; e0 < w * N; e0 += 256 * U) {
+            float sv[U], lv[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k, ec = e < w * N ? e : 0;
+                const int r = ec / N;
+                sv[k] = S[(long long)x0 * N + ec];
+                lv[k] = CE ? Lr[x0 + r] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                if (e < w * N) {
+                    const int r = e / N, jj = e - r * N;
+                    dS[r * ld + jj] = ds_of(sv[k], lv[k], x0 + r, jj);
+                }
+            }
         }
         __syncthreads();
         for (int e = tid; e < cn * w; e += 256) {
@@ -398,9 +437,23 @@ __global__ __launch_bounds__(256) void score_bwd_blocked_kernel(const float *e1,
     // ---- phase 2: columns x0..x1 ----
     {
         const int ld = SB_BLK + 1;
-        for (int e = tid; e < N * w; e += 256) {
-            const int i = e / w, r = e - i * w;
-            dS[i * ld + r] = ds_at(i, x0 + r);
+        for (int e0 = tid; e0 < N * w; e0 += 256 * U) {
+            float sv[U], lv[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k, ec = e < N * w ? e : 0;
+                const int i = ec / w, r = ec - i * w;
+                sv[k] = S[(long long)i * N + x0 + r];
+                lv[k] = CE ? Lr[i] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const int e = e0 + 256 * k;
+                if (e < N * w) {
+                    const int i = e / w, r = e - i * w;
+                    dS[i * ld + r] = ds_of(sv[k], lv[k], i, x0 + r);
+                }
+            }
         }
         __syncthreads();
         for (int e = tid; e < cn * w; e += 256) {
