@@ -289,6 +289,13 @@ DEVI void reduce_cols(const float *in, int rows, int cols, float scale, float *o
     const int ic = i < cols ? i : 0;              // clamped: loads stay unconditional
     float a = 0.f;
     int r = rg;
+    for (; r + 124 < rows; r += 128) {            // 32 independent loads in flight (256 workgroup rows: two round trips, not eight)
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = in[(long long)(r + 4 * k) * cols + ic];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a += v[k];
+    }
     for (; r + 28 < rows; r += 32) {              // 8 independent loads in flight
         float v[8];
 #pragma unroll
@@ -370,7 +377,7 @@ extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *st
                    "fgnn_pack_operands: job %d malformed", i);
         J.job[i] = jobs[i];
     }
-    hipLaunchKernelGGL(pack_operands_kernel, dim3(8, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(pack_operands_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, J);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
