@@ -202,7 +202,7 @@ extern "C" int fgnn_pack16_operands(const fgnn_pack_job *jobs, int njobs, void *
                    "fgnn_pack16_operands: job %d: slab widths must be 2 or 32", i);
         J.job[i] = jobs[i];
     }
-    hipLaunchKernelGGL(pack16_kernel, dim3(4, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(pack16_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, J);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
