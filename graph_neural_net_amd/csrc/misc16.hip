@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void colmax_bwd16_kernel(const float *de, cons
         s12 ? reinterpret_cast<const unsigned short *>(y.ptr) + (long long)g * y.gstride + (long long)c * y.ldp : nullptr;
     const float mean = s12 ? y.nrm[(long long)gc * 4] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    // N <= 256 (one row per thread): the z value at the arg-max position -- a second, dependent memory round trip -- is only
+    // requested here and consumed after the store sweep
+    const bool late = N <= 256;
+    unsigned short zlate = 0;
+    float dlate = 0.f;
     for (int i = tid; i < N; i += 256) {
         const long long t = (long long)gc * N + i;
         const int bi = idx[t];
@@ -181,19 +186,38 @@ __global__ __launch_bounds__(256) void colmax_bwd16_kernel(const float *de, cons
         sde[i] = db;
         if (s12 && i < nv) {
             const float d = bf_lo(db);
-            s1 += d;
-            s2 += d * (bf_lo(zm[(long long)i * ldr + bi]) - mean);
+            if (late) {
+                zlate = zm[(long long)i * ldr + bi];
+                dlate = d;
+            } else {
+                s1 += d;
+                s2 += d * (bf_lo(zm[(long long)i * ldr + bi]) - mean);
+            }
         }
     }
     __syncthreads();
-    const int hp = ldr / 2;            // pixel pairs per row
-    for (int q = tid; q < N * hp; q += 256) {
-        const int i = q / hp, jp = q - i * hp;
-        const int bi = sidx[i];
+    // the channel is written in 16-byte pieces of eight pixels (ldr is a multiple of 8, the channel base of 64 elements)
+    const int hp4 = ldr / 8;
+    uint4 *mat4 = reinterpret_cast<uint4 *>(mat);
+    for (int q = tid; q < N * hp4; q += 256) {
+        const int i = q / hp4, p8 = q - i * hp4;
+        const int rel = sidx[i] - 8 * p8;              // 0..7: the arg-max column lies in this piece
         const unsigned d = sde[i];
-        mat[q] = (bi == 2 * jp) ? d : ((bi == 2 * jp + 1) ? (d << 16) : 0u);
+        const unsigned w = (rel & 1) ? (d << 16) : d;
+        const bool in = (unsigned)rel < 8u;
+        const int k = rel >> 1;
+        uint4 v;
+        v.x = (in && k == 0) ? w : 0u;
+        v.y = (in && k == 1) ? w : 0u;
+        v.z = (in && k == 2) ? w : 0u;
+        v.w = (in && k == 3) ? w : 0u;
+        mat4[q] = v;
     }
     if (s12) {
+        if (late && tid < nv) {
+            s1 += dlate;
+            s2 += dlate * (bf_lo(zlate) - mean);
+        }
         s1 = wave_sum(s1);
         s2 = wave_sum(s2);
         if (lane == 0) {
