@@ -182,12 +182,40 @@ __global__ __launch_bounds__(256) void colmax_bwd_kernel(const float *de, const 
     }
     __syncthreads();
     const float invN = 1.f / (float)N;
-    for (int p = tid; p < N * N; p += 256) {
-        const int i = (int)(((float)p + 0.5f) * invN);
-        const int j = p - i * N;
-        const int bi = staged ? sidx[i] : idx[(long long)gc * N + i];
-        const float d = staged ? sde[i] : (i < nv ? de[(long long)gc * N + i] : 0.f);
-        mat[p] = (j == bi) ? d : 0.f;
+    if (staged && (ldp & 3) == 0 && (gstride & 3) == 0 && (reinterpret_cast<unsigned long long>(dy) & 15ull) == 0) {
+        // 16-byte stores: four consecutive elements of the channel (they may straddle a row boundary)
+        const int P = N * N;
+        float4 *mat4 = reinterpret_cast<float4 *>(mat);
+        for (int q = tid; 4 * q < P; q += 256) {
+            const int p0 = 4 * q;
+            int i = (int)(((float)p0 + 0.5f) * invN);
+            int j = p0 - i * N;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ic = i < N ? i : 0;
+                v[k] = (i < N && j == sidx[ic]) ? sde[ic] : 0.f;
+                if (++j == N) {
+                    j = 0;
+                    ++i;
+                }
+            }
+            if (p0 + 3 < P) {
+                mat4[q] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p0 + k < P) mat[p0 + k] = v[k];
+            }
+        }
+    } else {
+        for (int p = tid; p < N * N; p += 256) {
+            const int i = (int)(((float)p + 0.5f) * invN);
+            const int j = p - i * N;
+            const int bi = staged ? sidx[i] : idx[(long long)gc * N + i];
+            const float d = staged ? sde[i] : (i < nv ? de[(long long)gc * N + i] : 0.f);
+            mat[p] = (j == bi) ? d : 0.f;
+        }
     }
     if (s12) {
         if (late && tid < nv) {
