@@ -234,3 +234,35 @@ def test_expand_adjacency_bit_exact():
     bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
     x = expand_adjacency(bits, n, nvalid=torch.tensor([20, n], dtype=torch.int32))
     assert torch.equal(x.cpu(), torch.from_numpy(ref))
+
+
+@pytest.mark.parametrize('N', [1, 7, 32, 33, 50, 64])
+def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel(N):
+    """The shipped N <= 64 forward (one wave per matrix) keeps the k-step order and the normalisation expression of the
+    workgroup-per-matrix kernel it replaced: outputs must be equal bit for bit (dense and ragged, normalised operands)."""
+    lib = _lib.load()
+    G, Cc = 3, 5
+    g = torch.Generator().manual_seed(N)
+    a = torch.randn(G, Cc, N, N, generator=g).to(DEV)
+    b = torch.randn(G, Cc, N, N, generator=g).to(DEV)
+    nrm_a = (torch.rand(G, Cc, 4, generator=g) + 0.5).to(DEV)
+    nrm_b = (torch.rand(G, Cc, 4, generator=g) + 0.5).to(DEV)
+    beta = torch.randn(Cc, generator=g).to(DEV)
+    nv = torch.tensor([N, max(1, N // 2), max(0, N - 1)], dtype=torch.int32, device=DEV)
+    res = []
+    try:
+        for variant in (1, 0):
+            lib.fgnn_debug_matmul_variant(variant)
+            out = torch.full((G, Cc, N, N), 3.0, device=DEV)
+            sa, sb = _slab(a, nrm=nrm_a, beta=beta), _slab(b, nrm=nrm_b, beta=beta)
+            _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), _lib.ptr(nv), G, N, _lib.ptr(out), Cc * N * N, N * N,
+                      _lib.stream_ptr())
+            torch.cuda.synchronize()
+            res.append(out.cpu())
+    finally:
+        lib.fgnn_debug_matmul_variant(1)
+    assert torch.equal(res[0], res[1])
+    # padding rows / columns of the ragged graphs are exact zeros
+    for gi, n in enumerate(nv.tolist()):
+        assert float(res[0][gi, :, n:, :].abs().max()) == 0.0 if n < N else True
+        assert float(res[0][gi, :, :, n:].abs().max()) == 0.0 if n < N else True
