@@ -186,6 +186,12 @@ def main():
                     help="'engine': FgnnEngine.step (the fused launch sequence, the headline); 'module': the same batch through "
                          'the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward() (eager launches)')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
+    ap.add_argument('--chains', type=int, default=None, choices=(1, 2),
+                    help='2: the batch runs as two half-batch chains on two streams / disjoint halves of the CUs (FgnnEngineDual: '
+                         'about 2 %% faster at the default size, measured), 1 (default): one engine')
+    ap.add_argument('--mfma', default=None, choices=('f32', 'x3'),
+                    help="contraction of the fp32 MLP kernels: 'x3' (default) = bf16 matrix cores through the exact three-way operand "
+                         "split (csrc/fgnn_x3.h), 'f32' = v_mfma_f32_32x32x2_f32")
     ap.add_argument('--settle', type=int, default=64, help='untimed replays before the warm-up steps (clock / TLB settling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
@@ -227,12 +233,22 @@ def main():
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
         eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged)
     else:
-        eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged)
+        chains = args.chains if args.chains is not None else 1
+        if args.mfma is not None:
+            FgnnEngine.MFMA = args.mfma
+        if chains == 2:
+            from graph_neural_net_amd.engine_dual import FgnnEngineDual
+            eng = FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged)
+        else:
+            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged)
     x = torch.cat([x1, x2]).contiguous().to(dev)
+    dual = hasattr(eng, 'stage_inputs')
+    if dual:
+        eng.stage_inputs(x, nvalid)        # loader work, like the cat above: the chains' input buffers are resident before the timed region
     total_nodes = float((sum(sizes) if ragged else B * N) * world)      # loss normaliser of the concatenated global batch
 
     def model_work():
-        eng.step(params, grads, x, nvalid=nvalid, total_nodes=total_nodes)
+        eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
 
     if args.path == 'module':
         # the surface a user of the reference calls (models/trainers.py:60-76): same weights, same batch, eager launches
@@ -398,6 +414,10 @@ def main():
             'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
                        'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'path': args.path, 'settle_steps': args.settle,
+                       'chains': 2 if (not bf16 and args.path == 'engine' and dual) else 1,
+                       'mlp_contraction': ('bf16 MFMA' if bf16 else ('3 x bf16 split operands (6 products, fp32 accumulation) on the bf16 MFMA; '
+                                           'mlp3 backward on v_mfma_f32_32x32x2_f32' if (args.path == 'engine' and not ragged and FgnnEngine.MFMA == 'x3')
+                                           else 'v_mfma_f32_32x32x2_f32')),
                        'grad_allreduce': 'rccl sum of %d fp32 per step' % layout.total if world > 1 else 'none'},
             'roofline': roofline,
             'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfgnn_hip.so')
+LIB_PATH = os.environ.get('FGNN_LIB') or os.path.join(_HERE, 'libfgnn_hip.so')      # FGNN_LIB: A/B runs of one-off debug builds
 
 FGNN_H = 32
 FGNN_TILE = 32
@@ -37,7 +37,7 @@ class MlpFwdArgs(C.Structure):
                 ('ldz', C.c_longlong),
                 ('part', C.c_void_p * 2),
                 ('cnt', C.c_void_p), ('packed', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p),
-                ('ranges', C.c_void_p)]
+                ('ranges', C.c_void_p), ('cu_share', C.c_int)]
 
 
 class MlpBwdArgs(C.Structure):
@@ -54,7 +54,7 @@ class MlpBwdArgs(C.Structure):
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
                 ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p),
                 ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p),
-                ('ranges', C.c_void_p)]
+                ('ranges', C.c_void_p), ('cu_share', C.c_int)]
 
 
 class Slab16(C.Structure):
@@ -107,6 +107,10 @@ _SIGNATURES = {
     'fgnn_pack_floats': [_I, _I, _I, _I, _I],
     'fgnn_pack_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd': [C.POINTER(MlpFwdArgs), _VP],
+    'fgnn_mlp_x3_supported': [_I, _I, _I, _I],
+    'fgnn_pack_x3_floats': [_I, _I, _I, _I, _I],
+    'fgnn_pack_x3_operands': [_VP, _I, _VP],
+    'fgnn_mlp_fwd_x3': [C.POINTER(MlpFwdArgs), _VP],
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
@@ -137,6 +141,7 @@ _SIGNATURES = {
     'fgnn_grad_finalize': [_VP, _I, _I, _I, _I, _VP],
     'fgnn_gn_bwd_apply': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_mlp_bwd': [C.POINTER(MlpBwdArgs), _VP],
+    'fgnn_mlp_bwd_x3': [C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],

@@ -10,40 +10,6 @@ struct Pack16Jobs {
 };
 
 // grid (blocks per job, njobs): one thread per (step, lane) writes the lane's 4 dwords; the tail is plain fp32
-// The eight slots of one (step, lane) of pk16_value with the step-range branch taken ONCE: eight unconditional (index-clamped)
-// loads go out back to back, where eight inlined pk16_value calls each wait for their own load at the end of their if-chain
-// (86 s_waitcnt, about eight memory round trips per entry).
-DEVI void pk16_values8(int kind, const Pk16 &p, int ca, int cb, int depth, const float *const *W, int step, int l, float (&v)[8]) {
-    const int i = l & 31, h = l >> 5, cin = ca + cb;
-    if (step < p.off_wh) {                               // forward layer 0, slab a or b: channels may be padding (c < 0)
-        const bool second = step >= p.off_w0b;
-        const float *w = W[0] + i * cin + (second ? ca : 0);
-        int c[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) c[s] = second ? pk16_chan(cb, step - p.off_w0b, h, s) : pk16_chan(ca, step - p.off_w0a, h, s);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = w[c[s] >= 0 ? c[s] : 0];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = c[s] >= 0 ? v[s] : 0.f;
-    } else if (step < p.off_wt) {
-        const int u = step - p.off_wh;
-        const float *w = W[1 + (u >> 1)] + i * FGNN_H;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = w[pk16_ch(8 * (u & 1) + s, h)];
-    } else if (step < p.off_wt0a) {                      // W_{d-1}^T first, then W_{d-2}^T ...
-        const int u = step - p.off_wt, layer = depth - 1 - (u >> 1);
-        const float *w = W[layer] + i;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = w[pk16_ch(8 * (u & 1) + s, h) * FGNN_H];
-    } else {
-        const bool second = step >= p.off_wt0b;
-        const int u = step - (second ? p.off_wt0b : p.off_wt0a);
-        const float *w = W[0] + (second ? ca : 0) + i;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = w[pk16_ch(8 * u + s, h) * cin];
-    }
-}
-
 __global__ __launch_bounds__(256) void pack16_kernel(const Pack16Jobs J) {
     const fgnn_pack_job &jb = J.job[blockIdx.y];
     const Pk16 p = pk16_layout(jb.kind, jb.ca, jb.cb, jb.depth);

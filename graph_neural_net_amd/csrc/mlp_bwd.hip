@@ -770,8 +770,9 @@ int launch_bwd_impl(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t 
         (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    // always BWD_WG workgroups: the partials buffer layout (and fgnn_grad_finalize) assume it
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>), dim3(BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
+    // BWD_WG workgroups = rows of the partials buffer (fgnn_grad_finalize); cu_share == 2: half of the CUs, half the rows
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>), dim3(a->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st,
+                       *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -404,7 +404,8 @@ int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t 
         attr_set = true;
     }
     int grid = (total + NW - 1) / NW;
-    if (grid > 256) grid = 256;
+    const int cap = a->cu_share == 2 ? 128 : 256;      // 2: half of the CUs (two launches on two streams side by side)
+    if (grid > cap) grid = cap;
     if (SKIP) grid = FGNN_RANGE_WG;
     hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();

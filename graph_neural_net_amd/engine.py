@@ -14,6 +14,7 @@ Parameters and their gradients are flat fp32 buffers laid out in the reference's
 single all-reduce of ``grads``.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -109,8 +110,21 @@ class FgnnEngine:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
 
-    def __init__(self, layout, G, N, device, ragged=False):
+    # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
+    MFMA = os.environ.get('FGNN_MFMA', 'f32')
+
+    def __init__(self, layout, G, N, device, ragged=False, cu_share=0, mfma=None):
+        """cu_share=2: the persistent MLP kernels take half of the CUs (fgnn_mlp_fwd_args.cu_share), for engines that run
+        next to another one on a second stream (FgnnEngineDual).
+        mfma: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); 'x3' = the bf16 matrix cores through the exact
+        three-way operand split of csrc/fgnn_x3.h (fp32 tensors, fp32 accumulation, error of an fp32 rounding per product;
+        built for depth 3 and constant-size batches -- other cases use 'f32')."""
         _lib.load()
+        self.cu_share = int(cu_share)
+        mfma = self.MFMA if mfma is None else mfma
+        if mfma not in ('f32', 'x3'):
+            raise ValueError("mfma must be 'f32' or 'x3' (got %r)" % (mfma,))
+        self.x3 = (mfma == 'x3' and not ragged and layout.depth == 3 and layout.c0 in (2, 32))
         self.layout = layout
         self.G, self.N = G, N
         self.P = N * N
@@ -146,11 +160,19 @@ class FgnnEngine:
         self._packs = {}
         for k in range(1, K + 1):
             cin = layout.c0 if k == 1 else 32
-            self._packs[('f', k, 12)] = (0, cin, 0, 2, torch.empty(_lib.load().fgnn_pack_floats(0, cin, 0, layout.depth, 2), **f32))
-            self._packs[('f', k, 3)] = (0, 32, cin, 1, torch.empty(_lib.load().fgnn_pack_floats(0, 32, cin, layout.depth, 1), **f32))
+            # image kinds: 0 / 1 = forward / backward image of the kernel set in use; with x3, kind + 2 = an fp32-MFMA image
+            # packed by the same launch.  mlp3 stays on the fp32-MFMA kernels in BOTH directions: the two weight-gradient
+            # slabs of its backward leave no registers for the split operands (measured 52-56 us against 48 us), and a
+            # backward must recompute the hidden activations with the arithmetic of its forward (a ReLU mask that differs
+            # from the forward's on a pre-activation within rounding distance of 0 is a gradient error of the flip class).
+            fl = _lib.load().fgnn_pack_x3_floats if self.x3 else _lib.load().fgnn_pack_floats
+            f3 = 2 if self.x3 else 0
+            b3 = 3 if self.x3 else 1
+            self._packs[('f', k, 12)] = (0, cin, 0, 2, torch.empty(fl(0, cin, 0, layout.depth, 2), **f32))
+            self._packs[('f', k, 3)] = (f3, 32, cin, 1, torch.empty(fl(f3, 32, cin, layout.depth, 1), **f32))
             for j in (1, 2):
-                self._packs[('b', k, j)] = (1, cin, 0, 1, torch.empty(_lib.load().fgnn_pack_floats(1, cin, 0, layout.depth, 1), **f32))
-            self._packs[('b', k, 3)] = (1, 32, cin, 1, torch.empty(_lib.load().fgnn_pack_floats(1, 32, cin, layout.depth, 1), **f32))
+                self._packs[('b', k, j)] = (1, cin, 0, 1, torch.empty(fl(1, cin, 0, layout.depth, 1), **f32))
+            self._packs[('b', k, 3)] = (b3, 32, cin, 1, torch.empty(fl(b3, 32, cin, layout.depth, 1), **f32))
 
     # ------------------------------------------------------------------ helpers
     def _nv(self):
@@ -184,7 +206,10 @@ class FgnnEngine:
     def pack_operands(self, params):
         """Pack the LDS operand images of all MLP launches of one step (one small launch)."""
         L = self.layout
-        items = list(self._packs.items())
+        self._pack_launch(params, list(self._packs.items()), 'fgnn_pack_x3_operands' if self.x3 else 'fgnn_pack_operands')
+
+    def _pack_launch(self, params, items, entry):
+        L = self.layout
         for lo in range(0, len(items), _lib.MAX_PACK_JOBS):
             chunk = items[lo:lo + _lib.MAX_PACK_JOBS]
             jobs = (_lib.PackJob * len(chunk))()
@@ -197,7 +222,7 @@ class FgnnEngine:
                         jobs[i].W[m][l] = self._w(params, rec['w'][l])
                         jobs[i].bias[m][l] = self._w(params, rec['b'][l])
                 jobs[i].out = buf.data_ptr()
-            _lib.call('fgnn_pack_operands', jobs, len(chunk), _lib.stream_ptr())
+            _lib.call(entry, jobs, len(chunk), _lib.stream_ptr())
 
     def _mlp_fwd(self, params, k, js, a, b, finalize=True):
         """finalize=False: leave the tile statistics of the two MLPs un-finalized (the matmul that consumes them
@@ -222,8 +247,9 @@ class FgnnEngine:
         self._packed_input(args, k)
         if self.ranges is not None:
             args.ranges = self.ranges.data_ptr()
+        args.cu_share = self.cu_share
         st = _lib.stream_ptr()
-        _lib.call('fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        _lib.call('fgnn_mlp_fwd_x3' if (self.x3 and len(js) == 2) else 'fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         if not finalize:
             return
         if len(js) == 2:
@@ -244,7 +270,7 @@ class FgnnEngine:
             args.xdeg = self.xdeg.data_ptr()
 
     # ------------------------------------------------------------------ forward
-    def embed(self, params, x, nvalid=None, bits=None):
+    def embed(self, params, x, nvalid=None, bits=None, pack=True):
         """x: (G, c0, N, N) contiguous device tensor -- or bits: (G, N, ceil(N/32)) int32 words of the bit-packed
         adjacency (bit j of row i = W[i][j], the format of inputs.expand_adjacency / synthetic.pack_adjacency): the
         (2, N, N) representation of loaders/data_generator.py:118-125 is then built inside block 1's kernels and never
@@ -274,7 +300,8 @@ class FgnnEngine:
                 raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
                                    % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
             self.x, self.xbits = x, None
-        self.pack_operands(params)
+        if pack:                # (FgnnEngineDual packs once for both of its engines)
+            self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
             # finalize-in-prologue lengthens every matmul workgroup by ~2 us: it beats the separate finalize launch
@@ -304,12 +331,12 @@ class FgnnEngine:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
 
-    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None):
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None, pack=True):
         """Siamese forward on the stacked batch x = cat(x1, x2) (or its bit-packed adjacency, see embed): returns
         (scores, loss).
         defer_loss: leave the final sum of the per-pair losses to the gradient-finalize launch of the
         following backward() (one launch less per training step); `loss` is valid after that."""
-        self.embed(params, x, nvalid, bits=bits)
+        self.embed(params, x, nvalid, bits=bits, pack=pack)
         B, N = self.B, self.N
         st = _lib.stream_ptr()
         e1, e2 = self.E[:B], self.E[B:]
@@ -332,6 +359,8 @@ class FgnnEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         act = lambda: torch.empty(self.G * 32 * self.ldp, **f32)
         nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
+        if self.cu_share == 2:          # half of the CUs: half the workgroups, half the partial rows
+            nwg //= 2
         L = self.layout
         keys = [(k, j) for k in range(1, L.num_blocks + 1) for j in (1, 2, 3)]
         self._bwd = {
@@ -392,14 +421,16 @@ class FgnnEngine:
         self._packed_input(args, k)
         if self.ranges is not None:
             args.ranges = self.ranges.data_ptr()
+        args.cu_share = self.cu_share
         if emit:
             args.s12part = W['s12part'].data_ptr()
-        _lib.call('fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
+        _lib.call('fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
                   tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
                                                 (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 
-    def backward(self, params, grads, grad_scale=1.0):
-        """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer."""
+    def backward(self, params, grads, grad_scale=1.0, finalize=True):
+        """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer (finalize=False: everything but the
+        last launch, see backward_from_dE)."""
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
@@ -410,15 +441,16 @@ class FgnnEngine:
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
-        return self.backward_from_dE(params, grads, W['dE'])
+        return self.backward_from_dE(params, grads, W['dE'], finalize=finalize)
 
-    def backward_from_dE(self, params, grads, dE):
+    def backward_from_dE(self, params, grads, dE, finalize=True):
         """Backward of the node embedder given d loss / d E  (G, 32, N).
 
         Per block (last to first):  mlp3 bwd -> matmul bwd (+ S1/S2 of mlp1, mlp2) -> mlp1 bwd ->
         mlp2 bwd (accumulates d_in and emits the S1/S2 tile partials of the previous block's
         mlp3).  No separate reduction pass over the activations is needed; all parameter
-        gradients are finished by ONE fgnn_grad_finalize launch at the end."""
+        gradients are finished by ONE fgnn_grad_finalize launch at the end (finalize=False leaves that launch to the
+        caller: grad_finalize(grads, [engines]) reduces the partials of several engines at once)."""
         L = self.layout
         W = self._alloc_bwd()
         st = _lib.stream_ptr()
@@ -449,7 +481,18 @@ class FgnnEngine:
                 _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
             dy = din
-        # ---- one launch: reduce the workgroup partials + GraphNorm affine gradients of all MLPs ----
+        if finalize:
+            self.grad_finalize(grads)
+        return grads
+
+    def grad_finalize(self, grads, rows=None, graphs=None, pair_rows=None):
+        """ONE launch: reduce the workgroup partials + GraphNorm affine gradients of all MLPs (and the deferred loss sum).
+        rows / graphs / pair_rows: FgnnEngineDual reduces the partials of both of its engines at once -- their wpart, s12,
+        nrm and pair_loss buffers are consecutive halves of one allocation, this engine holding the first."""
+        L = self.layout
+        W = self._bwd
+        K = L.num_blocks
+        st = _lib.stream_ptr()
         keys = [(k, j) for k in range(1, K + 1) for j in (1, 2, 3)]
         if getattr(self, '_loss_pending', False):
             keys.append('loss')
@@ -462,7 +505,7 @@ class FgnnEngine:
                     jobs[i].wpart = self.pair_loss.data_ptr()
                     jobs[i].count = 1
                     jobs[i].out = self._loss_target.data_ptr()
-                    jobs[i].rows = self.B * self.score_blocks
+                    jobs[i].rows = self.B * self.score_blocks if pair_rows is None else pair_rows
                     jobs[i].scale = 1.0 / self.total_nodes
                     continue
                 rec = L.mlp[kj]
@@ -473,7 +516,8 @@ class FgnnEngine:
                 jobs[i].nrm = self.nrm[kj].data_ptr()
                 jobs[i].dgn_w = grads.data_ptr() + 4 * rec['gn_w']
                 jobs[i].dgn_b = grads.data_ptr() + 4 * rec['gn_b']
-            _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
+            _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'] if rows is None else rows,
+                      self.G if graphs is None else graphs, 32, st)
         return grads
 
     def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):

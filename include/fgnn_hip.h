@@ -99,8 +99,25 @@ typedef struct {
                                                padding are stepped over: their statistics records are written as empty, their
                                                z pixels are left untouched (consumers must do the same, or read the valid
                                                n x n corner only -- all kernels of this library do) */
+    int cu_share;                           /* 0 / 1: the whole GPU (up to 256 persistent workgroups).  2: HALF of the CUs (at most 128
+                                               workgroups): two launches on different streams -- independent half-batches, see
+                                               engine_dual.py -- run side by side on disjoint CUs, one chain's ramps under the
+                                               other's streaming.  Results do not depend on it. */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
+
+/* ---- the same two MLP entry points on the bf16 matrix cores ("x3": csrc/fgnn_x3.h) ------------------------------
+ * replaces the same reference lines as fgnn_mlp_fwd / fgnn_mlp_bwd (models/layers.py:126-131 and its autograd).  Tensors,
+ * argument structs, tile statistics and results are those of the fp32-MFMA kernels (same parity gates); inside, every fp32
+ * operand of a channel contraction is split exactly into three bf16 numbers and the product is accumulated in fp32 from
+ * the six partial products >= 2^-16 (error < 3 * 2^-24 |a b| per product, the size of an fp32 rounding).  Built for
+ * depth 3, slabs of 2 / 32 / 32+2 / 32+32 channels and constant-size batches (no `ranges`); `packed` is mandatory and
+ * comes from fgnn_pack_x3_operands (same job struct as fgnn_pack_operands, fgnn_pack_x3_floats floats per image; jobs of
+ * kind 2 / 3 produce the fp32 images of fgnn_pack_operands kind 0 / 1 in the same launch, for steps that mix both kernel sets). */
+int fgnn_mlp_x3_supported(int ca, int cb, int depth, int nmlp /* 1 or 2 forward; backward: 1 */);
+int fgnn_pack_x3_floats(int kind, int ca, int cb, int depth, int nmlp);
+int fgnn_pack_x3_operands(const fgnn_pack_job *jobs, int njobs, void *stream);
+int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *args, void *stream);
 
 /* ---- GraphNorm statistics ------------------------------------------------------------
  * replaces torch.mean / torch.var(unbiased=False) over (N,N) and the scale of normalize
@@ -250,8 +267,12 @@ typedef struct {
     const float *xdeg;                       /*   fgnn_mlp_fwd_args                                                      */
     const int *ranges;                       /* optional work-balanced tile bounds + padding-tile skipping, as in the forward
                                                 arguments; cannot be combined with s12tiles                                  */
+    int cu_share;                            /* as in fgnn_mlp_fwd_args; 2 = fgnn_mlp_bwd_num_workgroups() / 2 workgroups and rows of
+                                                wpart (never with `ranges`) */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
+int fgnn_mlp_bwd_x3(const fgnn_mlp_bwd_args *args, void *stream);   /* the x3 form (see fgnn_mlp_fwd_x3): image of kind 1 from
+                                                                         fgnn_pack_x3_operands; input gradients for 32-channel slabs */
 #define FGNN_BWD_COEF_GRAPHS 4
 int fgnn_mlp_bwd_coef_tiles_supported(int G, int N);   /* s12tiles usable: a workgroup spans <= FGNN_BWD_COEF_GRAPHS graphs */
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
