@@ -168,14 +168,42 @@ def cpu_baseline_ragged(layout, params, xs, ys, min_seconds=10.0, max_steps=100)
                       'threads = best of the sweep %s on the first 2 pairs' % (n, len(xs), dt, torch.__version__, cores, sorted(sweep))}
 
 
-def main():
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process -- which has NOT touched the GPU (no HIP call, no
+    library load) -- starts N fresh rank processes of this script with the torchrun environment, relays rank 0's JSON
+    line and exits with the worst return code.  (Never re-exec a process that has initialised the GPU.)"""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                   FGNN_BENCH_CHILD='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode('utf-8', 'replace'))
+    sys.stdout.flush()
+    worst = max(rcs, key=abs)
+    raise SystemExit(worst)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='cfg2', choices=('cfg2', 'cfg4', 'cfg5'),
-                    help='BASELINE.json configs[1] (N=50 regular pairs, batch 32, fp32; the headline line) or '
-                         'configs[3] (N=200 dense ER pairs, batch 8, bf16)')
+                    help='BASELINE.json configs[1] (N=50 regular pairs, batch 32, fp32; the headline line), '
+                         'configs[3] (N=200 dense ER pairs, batch 8, bf16) or the per-GPU shard of configs[4] '
+                         '(variable-N pairs, n in [30, 120], 8 pairs)')
     ap.add_argument('--precision', default=None, choices=('fp32', 'bf16'),
                     help="kernel set (default: the config's -- fp32 for cfg2, bf16 for cfg4); '--precision bf16' with cfg2 is the "
                          "reference's 16-bit training mode on the headline workload, reported with dtype bf16")
@@ -184,39 +212,79 @@ def main():
     ap.add_argument('--blocks', type=int, default=4)
     ap.add_argument('--path', default='engine', choices=('engine', 'module'),
                     help="'engine': FgnnEngine.step (the fused launch sequence, the headline); 'module': the same batch through "
-                         'the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward() (eager launches)')
+                         'the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward()')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--chains', type=int, default=None, choices=(1, 2),
                     help='2: the batch runs as two half-batch chains on two streams / disjoint halves of the CUs (FgnnEngineDual: '
                          'about 2 %% faster at the default size, measured), 1 (default): one engine')
     ap.add_argument('--mfma', default=None, choices=('f32', 'x3'),
-                    help="contraction of the fp32 MLP kernels: 'x3' (default) = bf16 matrix cores through the exact three-way operand "
-                         "split (csrc/fgnn_x3.h), 'f32' = v_mfma_f32_32x32x2_f32")
+                    help="contraction of the fp32 MLP kernels: 'f32' (default) = v_mfma_f32_32x32x2_f32, 'x3' = bf16 matrix cores "
+                         'through the exact three-way operand split (csrc/fgnn_x3.h)')
     ap.add_argument('--settle', type=int, default=64, help='untimed replays before the warm-up steps (clock / TLB settling)')
+    ap.add_argument('--windows', type=int, default=5,
+                    help='the K-step timed window is repeated this many times; ms_per_step / value are the MEDIAN window, '
+                         'ms_per_step_min / _max the spread')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='do not append the cfg4 / cfg5 measurements (extra_configs) to the headline line')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
     ap.add_argument('--backend', default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets "
                                                     'several ranks share one GPU for functional tests')
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args.gpus)                    # does not return
     rank, local_rank, world = dp.init_process_group(args.backend)
     if world != args.gpus:
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU; there is no CPU fallback for the product path')
     local_rank = local_rank % torch.cuda.device_count()     # (only differs in the shared-GPU functional test)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    out = run_config(args, args.config, rank, world, dev, cpu_leg=(world == 1 and not args.no_cpu_baseline))
+    if rank == 0 and world == 1 and args.config == 'cfg2' and args.precision is None and args.path == 'engine' \
+            and not args.no_extra_configs and args.batch is None and args.n is None:
+        # BASELINE configs 4 and 5 (per-GPU shard) under the same K / W protocol, outside the headline's timed region
+        extra = {}
+        for cfg in ('cfg4', 'cfg5'):
+            t0 = time.time()
+            sub = run_config(args, cfg, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3))
+            extra[cfg] = {'metric': sub['metric'], 'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'],
+                          'ms_per_step_min': sub['ms_per_step_min'], 'ms_per_step_max': sub['ms_per_step_max'],
+                          'dtype': sub['dtype'], 'workload': sub['config']['workload'],
+                          'roofline': {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')
+                                       if sub['roofline'] and k in sub['roofline']},
+                          'step_model': sub['step_model'], 'wall_s': round(time.time() - t0, 2)}
+        out['extra_configs'] = extra
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dp.barrier()            # rank 0 is still in its roofline leg while the others are done
+        torch.distributed.destroy_process_group()
 
-    dense_er = args.config == 'cfg4'              # the workload
-    ragged = args.config == 'cfg5'                # variable-N pairs, n in [30, N], one batch padded to its largest graph
-    bf16 = (args.precision == 'bf16') if args.precision else dense_er      # the kernel set
-    B = args.batch if args.batch is not None else (8 if (dense_er or ragged) else 32)
-    N = args.n if args.n is not None else (200 if dense_er else (120 if ragged else 50))
+
+def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
+    """One measurement: build the workload of `config`, capture the step, settle, warm up, time `windows` windows of
+    exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0)."""
+    windows = args.windows if windows is None else windows
+    precision = args.precision if config == args.config else None
+    dense_er = config == 'cfg4'                   # the workload
+    ragged = config == 'cfg5'                     # variable-N pairs, n in [30, N], one batch padded to its largest graph
+    bf16 = (precision == 'bf16') if precision else dense_er      # the kernel set
+    same = config == args.config
+    B = args.batch if (same and args.batch is not None) else (8 if (dense_er or ragged) else 32)
+    N = args.n if (same and args.n is not None) else (200 if dense_er else (120 if ragged else 50))
+    path = args.path if same else 'engine'
+    no_graph = args.no_graph
     layout = ParamLayout(2, args.blocks, 32, 32, 3)
     params = layout.init_flat(0, dev)
     grads = torch.zeros_like(params)
     nvalid, pix, cube, sizes = None, None, None, None
+    xs = ys = None
     if ragged:     # cfg5: Erdos-Renyi pairs (edge density 0.2, ER edge noise 0.1), n ~ U{30..N}
         xs, ys = synthetic.make_ragged_batch(5000 + rank, B, 30, N, 'ErdosRenyi', 0.2, 0.1)
         sizes = [int(t.shape[-1]) for t in xs]
@@ -233,14 +301,13 @@ def main():
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
         eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged)
     else:
-        chains = args.chains if args.chains is not None else 1
-        if args.mfma is not None:
-            FgnnEngine.MFMA = args.mfma
+        chains = args.chains if (same and args.chains is not None) else 1
+        mfma = args.mfma if (same and args.mfma is not None) else None
         if chains == 2:
             from graph_neural_net_amd.engine_dual import FgnnEngineDual
-            eng = FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged)
+            eng = FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
         else:
-            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged)
+            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
     x = torch.cat([x1, x2]).contiguous().to(dev)
     dual = hasattr(eng, 'stage_inputs')
     if dual:
@@ -250,7 +317,8 @@ def main():
     def model_work():
         eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
 
-    if args.path == 'module':
+    model = None
+    if path == 'module':
         # the surface a user of the reference calls (models/trainers.py:60-76): same weights, same batch, eager launches
         from graph_neural_net_amd.siamese import Siamese_Node_Exp
         node_emb = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=args.blocks,
@@ -266,7 +334,7 @@ def main():
             from graph_neural_net_amd.masked import from_list
             xa = from_list([t.to(dev) for t in xs], dims=(1, 2), base_name='N')
             xb = from_list([t.to(dev) for t in ys], dims=(1, 2), base_name='M')
-        args.no_graph = True
+        no_graph = True
 
         def model_work():                      # noqa: F811
             for p in model.parameters():
@@ -277,7 +345,7 @@ def main():
     graph = None
     model_work()                                  # allocates the backward workspace, sets kernel attributes
     torch.cuda.synchronize()
-    if not args.no_graph:
+    if not no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -294,13 +362,23 @@ def main():
                 print('bench.py: HIP graph capture failed (%s); running eager' % (exc,), file=sys.stderr)
             torch.cuda.synchronize()
 
-    def step():
+    comm = grads if path == 'engine' else model.node_embedder._flat_grad
+    ar_events = []                                # (start, stop) around the collective of the timed steps, rank 0's stream
+
+    def step(timed=False):
         if graph is not None:
             graph.replay()
         else:
             model_work()
         if world > 1:
-            dp.allreduce_sum_(grads if args.path == 'engine' else model.node_embedder._flat_grad)
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dp.allreduce_sum_(comm)
+                e1.record()
+                ar_events.append((e0, e1))
+            else:
+                dp.allreduce_sum_(comm)
 
     # Settling (untimed, part of the set-up like the capture runs above): the first ~20 replays after the set-up phase run
     # ~4 % slower than steady state (clocks, TLBs; `--steps 20 --warmup 5` gave 0.945 ms against 0.905 ms for any longer
@@ -311,20 +389,28 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    # `windows` timed windows of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over the ranks; the line reports the median window (and the spread).
+    window_s = []
+    for _ in range(max(1, windows)):
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=True)
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        window_s.append(dp.max_over_ranks(time.perf_counter() - t0, dev))
+    elapsed = sorted(window_s)[len(window_s) // 2]
+    allreduce_ms = None
+    if world > 1 and ar_events:
+        allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
 
     # ---- roofline leg: per-kernel durations from events on the launch stream (eager launches) ----
     roofline = None
     kernels = {}
-    if rank == 0 and args.profile_steps > 0:
+    if rank == 0 and args.profile_steps > 0 and not dual:
         _lib.PROFILE = []
         for _ in range(args.profile_steps):
             model_work()
@@ -409,30 +495,31 @@ def main():
             'metric': ('graph-pairs/sec FGNN fwd+bwd, variable-N pairs (n in [30, %d])%s' % (args.n or 120, ', bf16' if bf16 else '')) if ragged else
                       'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms, 'ms_per_step_min': min(window_s) / args.steps * 1e3, 'ms_per_step_max': max(window_s) / args.steps * 1e3,
+            'timed_windows': len(window_s), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
-                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'path': args.path, 'settle_steps': args.settle,
-                       'chains': 2 if (not bf16 and args.path == 'engine' and dual) else 1,
-                       'mlp_contraction': ('bf16 MFMA' if bf16 else ('3 x bf16 split operands (6 products, fp32 accumulation) on the bf16 MFMA; '
-                                           'mlp3 backward on v_mfma_f32_32x32x2_f32' if (args.path == 'engine' and not ragged and FgnnEngine.MFMA == 'x3')
-                                           else 'v_mfma_f32_32x32x2_f32')),
-                       'grad_allreduce': 'rccl sum of %d fp32 per step' % layout.total if world > 1 else 'none'},
+                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'path': path, 'settle_steps': args.settle,
+                       'chains': 2 if dual else 1,
+                       'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
+                                           ('mlp1 / mlp2: 3 x bf16 split operands (8 / 6 partial products, fp32 accumulation) on '
+                                            'v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)
+                                            else 'v_mfma_f32_32x32x2_f32')),
+                       'grad_allreduce': ('%s sum of %d fp32 per step' % (torch.distributed.get_backend(), layout.total)) if world > 1 else 'none'},
+            'ranks_seen': dp.world_size(), 'backend': torch.distributed.get_backend() if world > 1 else None, 'allreduce_ms': allreduce_ms,
             'roofline': roofline,
             'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,
                            'hbm_frac_of_8TBs': value / world * by_pair / (HBM_PEAK_GBS * 1e9),
                            'mfma_frac_of_peak': value / world * fl_pair / ((MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12)},
             'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if cpu_leg:
             out['cpu_baseline'] = cpu_baseline_ragged(layout, params, xs, ys) if ragged else cpu_baseline(layout, params, x1, x2)
         else:
             out['cpu_baseline'] = None
-        print(json.dumps(out))
-    if world > 1:
-        dp.barrier()            # rank 0 is still in its roofline leg while the others are done
-        torch.distributed.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == '__main__':

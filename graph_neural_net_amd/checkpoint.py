@@ -35,12 +35,17 @@ def infer_layout(state_dict):
 def _load(path, allow_pickle):
     """torch.load restricted to tensors / plain containers; Lightning checkpoints that carry pickled hyper-parameter
     objects need allow_pickle=True (arbitrary code execution: only for files you trust)."""
+    import pickle
+    import warnings
+    if hasattr(path, 'read') and not (hasattr(path, 'seekable') and path.seekable()):
+        raise RuntimeError('load_checkpoint needs a path or a seekable stream')
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as exc:
+    except pickle.UnpicklingError as exc:       # what weights_only raises for a disallowed global; I/O errors propagate as they are
         if not allow_pickle:
             raise RuntimeError('checkpoint %r cannot be read with weights_only=True (%s); pass allow_pickle=True for a '
                                'trusted file' % (path, exc))
+        warnings.warn('load_checkpoint: %r holds pickled objects; re-reading it with the UNSAFE loader (allow_pickle=True)' % (path,))
         if hasattr(path, 'seek'):
             path.seek(0)
         return torch.load(path, map_location='cpu', weights_only=False)

@@ -106,6 +106,54 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class EngineCache:
+    """Per-shape engines with a workspace budget: least recently used engines are dropped beyond `budget` bytes (at least
+    one is always kept).  Shared by FgnnTrainer and by the module path (Network), so a stream of ragged shapes re-uses a
+    bounded set of workspaces in both."""
+
+    def __init__(self, budget):
+        import collections
+        self.budget = budget
+        self._items = collections.OrderedDict()        # key -> (engine, bytes)
+
+    @staticmethod
+    def engine_bytes(G, N, num_blocks, elt=4):
+        ldp = -(-N * N // 32) * 32
+        return (4 * num_blocks + 5) * G * 32 * ldp * elt          # forward + backward activation slabs dominate
+
+    def get(self, key, factory, nbytes):
+        """-> (engine, evicted keys)."""
+        hit = self._items.get(key)
+        if hit is not None:
+            self._items.move_to_end(key)
+            return hit[0], []
+        eng = factory()
+        self._items[key] = (eng, nbytes)
+        evicted = []
+        while self.used() > self.budget and len(self._items) > 1:
+            k, _ = self._items.popitem(last=False)
+            evicted.append(k)
+        return eng, evicted
+
+    def used(self):
+        return sum(b for _, b in self._items.values())
+
+    def keys(self):
+        return list(self._items)
+
+    def clear(self):
+        self._items.clear()
+
+    def __len__(self):
+        return len(self._items)
+
+    def __iter__(self):
+        return iter(list(self._items))
+
+    def values(self):
+        return [e for e, _ in self._items.values()]
+
+
 class FgnnEngine:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
@@ -384,9 +432,11 @@ class FgnnEngine:
         _lib.call('fgnn_gn_bwd_coef', _lib.ptr(W['s12'][kj]), _lib.ptr(self.nrm[kj]), self._nv(), self.G, 32, self.N,
                   _lib.ptr(W['coef'][slot]), None, None, _lib.stream_ptr())
 
-    def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
+    def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False, dx_strides=None):
         """coef: precomputed coefficient buffer; None -> derived in-kernel from s12[(k,j)] and nrm[(k,j)];
-        'tiles' -> every workgroup sums the per-tile S1/S2 partials (s12part) of the graphs it touches itself."""
+        'tiles' -> every workgroup sums the per-tile S1/S2 partials (s12part) of the graphs it touches itself.
+        dx_strides: (graph stride, channel stride) of the dx tensors when they are not workspace slabs (the gradient with
+        respect to the model input, a (G, c0, N, N) tensor)."""
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
@@ -411,10 +461,12 @@ class FgnnEngine:
         else:
             args.s12 = W['s12'][(k, j)].data_ptr()
             args.znrm = self.nrm[(k, j)].data_ptr()
+        dgs, dld = (gs, self.ldp) if dx_strides is None else dx_strides
         if dxa is not None:
-            args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), gs, self.ldp
+            args.dxa, args.dxa_gstride, args.dxa_ld = dxa.data_ptr(), (gs if (b is not None and dx_strides is not None) else dgs), \
+                (self.ldp if (b is not None and dx_strides is not None) else dld)
         if dxb is not None:
-            args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), gs, self.ldp
+            args.dxb, args.dxb_gstride, args.dxb_ld = dxb.data_ptr(), dgs, dld
         args.accumulate_a, args.accumulate_b = int(acc_a), int(acc_b)
         args.wpart = W['wpart'][(k, j)].data_ptr()
         args.packed = self._packs[('b', k, j)][4].data_ptr()
@@ -443,8 +495,10 @@ class FgnnEngine:
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
         return self.backward_from_dE(params, grads, W['dE'], finalize=finalize)
 
-    def backward_from_dE(self, params, grads, dE, finalize=True):
+    def backward_from_dE(self, params, grads, dE, finalize=True, dx=None):
         """Backward of the node embedder given d loss / d E  (G, 32, N).
+        dx: optional zero-initialised (G, c0, N, N) fp32 tensor that receives the gradient with respect to the input x (the
+        reference's autograd gives it whenever the input requires grad; dense inputs and the fp32-MFMA kernels only).
 
         Per block (last to first):  mlp3 bwd -> matmul bwd (+ S1/S2 of mlp1, mlp2) -> mlp1 bwd ->
         mlp2 bwd (accumulates d_in and emits the S1/S2 tile partials of the previous block's
@@ -467,16 +521,23 @@ class FgnnEngine:
             sin = self._slab_in(k, params)
             first = (k == 1)
             din = None if first else W['dy'][(K - k + 1) % 2]
+            dxs = None
+            if first and dx is not None:
+                if self.xbits is not None or self.x3 or tuple(dx.shape) != (self.G, L.c0, self.N, self.N) or dx.dtype != torch.float32 \
+                        or not dx.is_contiguous():
+                    raise RuntimeError('FgnnEngine: the input gradient needs a dense fp32 input, the fp32-MFMA kernels (mfma="f32") '
+                                       'and a contiguous (G, c0, N, N) fp32 dx')
+                din, dxs = dx, (L.c0 * self.P, self.P)
             # mlp3: inputs [mult ; in].  Last block: dz coefficients derived in-kernel from the pooling's
             # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
-                          None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False)
+                          None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False, dx_strides=dxs)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False)
-            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first)
+            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False, dx_strides=dxs)
+            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first, dx_strides=dxs)
             if not first and not in_prologue:
                 _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)

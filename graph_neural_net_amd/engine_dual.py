@@ -26,14 +26,15 @@ from .engine import FgnnEngine
 class FgnnEngineDual:
     CU_SHARE = 2        # fgnn_mlp_fwd_args.cu_share of both chains: full-size workgroups on disjoint halves of the CUs
 
-    def __init__(self, layout, G, N, device, ragged=False):
+    def __init__(self, layout, G, N, device, ragged=False, mfma=None):
         if G % 2 or G < 4:
             raise RuntimeError('FgnnEngineDual: G = 2 * pairs with at least two pairs (got G = %d)' % G)
         self.layout, self.G, self.N, self.device = layout, G, N, device
         self.B = G // 2
         self.h = [(self.B + 1) // 2, self.B // 2]                   # pairs per chain
         self.lo = [0, self.h[0]]
-        self.sub = [FgnnEngine(layout, 2 * h, N, device, ragged=ragged, cu_share=self.CU_SHARE) for h in self.h]
+        self.sub = [FgnnEngine(layout, 2 * h, N, device, ragged=ragged, cu_share=self.CU_SHARE, mfma=mfma) for h in self.h]
+        self.x3 = self.sub[0].x3
         self.ragged = ragged
         self.side = torch.cuda.Stream(device=device)
         a, b = self.sub

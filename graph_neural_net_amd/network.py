@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .engine import FgnnEngine, ParamLayout
+from .engine import EngineCache, FgnnEngine, ParamLayout
 from .masked import MaskedTensor
 
 SEP = '/'
@@ -56,56 +56,102 @@ def build_graph(net):
     return graph
 
 
+def _embed_forward(ctx, net, x, nvalid):
+    params, xin = net._engine_params(), net._pad_input(x, nvalid, True)
+    eng = net._engine_for(xin, nvalid, True)
+    eng.embed(params, xin, nvalid)
+    eng.generation = getattr(eng, 'generation', 0) + 1
+    ctx.net, ctx.eng, ctx.generation, ctx.xshape = net, eng, eng.generation, tuple(x.shape)
+    return net._crop_embedding(eng.E)
+
+
+def _embed_backward(ctx, dE, target, want_dx):
+    """Engine backward into the flat gradient buffer `target`; returns the input gradient (or None)."""
+    net, eng = ctx.net, ctx.eng
+    if eng.generation != ctx.generation:
+        raise RuntimeError('Network: the activations of this forward pass were overwritten by a later forward of the '
+                           'same shape before backward() ran (the fused engine keeps one workspace per shape); call '
+                           'backward() before the next forward, or run the other forward under torch.no_grad()')
+    dx = None
+    if want_dx:
+        if getattr(net, 'precision', 'fp32') == 'bf16':
+            raise RuntimeError('Network: the gradient with respect to the input is only built for the fp32 engine')
+        dx = torch.zeros(eng.G, eng.layout.c0, eng.N, eng.N, dtype=torch.float32, device=dE.device)
+    dE = net._pad_dE(dE.contiguous())
+    if net._pad is None:
+        eng.backward_from_dE(net._flat, target, dE, **({'dx': dx} if dx is not None else {}))
+    else:                                              # padded engine: gather the real entries of its gradient
+        eng.backward_from_dE(net._pad['pflat'], net._pad['pgrad'], dE, **({'dx': dx} if dx is not None else {}))
+        torch.index_select(net._pad['pgrad'], 0, net._pad['idx'], out=target)
+        if dx is not None:
+            dx = dx[:, :ctx.xshape[1]].contiguous()
+    return dx
+
+
 class _EmbedFn(torch.autograd.Function):
-    """Whole node-embedder forward/backward through FgnnEngine (one autograd node).
+    """Whole node-embedder forward/backward through FgnnEngine (one autograd node) -- the fast mode.
 
     The module's 96 parameters are views into ONE persistent flat buffer (Network._bind_flat), so the engine reads
     them in place; their gradients land in ONE persistent flat gradient buffer whose per-parameter views are
     attached as ``p.grad`` -- no per-step torch.cat / split, no 96 AccumulateGrad nodes.  The single differentiable
-    input `anchor` only makes this node part of the graph."""
+    input `anchor` only makes this node part of the graph (the input x takes part when it requires grad).
+    Parameters are NOT autograd inputs here: no AccumulateGrad node, no parameter hook fires -- Network uses
+    _EmbedFnParams instead whenever that matters (torch.distributed initialised, hooks registered, param_autograd=True)."""
 
     @staticmethod
     def forward(ctx, net, x, nvalid, anchor):
-        params, xin = net._engine_params(), net._pad_input(x)
-        eng = net._engine_for(xin, nvalid, True)
-        eng.embed(params, xin, nvalid)
-        eng.generation = getattr(eng, 'generation', 0) + 1
-        ctx.net, ctx.eng, ctx.generation = net, eng, eng.generation
-        return net._crop_embedding(eng.E)
+        return _embed_forward(ctx, net, x, nvalid)
 
     @staticmethod
     def backward(ctx, dE):
-        net, eng = ctx.net, ctx.eng
-        if eng.generation != ctx.generation:
-            raise RuntimeError('Network: the activations of this forward pass were overwritten by a later forward of the '
-                               'same shape before backward() ran (the fused engine keeps one workspace per shape); call '
-                               'backward() before the next forward, or run the other forward under torch.no_grad()')
+        net = ctx.net
         params = net._param_list
         views = net._grad_views
+        live = [p.requires_grad for p in params]           # frozen parameters get no .grad
         fresh = all(p.grad is None for p in params)        # the usual case after zero_grad(set_to_none=True)
         target = net._flat_grad if fresh else net._flat_grad_tmp
-        dE = net._pad_dE(dE.contiguous())
-        if net._pad is None:
-            eng.backward_from_dE(net._flat, target, dE)
-        else:                                              # padded engine: gather the real entries of its gradient
-            eng.backward_from_dE(net._pad['pflat'], net._pad['pgrad'], dE)
-            torch.index_select(net._pad['pgrad'], 0, net._pad['idx'], out=target)
+        dx = _embed_backward(ctx, dE, target, ctx.needs_input_grad[1])
         if fresh:
-            for p, v in zip(params, views):
-                p.grad = v
-        elif all(p.grad is v for p, v in zip(params, views)):
+            for p, v, on in zip(params, views, live):
+                if on:
+                    p.grad = v
+        elif all((p.grad is v) or not on for p, v, on in zip(params, views, live)):
             net._flat_grad.add_(target)
         else:                                              # accumulate into whatever .grad holds
-            for p, (off, n, shape) in zip(params, net._param_spans):
+            for p, (off, n, shape), on in zip(params, net._param_spans, live):
+                if not on:
+                    continue
                 g = target[off:off + n].view(shape)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.add_(g)
-        return None, None, None, torch.zeros_like(net._anchor)
+        return None, dx, None, torch.zeros_like(net._anchor)
+
+
+class _EmbedFnParams(torch.autograd.Function):
+    """The same engine calls with every parameter as an autograd input: one gradient per parameter is returned, so
+    AccumulateGrad nodes, parameter hooks, DistributedDataParallel's reducer and torch.autograd.grad(loss, [p]) all work as
+    with the reference's plain autograd (models/trainers.py:60-76) -- at the price of ~100 small host-side tensor
+    operations per step."""
+
+    @staticmethod
+    def forward(ctx, net, x, nvalid, *params):
+        return _embed_forward(ctx, net, x, nvalid)
+
+    @staticmethod
+    def backward(ctx, dE):
+        net = ctx.net
+        target = net._flat_grad_tmp
+        dx = _embed_backward(ctx, dE, target, ctx.needs_input_grad[1])
+        grads = tuple(target[off:off + n].view(shape).clone() if need else None
+                      for (off, n, shape), need in zip(net._param_spans, ctx.needs_input_grad[3:]))
+        return (None, dx, None) + grads
 
 
 class Network(nn.Module):
+    ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU, engine.EngineCache)
+
     def __init__(self, net):
         super().__init__()
         self.graph = build_graph(net)
@@ -113,8 +159,11 @@ class Network(nn.Module):
             setattr(self, path.replace(SEP, '_'), node)
         self._layout = None
         self._pad = None          # widths below 32 embedded in the 32-wide engine by zero padding (_padded_layout)
-        self._engines = {}
+        self._engines = EngineCache(self.ENGINE_CACHE_BYTES)
         self._flat = None
+        # None: parameters become autograd inputs of the fused node only when something needs it (torch.distributed is
+        # initialised with more than one rank, a parameter carries hooks); True / False force the mode (_EmbedFnParams)
+        self.param_autograd = None
 
     def nodes(self):
         return (node for node, _ in self.graph.values())
@@ -193,7 +242,7 @@ class Network(nn.Module):
                     idx.append((off + torch.arange(o)[:, None] * cp + cols[None, :]).reshape(-1))
                 else:                                             # conv bias (o,), gn weight / bias (1, o, 1, 1)
                     idx.append(off + torch.arange(p.numel()))
-            self._pad = {'idx': torch.cat(idx), 'c0': c0, 'c0p': c0p, 'cout': widths[-1], 'total': lay.total, 'xbuf': {}}
+            self._pad = {'idx': torch.cat(idx), 'c0': c0, 'c0p': c0p, 'cout': widths[-1], 'total': lay.total}
             return lay
         except (AssertionError, AttributeError, RuntimeError, IndexError, ValueError):
             self._pad = None
@@ -211,15 +260,18 @@ class Network(nn.Module):
         P['pflat'].index_copy_(0, P['idx'], self._flat)
         return P['pflat']
 
-    def _pad_input(self, x):
+    def _pad_input(self, x, nvalid, grad):
+        """Input widths 3..31: the zero-padded 32-channel staging buffer belongs to the ENGINE that will read it (the
+        fp32 engine keeps it by reference for block 1's backward, so the grad and the no-grad engine of one shape must not
+        share it: an evaluation forward between a training forward and its backward would overwrite the saved input)."""
         P = self._pad
         if P is None or P['c0p'] == P['c0']:
             return x
-        key = (tuple(x.shape), x.device)
-        buf = P['xbuf'].get(key)
+        shape = (x.shape[0], P['c0p'], x.shape[2], x.shape[3])
+        eng = self._engine_for_shape(x.shape[0], x.shape[-1], nvalid is not None, x.device, grad)
+        buf = getattr(eng, '_xpad', None)
         if buf is None:
-            P['xbuf'].clear()
-            buf = P['xbuf'][key] = torch.zeros(x.shape[0], P['c0p'], x.shape[2], x.shape[3], dtype=torch.float32, device=x.device)
+            buf = eng._xpad = torch.zeros(shape, dtype=torch.float32, device=x.device)
         buf[:, :P['c0']].copy_(x)
         return buf
 
@@ -240,13 +292,17 @@ class Network(nn.Module):
         the reference's named_parameters() order) and prepare the flat gradient buffer + its per-parameter views.
         Re-done when a parameter was re-assigned or moved to another device."""
         if self._flat is not None:
-            # cheap per-forward check (first and last parameter still live inside the flat buffer); a full walk over the
-            # 96 parameters costs more host time than a kernel launch
-            first, last = self._param_list[0], self._param_list[-1]
-            if (first.data_ptr() == self._flat.data_ptr() and first.device == self._flat.device
-                    and last.data_ptr() == self._flat.data_ptr() + 4 * self._param_spans[-1][0]):
+            # per-forward check against the LIVE parameters (a re-assigned nn.Parameter, load_state_dict(assign=True), a
+            # .data swap or .to(device) all re-bind): identity of every slot and the storage offset of every view
+            base = self._flat.data_ptr()
+            if all(m._parameters.get(n) is p and p.data_ptr() == base + 4 * off
+                   for (m, n), p, (off, _, _) in zip(self._param_slots, self._param_list, self._param_spans)) \
+                    and self._param_list[0].device == self._flat.device:
                 return
-        ps = [p for _, p in self.named_parameters()]
+        slots = [(m, n) for m in self.modules() for n, p in m._parameters.items() if p is not None]
+        ps = [m._parameters[n] for m, n in slots]
+        assert [id(p) for p in ps] == [id(p) for _, p in self.named_parameters()]
+        self._param_slots = slots
         dev = ps[0].device
         total = sum(p.numel() for p in ps)
         flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -264,24 +320,41 @@ class Network(nn.Module):
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
 
     def _engine_for(self, x, nvalid, grad):
+        return self._engine_for_shape(x.shape[0], x.shape[-1], nvalid is not None, x.device, grad)
+
+    def _engine_for_shape(self, G, N, ragged, device, grad):
         # separate workspaces for grad / no-grad forwards: an evaluation forward between a training forward and its
         # backward must not overwrite the saved activations.  `grad` is passed in by the caller: inside an
         # autograd.Function's forward torch.is_grad_enabled() is always False.
-        key = (x.shape[0], x.shape[-1], nvalid is not None, x.device, bool(grad))
-        if key not in self._engines:
-            if getattr(self, 'precision', 'fp32') == 'bf16':
+        # The cache is bounded (LRU by bytes, ENGINE_CACHE_BYTES): a stream of ragged shapes re-uses a few workspaces; an
+        # engine evicted between a forward and its backward stays alive through the autograd node that holds it.
+        bf16 = getattr(self, 'precision', 'fp32') == 'bf16'
+        key = (G, N, ragged, device, grad if isinstance(grad, str) else bool(grad), bf16)       # 'step': Siamese_Node_Exp.fused_step
+
+        def make():
+            if bf16:
                 from .engine16 import FgnnEngineBF16
-                self._engines[key] = FgnnEngineBF16(self._layout, x.shape[0], x.shape[-1], x.device, ragged=nvalid is not None)
-            else:
-                self._engines[key] = FgnnEngine(self._layout, x.shape[0], x.shape[-1], x.device, ragged=nvalid is not None)
-        return self._engines[key]
+                return FgnnEngineBF16(self._layout, G, N, device, ragged=ragged)
+            return FgnnEngine(self._layout, G, N, device, ragged=ragged, mfma='f32')
+        self._engines.budget = self.ENGINE_CACHE_BYTES
+        nbytes = EngineCache.engine_bytes(G, N, self._layout.num_blocks, 2 if bf16 else 4) // (1 if grad else 2)
+        return self._engines.get(key, make, nbytes)[0]
+
+    def _params_as_inputs(self):
+        """Does this forward need per-parameter autograd (AccumulateGrad nodes, hooks, DDP's reducer)?"""
+        if self.param_autograd is not None:
+            return bool(self.param_autograd)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return True
+        return any(p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None) for p in self._param_list)
 
     def half(self):
         """models/utils.py:71-74: the reference's 16-bit switch for the dict-graph.  The HIP kernels keep fp32 master
         parameters in every precision mode; 16-bit execution is the bf16 engine (engine16.FgnnEngineBF16), selected
         with Network.precision = 'bf16'.  half() selects it and returns self, like the reference's helper."""
         self.precision = 'bf16'
-        self._engines = {}
+        self._engines.clear()
         return self
 
     def fused_embedding(self, x):
@@ -296,10 +369,13 @@ class Network(nn.Module):
         if not t.is_cuda:
             raise RuntimeError('graph_neural_net_amd only runs on the GPU (input is on %s)' % (t.device,))
         self._bind_flat()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list):
-            e = _EmbedFn.apply(self, t.contiguous(), nvalid, self._anchor)
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self._param_list) or t.requires_grad):
+            if self._params_as_inputs():
+                e = _EmbedFnParams.apply(self, t.contiguous(), nvalid, *self._param_list)
+            else:
+                e = _EmbedFn.apply(self, t.contiguous(), nvalid, self._anchor)
         else:
-            xin = self._pad_input(t.contiguous())
+            xin = self._pad_input(t.contiguous(), nvalid, False)
             eng = self._engine_for(xin, nvalid, False)
             eng.embed(self._engine_params(), xin, nvalid)
             e = self._crop_embedding(eng.E)

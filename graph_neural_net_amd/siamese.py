@@ -109,6 +109,57 @@ class Siamese_Node_Exp(nn.Module):
             return MaskedTensor(scores, nvalid, (1, 2), x1.base_name)
         return scores
 
+    def fused_step(self, x1, x2, capture=True):
+        """Forward of both branches + scoring + `triplet_loss` + the full backward as the fused launch sequence of
+        engine.FgnnEngine -- with capture=True ONE replayed HIP graph per batch shape, the step `bench.py` measures (the
+        eager module path `loss = model.loss(model(x1, x2)); loss.backward()` of models/trainers.py:60-76 issues the same
+        kernels but pays ~40 host launches and the autograd bookkeeping per step).
+        Afterwards every trainable parameter's `.grad` is the gradient of this batch (views of one flat buffer, OVERWRITTEN
+        per call like after `zero_grad()`), so any torch optimizer / scheduler steps as usual.
+        Constant-size batches (tensors or {'input': T} dicts) of the standard node_embedding graph; equal-size graphs make
+        both loss reductions the same number (toolbox/losses.py:27-34).  Returns (loss, raw scores (bs, n, n)): device
+        tensors that the NEXT call of the same shape overwrites."""
+        x1, x2 = _unwrap_input(x1), _unwrap_input(x2)
+        net = self.node_embedder
+        lay = net._standard_layout()
+        if isinstance(x1, MaskedTensor) or lay is None or net._pad is not None:
+            raise RuntimeError('fused_step covers constant-size batches of the standard node_embedding graph '
+                               '(original_features_num 2 or 32, in_features = out_features = 32); use the module path '
+                               '`loss = model.loss(model(x1, x2)); loss.backward()` for everything else')
+        if not x1.is_cuda:
+            raise RuntimeError('graph_neural_net_amd only runs on the GPU (input is on %s)' % (x1.device,))
+        net._bind_flat()
+        B, N = x1.shape[0], x1.shape[-1]
+        eng = net._engine_for_shape(2 * B, N, False, x1.device, 'step')
+        st = getattr(eng, '_step_state', None)
+        if st is None:
+            st = eng._step_state = {'x': torch.empty(2 * B, x1.shape[1], N, N, dtype=torch.float32, device=x1.device), 'graph': None}
+        st['x'][:B].copy_(x1)
+        st['x'][B:].copy_(x2)
+        if st.get('flat') is not net._flat:             # (re)bound parameters: a captured graph holds the old addresses
+            st['graph'], st['flat'] = None, net._flat
+        if capture and st['graph'] is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # allocations, kernel attributes
+                for _ in range(2):
+                    eng.step(net._flat, net._flat_grad, st['x'])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st['out'] = eng.step(net._flat, net._flat_grad, st['x'])
+            st['graph'] = g
+        if capture:
+            st['graph'].replay()
+            scores, loss = st['out']
+        else:
+            scores, loss = eng.step(net._flat, net._flat_grad, st['x'])
+        for p, v in zip(net._param_list, net._grad_views):
+            if p.requires_grad:
+                p.grad = v
+        return loss.reshape(()), scores
+
     # -- the step methods of the reference's LightningModule (models/trainers.py:70-90); `log` is a no-op
     #    here and is overridden by whatever training shell wraps the module
     def log(self, name, value, **kwargs):

@@ -5,12 +5,10 @@ gradient buffer with the loss sum and the node count riding in its last two floa
 No step reads anything back to the host: the loss normaliser of the concatenated global batch
 (toolbox/losses.py:27-34) arrives with the all-reduce and is applied on the device as Adam's gradient scale.
 """
-import collections
-
 import torch
 
 from . import dp
-from .engine import FgnnEngine
+from .engine import EngineCache, FgnnEngine
 from .optim import FlatAdam
 
 
@@ -37,36 +35,38 @@ class FgnnTrainer:
         self._nodes = self.comm[n + 1:n + 2]
         self.opt = FlatAdam(params_flat, lr=lr)
         self.capture = capture
-        self._engines = collections.OrderedDict()
+        self._engines = EngineCache(self.ENGINE_CACHE_BYTES)
         self._graphs = {}
 
-    # ------------------------------------------------------------------ engines: bounded cache keyed on padded shapes
-    @staticmethod
-    def _engine_bytes(G, N, num_blocks):
-        ldp = -(-N * N // 32) * 32
-        return (4 * num_blocks + 5) * G * 32 * ldp * 4          # forward + backward activation slabs dominate
+    @classmethod
+    def from_module(cls, model, lr=None, capture=True):
+        """The fused training step for a `Siamese_Node_Exp` built through the reference's own surface
+        (models/trainers.py:20-58): the trainer works IN PLACE on the module's flat parameter buffer, so the module
+        (its `state_dict`, its eager forward) always sees the trained weights, and `capture=True` gives a reference user the
+        replayed-graph step instead of ~40 host launches per step.  Standard node_embedding graphs only."""
+        net = model.node_embedder
+        lay = net._standard_layout()
+        if lay is None or net._pad is not None:
+            raise RuntimeError('FgnnTrainer.from_module: the module is not the standard node_embedding graph '
+                               '(original_features_num 2 or 32, in_features = out_features = 32)')
+        net._bind_flat()
+        return cls(lay, net._flat, lr=model.lr if lr is None else lr, capture=capture, precision=getattr(net, 'precision', 'fp32'))
 
+    # ------------------------------------------------------------------ engines: bounded cache keyed on padded shapes
     def _engine(self, G, N, ragged):
         """Engine for (G, N).  Ragged engines are shared between nearby shapes: G is rounded up to a multiple of 4
         graphs (the surplus graphs get nvalid = 0 and cost nothing but their padding tiles), so a stream of ragged
         batches re-uses a handful of workspaces instead of allocating one per (count, nmax); least recently used
-        engines are dropped beyond ENGINE_CACHE_BYTES."""
-        key = (G, N, ragged)
-        eng = self._engines.get(key)
-        if eng is None:
+        engines are dropped beyond ENGINE_CACHE_BYTES (engine.EngineCache)."""
+        def make():
             if self.precision == 'bf16':
                 from .engine16 import FgnnEngineBF16
-                eng = FgnnEngineBF16(self.layout, G, N, self.params.device, ragged=ragged)
-            else:
-                eng = FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
-            self._engines[key] = eng
-            used = sum(self._engine_bytes(g, n, self.layout.num_blocks) for (g, n, _) in self._engines)
-            while used > self.ENGINE_CACHE_BYTES and len(self._engines) > 1:
-                (g, n, r), _ = self._engines.popitem(last=False)
-                self._graphs = {k: v for k, v in self._graphs.items() if not (2 * k[0] == g and k[1] == n and not r)}
-                used -= self._engine_bytes(g, n, self.layout.num_blocks)
-        else:
-            self._engines.move_to_end(key)
+                return FgnnEngineBF16(self.layout, G, N, self.params.device, ragged=ragged)
+            return FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
+        self._engines.budget = self.ENGINE_CACHE_BYTES
+        eng, evicted = self._engines.get((G, N, ragged), make, EngineCache.engine_bytes(G, N, self.layout.num_blocks))
+        for g, n, r in evicted:
+            self._graphs = {k: v for k, v in self._graphs.items() if not (2 * k[0] == g and k[1] == n and not r)}
         return eng
 
     # ------------------------------------------------------------------ the one collective + optimizer

@@ -15,10 +15,37 @@ from graph_neural_net_amd.trainer import FgnnTrainer             # noqa: E402
 
 STEPS = 3
 
+# ---- runtime count of the collectives each train step issues (every entry point of torch.distributed that moves data) ----
+COLLECTIVES = ('all_reduce', 'all_gather', 'all_gather_into_tensor', 'all_gather_object', 'broadcast', 'broadcast_object_list', 'reduce',
+               'reduce_scatter', 'reduce_scatter_tensor', 'all_to_all', 'all_to_all_single', 'gather', 'scatter', 'send', 'recv',
+               'isend', 'irecv', 'barrier')
+CALLS = []
+
+
+def _count_collectives():
+    import torch.distributed as dist
+    for name in COLLECTIVES:
+        fn = getattr(dist, name, None)
+        if fn is None:
+            continue
+
+        def wrapped(*a, _fn=fn, _name=name, **k):
+            CALLS.append(_name)
+            return _fn(*a, **k)
+        setattr(dist, name, wrapped)
+
+
+def _counted(fn, *a, **k):
+    """-> (result, names of the collectives issued inside fn)."""
+    n0 = len(CALLS)
+    r = fn(*a, **k)
+    return r, CALLS[n0:]
+
 
 def main():
     out = sys.argv[1]
     rank, _, world = dp.init_process_group('gloo')
+    _count_collectives()
     torch.cuda.set_device(0)
     dev = torch.device('cuda:0')
     lay = ParamLayout(2, 2, 32, 32, 3)
@@ -29,10 +56,12 @@ def main():
     for mode in ('eager', 'capture'):
         tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, capture=(mode == 'capture'))
         losses = []
+        res[mode + '_collectives'] = []
         for s in range(STEPS):
             x1, x2 = batches[s]
             lo, hi = dp.shard_range(8, rank, world)
-            loss, _ = tr.train_step(x1[lo:hi].to(dev), x2[lo:hi].to(dev))
+            (loss, _), calls = _counted(tr.train_step, x1[lo:hi].to(dev), x2[lo:hi].to(dev))
+            res[mode + '_collectives'].append(calls)
             losses.append(loss.item())
             if s == 0:
                 res[mode + '_comm'] = tr.comm.cpu().clone()      # [summed gradients | loss sum | node count] after the all-reduce
@@ -40,10 +69,12 @@ def main():
     # ---- ragged: 6 pairs with different sizes, ranks hold different node counts ----
     tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
     losses = []
+    res['ragged_collectives'] = []
     for s in range(STEPS):
         xs, ys = synthetic.make_ragged_batch(7200 + s, 6, 9, 40)
         lo, hi = dp.shard_range(6, rank, world)
-        loss, _ = tr.train_step_ragged([x.to(dev) for x in xs[lo:hi]], [y.to(dev) for y in ys[lo:hi]], granule=16)
+        (loss, _), calls = _counted(tr.train_step_ragged, [x.to(dev) for x in xs[lo:hi]], [y.to(dev) for y in ys[lo:hi]], granule=16)
+        res['ragged_collectives'].append(calls)
         losses.append(loss.item())
         if s == 0:
             res['ragged_comm'] = tr.comm.cpu().clone()
@@ -61,7 +92,8 @@ def main():
         x1 = torch.stack([pad(x) for x in xs[lo:hi]]).to(dev)
         x2 = torch.stack([pad(y) for y in ys[lo:hi]]).to(dev)
         nv = torch.tensor([x.shape[-1] for x in xs[lo:hi]], dtype=torch.int32, device=dev)
-        loss, _ = tr.train_step(x1, x2, nvalid=nv)
+        (loss, _), calls = _counted(tr.train_step, x1, x2, nvalid=nv)
+        res.setdefault('padded_collectives', []).append(calls)
         losses.append(loss.item())
         if s == 0:
             res['padded_comm'] = tr.comm.cpu().clone()

@@ -78,8 +78,40 @@ def test_two_ranks_equal_single_process(tmp_path):
     assert torch.equal(two['eager'][0], two['capture'][0])
 
 
-def test_one_collective_per_step(monkeypatch):
-    """Count the all_reduce calls FgnnTrainer issues per step (eager, captured after its first step, ragged)."""
-    import graph_neural_net_amd.dp as dp
-    src = open(os.path.join(ROOT, 'graph_neural_net_amd', 'trainer.py')).read()
-    assert src.count('dp.allreduce_sum_(') == 1 and 'global_node_count' not in src and '.item()' not in src
+def test_one_collective_per_step(tmp_path):
+    """Runtime count: inside each child every data-moving entry point of torch.distributed is wrapped by a counter
+    (tests/dp_worker.py), and each FgnnTrainer step -- eager, captured (including its capturing first step), size-bucketed
+    ragged, padded ragged -- must have issued exactly ONE collective, an all_reduce (north_star: "a single RCCL all-reduce of
+    gradients ... per step"; the loss sum and the node count ride in the same buffer)."""
+    if torch.cuda.is_initialized():
+        pytest.skip('the GPU is already initialised in this process; run this file first / on its own')
+    tmp = str(tmp_path)
+    _launch(2, os.path.join(tmp, 'count'), tmp)
+    two = torch.load(os.path.join(tmp, 'count.pt'))
+    for mode in ('eager', 'capture', 'ragged', 'padded'):
+        per_step = two[mode + '_collectives']
+        assert len(per_step) == 3
+        for calls in per_step:
+            assert calls == ['all_reduce'], (mode, per_step)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent (which never touches the GPU) starts two rank processes,
+    relays rank 0's JSON line and exits 0.  gloo backend: both ranks share cuda:0 on a one-GPU box; with the default backend
+    (nccl = RCCL) the same command is the 1/2/4/8-GPU scaling run."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
+                        '--windows', '2', '--settle', '4', '--no-cpu-baseline', '--profile-steps', '0'], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == 'gloo'
+    assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
+    assert out['allreduce_ms'] is not None and out['allreduce_ms'] > 0
+    assert out['value'] > 0 and abs(out['value'] - 64 / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
+    assert out['ms_per_step_min'] <= out['ms_per_step'] <= out['ms_per_step_max'] and out['timed_windows'] == 2

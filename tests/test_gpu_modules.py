@@ -304,3 +304,170 @@ def test_stale_workspace_is_detected_and_no_grad_forward_is_allowed():
         p.grad = None
     model.loss(model(x1, x2)).backward()
     assert all(torch.equal(a, p.grad) for a, p in zip(g_ok, model.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: the autograd surface of the fused module path (models/trainers.py:60-76 is plain autograd in the reference)
+def _default_model(blocks=1, c0=2, seed=3):
+    torch.manual_seed(seed)
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=blocks,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    return Siamese_Node_Exp(c0, ne).to(DEV)
+
+
+def _oracle_grads(model, x1, x2):
+    sd = {k[len('node_embedder.'):]: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return O.step_fwd_bwd(x1.cpu(), x2.cpu(), sd)
+
+
+def test_padded_input_buffer_is_not_shared_between_grad_and_eval_forwards():
+    """original_features_num = 3 runs on the 32-wide engine through a zero-padded input staging buffer that block 1's
+    backward re-reads: an evaluation forward of the same shape between a training forward and its backward() must not
+    overwrite it.  Gradients are checked against the oracle."""
+    model = _default_model(blocks=2, c0=3, seed=21)
+    g = torch.Generator().manual_seed(4)
+    x1, x2 = torch.randn(2, 3, 14, 14, generator=g), torch.randn(2, 3, 14, 14, generator=g)
+    other = torch.randn(2, 3, 14, 14, generator=g)
+    loss = model.loss(model(x1.to(DEV), x2.to(DEV)))
+    with torch.no_grad():
+        model(other.to(DEV), other.flip(0).to(DEV))      # same shape, different data, no_grad: its own engine AND its own buffer
+    loss.backward()
+    _, l_ref, g_ref = _oracle_grads(model, x1, x2)
+    assert abs(loss.item() - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if not is_zero_grad(k):
+            assert rel(p.grad.cpu(), g_ref[k]) < 1e-4, k
+
+
+def test_per_parameter_autograd_mode_hooks_autograd_grad_and_frozen_parameters():
+    """With param_autograd=True (picked automatically when torch.distributed is initialised or a parameter carries hooks)
+    the parameters are real autograd inputs of the fused node: hooks fire, torch.autograd.grad(loss, [p]) works, DDP's
+    reducer would see every gradient; the gradients equal the fast mode's bit for bit.  Frozen parameters get no .grad."""
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    model = _default_model(blocks=1)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    x1, x2 = d['x1'].to(DEV), d['x2'].to(DEV)
+    model.loss(model(x1, x2)).backward()                                       # fast mode
+    fast = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    names = [n for n, _ in model.named_parameters()]
+    w = dict(model.named_parameters())[names[0]]
+    seen = []
+    h = w.register_hook(lambda g: seen.append(g.clone()))                      # a hook switches the mode on by itself
+    assert model.node_embedder._params_as_inputs() is False or True
+    model.node_embedder._bind_flat()
+    assert model.node_embedder._params_as_inputs()
+    loss = model.loss(model(x1, x2))
+    (g_one,) = torch.autograd.grad(loss, [w], retain_graph=True)
+    assert torch.equal(g_one, fast[names[0]])
+    loss.backward()
+    assert len(seen) == 2 and torch.equal(seen[-1], fast[names[0]])
+    for n, p in model.named_parameters():
+        assert torch.equal(p.grad, fast[n]), n
+    h.remove()
+    # frozen parameters: no .grad in either mode
+    for mode in (False, True):
+        model.node_embedder.param_autograd = mode
+        for p in model.parameters():
+            p.grad = None
+        w.requires_grad_(False)
+        model.loss(model(x1, x2)).backward()
+        assert w.grad is None
+        assert all(torch.equal(p.grad, fast[n]) for n, p in model.named_parameters() if p is not w)
+        w.requires_grad_(True)
+
+
+def test_gradient_with_respect_to_the_input():
+    """The reference's autograd also differentiates with respect to the input tensor when it requires grad; the fused
+    path returns it (dense fp32 inputs), for the 2-channel default model and a 3-channel (padded) one."""
+    for c0 in (2, 3):
+        model = _default_model(blocks=2, c0=c0, seed=8)
+        g = torch.Generator().manual_seed(9)
+        x1, x2 = torch.randn(2, c0, 17, 17, generator=g), torch.randn(2, c0, 17, 17, generator=g)
+        a, b = x1.clone().to(DEV).requires_grad_(True), x2.clone().to(DEV).requires_grad_(True)
+        model.loss(model(a, b)).backward()
+        sd = {k[len('node_embedder.'):]: v.detach().cpu().double() for k, v in model.state_dict().items()}
+        r1, r2 = x1.double().requires_grad_(True), x2.double().requires_grad_(True)
+        O.triplet_loss_mean(O.siamese_scores(r1, r2, sd)).backward()
+        assert rel(a.grad.cpu(), r1.grad.float()) < 1e-4 and rel(b.grad.cpu(), r2.grad.float()) < 1e-4
+
+
+def test_a_replaced_parameter_is_picked_up():
+    """The engine reads one flat buffer the parameters are views of; a re-assigned nn.Parameter (or load_state_dict(...,
+    assign=True)) must re-bind, not keep training stale weights."""
+    d = load_golden('cfg1_er_n20_b4_1blk.npz')
+    model = _default_model(blocks=1)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    x1, x2 = d['x1'].to(DEV), d['x2'].to(DEV)
+    with torch.no_grad():
+        s0 = model(x1, x2).clone()
+        mlp = model.node_embedder.ne_bm_block1_mlp2
+        mlp.convs[1].weight = torch.nn.Parameter(mlp.convs[1].weight.detach() * 0.5)        # a NEW parameter object
+        s1 = model(x1, x2).clone()
+        sd = {k[len('node_embedder.'):]: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        assert rel(s1.cpu(), O.siamese_scores(x1.cpu(), x2.cpu(), sd)) < 3e-5
+        assert rel(s1.cpu(), s0.cpu()) > 1e-3
+        new = {k: v.clone() for k, v in sub(d, 'sd/').items()}
+        model.load_state_dict({'node_embedder.' + k: v.to(DEV) for k, v in new.items()}, assign=True)
+        assert rel(model(x1, x2).cpu(), s0.cpu()) < 1e-6
+
+
+def test_module_engine_cache_is_bounded():
+    """A stream of ragged shapes through the module path re-uses a bounded set of workspaces (LRU by bytes)."""
+    from graph_neural_net_amd.network import Network
+    model = _default_model(blocks=2)
+    old = Network.ENGINE_CACHE_BYTES
+    Network.ENGINE_CACHE_BYTES = 1 << 30
+    try:
+        import numpy as np
+        rng = np.random.default_rng(0)
+        for it in range(200):
+            n = int(rng.integers(8, 90))
+            sizes = [int(v) for v in rng.integers(max(4, n // 3), n + 1, size=int(rng.integers(1, 5)))]
+            sizes[0] = n
+            g = torch.Generator().manual_seed(it)
+            xs = [torch.randn(2, m, m, generator=g).to(DEV) for m in sizes]
+            with torch.no_grad():
+                model(from_list(xs, dims=(1, 2), base_name='N'), from_list(xs, dims=(1, 2), base_name='M'))
+            cache = model.node_embedder._engines
+            assert cache.used() <= Network.ENGINE_CACHE_BYTES or len(cache) == 1, (it, cache.used())
+        assert len(cache) < 200
+    finally:
+        Network.ENGINE_CACHE_BYTES = old
+
+
+def test_fused_step_equals_the_eager_module_path_and_trains_in_place():
+    """Siamese_Node_Exp.fused_step: forward + loss + backward as one replayed HIP graph; loss, scores and every p.grad
+    equal the eager module path (same kernels: bit for bit); FgnnTrainer.from_module trains the module's own buffer."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=4,
+              in_features=32, out_features=32, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne, lr=1e-3).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    x1, x2 = d['x1'].to(DEV), d['x2'].to(DEV)
+    scores = model(x1, x2)
+    loss = model.loss(scores)
+    loss.backward()
+    eager = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for cap in (False, True, True):
+        for p in model.parameters():
+            p.grad = None
+        l2, s2 = model.fused_step({'input': x1}, {'input': x2}, capture=cap)
+        assert torch.equal(s2, scores.detach()) and abs(l2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, eager[n]), (cap, n)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    opt.step()                                                                  # an ordinary optimizer on the views
+    l3, _ = model.fused_step(x1, x2)
+    assert l3.item() != loss.item()
+    tr = FgnnTrainer.from_module(model, capture=True)
+    before = model.state_dict()['node_embedder.ne_bm_block1_mlp1.convs.0.weight'].clone()
+    losses = [tr.train_step(x1, x2)[0].item() for _ in range(5)]
+    after = model.state_dict()['node_embedder.ne_bm_block1_mlp1.convs.0.weight']
+    assert not torch.equal(before, after) and losses[-1] < losses[0]
+    with torch.no_grad():                                                       # the module's eager forward sees the trained weights
+        l_eager = model.loss(model(x1, x2)).item()
+    assert l_eager < losses[0]

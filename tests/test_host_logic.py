@@ -1,6 +1,7 @@
 """CPU: host-side logic (no compute calls into the HIP library)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -279,3 +280,17 @@ def test_committed_bench_lines_follow_the_contract():
         if d.get('cpu_baseline'):
             c = d['cpu_baseline']
             assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+
+
+def test_bench_self_launch_relays_the_worst_return_code():
+    """`python bench.py --gpus 2` without RANK in the environment starts its own rank processes (before touching the GPU) and
+    exits with their worst return code: without a GPU both ranks stop with "bench.py needs a GPU" (there is no CPU path)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is present: covered by tests/test_00_gpu_two_ranks.py::test_bench_launches_its_own_ranks')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert 'needs a GPU' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
