@@ -243,7 +243,7 @@ class FgnnEngineBF16:
                   tag='mlp_bwd16[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
                                                   (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 
-    def backward(self, params, grads, grad_scale=1.0):
+    def backward(self, params, grads, grad_scale=1.0, hook=None):
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
@@ -254,9 +254,13 @@ class FgnnEngineBF16:
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
-        return self.backward_from_dE(params, grads, W['dE'])
+        return self.backward_from_dE(params, grads, W['dE'], hook=hook)
 
-    def backward_from_dE(self, params, grads, dE):
+    def backward_from_dE(self, params, grads, dE, hook=None):
+        """hook(stage, k): optional inspection callback, called after every kernel of the block backward ('colmax_bwd',
+        'mlp3_bwd', 'matmul_bwd', 'mlp1_bwd', 'mlp2_bwd'); the kernel-level parity tests use it to compare each kernel's
+        output slabs element by element and to substitute the oracle's values for the next kernel's inputs."""
+        hook = hook or (lambda stage, k: None)
         L = self.layout
         W = self._alloc_bwd()
         st = _lib.stream_ptr()
@@ -270,6 +274,7 @@ class FgnnEngineBF16:
         _lib.call('fgnn_colmax_bwd16_coef', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N, self.ldr,
                   _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), _lib.ptr(W['coef'][2]), st,
                   tag='fgnn_colmax_bwd16')
+        hook('colmax_bwd', K)
         coef3 = W['coef'][2]
         for k in range(K, 0, -1):
             sin = self._slab_in(k, params)
@@ -278,13 +283,17 @@ class FgnnEngineBF16:
             # mlp3's backward also emits the per-tile trace term <dmult, mult>; the matmul backward derives the S2 sums of both
             # its outputs from it instead of re-reading the two raw operand slabs
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False, emit=True)
+            hook('mlp3_bwd', k)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd16_tc', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       _lib.ptr(W['s12part']), self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']),
                       _lib.ptr(W['dy2']), gs, self.ldp, _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
                       _lib.ptr(W['coef'][0]), _lib.ptr(W['coef'][1]), st, tag='fgnn_chan_matmul_bwd16')
+            hook('matmul_bwd', k)
             self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
+            hook('mlp1_bwd', k)
             self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
+            hook('mlp2_bwd', k)
             if not first:
                 _lib.call('fgnn_gn_bwd_coef_tiles_tpg', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, self.tpg, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)
@@ -322,6 +331,13 @@ class FgnnEngineBF16:
         return scores, loss
 
     # ------------------------------------------------------------------ inspection (tests)
+    def load_dense(self, buf, t):
+        """(G, C, N, N) fp32 tensor -> bf16 workspace slab `buf` (rounded to nearest even, padding zero-filled)."""
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        Cc = t.shape[1]
+        _lib.call('fgnn_to_bf16', _lib.ptr(t), self._nv(), self.G, Cc, self.N, self.ldr, _lib.ptr(buf), Cc * self.ldp, self.ldp,
+                  _lib.stream_ptr())
+
     def dense(self, buf, channels=32):
         """bf16 workspace slab -> (G, channels, N, N) fp32 tensor (copy)."""
         y = torch.empty(self.G, channels, self.N, self.N, dtype=torch.float32, device=self.device)

@@ -143,7 +143,7 @@ def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
     dE = R(torch.cat([de1, de2]))
     dy = torch.zeros_like(out).scatter_(-1, idx.unsqueeze(-1), dE.unsqueeze(-1))
     if keep is not None:
-        keep['E'], keep['idx'], keep['dE'] = E, idx, dE
+        keep['E'], keep['idx'], keep['dE'], keep['dy_last'] = E, idx, dE, dy
     grads = {}
     for k in range(K, 0, -1):
         m1, m2, m3 = mlps[(k, 1)], mlps[(k, 2)], mlps[(k, 3)]
@@ -158,7 +158,11 @@ def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
         if keep is not None:
             keep[(k, 'dmult')], keep[(k, 'dy1')], keep[(k, 'dy2')] = dmult, dy1, dy2
         if not first:
+            if keep is not None:
+                keep[(k, 'din3')] = din                 # what mlp3's backward stores
             din = R(din + dx1)
+            if keep is not None:
+                keep[(k, 'din31')] = din                # ... after mlp1's backward has accumulated into it
             din = R(din + dx2)
             if keep is not None:
                 keep[(k, 'din')] = din

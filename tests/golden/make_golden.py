@@ -488,8 +488,55 @@ def main_widths():
     print(json.dumps({k: v for k, v in meta['cases'].items() if k.startswith('widths')}, indent=1, sort_keys=True))
 
 
+def main_round3():
+    """Round-3 fixtures: ONE block, where 16-bit arithmetic is not yet chaotic -- the reference run in bf16 (ref_step_bf16:
+    the Network.half recipe of models/utils.py:71-74), fp32 and fp64 on N = 50 regular pairs (B = 2) and one N = 200 dense
+    ER pair, with a perturbed 1-block model.  tests/test_gpu_bf16.py gates the HIP bf16 engine against them:
+    distance to the fp64 truth <= 1.0 x the reference-bf16 distance, scores and every gradient tensor."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from graph_neural_net_amd import synthetic
+    from oracle import fgnn_oracle as O
+    torch.set_num_threads(8)
+    with open(os.path.join(OUT, 'golden_meta.json')) as f:
+        meta = json.load(f)
+    model = build_reference_model(1, seed=3)
+    perturb_(model, 300)
+    for tag, (x1, x2) in (('bf16ref_reg_n50_b2_1blk', synthetic.make_batch(2300, 2, 50, 'Regular', 0.2, 0.1)),
+                          ('bf16ref_er_n200_b1_1blk', synthetic.make_batch(4300, 1, 200, 'ErdosRenyi', 0.5, 0.1))):
+        worst = check_oracle_bit_equal(model, x1, x2, tag)
+        s, l, g = ref_step(model, x1, x2)
+        s64, l64, g64 = ref_step(f64(model), x1.double(), x2.double())
+        s16, l16, g16 = ref_step_bf16(model, x1, x2)
+        b1, b2 = _pack_pairs(synthetic, x1, x2)
+        d = {'bits1': b1, 'bits2': b2, 'n': np.array(x1.shape[-1]), 'scores': s.numpy(), 'scores64_as_f32': s64.float().numpy(),
+             'scores_refbf16': s16.numpy(), 'loss': l.numpy(), 'loss64': l64.numpy(), 'loss_refbf16': l16.numpy()}
+        for k, v in model.state_dict().items():
+            d['sd/' + k[len('node_embedder.'):]] = v.numpy()
+        for k, v in g.items():
+            d['grad/' + k] = v.numpy()
+        for k, v in g64.items():
+            d['grad64/' + k] = v.float().numpy()
+        for k, v in g16.items():
+            d['grad_refbf16/' + k] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, tag + '.npz'), **d)
+        names = [k for k in g if not k.endswith('convs.2.bias')]
+        flat = lambda gg: torch.cat([gg[k].reshape(-1).double() for k in names])
+        l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        meta['cases'][tag] = {
+            'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst,
+            'ref_fp32_vs_fp64_scores_l2': l2(s, s64), 'ref_bf16_vs_fp64_scores_l2': l2(s16, s64),
+            'ref_fp32_vs_fp64_flatgrad_l2': l2(flat(g), flat(g64)), 'ref_bf16_vs_fp64_flatgrad_l2': l2(flat(g16), flat(g64)),
+            'ref_bf16_vs_fp64_worst_tensor_l2': max(l2(g16[k], g64[k]) for k in names)}
+        print(tag, json.dumps(meta['cases'][tag], indent=1, sort_keys=True))
+    with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'round2':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round3':
+        main_round3()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round2':
         main_round2()
     elif len(sys.argv) > 1 and sys.argv[1] == 'widths':
         main_widths()

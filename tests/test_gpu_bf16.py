@@ -380,3 +380,103 @@ def test_bf16_ragged_padding_tiles_are_skipped_not_trusted(ns):
     run(skip, torch.cat([xf1, xf2]).contiguous().to(DEV), torch.full((G,), N, dtype=torch.int32, device=DEV))
     s3, l3, g3 = run(skip)
     assert torch.equal(s3, s1) and torch.equal(l3, l1) and torch.equal(g3, g1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: pinned to the reference where bf16 is not yet chaotic, and the backward kernels element by element
+def test_one_block_against_the_reference_bf16_run():
+    """The HIP bf16 engine on the reference-generated ONE-block fixtures (the reference itself run in bf16 / fp32 / fp64):
+    at least as close to the fp64 truth as the reference's own bf16 run -- the gates of tests/test_oracle_bf16.py
+    (flat gradient <= 1.0 x, per-tensor median <= 1.0 x and worst <= 3.0 x, scores <= 1.5 x)."""
+    from test_oracle_bf16 import ONE_BLOCK_FIXTURES, one_block_gates
+    for name in ONE_BLOCK_FIXTURES:
+        d = load_golden(name)
+        n = int(d['n'])
+        x1, x2 = unpack_pairs(d['bits1'], n), unpack_pairs(d['bits2'], n)
+        eng, lay, scores, loss, grads = _run(sub(d, 'sd/'), x1, x2, 1)
+        one_block_gates(scores, grads, d)
+        assert abs(loss - d['loss64'].item()) <= 1.0 * abs(d['loss_refbf16'].item() - d['loss64'].item()) + 2e-4
+
+
+def _ulp_close_grad(got, ref, max_frac, what, flips=1e-2):
+    """Gradient slabs: elements within one bf16 ulp of the oracle's value -- one ulp of the value itself or, for the entries
+    that are small because their 32..64 products cancel (there the order of the fp32 accumulation and a one-ulp flip of an
+    operand move the tiny result by more than ITS ulp), one ulp of the slab's root-mean-square magnitude -- and at most
+    max_frac of the elements differing at all.  The MLP backward re-derives two ReLU masks from recomputed activations: where
+    a pre-activation sits within rounding distance of 0 the mask -- and with it one of the 32 terms of that pixel's sums --
+    may differ; such pixels are allowed for at most `flips` of the elements and stay below a quarter of the scale."""
+    got, ref = got.float().cpu(), ref.float()
+    diff = (got - ref).abs()
+    scale = torch.maximum(ref.abs(), ref.pow(2).mean().sqrt().expand_as(ref))
+    beyond = diff > ULP * scale + 1e-30
+    assert beyond.float().mean().item() <= flips, (what, beyond.float().mean().item())
+    assert (diff <= 0.25 * scale).all(), (what, (diff / scale).max().item())
+    frac = (diff > 0).float().mean().item()
+    assert frac <= max_frac, (what, frac)
+
+
+@pytest.mark.parametrize('N,B', [(24, 2), (50, 2), (200, 1)])
+def test_backward_kernels_element_wise_on_identical_inputs(N, B):
+    """fgnn_colmax_bwd16, fgnn_mlp_bwd16 (mlp3: two input gradients; mlp1 / mlp2: read-modify-write of the block-input
+    gradient) and fgnn_chan_matmul_bwd16 through the C ABI, each fed the ORACLE's bf16 values (forward slabs, arg-max indices,
+    dE and, stage by stage, the previous kernel's output) and compared with oracle/fgnn_oracle_bf16.py's corresponding step:
+    elements within one bf16 ulp (up to 1 % ReLU-flip pixels -- measured 0.2-0.7 % -- see _ulp_close_grad).  How many elements differ AT ALL
+    depends on the depth of the rounded chain: at most 2 % for the matmul (one rounding after one product; measured 1.0 %); the MLP backward
+    rounds dz, dpre_1 and dpre_0 to bf16 before each of its three dgrad GEMMs, a one-ulp flip of one of a sum's 32 operands
+    moves the sum by ~0.2 ulp and re-rounds it with that probability, so the differing fraction grows ~6 x per stage
+    (1e-3 -> 0.6 % -> 3.5 % -> 15-30 % measured on dmult / din3, 37-44 % after the accumulation of mlp1's share has rounded the
+    block-input gradient once more; every one of them a single ulp).  Two blocks, so the
+    accumulating variants run too."""
+    sd = _sd(2, 40 + N)
+    x1, x2 = synthetic.make_batch(300 + N, B, N, 'ErdosRenyi', 0.3 if N < 100 else 0.5, 0.1)
+    keep = {}
+    s_ref, l_ref, g_ref = OB.step_fwd_bwd(x1, x2, sd, keep=keep)
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    grads = torch.zeros_like(params)
+    eng = FgnnEngineBF16(lay, 2 * B, N, DEV)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    eng.forward(params, x, defer_loss=True)
+    # identical inputs: the oracle's forward slabs, arg-max indices and dE replace the engine's own
+    for k in (1, 2):
+        eng.load_dense(eng.z[(k, 1)], keep[(k, 'z1')])
+        eng.load_dense(eng.z[(k, 2)], keep[(k, 'z2')])
+        eng.load_dense(eng.mult[k], keep[(k, 'mult')])
+        eng.load_dense(eng.z[(k, 3)], keep[(k, 'z3')])
+    eng.idx.copy_(keep['idx'].to(torch.int32))
+    W = eng._alloc_bwd()
+    seen = []
+
+    def hook(stage, k):
+        dy_in = W['dy'][(2 - k) % 2]             # gradient slab this block's mlp3 consumes
+        din = W['dy'][(2 - k + 1) % 2]           # ... and the one its three MLPs produce (blocks > 1)
+        if stage == 'colmax_bwd':
+            assert torch.equal(eng.dense(dy_in).cpu(), keep['dy_last'])          # a pure scatter of bf16 values: exact
+        elif stage == 'mlp3_bwd':
+            _ulp_close_grad(eng.dense(W['dmult']), keep[(k, 'dmult')], 0.35, ('dmult', k))
+            eng.load_dense(W['dmult'], keep[(k, 'dmult')])
+            if k > 1:
+                _ulp_close_grad(eng.dense(din), keep[(k, 'din3')], 0.35, ('din3', k))
+                eng.load_dense(din, keep[(k, 'din3')])
+        elif stage == 'matmul_bwd':
+            _ulp_close_grad(eng.dense(W['dy1']), keep[(k, 'dy1')], 2e-2, ('dy1', k), flips=1e-4)     # no masks; isolated operand flips under cancellation
+            _ulp_close_grad(eng.dense(W['dy2']), keep[(k, 'dy2')], 2e-2, ('dy2', k), flips=1e-4)
+            eng.load_dense(W['dy1'], keep[(k, 'dy1')])
+            eng.load_dense(W['dy2'], keep[(k, 'dy2')])
+        elif stage == 'mlp1_bwd' and k > 1:
+            _ulp_close_grad(eng.dense(din), keep[(k, 'din31')], 0.6, ('din31', k))
+            eng.load_dense(din, keep[(k, 'din31')])
+        elif stage == 'mlp2_bwd' and k > 1:
+            _ulp_close_grad(eng.dense(din), keep[(k, 'din')], 0.6, ('din', k))
+            eng.load_dense(din, keep[(k, 'din')])
+        seen.append((stage, k))
+
+    eng.backward_from_dE(params, grads, keep['dE'].to(DEV).contiguous(), hook=hook)
+    torch.cuda.synchronize()
+    assert [s for s, _ in seen] == ['colmax_bwd'] + ['mlp3_bwd', 'matmul_bwd', 'mlp1_bwd', 'mlp2_bwd'] * 2
+    # with every kernel on the oracle's inputs the parameter gradients (fp32 sums of bf16 products; the operands still carry
+    # the kernels' own one-ulp flips and ReLU-flip pixels) agree to better than 1 % (measured 0.2-0.7 %; the end-to-end gate of
+    # test_first_block_is_exact_up_to_rounding_flips is 5 %)
+    got = lay.unflatten(grads.cpu())
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    assert l2rel(flat_of(got, keys), flat_of(g_ref, keys)) < 1e-2

@@ -348,10 +348,15 @@ def test_ragged_with_single_vertex_and_full_size_graphs():
         assert rel(scores[i, :n, :n], s_ref[i]) < 1e-4 or (scores[i, :n, :n] - s_ref[i]).abs().max() < 1e-6
         assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
     assert abs(loss - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    # gradients against the fp64 truth with the oracle's own fp32 error as yard-stick (as for the constant-size cases)
+    _, _, g64 = O.step_fwd_bwd_ragged([x.double() for x in xs], [y.double() for y in ys], {k: v.double() for k, v in sd.items()})
     keys = [k for k in g_ref if not is_zero_grad(k)]
-    a = torch.cat([grads[k].reshape(-1).double() for k in keys])
-    b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])
-    assert (a - b).norm() < 5e-3 * b.norm()
+    flat = lambda g: torch.cat([g[k].reshape(-1).double() for k in keys])
+    a, b, t = flat(grads), flat(g_ref), flat(g64)
+    # (n = 1 and n = 2 graphs: zero variance under the GraphNorm, the eps-regularised 1 / sqrt amplifies fp32 noise -- the
+    # batch-level factor of the large cases, BIG_TENSOR = 10, instead of 4; measured 8.6 x; the old gate was 5e-3 |g|,
+    # i.e. 160 x looser)
+    assert (a - t).norm() <= BIG_TENSOR * (b - t).norm() + 1e-6 * t.norm() + 1e-4, ((a - t).norm().item(), (b - t).norm().item(), t.norm().item())
 
 
 def test_ragged_bucketed_step_equals_padded_batch_and_oracle():

@@ -66,3 +66,42 @@ def test_bf16_scheme_not_worse_than_reference_bf16_run():
     assert ours_s <= BF16_CLASS * ref_s, (ours_s, ref_s)
     assert ours_g <= BF16_CLASS * ref_g, (ours_g, ref_g)
     assert abs(l.item() - d['loss64'].item()) <= BF16_CLASS * abs(d['loss_refbf16'].item() - d['loss64'].item()) + 1e-3
+
+
+ONE_BLOCK_FIXTURES = ('bf16ref_reg_n50_b2_1blk.npz', 'bf16ref_er_n200_b1_1blk.npz')
+
+
+def one_block_gates(scores, grads, d):
+    """Gates against the reference-generated ONE-block fixtures (tests/golden/make_golden.py round3: the reference itself run
+    in bf16 -- Network.half, models/utils.py:71-74 -- next to its fp32 and fp64 runs), where 16-bit arithmetic is not yet
+    chaotic.  Distances are L2-relative to the fp64 truth.  A scheme with fp32 accumulation and statistics should be at
+    least as close as the all-bf16 reference run; two bf16 evaluations with different rounding points are still two samples
+    of the same noise, so single tensors scatter around the ratio 1:
+      * the whole flat gradient:            ours <= 1.0 x reference-bf16   (measured: oracle scheme 0.84 / 0.50)
+      * per gradient tensor:  median ratio  <= 1.0, every tensor <= 3.0 x  (measured: medians 0.84 / 0.56, worst 1.83 / 1.26 for
+                                            the oracle scheme, 0.71 / 2.17 on the N = 50 fixture for the HIP engine: a single
+                                            tensor's ratio is the quotient of two noise samples)
+      * scores:                             ours <= 1.5 x reference-bf16   (measured: 1.37 / 0.80; the pooled maxima of one
+                                                                            block are a handful of bf16-rounded values)
+    Returns the measured ratios."""
+    keys = [k for k in sub(d, 'grad/') if not is_zero_grad(k)]
+    g64, g16 = sub(d, 'grad64/'), sub(d, 'grad_refbf16/')
+    s64 = d['scores64_as_f32']
+    r_scores = l2rel(scores, s64) / l2rel(d['scores_refbf16'], s64)
+    r_flat = l2rel(flat_of(grads, keys), flat_of(g64, keys)) / l2rel(flat_of(g16, keys), flat_of(g64, keys))
+    per = sorted(l2rel(grads[k], g64[k]) / l2rel(g16[k], g64[k]) for k in keys)
+    median = per[len(per) // 2]
+    assert r_flat <= 1.0, r_flat
+    assert median <= 1.0 and per[-1] <= 3.0, (median, per[-3:])
+    assert r_scores <= 1.5, r_scores
+    return r_scores, r_flat, median, per[-1]
+
+
+def test_one_block_scheme_is_at_least_as_close_as_the_reference_bf16_run():
+    for name in ONE_BLOCK_FIXTURES:
+        d = load_golden(name)
+        n = int(d['n'])
+        x1, x2 = unpack_pairs(d['bits1'], n), unpack_pairs(d['bits2'], n)
+        s, l, g = OB.step_fwd_bwd(x1, x2, sub(d, 'sd/'))
+        one_block_gates(s, g, d)
+        assert abs(l.item() - d['loss64'].item()) <= 1.0 * abs(d['loss_refbf16'].item() - d['loss64'].item()) + 2e-4
