@@ -52,6 +52,9 @@ def kernel_model(tag, G, N, pix=None, cube=None):
     if tag.startswith('mlp_fwd['):
         cin, nmlp = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
         return 4.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
+    if tag.startswith('mlp_bwd_pair['):       # mlp1 + mlp2 of a block: x, 2 x (dy, z), the old d_in, one d_in store
+        cin, dx = [int(v.split('=')[1]) for v in tag[13:-1].split(',')]
+        return 4.0 * G * P * (cin + 128 + 2 * dx), 2 * 4.0 * G * P * (cin * 32 + 2 * 1024)
     if tag.startswith('mlp_bwd['):
         cin, dx = [int(v.split('=')[1]) for v in tag[8:-1].split(',')]
         return 4.0 * G * P * (cin + 64 + dx), 4.0 * G * P * (cin * 32 + 2 * 1024)

@@ -157,6 +157,7 @@ class EngineCache:
 class FgnnEngine:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
+    PAIR_BWD = os.environ.get('FGNN_PAIR_BWD', '1') != '0'      # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd_pair)
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -437,6 +438,21 @@ class FgnnEngine:
         'tiles' -> every workgroup sums the per-tile S1/S2 partials (s12part) of the graphs it touches itself.
         dx_strides: (graph stride, channel stride) of the dx tensors when they are not workspace slabs (the gradient with
         respect to the model input, a (G, c0, N, N) tensor)."""
+        args = self._mlp_bwd_args(params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides)
+        _lib.call('fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
+                  tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
+                                                (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
+
+    def _mlp_bwd_pair(self, params, k, sin, din, emit):
+        """mlp1 + mlp2 of block k in ONE launch (csrc/mlp_bwd_pair.hip): the two waves of a SIMD take one MLP each and sum the
+        gradient of the shared input in LDS; d_in is bit-identical to the two accumulating launches it replaces."""
+        W = self._bwd
+        a1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], None, None, None, False, False, False, None)
+        a2 = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit, None)
+        _lib.call('fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
+                  tag='mlp_bwd_pair[cin=%d,dx=%d]' % (sin.C, sin.C if din is not None else 0))
+
+    def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides):
         L = self.layout
         W = self._bwd
         rec = L.mlp[(k, j)]
@@ -476,9 +492,7 @@ class FgnnEngine:
         args.cu_share = self.cu_share
         if emit:
             args.s12part = W['s12part'].data_ptr()
-        _lib.call('fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
-                  tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
-                                                (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
+        return args
 
     def backward(self, params, grads, grad_scale=1.0, finalize=True):
         """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer (finalize=False: everything but the
@@ -536,8 +550,11 @@ class FgnnEngine:
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False, dx_strides=dxs)
-            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first, dx_strides=dxs)
+            if self.PAIR_BWD and not self.x3 and self.nvalid is None and dxs is None and L.depth == 3 and sin.C in (2, 32):
+                self._mlp_bwd_pair(params, k, sin, din, emit=not first)
+            else:
+                self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False, dx_strides=dxs)
+                self._mlp_bwd(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit=not first, dx_strides=dxs)
             if not first and not in_prologue:
                 _lib.call('fgnn_gn_bwd_coef_tiles', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)

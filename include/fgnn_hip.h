@@ -273,6 +273,12 @@ typedef struct {
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 int fgnn_mlp_bwd_x3(const fgnn_mlp_bwd_args *args, void *stream);   /* the x3 form (see fgnn_mlp_fwd_x3): image of kind 1 from
                                                                          fgnn_pack_x3_operands; input gradients for 32-channel slabs */
+/* mlp1 + mlp2 of one block (models/blocks_emb.py:16-27: two MlpBlock_Real on the same input; their autograd) in ONE launch:
+ * `m1` / `m2` are the argument blocks of the two fgnn_mlp_bwd calls it replaces, describing the same input slab; the input
+ * gradient (dxa, accumulate_a) and its tile sums (s12part) are given in m2 only and receive (old + dx1) + dx2, bit-identical to
+ * the two accumulating launches.  Depth 3, one slab of 2 or 32 channels, constant-size batches, both operand images. */
+int fgnn_mlp_bwd_pair_supported(int ca, int depth);
+int fgnn_mlp_bwd_pair(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
 int fgnn_mlp_bwd_coef_tiles_supported(int G, int N);   /* s12tiles usable: a workgroup spans <= FGNN_BWD_COEF_GRAPHS graphs */
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:

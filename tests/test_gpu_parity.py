@@ -650,3 +650,36 @@ def test_ragged_skipping_engine_equals_full_engine_on_boundary_shapes(ns):
     assert torch.equal(s1, s0)
     assert abs(l1.item() - l0.item()) <= 1e-6 * abs(l0.item())
     assert (g1 - g0).norm().item() <= 5e-6 * g0.norm().item() + 1e-7
+
+
+@pytest.mark.parametrize('B,N,bits', [(3, 33, False), (4, 50, True), (2, 64, False)])
+def test_pair_backward_equals_the_two_launches_it_replaces(B, N, bits):
+    """fgnn_mlp_bwd_pair (mlp1 + mlp2 of a block in one launch, the input gradient summed inside the wave pair): the block-input
+    gradient slabs are bit-identical to those of the two accumulating fgnn_mlp_bwd launches -- (d_in3 + dx1) + dx2 in both --
+    and every parameter gradient agrees up to the association of the per-wave partial sums; dense and bit-packed input."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x1, x2 = synthetic.make_batch(600 + N, B, N, 'ErdosRenyi', 0.3, 0.1)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    packed = torch.from_numpy(synthetic.pack_adjacency(torch.cat([x1, x2])[:, 0].numpy()).astype('int32')).to(DEV) if bits else None
+    out = []
+    for pair in (False, True):
+        old = FgnnEngine.PAIR_BWD
+        FgnnEngine.PAIR_BWD = pair
+        try:
+            eng = FgnnEngine(lay, 2 * B, N, DEV, mfma='f32')
+            g = torch.zeros_like(params)
+            sc, loss = eng.step(params, g, None if bits else x, bits=packed)
+            torch.cuda.synchronize()
+            out.append((sc.clone(), loss.clone(), g.clone(), eng._bwd['dy'][0].clone(), eng._bwd['dy'][1].clone()))
+            g2 = torch.zeros_like(params)
+            eng.step(params, g2, None if bits else x, bits=packed)
+            torch.cuda.synchronize()
+            assert torch.equal(g, g2)                                    # run-to-run bit-reproducible
+        finally:
+            FgnnEngine.PAIR_BWD = old
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
