@@ -40,6 +40,9 @@ def kernel_model(tag, G, N, pix=None, cube=None):
     if tag.startswith('mlp_fwd16['):
         cin, nmlp = [int(v.split('=')[1]) for v in tag[10:-1].split(',')]
         return 2.0 * G * P * (cin + 32 * nmlp), 2.0 * G * P * nmlp * (cin * 32 + 2 * 1024)
+    if tag.startswith('mlp_bwd16_pair['):
+        cin, dx = [int(v.split('=')[1]) for v in tag[15:-1].split(',')]
+        return 2.0 * G * P * (cin + 128 + 2 * dx), 2 * 4.0 * G * P * (cin * 32 + 2 * 1024)
     if tag.startswith('mlp_bwd16['):
         cin, dx = [int(v.split('=')[1]) for v in tag[10:-1].split(',')]
         return 2.0 * G * P * (cin + 64 + dx), 4.0 * G * P * (cin * 32 + 2 * 1024)

@@ -176,6 +176,7 @@ _SIGNATURES = {
     'fgnn_colmax_fwd16': [C.POINTER(Slab16), _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_colmax_bwd16': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, C.POINTER(Slab16), _VP, _VP],
     'fgnn_mlp_bwd16': [C.POINTER(MlpBwd16Args), _VP],
+    'fgnn_mlp_bwd16_pair': [C.POINTER(MlpBwd16Args), C.POINTER(MlpBwd16Args), _VP],
 }
 _RESTYPES = {'fgnn_last_error': C.c_char_p}
 EXPORTS = tuple(_SIGNATURES)

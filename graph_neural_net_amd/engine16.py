@@ -21,6 +21,7 @@ from .engine import EPS, ParamLayout, _round_up  # noqa: F401
 class FgnnEngineBF16:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device, bf16 storage."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges16 + tile skipping in fgnn_mlp_fwd16 / fgnn_mlp_bwd16
+    PAIR_BWD = True               # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd16_pair), constant-size batches
 
     def __init__(self, layout, G, N, device, ragged=False):
         lib = _lib.load()
@@ -216,6 +217,21 @@ class FgnnEngineBF16:
         return self._bwd
 
     def _mlp_bwd(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit=False):
+        args = self._mlp_bwd_args(params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit)
+        _lib.call('fgnn_mlp_bwd16', C.byref(args), _lib.stream_ptr(),
+                  tag='mlp_bwd16[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
+                                                  (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
+
+    def _mlp_bwd_pair(self, params, k, sin, din, emit):
+        """mlp1 + mlp2 of block k in ONE launch (csrc/mlp_bwd16_pair.hip): the stored d_in is bit-identical to the two
+        read-modify-write launches it replaces."""
+        W = self._bwd
+        a1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], W['coef'][0], None, None, False, False, False)
+        a2 = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit)
+        _lib.call('fgnn_mlp_bwd16_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
+                  tag='mlp_bwd16_pair[cin=%d,dx=%d]' % (sin.C, sin.C if din is not None else 0))
+
+    def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit):
         L = self.layout
         W = self._bwd
         gs = 32 * self.ldp
@@ -239,9 +255,7 @@ class FgnnEngineBF16:
             args.ranges = self.ranges.data_ptr()
         if emit:
             args.s12part = W['s12part'].data_ptr()
-        _lib.call('fgnn_mlp_bwd16', C.byref(args), _lib.stream_ptr(),
-                  tag='mlp_bwd16[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
-                                                  (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
+        return args
 
     def backward(self, params, grads, grad_scale=1.0, hook=None):
         W = self._alloc_bwd()
@@ -260,7 +274,9 @@ class FgnnEngineBF16:
         """hook(stage, k): optional inspection callback, called after every kernel of the block backward ('colmax_bwd',
         'mlp3_bwd', 'matmul_bwd', 'mlp1_bwd', 'mlp2_bwd'); the kernel-level parity tests use it to compare each kernel's
         output slabs element by element and to substitute the oracle's values for the next kernel's inputs."""
-        hook = hook or (lambda stage, k: None)
+        if hook is None:
+            hook = lambda stage, k: None
+        # (a hook with the attribute per_mlp = True asks for the two single-MLP launches, to look at mlp1's output alone)
         L = self.layout
         W = self._alloc_bwd()
         st = _lib.stream_ptr()
@@ -290,10 +306,14 @@ class FgnnEngineBF16:
                       _lib.ptr(W['dy2']), gs, self.ldp, _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
                       _lib.ptr(W['coef'][0]), _lib.ptr(W['coef'][1]), st, tag='fgnn_chan_matmul_bwd16')
             hook('matmul_bwd', k)
-            self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
-            hook('mlp1_bwd', k)
-            self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
-            hook('mlp2_bwd', k)
+            if self.PAIR_BWD and self.nvalid is None and not getattr(hook, 'per_mlp', False):
+                self._mlp_bwd_pair(params, k, sin, din, emit=not first)
+                hook('mlp2_bwd', k)
+            else:
+                self._mlp_bwd(params, k, 1, sin, None, W['dy1'], W['coef'][0], din, None, True, False)
+                hook('mlp1_bwd', k)
+                self._mlp_bwd(params, k, 2, sin, None, W['dy2'], W['coef'][1], din, None, True, False, emit=not first)
+                hook('mlp2_bwd', k)
             if not first:
                 _lib.call('fgnn_gn_bwd_coef_tiles_tpg', _lib.ptr(W['s12part']), _lib.ptr(self.nrm[(k - 1, 3)]), self._nv(),
                           self.G, 32, self.N, self.tpg, _lib.ptr(W['s12'][(k - 1, 3)]), _lib.ptr(W['coef'][2]), st)

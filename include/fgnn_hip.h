@@ -457,6 +457,10 @@ typedef struct {
     const int *ranges;                       /* optional (ragged): tile bounds from fgnn_ragged_tile_ranges16 */
 } fgnn_mlp_bwd16_args;
 int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *args, void *stream);
+/* mlp1 + mlp2 of one block in ONE launch, bf16 (the twin of fgnn_mlp_bwd_pair): m1 / m2 are the argument blocks of the two
+ * fgnn_mlp_bwd16 calls it replaces; the input gradient (dxa, accumulate_a, s12part) is given in m2 only and receives
+ * R(R(old + dx1) + dx2), bit-identical to the two read-modify-write launches.  One slab of 2 or 32 channels, constant-size batches. */
+int fgnn_mlp_bwd16_pair(const fgnn_mlp_bwd16_args *m1, const fgnn_mlp_bwd16_args *m2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -471,6 +471,7 @@ def test_backward_kernels_element_wise_on_identical_inputs(N, B):
             eng.load_dense(din, keep[(k, 'din')])
         seen.append((stage, k))
 
+    hook.per_mlp = True          # the two single-MLP launches (the pair kernel has no state between mlp1 and mlp2 to look at)
     eng.backward_from_dE(params, grads, keep['dE'].to(DEV).contiguous(), hook=hook)
     torch.cuda.synchronize()
     assert [s for s, _ in seen] == ['colmax_bwd'] + ['mlp3_bwd', 'matmul_bwd', 'mlp1_bwd', 'mlp2_bwd'] * 2
@@ -480,3 +481,35 @@ def test_backward_kernels_element_wise_on_identical_inputs(N, B):
     got = lay.unflatten(grads.cpu())
     keys = [k for k in g_ref if not is_zero_grad(k)]
     assert l2rel(flat_of(got, keys), flat_of(g_ref, keys)) < 1e-2
+
+
+@pytest.mark.parametrize('N,B', [(24, 3), (50, 8), (200, 2)])
+def test_pair_backward16_equals_the_two_launches_it_replaces(N, B):
+    """fgnn_mlp_bwd16_pair (mlp1 + mlp2 of a block in one launch): scores, loss and the stored block-input gradient slabs are
+    bit-identical to the two read-modify-write fgnn_mlp_bwd16 launches -- R(R(d_in3 + dx1) + dx2) in both -- and the parameter
+    gradients agree up to the association of the per-wave fp32 partial sums; bit-reproducible run to run."""
+    sd = _sd(3, 70 + N)
+    x1, x2 = synthetic.make_batch(800 + N, B, N, 'ErdosRenyi', 0.3 if N < 100 else 0.5, 0.1)
+    lay = ParamLayout(2, 3, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    out = []
+    for pair in (False, True):
+        old = FgnnEngineBF16.PAIR_BWD
+        FgnnEngineBF16.PAIR_BWD = pair
+        try:
+            eng = FgnnEngineBF16(lay, 2 * B, N, DEV)
+            g = torch.zeros_like(params)
+            sc, loss = eng.step(params, g, x)
+            torch.cuda.synchronize()
+            out.append((sc.clone(), loss.clone(), g.clone(), eng.dense(eng._bwd['dy'][0]).clone(), eng.dense(eng._bwd['dy'][1]).clone()))
+            g2 = torch.zeros_like(params)
+            eng.step(params, g2, x)
+            torch.cuda.synchronize()
+            assert torch.equal(g, g2)
+        finally:
+            FgnnEngineBF16.PAIR_BWD = old
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
