@@ -14,8 +14,9 @@
 //     (three rounds of which the third is half empty).
 // Operand images, tile statistics emission (S1/S2 of the previous block's mlp3) and the partial layout are unchanged:
 // each MLP's partial is the fixed-order sum of its four waves, so results are bit-reproducible run to run.
-// Constant-size batches, depth 3, input slab of 32 channels (blocks > 1) or 2 channels (block 1, dense or bit-packed; no
-// input gradient there, the pair only shares the launch).
+// Depth 3, input slab of 32 channels (blocks > 1) or 2 channels (block 1, dense or bit-packed; no input gradient there, the
+// pair only shares the launch); constant-size and ragged batches (nvalid, optionally with the padding-tile skipping of
+// fgnn_ragged_tile_ranges).
 #include "fgnn_tile.h"
 #include "fgnn_pack.h"
 
@@ -111,7 +112,9 @@ struct PairArgs {
     fgnn_mlp_bwd_args m[2];
 };
 
-template <int CA, bool PK>
+// SKIP (ragged batches with ranges): work-balanced tile range from fgnn_ragged_tile_ranges, padding-only tiles are stepped over
+// (the two waves of a pair walk the same tile sequence, so the hand-over protocol is unchanged)
+template <int CA, bool PK, bool SKIP>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs P, const int tpg, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = PairLayout<CA>;
@@ -155,8 +158,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
 
     const int nwg = gridDim.x;
     const int q = total_tiles / nwg, rem = total_tiles % nwg;
-    const int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
-    const int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    int T0 = blockIdx.x * q + ((int)blockIdx.x < rem ? (int)blockIdx.x : rem);
+    int T1 = T0 + q + ((int)blockIdx.x < rem ? 1 : 0);
+    if constexpr (SKIP) {
+        T0 = A.ranges[blockIdx.x];
+        T1 = A.ranges[blockIdx.x + 1];
+    }
     const bool normA = A.a.nrm != nullptr;
     const bool has_dx = (CA == 32) && P.m[1].dxa != nullptr;
     const bool emit = (CA == 32) && role == 1 && normA && has_dx && P.m[1].s12part != nullptr;
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
     float xa[SA > 0 ? SA : 1];
     float4 rk = make_float4(0.f, 0.f, 0.f, 0.f), ra = rk;
     int cached_g = -1, cur_nv = A.N;
-    const int first = T0 + pair;
+    int first = T0 + pair;
+    if constexpr (SKIP) first = __builtin_amdgcn_readfirstlane(next_live_tile(first, T1, NP, tpg, A.N, A.nvalid));
     {
         const int t = first;
         const TileCtx c = decode_tile(t, t < T1, tpg, A.N, P2, j);
@@ -216,9 +224,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
     if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = -1;
     __syncthreads();
 
-    int tnext = 0;
+    int tnext = 0, prev_tile = -1;
     for (int tile = first; tile < T1; tile = tnext) {
         tnext = tile + NP;
+        if constexpr (SKIP) tnext = __builtin_amdgcn_readfirstlane(next_live_tile(tnext, T1, NP, tpg, A.N, A.nvalid));
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P2, j);
         if (c.g != cached_g) {
             if (lane < 32) {
@@ -269,8 +278,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
         }
         if (has_dx && role == 0 && tile != first) {
             // S1 still holds the dx handed over one tile ago: wait until the mlp2 wave has read it
-            while (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != tile - NP) __builtin_amdgcn_s_sleep(1);
+            while (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != prev_tile) __builtin_amdgcn_s_sleep(1);
         }
+        prev_tile = tile;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S1[ch_of(r, h) * TLD + j] = relu1(acc[r]);
 
@@ -399,6 +409,18 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
         }
     }
 
+    if constexpr (SKIP) {
+        // padding-only tiles of this pair's share: empty S1/S2 records (their dx is not written: consumers skip the same tiles)
+        if (emit) {
+            for (int t = T0 + pair; t < T1; t += NP) {
+                const TileCtx c = decode_tile(t, true, tpg, A.N, P2, j);
+                if (tile_live(c.tt, A.N, A.nvalid[c.g])) continue;
+                if (h == 0)
+                    reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)c.g * tpg + c.tt) * FGNN_H + j] = make_float2(0.f, 0.f);
+            }
+        }
+    }
+
     // ---- workgroup reduction: each MLP's partial = fixed-order sum of its four waves ----
     // layout per MLP: [W0 (32*CA) | b0 (32) | W1 (1024) | b1 (32) | W2 (1024) | b2 (32)]
     constexpr int PCOUNT = L::PCOUNT;
@@ -456,21 +478,28 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
     }
 }
 
-template <int CA, bool PK>
-int launch_pair(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
+template <int CA, bool PK, bool SKIP>
+int launch_pair_impl(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
     constexpr int LDS = PairLayout<CA>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_pair_kernel<CA, PK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)mlp_bwd_pair_kernel<CA, PK, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     PairArgs P;
     P.m[0] = *a1;
     P.m[1] = *a2;
-    hipLaunchKernelGGL((mlp_bwd_pair_kernel<CA, PK>), dim3(a1->cu_share == 2 ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st, P, tpg, total);
+    hipLaunchKernelGGL((mlp_bwd_pair_kernel<CA, PK, SKIP>), dim3(a1->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st, P,
+                       tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <int CA, bool PK>
+int launch_pair(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
+    static_assert(BWD_WG == FGNN_RANGE_WG, "fgnn_ragged_tile_ranges splits for the backward grid");
+    if (a1->ranges) return launch_pair_impl<CA, PK, true>(a1, a2, tpg, total, st);
+    return launch_pair_impl<CA, PK, false>(a1, a2, tpg, total, st);
 }
 
 }  // namespace
@@ -488,7 +517,7 @@ extern "C" int fgnn_mlp_bwd_pair(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd
     FGNN_CHECK(a1->a.ptr == a2->a.ptr && a1->a.C == a2->a.C && a1->a.gstride == a2->a.gstride && a1->a.ldp == a2->a.ldp &&
                a1->a.nrm == a2->a.nrm && a1->a.beta == a2->a.beta && a1->xbits == a2->xbits && a1->xdeg == a2->xdeg &&
                a1->nvalid == a2->nvalid, "fgnn_mlp_bwd_pair: the two MLPs must read the same input slab");
-    FGNN_CHECK(!a1->ranges && !a2->ranges && !a1->nvalid, "fgnn_mlp_bwd_pair: constant-size batches only; use fgnn_mlp_bwd");
+    FGNN_CHECK(a1->ranges == a2->ranges && (!a1->ranges || a1->nvalid), "fgnn_mlp_bwd_pair: both MLPs take the same ranges (with nvalid)");
     FGNN_CHECK(a1->packed && a2->packed, "fgnn_mlp_bwd_pair: needs both operand images (fgnn_pack_operands, kind 1)");
     FGNN_CHECK(!a1->dxa && !a1->s12part, "fgnn_mlp_bwd_pair: the input gradient and its tile sums belong to the SECOND argument block");
     FGNN_CHECK(!a1->s12tiles && !a2->s12tiles, "fgnn_mlp_bwd_pair: s12tiles is an mlp3 feature");

@@ -550,7 +550,7 @@ class FgnnEngine:
             _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
-            if self.PAIR_BWD and not self.x3 and self.nvalid is None and dxs is None and L.depth == 3 and sin.C in (2, 32):
+            if self.PAIR_BWD and not self.x3 and dxs is None and L.depth == 3 and sin.C in (2, 32):
                 self._mlp_bwd_pair(params, k, sin, din, emit=not first)
             else:
                 self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False, dx_strides=dxs)

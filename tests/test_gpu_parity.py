@@ -683,3 +683,39 @@ def test_pair_backward_equals_the_two_launches_it_replaces(B, N, bits):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
+
+
+def test_pair_backward_on_ragged_batches():
+    """The pair backward with per-graph vertex counts, with and without the padding-tile skipping: block-input gradients
+    (valid corners) bit-identical to the two launches, parameter gradients up to the association of partial sums."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    xs, ys = synthetic.make_ragged_batch(31, 6, 9, 70)
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nvd = torch.cat([nv, nv]).to(DEV)
+    for skip in (True, False):
+        out = []
+        for pair in (False, True):
+            old = (FgnnEngine.PAIR_BWD, FgnnEngine.SKIP_PADDING_TILES)
+            FgnnEngine.PAIR_BWD, FgnnEngine.SKIP_PADDING_TILES = pair, skip
+            try:
+                eng = FgnnEngine(lay, x.shape[0], x.shape[-1], DEV, ragged=True, mfma='f32')
+            finally:
+                FgnnEngine.PAIR_BWD, FgnnEngine.SKIP_PADDING_TILES = old
+            eng.PAIR_BWD = pair
+            g = torch.zeros_like(params)
+            for buf in eng._alloc_bwd()['dy']:
+                buf.zero_()                      # (skipped padding tiles are never written)
+            sc, loss = eng.step(params, g, x, nvalid=nvd)
+            torch.cuda.synchronize()
+            din = [eng.unpadded(b) for b in eng._bwd['dy']]
+            n = nvd.tolist()
+            corners = [torch.cat([d[i, :, :n[i], :n[i]].reshape(-1) for i in range(len(n))]) for d in din]
+            out.append((sc.clone(), loss.clone(), g.clone(), corners))
+        a, b = out
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert all(torch.equal(u, v) for u, v in zip(a[3], b[3])), skip
+        assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
