@@ -13,6 +13,7 @@ TAGS = {
     'chan_matmul_bwd1_kernel': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd1_kernel': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_w_kernel<7, true>': 'fgnn_chan_matmul_fwd',
 }
 TAGS16 = {
+    'mlp_bwd16_pair_kernel<32>': 'mlp_bwd16_pair[cin=32,dx=32]', 'mlp_bwd16_pair_kernel<2>': 'mlp_bwd16_pair[cin=2,dx=0]',
     'mlp_bwd16_kernel<32, 0, 3>': 'mlp_bwd16[cin=32,dx=32]', 'mlp_bwd16_kernel<32, 32, 3>': 'mlp_bwd16[cin=64,dx=64]',
     'mlp_bwd16_kernel<2, 0, 3>': 'mlp_bwd16[cin=2,dx=0]', 'mlp_bwd16_kernel<32, 2, 3>': 'mlp_bwd16[cin=34,dx=32]',
     'mlp_fwd16_kernel<32, 0, 2, 3>': 'mlp_fwd16[cin=32,nmlp=2]', 'mlp_fwd16_kernel<32, 32, 1, 3>': 'mlp_fwd16[cin=64,nmlp=1]',

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction mix of the largest loop of one kernel in a `hipcc -S --cuda-device-only` listing:
+"""Instruction mix of the main loop (the one with the most MFMAs) of one kernel in a `hipcc -S --cuda-device-only` listing:
     python tools/isa_loop.py file.s <substring of the mangled kernel name> [top N opcodes]"""
 import collections
 import sys
@@ -12,12 +12,14 @@ end = [i for i in range(start, len(lines)) if 's_endpgm' in lines[i]][0]
 body = lines[start:end + 1]
 best = None
 for hi, l in enumerate(body):
-    if 'Loop Header: Depth=1' not in l:
+    if 'Loop Header: Depth=' not in l:
         continue
     lab = l.split(':')[0]
     back = [i for i, b in enumerate(body) if ('s_cbranch' in b or 's_branch' in b) and b.split()[-1] == lab and i > hi]
-    if back and (best is None or back[-1] - hi > best[1] - best[0]):
-        best = (hi, back[-1])
+    if back:
+        n_mfma = sum(1 for b in body[hi:back[-1] + 1] if b.strip().startswith('v_mfma'))
+        if best is None or (n_mfma, back[-1] - hi) > (best[2], best[1] - best[0]):
+            best = (hi, back[-1], n_mfma)
 seg = body[best[0]:best[1] + 1]
 cnt = collections.Counter()
 for l in seg:
