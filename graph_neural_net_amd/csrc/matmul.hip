@@ -664,6 +664,7 @@ int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, in
 // through the buffer descriptor and land in panel rows that are never consumed).
 // =======================================================================================
 constexpr int BIG_NW = 8, BIG_THREADS = 64 * BIG_NW, BIG_KC = 32, BIG_LDK = 36;
+constexpr int BIG_SPLIT_MAX_MATRICES = 8 * 256;         // four rounds of two workgroups on each of the 256 CUs
 
 struct BigSrc {
     View v;
@@ -747,6 +748,22 @@ DEVI void big_operand(float (&o)[16], const float *P, int t, int j, int h) {
     }
 }
 
+// k-steps 4q .. 4q+3 of the same strip
+template <int NT, bool KC>
+DEVI void big_operand4(float (&o)[4], const float *P, int t, int j, int h, int q) {
+    if (KC) {
+        const float4 v = reinterpret_cast<const float4 *>(P + (32 * t + j) * BIG_LDK + 16 * h)[q];
+        o[0] = v.x;
+        o[1] = v.y;
+        o[2] = v.z;
+        o[3] = v.w;
+    } else {
+        const float *p = P + (16 * h + 4 * q) * BigCfg<NT>::XM + 32 * t + j;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) o[s] = p[s * BigCfg<NT>::XM];
+    }
+}
+
 // acc[ti] (tile wv + 8*ti of the ntv x ntv valid tiles) += OpA OpB over all k chunks
 template <int NT, bool A_KC, bool B_KC>
 DEVI void big_gemm(f32x16 (&acc)[BigCfg<NT>::MAXT], const BigSrc &A, const BigSrc &B, float *lds, int N, int nv,
@@ -763,6 +780,15 @@ DEVI void big_gemm(f32x16 (&acc)[BigCfg<NT>::MAXT], const BigSrc &A, const BigSr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
     const int nkc = (nv + BIG_KC - 1) / BIG_KC;
+    int tms[Cf::MAXT], tns[Cf::MAXT];                       // wave-uniform tile coordinates (rolled form)
+    if constexpr (NT != 8) {
+#pragma unroll
+        for (int ti = 0; ti < Cf::MAXT; ++ti) {
+            const int t = wv + BIG_NW * ti;
+            tms[ti] = t / ntv;
+            tns[ti] = t - tms[ti] * ntv;
+        }
+    }
     float xa[Cf::SWEEPS], xb[Cf::SWEEPS];
     big_load<NT, A_KC>(xa, A, N, nv, 0, tid);
     big_load<NT, B_KC>(xb, B, N, nv, 0, tid);
@@ -777,17 +803,38 @@ DEVI void big_gemm(f32x16 (&acc)[BigCfg<NT>::MAXT], const BigSrc &A, const BigSr
             big_load<NT, B_KC>(xb, B, N, nv, (c + 1) * BIG_KC, tid);
         }
         const float *pa = lds + cur * Cf::BUF_F, *pb = pa + FA;
+        // k-steps in groups of four (k = k0 + 16 h + s, s = 4q .. 4q+3); in the last chunk of a matrix only the groups
+        // with 4q < kv hold a valid k -- the skipped products are exact zeros (padding is staged as 0).  The group loop is
+        // rolled: 4 waves per SIMD cover the LDS latency of a group, and the registers stay under the 128 of that occupancy.
+        const int kv = nv - c * BIG_KC;
+        const int nq = kv >= 13 ? 4 : (kv + 3) >> 2;
+        if constexpr (NT == 8) {
+            // one workgroup per CU (LDS), two waves per SIMD: the straight-line form (no trimming) is 2 % faster at N = 200
 #pragma unroll
-        for (int ti = 0; ti < Cf::MAXT; ++ti) {
-            const int t = wv + BIG_NW * ti;
-            if (t < T) {
-                const int tm = t / ntv, tn = t - tm * ntv;
-                float a[16], b[16];
-                big_operand<NT, A_KC>(a, pa, tm, j, h);
-                big_operand<NT, B_KC>(b, pb, tn, j, h);
+            for (int ti = 0; ti < Cf::MAXT; ++ti) {
+                const int t = wv + BIG_NW * ti;
+                if (t < T) {
+                    const int tm = t / ntv, tn = t - tm * ntv;
+                    float a[16], b[16];
+                    big_operand<NT, A_KC>(a, pa, tm, j, h);
+                    big_operand<NT, B_KC>(b, pb, tn, j, h);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) acc[ti] = mfma32(a[s], b[s], acc[ti]);
+                    for (int s = 0; s < 16; ++s) acc[ti] = mfma32(a[s], b[s], acc[ti]);
+                }
             }
+        } else {
+        for (int q = 0; q < nq; ++q) {
+#pragma unroll
+            for (int ti = 0; ti < Cf::MAXT; ++ti) {
+                if (wv + BIG_NW * ti < T) {
+                    float a[4], b[4];
+                    big_operand4<NT, A_KC>(a, pa, tms[ti], j, h, q);
+                    big_operand4<NT, B_KC>(b, pb, tns[ti], j, h, q);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[ti] = mfma32(a[s], b[s], acc[ti]);
+                }
+            }
+        }
         }
         if (more) {
             float *nx = lds + (cur ^ 1) * Cf::BUF_F;
@@ -867,9 +914,11 @@ DEVI BigSrc big_src_plain(const float *p, long long gs, long long ld, int G, int
 template <int NT>
 __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_fwd_big_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                            const int *nvalid, int N, int G, float *out,
-                                                                           long long ogstride, long long ldo) {
+                                                                           long long ogstride, long long ldo,
+                                                                           const int *order) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];
-    const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
+    const int C = ya.C, gi = blockIdx.x / C, c = blockIdx.x - gi * C, tid = threadIdx.x;
+    const int g = order ? order[gi] : gi;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
     const BigSrc A = big_src(ya, G, g, c), B = big_src(yb, G, g, c);
     const View vO = make_view(out, ogstride, ldo, G);
@@ -887,27 +936,37 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
                                                                            const float *dm, long long dmg, long long ldm,
                                                                            const int *nvalid, int N, int G, float *da,
                                                                            float *db, long long ogstride, long long ldo,
-                                                                           float *s12a, float *s12b) {
+                                                                           float *s12a, float *s12b, const int *order,
+                                                                           int split) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];
     __shared__ float red[BIG_NW][4];
-    const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
+    // split: two workgroups per matrix, one per product (the longest-job-first schedule of ragged batches wants the finer
+    // grain: the largest matrix of a batch is otherwise a quarter of its CU's whole share of the launch)
+    const int item = split ? blockIdx.x >> 1 : blockIdx.x;
+    const bool do_a = !split || (blockIdx.x & 1) == 0, do_b = !split || (blockIdx.x & 1) == 1;
+    const int C = ya.C, gi = item / C, c = item - gi * C, tid = threadIdx.x;
+    const int g = order ? order[gi] : gi, gc = g * C + c;
     const int lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
     const BigSrc A = big_src(ya, G, g, c), B = big_src(yb, G, g, c);
     const BigSrc D = big_src_plain(dm, dmg, ldm, G, g, c);
     const View vOA = make_view(da, ogstride, ldo, G), vOB = make_view(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs4 + c * vOA.ld4;
-    big_zero_fill(vOA, o_off, N, 32 * ntv, tid);
-    big_zero_fill(vOB, o_off, N, 32 * ntv, tid);
+    if (do_a) big_zero_fill(vOA, o_off, N, 32 * ntv, tid);
+    if (do_b) big_zero_fill(vOB, o_off, N, 32 * ntv, tid);
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     if (ntv > 0) {
         f32x16 acc[BigCfg<NT>::MAXT];
-        big_gemm<NT, true, true>(acc, D, B, big_lds, N, nv, ntv, tid);          // dA = dM Yb^T
-        if (s12a) big_store<NT, true>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
-        else big_store<NT, false>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
-        big_gemm<NT, false, false>(acc, A, D, big_lds, N, nv, ntv, tid);        // dB = Ya^T dM
-        if (s12a) big_store<NT, true>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
-        else big_store<NT, false>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
+        if (do_a) {
+            big_gemm<NT, true, true>(acc, D, B, big_lds, N, nv, ntv, tid);          // dA = dM Yb^T
+            if (s12a) big_store<NT, true>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
+            else big_store<NT, false>(acc, vOA, o_off, A, N, nv, ntv, sa1, sa2, tid);
+        }
+        if (do_b) {
+            big_gemm<NT, false, false>(acc, A, D, big_lds, N, nv, ntv, tid);        // dB = Ya^T dM
+            if (s12a) big_store<NT, true>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
+            else big_store<NT, false>(acc, vOB, o_off, B, N, nv, ntv, sb1, sb2, tid);
+        }
     }
     if (s12a) {
         sa1 = wave_sum(sa1);
@@ -921,7 +980,7 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
             red[wv][3] = sb2;
         }
         __syncthreads();
-        if (tid < 4) {
+        if (tid < 4 && (tid < 2 ? do_a : do_b)) {
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < BIG_NW; ++w) v += red[w][tid];                      // fixed order
@@ -935,13 +994,23 @@ inline bool big_path(int N) { return N > TM && N <= 256; }
 
 // debug only (tests/diag/gpu_mm_variants_equal.py): 0 selects the workgroup-per-matrix forward kernel for N <= 64, whose
 // results the wave-per-matrix kernel reproduces bit for bit
+// bit 1: keep both products of a matrix in one workgroup even when an order is given; bit 2: ignore the order (tools/gpu_mm_big_probe.py)
 int g_mm_wave_variant = 1;
-inline bool mm_wave_variant() { return g_mm_wave_variant != 0; }
+inline bool mm_wave_variant() { return (g_mm_wave_variant & 1) != 0; }
+inline bool mm_no_split() { return (g_mm_wave_variant & 2) != 0; }
+inline bool mm_no_order() { return (g_mm_wave_variant & 4) != 0; }
 
 }  // namespace
 
 extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
                                     float *out, long long ogstride, long long ldo, void *stream) {
+    return fgnn_chan_matmul_fwd_ord(ya, yb, nvalid, G, N, out, ogstride, ldo, nullptr, stream);
+}
+
+extern "C" int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
+                                        float *out, long long ogstride, long long ldo, const int *order, void *stream) {
+    FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_fwd_ord: an order needs the nvalid it was derived from");
+    if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr, "fgnn_chan_matmul_fwd: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_fwd: bad shapes");
     FGNN_CHECK((long long)G * ya->C <= 65535 * 1024ll, "fgnn_chan_matmul_fwd: G*C too large");
@@ -974,7 +1043,7 @@ extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, co
             attr = true;                                                                                              \
         }                                                                                                             \
         hipLaunchKernelGGL(chan_matmul_fwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
-                           (hipStream_t)stream, *ya, *yb, nvalid, N, G, out, ogstride, ldo);                          \
+                           (hipStream_t)stream, *ya, *yb, nvalid, N, G, out, ogstride, ldo, order);                   \
     }
         if (N <= 128) FGNN_BIG_FWD(4)
         else FGNN_BIG_FWD(8)
@@ -1023,6 +1092,16 @@ extern "C" int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb
 extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride,
                                     long long ldm, const int *nvalid, int G, int N, float *da, float *db,
                                     long long ogstride, long long ldo, float *s12a, float *s12b, void *stream) {
+    return fgnn_chan_matmul_bwd_ord(ya, yb, dm, dmgstride, ldm, nvalid, G, N, da, db, ogstride, ldo, s12a, s12b, nullptr,
+                                    stream);
+}
+
+extern "C" int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride,
+                                        long long ldm, const int *nvalid, int G, int N, float *da, float *db,
+                                        long long ogstride, long long ldo, float *s12a, float *s12b, const int *order,
+                                        void *stream) {
+    FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_bwd_ord: an order needs the nvalid it was derived from");
+    if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd: null argument");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_bwd: bad shapes");
     FGNN_CHECK((s12a == nullptr) == (s12b == nullptr), "fgnn_chan_matmul_bwd: s12a and s12b come together");
@@ -1052,10 +1131,12 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<MT>::LDS_BYTES);             \
             attr = true;                                                                                              \
         }                                                                                                             \
-        hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
-                           (hipStream_t)stream, *ya, *yb, dm, dmgstride, ldm, nvalid, N, G, da, db, ogstride, ldo,    \
-                           s12a, s12b);                                                                               \
+        hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C * (split ? 2 : 1)), dim3(BIG_THREADS),      \
+                           BigCfg<MT>::LDS_BYTES, (hipStream_t)stream, *ya, *yb, dm, dmgstride, ldm, nvalid, N, G, da, \
+                           db, ogstride, ldo, s12a, s12b, order, split);                                              \
     }
+        // fewer than four rounds of workgroups (two per CU): schedule the products separately
+        const int split = (order && !mm_no_split() && (long long)G * ya->C <= BIG_SPLIT_MAX_MATRICES) ? 1 : 0;
         if (N <= 128) FGNN_BIG_BWD(4)
         else FGNN_BIG_BWD(8)
 #undef FGNN_BIG_BWD

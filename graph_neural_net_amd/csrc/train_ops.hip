@@ -228,7 +228,7 @@ struct TileWalk {
 };
 
 __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int *nvalid, int G, int T, int pitch, int tpg,
-                                                                       int *ranges) {
+                                                                       int *ranges, int *order) {
     __shared__ long long incl[RANGE_THREADS];
     const int tid = threadIdx.x, total = G * tpg;
     const int chunk = (total + RANGE_THREADS - 1) / RANGE_THREADS;
@@ -278,17 +278,31 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
         }
         ranges[b] = t;
     }
+    if (order) {        // rank sort by (nvalid descending, index ascending): G^2 / 1024 comparisons per thread
+        for (int g = tid; g < G; g += RANGE_THREADS) {
+            const int nv = nvalid[g];
+            int rank = 0;
+            for (int o = 0; o < G; ++o) {
+                const int no = nvalid[o];
+                rank += (no > nv || (no == nv && o < g)) ? 1 : 0;
+            }
+            order[rank] = g;
+        }
+    }
 }
 }  // namespace
 
-extern "C" int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges, void *stream) {
+extern "C" int fgnn_ragged_tile_ranges_order(const int *nvalid, int G, int N, int *ranges, int *order, void *stream) {
     FGNN_CHECK(nvalid && ranges && G > 0 && N > 0, "fgnn_ragged_tile_ranges: bad arguments");
     const long long tpg = fgnn_tiles_per_graph(N);
     FGNN_CHECK(G * tpg < (1ll << 30), "fgnn_ragged_tile_ranges: too many tiles");
     hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, FGNN_TILE, N,
-                       (int)tpg, ranges);
+                       (int)tpg, ranges, order);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges, void *stream) {
+    return fgnn_ragged_tile_ranges_order(nvalid, G, N, ranges, nullptr, stream);
 }
 
 extern "C" int fgnn_ragged_tile_ranges16(const int *nvalid, int G, int N, int ldr, int *ranges, void *stream) {
@@ -296,7 +310,7 @@ extern "C" int fgnn_ragged_tile_ranges16(const int *nvalid, int G, int N, int ld
     const long long tpg = fgnn_tiles_per_graph16(N, ldr);
     FGNN_CHECK(G * tpg < (1ll << 30), "fgnn_ragged_tile_ranges16: too many tiles");
     hipLaunchKernelGGL(ragged_ranges_kernel, dim3(1), dim3(RANGE_THREADS), 0, (hipStream_t)stream, nvalid, G, 64, ldr, (int)tpg,
-                       ranges);
+                       ranges, (int *)nullptr);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

@@ -157,6 +157,7 @@ class EngineCache:
 class FgnnEngine:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
+    MM_ORDER = True               # ragged engines: longest-job-first order of the whole-matrix per-channel products
     PAIR_BWD = os.environ.get('FGNN_PAIR_BWD', '1') != '0'      # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd_pair)
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
@@ -200,6 +201,10 @@ class FgnnEngine:
         # ragged batches: work-balanced tile ranges of the MLP kernels (padding-only tiles are stepped over)
         self.ranges = (torch.empty(_lib.FGNN_RANGE_WG + 1, dtype=torch.int32, device=device)
                        if ragged and self.SKIP_PADDING_TILES else None)
+        # ... and the largest-graph-first workgroup order of the whole-matrix per-channel products (64 < N <= 256), written
+        # by the same launch
+        self.mm_order = (torch.empty(G, dtype=torch.int32, device=device)
+                         if self.ranges is not None and self.MM_ORDER and 64 < N <= 256 else None)
         # backward workspace (allocated lazily)
         self._bwd = None
         self.x = None
@@ -331,7 +336,8 @@ class FgnnEngine:
             self.nvalid.copy_(nvalid.to(torch.int32))
         st = _lib.stream_ptr()
         if self.ranges is not None:
-            _lib.call('fgnn_ragged_tile_ranges', _lib.ptr(self.nvalid), self.G, self.N, _lib.ptr(self.ranges), st)
+            _lib.call('fgnn_ragged_tile_ranges_order', _lib.ptr(self.nvalid), self.G, self.N, _lib.ptr(self.ranges),
+                      _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_ragged_tile_ranges')
         if bits is not None:
             words = (self.N + 31) // 32
             if x is not None or L.c0 != 2 or L.depth != 3:
@@ -365,8 +371,9 @@ class FgnnEngine:
                           EPS, self._nv(), self.G, self.N, _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st,
                           tag='fgnn_chan_matmul_fwd')
             else:
-                _lib.call('fgnn_chan_matmul_fwd', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
-                          _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st)
+                _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
+                          _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp,
+                          _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_fwd')
             # the last block's statistics are finalized by the pooling kernel that consumes them
             pool_fin = k == L.num_blocks and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
             self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin, finalize=not pool_fin)
@@ -547,9 +554,10 @@ class FgnnEngine:
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
                           None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False, dx_strides=dxs)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
-            _lib.call('fgnn_chan_matmul_bwd', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
+            _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
-                      _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]), st)
+                      _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
+                      _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_bwd')
             if self.PAIR_BWD and not self.x3 and dxs is None and L.depth == 3 and sin.C in (2, 32):
                 self._mlp_bwd_pair(params, k, sin, din, emit=not first)
             else:

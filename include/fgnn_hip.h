@@ -163,6 +163,12 @@ int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d_ld, const 
  * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
 int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
                          float *out, long long ogstride, long long ldo, void *stream);
+/* Ragged batches (64 < N <= 256, one workgroup per matrix): the same product with the workgroups issued in the order of
+ * `order` (G graph indices from fgnn_ragged_tile_ranges_order: largest graph first), so that the hardware's in-order
+ * dispatch is a longest-job-first schedule -- the matrices of a batch differ by up to (Nmax / nmin)^3 in work.  Results
+ * do not depend on the order (every matrix is computed by one workgroup on its own).  order == NULL: as above.          */
+int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
+                             float *out, long long ogstride, long long ldo, const int *order, void *stream);
 /* The same product with the work of fgnn_gn_finalize2 folded into its prologue (single-tile matrices, N <= 64):
  * each (g,c) workgroup finalizes the two GraphNorm records it needs from the tile statistics (part_a / part_b /
  * cnt of the preceding two-MLP fgnn_mlp_fwd call) while its tile loads are in flight, normalises with them and
@@ -305,6 +311,11 @@ int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *
                          float *da, float *db, long long ogstride, long long ldo,
                          float *s12a /* optional (G*C*2): {sum da, sum da*(z_a-mean_a)} */,
                          float *s12b /* optional (G*C*2) */, void *stream);
+/* longest-job-first order as in fgnn_chan_matmul_fwd_ord; with an order the two products of a matrix are separate work
+ * items (dm is then read by both) */
+int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride, long long ldm,
+                             const int *nvalid, int G, int N, float *da, float *db, long long ogstride, long long ldo,
+                             float *s12a, float *s12b, const int *order, void *stream);
 
 /* ---- next to the hot path -------------------------------------------
  * Fused Adam over a flat fp32 buffer: torch.optim.Adam(amsgrad=False, weight_decay=0) single-tensor
@@ -333,6 +344,10 @@ int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N,
  * (Nmax x Nmax) tensors in full (maskedtensors/maskedtensor.py:98-112).                                                  */
 #define FGNN_RANGE_WG 256
 int fgnn_ragged_tile_ranges(const int *nvalid, int G, int N, int *ranges /* FGNN_RANGE_WG + 1 */, void *stream);
+/* the same launch also writes order[0 .. G): the graph indices sorted by nvalid, largest first (ties: lower index first),
+ * the schedule of fgnn_chan_matmul_fwd_ord / fgnn_chan_matmul_bwd_ord */
+int fgnn_ragged_tile_ranges_order(const int *nvalid, int G, int N, int *ranges /* FGNN_RANGE_WG + 1 */, int *order /* G */,
+                                  void *stream);
 /* the same for the bf16 slabs (tiles of 64 elements of the ldr-pitched planes) */
 int fgnn_ragged_tile_ranges16(const int *nvalid, int G, int N, int ldr, int *ranges /* FGNN_RANGE_WG + 1 */, void *stream);
 

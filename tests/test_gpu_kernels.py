@@ -85,6 +85,54 @@ def test_chan_matmul_random_ragged_shapes(seed):
         assert (s12b[g].double() - ref_b).abs().max() < 2e-5 * scale
 
 
+@pytest.mark.parametrize('N,G,Cc', [(103, 6, 3), (128, 4, 2), (70, 5, 4), (200, 3, 2)])
+def test_chan_matmul_longest_first_order_is_bit_identical(N, G, Cc):
+    """fgnn_ragged_tile_ranges_order sorts the graphs by size (largest first, ties by index); the whole-matrix products
+    launched in that order -- the backward with one workgroup per product -- and the k-steps skipped in a matrix' last
+    chunk change nothing in the results: same bits as the plain entry points, S1 / S2 by-products included."""
+    rng = torch.Generator().manual_seed(7 * N + G)
+    nv = torch.randint(1, N + 1, (G,), generator=rng).to(torch.int32)
+    nv[G // 2] = N
+    if G > 2:
+        nv[0] = nv[G - 1]                                   # a tie
+    nvd = nv.to(DEV)
+    ranges = torch.empty(_lib.FGNN_RANGE_WG + 1, dtype=torch.int32, device=DEV)
+    order = torch.full((G,), -1, dtype=torch.int32, device=DEV)
+    _lib.call('fgnn_ragged_tile_ranges_order', _lib.ptr(nvd), G, N, _lib.ptr(ranges), _lib.ptr(order), _lib.stream_ptr())
+    want = sorted(range(G), key=lambda g: (-int(nv[g]), g))
+    assert order.cpu().tolist() == want
+    ranges2 = torch.empty_like(ranges)
+    _lib.call('fgnn_ragged_tile_ranges', _lib.ptr(nvd), G, N, _lib.ptr(ranges2), _lib.stream_ptr())
+    assert torch.equal(ranges, ranges2)
+    P = N * N
+    a = torch.randn(G, Cc, N, N, generator=rng).to(DEV)
+    b = torch.randn(G, Cc, N, N, generator=rng).to(DEV)
+    dm = torch.randn(G, Cc, N, N, generator=rng).to(DEV)
+    na = (torch.rand(G, Cc, 4, generator=rng) + 0.5).to(DEV).contiguous()
+    nb = (torch.rand(G, Cc, 4, generator=rng) + 0.5).to(DEV).contiguous()
+    ba, bb = torch.randn(Cc, generator=rng).to(DEV), torch.randn(Cc, generator=rng).to(DEV)
+    sa, sb = _slab(a, nrm=na, beta=ba), _slab(b, nrm=nb, beta=bb)
+    res = []
+    for o in (None, order):
+        out = torch.full((G, Cc, N, N), 3.0, device=DEV)
+        da, db = torch.full_like(out, 3.0), torch.full_like(out, 3.0)
+        s12a, s12b = torch.full((G * Cc * 2,), 3.0, device=DEV), torch.full((G * Cc * 2,), 3.0, device=DEV)
+        _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(nvd), G, N, _lib.ptr(out), Cc * P, P,
+                  _lib.ptr(o), _lib.stream_ptr())
+        _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * P, P, _lib.ptr(nvd), G, N,
+                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(o), _lib.stream_ptr())
+        res.append((out, da, db, s12a, s12b))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    # and against the definition (the skipped k-steps): fp64 reference on the valid corner of the largest graph
+    g = G // 2
+    ya = (a[g].double() - na[g, :, 0, None, None]) * na[g, :, 1, None, None] + ba[:, None, None]
+    yb = (b[g].double() - nb[g, :, 0, None, None]) * nb[g, :, 1, None, None] + bb[:, None, None]
+    assert rel(res[1][0][g].cpu(), (ya @ yb).cpu()) < 5e-6
+    assert rel(res[1][1][g].cpu(), (dm[g].double() @ yb.transpose(-1, -2)).cpu()) < 5e-6
+    assert rel(res[1][2][g].cpu(), (ya.transpose(-1, -2) @ dm[g].double()).cpu()) < 5e-6
+
+
 def test_chan_matmul_ragged_padding_is_zero():
     G, Cc, N = 3, 2, 20
     nv = torch.tensor([20, 13, 5], dtype=torch.int32)

@@ -1,4 +1,4 @@
-"""Isolated timing of the N <= 64 per-channel matmul entry points (forward / backward), eager launches, event-timed.
+"""Isolated timing of the N <= 64 per-channel matmul entry points (gpu_mm_big_probe.py: the whole-matrix kernels on ragged batches) (forward / backward), eager launches, event-timed.
 usage: python tools/gpu_mm_probe.py [G] ; FGNN_MM_WAVE=0 selects the workgroup-per-matrix kernels."""
 import ctypes as C, os, sys
 import torch
