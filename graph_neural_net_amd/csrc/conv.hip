@@ -3,10 +3,14 @@
 //   out = activation(conv_layer(out))       models/layers.py:125-131 (nn.Conv2d(k=1, bias=True) + F.relu)
 // and its autograd backward.  fp32 storage, v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain over the input channels).
 //
-//   conv1x1_kernel      y[g][o][p] = act( b[o] + sum_k W[o][k] * x[g][k][p] )         forward, and (with W^T given by
-//                       strides, an optional ReLU mask on the input, no bias) the input gradient
+//   conv1x1_pre_kernel  y[g][o][p] = act( b[o] + sum_k W[o][k] * x[g][k][p] )         forward, and (with W^T given by
+//                       strides, an optional ReLU mask on the input, no bias) the input gradient.  K <= 128: a wave requests
+//                       ALL input channels of its tile at once (K/2 loads in flight per lane), then runs every 32-wide
+//                       output group from those registers -- the input is read once, whatever M is
+//   conv1x1_kernel      the same for 128 < K <= 256: input streamed in groups of 8 channels, once per output group
 //   conv1x1_dw_kernel   dW[o][c] = sum_{g,p} dz[g][o][p] * x[g][c][p],  db[o] = sum_{g,p} dz[g][o][p]
-//                       per-chunk partials, finished by fgnn_reduce_partials in a fixed order (bit-reproducible)
+//                       per-chunk partials, finished by fgnn_reduce_partials in a fixed order (bit-reproducible).  A workgroup
+//                       owns a 2 x 2 set of 32 x 32 blocks of dW: up to 64 x 64 channels dz and x are read once
 //
 // A tile is 32 consecutive pixels of one graph times 32 output channels.  Pixels outside the valid n x n corner of a
 // ragged graph produce exact zeros (the MaskedTensor re-mask of maskedtensors/maskedtensor.py:98-112) and contribute
@@ -94,78 +98,196 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv1x1_kernel(
     }
 }
 
-// grid (chunks, MG*KG): workgroup (chunk, pair) accumulates the 32 x 32 block (og, cg) of dW over its chunk of tiles.
-__global__ __launch_bounds__(64 * CONV_WAVES) void conv1x1_dw_kernel(
+// K <= 2 * KH input channels held in registers.  LDS: weights [og][k][32 outputs] (k padded to even), then the biases.
+template <int KH>
+struct ConvTile {
+    float b[KH];
+    TileCtx c;
+};
+template <int KH>
+DEVI void conv_request(ConvTile<KH> &T, int t, const View &xv, const View &mv, bool masked, int tpg, int N, const int *nvalid,
+                       int K, int K2, int col, int h) {
+    T.c = tile_ctx(t, tpg, N, nvalid, col);
+    const int sx = T.c.g * xv.gs4;
+    // lane (pixel col, half h) reads channel k = 2u + h: the pixel / half part of the address in ONE VGPR, the 2u rows in
+    // the scalar offset; only the last pair of an odd K needs its own (half 1 is past K)
+    const int voff = T.c.inb ? h * xv.ld4 + T.c.p * 4 : OOB_OFF;
+    const int voff_last = (T.c.inb && 2 * (K2 - 1) + h < K) ? voff : OOB_OFF;
+#pragma unroll
+    for (int u = 0; u < KH; ++u) {
+        const int vo = u < K2 - 1 ? voff : (u == K2 - 1 ? voff_last : OOB_OFF);     // uniform selects
+        T.b[u] = buf_load(xv, vo, sx + 2 * u * xv.ld4);
+        if (masked) {
+            const float m = buf_load(mv, vo, sx + 2 * u * xv.ld4);
+            T.b[u] = m > 0.f ? T.b[u] : 0.f;
+        }
+    }
+}
+template <int KH>
+DEVI void conv_multiply(ConvTile<KH> &T, const float *wl, const float *bl, const View &yv, int relu, int M, int K2,
+                        int MG, int col, int h) {
+    const int sy = T.c.g * yv.gs4;
+    for (int og = 0; og < MG; ++og) {
+        const float *wg = wl + og * K2 * 64 + h * 32 + col;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bl[og * 32 + ch_of(r, h)];
+#pragma unroll
+        for (int u = 0; u < KH; ++u) {
+            if (u < K2) acc = mfma32(wg[u * 64], T.b[u], acc);     // uniform; same k order as the streaming kernel
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = og * 32 + ch_of(r, h);
+            float v = relu ? fmaxf(acc[r], 0.f) : acc[r];
+            v = T.c.ok ? v : 0.f;
+            buf_store(v, yv, (T.c.inb && o < M) ? o * yv.ld4 + T.c.p * 4 : OOB_OFF, sy);
+        }
+    }
+}
+template <int KH>
+__global__ __launch_bounds__(64 * CONV_WAVES) void conv1x1_pre_kernel(
+    const float *xp, long long x_gs, long long x_ld, const float *mp, const float *W, long long w_so, long long w_sk,
+    const float *bias, int relu, const int *nvalid, int G, int N, int M, int K, float *yp, long long y_gs, long long y_ld,
+    int tpg, int ntiles) {
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
+    const int K2 = (K + 1) / 2, MG = (M + 31) / 32;
+    float *bl = wl + MG * K2 * 64;
+    const View xv = make_view(xp, x_gs, x_ld, G), yv = make_view(yp, y_gs, y_ld, G);
+    const bool masked = mp != nullptr;
+    const View mv = masked ? make_view(mp, x_gs, x_ld, G) : xv;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    ConvTile<KH> A;
+    int t = t_begin + wv;
+    if (t < t_end) conv_request<KH>(A, t, xv, mv, masked, tpg, N, nvalid, K, K2, col, h);     // in flight under the weight copy
+    for (int e = tid; e < MG * K2 * 64; e += 64 * CONV_WAVES) {
+        const int og = e / (K2 * 64), rem = e - og * (K2 * 64);
+        const int k = rem >> 5, o = og * 32 + (rem & 31);
+        wl[e] = (k < K && o < M) ? W[o * w_so + k * w_sk] : 0.f;
+    }
+    for (int e = tid; e < MG * 32; e += 64 * CONV_WAVES) bl[e] = (bias && e < M) ? bias[e] : 0.f;
+    __syncthreads();
+    // (requesting tile t + 1 ahead of tile t's products -- two register sets -- measured slower: 47.6 against 40.3 us at
+    //  64 -> 64 channels, B = 32, N = 50; the occupancy the second set costs is worth more than the overlap it buys)
+    for (; t < t_end; t += CONV_WAVES) {
+        if (t != t_begin + wv) conv_request<KH>(A, t, xv, mv, masked, tpg, N, nvalid, K, K2, col, h);
+        conv_multiply<KH>(A, wl, bl, yv, relu, M, K2, MG, col, h);
+    }
+}
+
+// grid (chunks, sets): workgroup (chunk, set) accumulates a 2 x 2 set of 32 x 32 blocks of dW -- output groups og0, og0 + 1
+// times input groups cg0, cg0 + 1 -- over its chunk of tiles; groups past M / K load nothing and their blocks are not stored.
+constexpr int DW_TILES = 4;         // LDS transposing tiles per wave: dz of two output groups, x of two input groups
+constexpr int DW_WAVES = 8;         // 135 KB of LDS: one workgroup per CU, two waves per SIMD
+__global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_kernel(
     const float *dyp, long long d_gs, long long d_ld, const float *mp, const float *xp, long long x_gs, long long x_ld,
     const int *nvalid, int G, int N, int M, int K, float *wpart, int tpg, int ntiles) {
-    __shared__ float ta[CONV_WAVES][32 * CONV_TLD], tb[CONV_WAVES][32 * CONV_TLD];
+    extern __shared__ float dw_lds[];       // [wave][4 tiles][32 * CONV_TLD]; reused for the final reduction
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
-    const int KG = (K + 31) / 32;
-    const int og = blockIdx.y / KG, cg = blockIdx.y - og * KG;
+    const int KS = ((K + 31) / 32 + 1) / 2;
+    const int os = blockIdx.y / KS, cs = blockIdx.y - os * KS;
+    const int o0 = os * 64, c0 = cs * 64;                       // first output / input channel of the set
+    float *tl = dw_lds + wv * DW_TILES * 32 * CONV_TLD;
     const View dv = make_view(dyp, d_gs, d_ld, G), xv = make_view(xp, x_gs, x_ld, G);
     const View mv = mp ? make_view(mp, d_gs, d_ld, G) : dv;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
 
-    f32x16 acc;
+    f32x16 acc[4];                                              // blocks (og, cg) = (0,0) (0,1) (1,0) (1,1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;
-    for (int t = t_begin + wv; t < t_end; t += CONV_WAVES) {
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    for (int t = t_begin + wv; t < t_end; t += DW_WAVES) {
         const TileCtx c = tile_ctx(t, tpg, N, nvalid, col);
         const int sd = c.g * dv.gs4, sx = c.g * xv.gs4;
-        // coalesced loads ([channel row][32 pixels]), transposed through this wave's LDS tiles
-        float d[16], m[16], x[16];
+        // coalesced loads ([channel row][32 pixels]), everything in flight before the first wait
+        // (row 2r + h of a group: the half's row and the pixel in the VGPR offset, the 2r rows in the scalar offset)
+        float d[2][16], x[2][16];
+        const int vd = c.ok ? h * dv.ld4 + c.p * 4 : OOB_OFF, vx = c.ok ? h * xv.ld4 + c.p * 4 : OOB_OFF;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = og * 32 + 2 * r + h, cc = cg * 32 + 2 * r + h;
-            const int od = (c.ok && o < M) ? o * dv.ld4 + c.p * 4 : OOB_OFF;
-            d[r] = buf_load(dv, od, sd);
-            m[r] = mp ? buf_load(mv, od, sd) : 1.f;
-            x[r] = buf_load(xv, (c.ok && cc < K) ? cc * xv.ld4 + c.p * 4 : OOB_OFF, sx);
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ob = o0 + 32 * q + 2 * r, cb = c0 + 32 * q + 2 * r;       // uniform
+                const int od = ob + h < M ? vd : OOB_OFF;
+                d[q][r] = buf_load(dv, od, sd + ob * dv.ld4);
+                if (mp) {
+                    const float m = buf_load(mv, od, sd + ob * dv.ld4);
+                    d[q][r] = m > 0.f ? d[q][r] : 0.f;
+                }
+                x[q][r] = buf_load(xv, cb + h < K ? vx : OOB_OFF, sx + cb * xv.ld4);
+            }
         }
+        // transposed through this wave's LDS tiles: tile q = dz of output group q, tile 2 + q = x of input group q
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            ta[wv][(2 * r + h) * CONV_TLD + col] = m[r] > 0.f ? d[r] : 0.f;
-            tb[wv][(2 * r + h) * CONV_TLD + col] = x[r];
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tl[q * 32 * CONV_TLD + (2 * r + h) * CONV_TLD + col] = d[q][r];
+                tl[(2 + q) * 32 * CONV_TLD + (2 * r + h) * CONV_TLD + col] = x[q][r];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane (channel col, half h), k-step s = pixel 2s + h
+        float a[2][16], b[2][16];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                a[q][s] = tl[q * 32 * CONV_TLD + col * CONV_TLD + 2 * s + h];
+                b[q][s] = tl[(2 + q) * 32 * CONV_TLD + col * CONV_TLD + 2 * s + h];
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const float a = ta[wv][col * CONV_TLD + 2 * s + h];       // dz[o = col][pixel 2s + h]
-            const float b = tb[wv][col * CONV_TLD + 2 * s + h];       // x [c = col][pixel 2s + h]
-            acc = mfma32(a, b, acc);
-            bsum += a;
+            acc[0] = mfma32(a[0][s], b[0][s], acc[0]);
+            acc[1] = mfma32(a[0][s], b[1][s], acc[1]);
+            acc[2] = mfma32(a[1][s], b[0][s], acc[2]);
+            acc[3] = mfma32(a[1][s], b[1][s], acc[3]);
+            bsum[0] += a[0][s];
+            bsum[1] += a[1][s];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // the four waves' blocks summed in wave order
+    // the waves' blocks summed in wave order
     __syncthreads();
-    float *red = &ta[0][0];          // [wave][16 * 64]   (4 * 1056 floats available)
-    float *redb = &tb[0][0];         // [wave][64]
+    float *red = dw_lds;                                        // [wave][4 blocks][16 * 64]
+    float *redb = dw_lds + DW_WAVES * 4 * 1024;               // [wave][2][64]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wv * 1024 + r * 64 + lane] = acc[r];
-    redb[wv * 64 + lane] = bsum;
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wv * 4 + q) * 1024 + r * 64 + lane] = acc[q][r];
+    redb[wv * 128 + lane] = bsum[0];
+    redb[wv * 128 + 64 + lane] = bsum[1];
     __syncthreads();
     const long long cnt = (long long)M * K + M;
     float *out = wpart + blockIdx.x * cnt;
-    for (int e = tid; e < 1024; e += 64 * CONV_WAVES) {
-        const int r = e >> 6, l = e & 63;
-        const float s = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
-        const int o = og * 32 + ch_of(r, l >> 5), cc = cg * 32 + (l & 31);
+    for (int e = tid; e < 4 * 1024; e += 64 * DW_WAVES) {
+        const int q = e >> 10, f = e & 1023, r = f >> 6, l = f & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < DW_WAVES; ++w) s += red[(4 * w + q) * 1024 + f];
+        const int o = o0 + 32 * (q >> 1) + ch_of(r, l >> 5), cc = c0 + 32 * (q & 1) + (l & 31);
         if (o < M && cc < K) out[(long long)o * K + cc] = s;
     }
-    if (cg == 0 && tid < 32) {
+    if (cs == 0 && tid < 64) {
+        const int q = tid >> 5, oc = tid & 31;
         float s = 0.f;
-        for (int w = 0; w < CONV_WAVES; ++w) s += redb[w * 64 + tid] + redb[w * 64 + 32 + tid];
-        const int o = og * 32 + tid;
+        for (int w = 0; w < DW_WAVES; ++w) s += redb[w * 128 + q * 64 + oc] + redb[w * 128 + q * 64 + 32 + oc];
+        const int o = o0 + 32 * q + oc;
         if (o < M) out[(long long)M * K + o] = s;
     }
 }
+constexpr int DW_LDS_BYTES = DW_WAVES * DW_TILES * 32 * CONV_TLD * 4;
+static_assert(DW_LDS_BYTES >= DW_WAVES * 4 * 1024 * 4 + DW_WAVES * 128 * 4, "dw LDS: the reduction image must fit");
 
 int conv_tiles(int G, int N, int *tpg) {
     *tpg = (N * N + CONV_T - 1) / CONV_T;
@@ -188,7 +310,31 @@ extern "C" int fgnn_conv1x1(const float *x, long long x_gstride, long long x_ld,
     const int ntiles = conv_tiles(G, N, &tpg);
     int grid = (ntiles + 2 * CONV_WAVES - 1) / (2 * CONV_WAVES);
     if (grid > 1024) grid = 1024;
-    const size_t lds = (size_t)((K + 1) / 2) * 64 * sizeof(float);
+    const int K2 = (K + 1) / 2, MG = (M + 31) / 32;
+
+    if (K2 <= 64) {         // all input channels of a tile in registers
+        const size_t lds = ((size_t)MG * K2 * 64 + MG * 32) * sizeof(float);
+#define FGNN_CONV_PRE(KH)                                                                                              \
+    {                                                                                                                  \
+        static size_t attr = 0;                                                                                        \
+        if (lds > attr) {                                                                                              \
+            FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_pre_kernel<KH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds) == hipSuccess, "fgnn_conv1x1: %zu bytes of LDS refused", lds);     \
+            attr = lds;                                                                                                \
+        }                                                                                                              \
+        hipLaunchKernelGGL(conv1x1_pre_kernel<KH>, dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, x,      \
+                           x_gstride, x_ld, relu_mask, W, w_ostride, w_kstride, bias, relu, nvalid, G, N, M, K, y,     \
+                           y_gstride, y_ld, tpg, ntiles);                                                              \
+    }
+        if (K2 <= 4) FGNN_CONV_PRE(4)
+        else if (K2 <= 16) FGNN_CONV_PRE(16)
+        else if (K2 <= 32) FGNN_CONV_PRE(32)
+        else FGNN_CONV_PRE(64)
+#undef FGNN_CONV_PRE
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
+    const size_t lds = (size_t)K2 * 64 * sizeof(float);
     hipLaunchKernelGGL(conv1x1_kernel, dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, x, x_gstride, x_ld,
                        relu_mask, W, w_ostride, w_kstride, bias, relu, nvalid, G, N, M, K, y, y_gstride, y_ld, tpg, ntiles);
     FGNN_LAUNCH_CHECK();
@@ -199,7 +345,7 @@ extern "C" int fgnn_conv1x1_dw_chunks(int G, int N) {
     int tpg;
     const int ntiles = conv_tiles(G, N, &tpg);
     int chunks = (ntiles + 4 * CONV_WAVES - 1) / (4 * CONV_WAVES);
-    return chunks > 128 ? 128 : (chunks < 1 ? 1 : chunks);
+    return chunks > 256 ? 256 : (chunks < 1 ? 1 : chunks);      // one workgroup per CU and set of blocks
 }
 
 extern "C" int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d_ld, const float *relu_mask, const float *x,
@@ -214,9 +360,15 @@ extern "C" int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d
     int tpg;
     const int ntiles = conv_tiles(G, N, &tpg);
     const int chunks = fgnn_conv1x1_dw_chunks(G, N);
-    const int pairs = ((M + 31) / 32) * ((K + 31) / 32);
-    hipLaunchKernelGGL(conv1x1_dw_kernel, dim3(chunks, pairs), dim3(64 * CONV_WAVES), 0, (hipStream_t)stream, dy, d_gstride,
-                       d_ld, relu_mask, x, x_gstride, x_ld, nvalid, G, N, M, K, wpart, tpg, ntiles);
+    const int sets = (((M + 31) / 32 + 1) / 2) * (((K + 31) / 32 + 1) / 2);
+    static bool attr = false;
+    if (!attr) {
+        FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       DW_LDS_BYTES) == hipSuccess, "fgnn_conv1x1_dw: %d bytes of LDS refused", DW_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv1x1_dw_kernel, dim3(chunks, sets), dim3(64 * DW_WAVES), DW_LDS_BYTES, (hipStream_t)stream, dy,
+                       d_gstride, d_ld, relu_mask, x, x_gstride, x_ld, nvalid, G, N, M, K, wpart, tpg, ntiles);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

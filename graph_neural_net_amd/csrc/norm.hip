@@ -102,20 +102,45 @@ __global__ void gn_stats_kernel(const float *x, long long gstride, long long ldp
     const int nv = nvalid_of(nvalid, g, N);
     const float *xp = x + (long long)g * gstride + (long long)c * ldp;
     const int P = N * N;
-    float s = 0.f;
-    for (int p = lane; p < P; p += WAVE) {
-        const int i = p / N, j = p - i * N;
-        if (i < nv && j < nv) s += xp[p];
-    }
+    float s = 0.f, s2 = 0.f;
     const float m = (float)nv * (float)nv;
-    const float mean = m > 0.f ? wave_sum(s) / m : 0.f;
-    float s2 = 0.f;
-    for (int p = lane; p < P; p += WAVE) {
-        const int i = p / N, j = p - i * N;
-        if (i < nv && j < nv) {
+    float mean;
+    if (nv == N) {          // dense plane: no index arithmetic, eight loads in flight per lane (same summation order)
+        constexpr int U = 8;
+        int p = lane;
+        for (; p + (U - 1) * WAVE < P; p += U * WAVE) {
+            float v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) v[k] = xp[p + k * WAVE];
+#pragma unroll
+            for (int k = 0; k < U; ++k) s += v[k];
+        }
+        for (; p < P; p += WAVE) s += xp[p];
+        mean = m > 0.f ? wave_sum(s) / m : 0.f;
+        p = lane;
+        for (; p + (U - 1) * WAVE < P; p += U * WAVE) {
+            float v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) v[k] = xp[p + k * WAVE];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                const float d = v[k] - mean;
+                s2 += d * d;
+            }
+        }
+        for (; p < P; p += WAVE) {
             const float d = xp[p] - mean;
             s2 += d * d;
         }
+    } else {                // ragged: walk the valid rows (the padding is never touched)
+        for (int i = 0; i < nv; ++i)
+            for (int j = lane; j < nv; j += WAVE) s += xp[i * N + j];
+        mean = m > 0.f ? wave_sum(s) / m : 0.f;
+        for (int i = 0; i < nv; ++i)
+            for (int j = lane; j < nv; j += WAVE) {
+                const float d = xp[i * N + j] - mean;
+                s2 += d * d;
+            }
     }
     s2 = wave_sum(s2);
     if (lane == 0) write_nrm(nrm, idx, mean, s2, m, (float)nv, gw ? gw[c] : 1.f, eps);
@@ -128,11 +153,15 @@ __global__ void gn_apply_kernel(const float *z, long long zg, long long ldz, con
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N * N) return;
     const int nv = nvalid_of(nvalid, g, N);
-    const int i = p / N, j = p - i * N;
+    bool ok = true;
+    if (nv < N) {           // (uniform per workgroup: a dense plane needs no index arithmetic)
+        const int i = p / N, j = p - i * N;
+        ok = i < nv && j < nv;
+    }
     const float4 n = reinterpret_cast<const float4 *>(nrm)[gc];
     const float v = z[(long long)g * zg + (long long)c * ldz + p];
     const float be = beta ? beta[c] : 0.f;
-    y[(long long)g * yg + (long long)c * ldy + p] = (i < nv && j < nv) ? (v - n.x) * n.y + be : 0.f;
+    y[(long long)g * yg + (long long)c * ldy + p] = ok ? (v - n.x) * n.y + be : 0.f;
 }
 
 // S1 = sum dy, S2 = sum dy*(z-mean) per (g,c); one wave each.
@@ -148,13 +177,34 @@ __global__ void gn_bwd_stats_kernel(const float *dy, long long dg, long long ldd
     const float *zp = z + (long long)g * zg + (long long)c * ldz;
     float s1 = 0.f, s2 = 0.f;
     const int P = N * N;
-    for (int p = lane; p < P; p += WAVE) {
-        const int i = p / N, j = p - i * N;
-        if (i < nv && j < nv) {
+    if (nv == N) {          // dense plane: same summation order, four pairs of loads in flight per lane
+        constexpr int U = 4;
+        int p = lane;
+        for (; p + (U - 1) * WAVE < P; p += U * WAVE) {
+            float d[U], z4[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                d[k] = dp[p + k * WAVE];
+                z4[k] = zp[p + k * WAVE];
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                s1 += d[k];
+                s2 += d[k] * (z4[k] - mean);
+            }
+        }
+        for (; p < P; p += WAVE) {
             const float d = dp[p];
             s1 += d;
             s2 += d * (zp[p] - mean);
         }
+    } else {
+        for (int i = 0; i < nv; ++i)
+            for (int j = lane; j < nv; j += WAVE) {
+                const float d = dp[i * N + j];
+                s1 += d;
+                s2 += d * (zp[i * N + j] - mean);
+            }
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
@@ -275,11 +325,15 @@ __global__ void gn_bwd_apply_kernel(const float *dy, long long dg, long long ldd
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N * N) return;
     const int nv = nvalid_of(nvalid, g, N);
-    const int i = p / N, j = p - i * N;
+    bool ok = true;
+    if (nv < N) {
+        const int i = p / N, j = p - i * N;
+        ok = i < nv && j < nv;
+    }
     const float4 k = reinterpret_cast<const float4 *>(coef)[gc];
     const float d = dy[(long long)g * dg + (long long)c * ldd + p];
     const float u = z[(long long)g * zg + (long long)c * ldz + p] - k.x;
-    dz[(long long)g * og + (long long)c * ldo + p] = (i < nv && j < nv) ? k.y * d + k.z * u + k.w : 0.f;
+    dz[(long long)g * og + (long long)c * ldo + p] = ok ? k.y * d + k.z * u + k.w : 0.f;
 }
 
 // out[i] = scale * sum_r in[r][i]; block = 4 row groups x 64 columns, fixed order.

@@ -115,3 +115,28 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out['allreduce_ms'] is not None and out['allreduce_ms'] > 0
     assert out['value'] > 0 and abs(out['value'] - 64 / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
     assert out['ms_per_step_min'] <= out['ms_per_step'] <= out['ms_per_step_max'] and out['timed_windows'] == 2
+
+
+def test_rccl_all_reduce_on_the_gradient_buffer(tmp_path):
+    """The backend the N-GPU run uses (nccl = RCCL) initialises on this box and sums the trainer's communication buffer
+    [flat gradient | loss sum | node count] in place on the device -- with the one rank a one-GPU box can host (the two-rank
+    tests above share cuda:0, which RCCL refuses, and therefore run on gloo).  A fresh child process: this one never touches
+    the GPU before starting it."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "flat = torch.randn(40002, device='cuda:0'); ref = flat.clone()\n"
+        "dist.all_reduce(flat, op=dist.ReduceOp.SUM); torch.cuda.synchronize()\n"
+        "assert torch.equal(flat, ref)\n"
+        "e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)\n"
+        "e0.record()\n"
+        "for _ in range(20): dist.all_reduce(flat, op=dist.ReduceOp.SUM)\n"
+        "e1.record(); torch.cuda.synchronize()\n"
+        "print('RCCL_OK backend=%s us_per_call=%.1f' % (dist.get_backend(), e0.elapsed_time(e1) * 50))\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_OK backend=nccl' in r.stdout, (r.stdout + r.stderr)[-3000:]

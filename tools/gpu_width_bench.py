@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ms/step of the module path (Siamese_Node_Exp.forward -> loss -> backward) for channel widths outside the fused engine
-(generic conv.hip kernels), next to the fused 32-wide configuration.  usage: python tools/gpu_width_bench.py [B=32] [N=50]"""
+(generic conv.hip kernels), next to the fused 32-wide configuration.  usage: python tools/gpu_width_bench.py [B=32] [N=50] [only this width]"""
 import sys
 import time
 
@@ -16,7 +16,10 @@ def main():
     dev = torch.device('cuda', 0)
     x1, x2 = synthetic.make_batch(2000, B, N, 'Regular', 0.2, 0.1)
     x1, x2 = x1.to(dev), x2.to(dev)
+    only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # e.g. 64: just the in = out = 64 model (profiling)
     for c0, cin, cout, depth in ((2, 32, 32, 3), (2, 16, 16, 3), (2, 64, 64, 3), (2, 48, 24, 2), (3, 32, 32, 3)):
+        if only is not None and (cin != only or c0 != 2):
+            continue
         ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=4, in_features=cin,
                   out_features=cout, depth_of_mlp=depth)
         model = Siamese_Node_Exp(c0, ne, metric='max').to(dev)
