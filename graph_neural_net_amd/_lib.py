@@ -157,6 +157,7 @@ _SIGNATURES = {
     'fgnn_expand_adjacency': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_adjacency_degree': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_accuracy_max': [_VP, _VP, _I, _I, _VP, _VP],
+    'fgnn_lsap_accuracy': [_VP, _LL, _I, _VP, _I, _I, _VP, _VP, _VP],
     # ---- bf16 path ----
     'fgnn_tiles_per_graph16': [_I, _I],
     'fgnn_to_bf16': [_VP, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],

@@ -1,8 +1,7 @@
-"""accuracy_max (toolbox/metrics.py:119-141) on the device: argmax over each score row compared with
-the identity matching, plus the Hungarian metric of the reference (toolbox/metrics.py:92-116) as a host-side
-evaluation metric: ONE device->host copy of the log-softmax scores per call, SciPy assignment per graph --
-meant for validation, not for the per-step path."""
-import numpy as np
+"""The two matching accuracies of the reference on the device: accuracy_max (toolbox/metrics.py:119-141: argmax over each
+score row compared with the identity matching) and accuracy_linear_assignment (toolbox/metrics.py:92-116: the minimum-cost
+matching of -log_softmax(scores), SciPy's assignment reproduced by csrc/lsap.hip).  Neither copies the scores to the host;
+the only synchronisation is the final count handed back as Python numbers, as the reference's return type demands."""
 import torch
 
 from . import _lib
@@ -31,23 +30,27 @@ def accuracy_max(weights, aggregate_score=True):
 
 
 def accuracy_linear_assignment(rawscores, aggregate_score=True):
-    """rawscores: (bs, n, n) tensor or MaskedTensor.  Maximum-weight matching on log_softmax(scores) per graph,
-    counted against the identity matching: (n_correct, n_vertices) or the list of per-graph accuracies."""
-    from scipy.optimize import linear_sum_assignment
+    """rawscores: (bs, n, n) device tensor or MaskedTensor.  Minimum-cost matching on -log_softmax(scores) per graph (the
+    assignment scipy.optimize.linear_sum_assignment returns, computed on the device by fgnn_lsap_accuracy: no copy of the
+    scores to the host, no host loop), counted against the identity matching: (n_correct, n_vertices) or the list of
+    per-graph accuracies."""
     if isinstance(rawscores, MaskedTensor):
-        s, sizes = rawscores.tensor, rawscores.sizes()
+        s, nvalid = rawscores.tensor, rawscores.nvalid
+        sizes = nvalid.to(torch.int64)
     else:
-        s, sizes = rawscores, [rawscores.shape[1]] * rawscores.shape[0]
+        s, nvalid = rawscores, None
+        sizes = torch.full((s.shape[0],), s.shape[1], dtype=torch.int64, device=s.device)
+    if not s.is_cuda:
+        raise RuntimeError('accuracy_linear_assignment: scores are on %s; no CPU path' % (s.device,))
     s = s.detach()
-    if isinstance(rawscores, MaskedTensor):      # padding columns must not take part in the row softmax
-        col = torch.arange(s.shape[-1], device=s.device)[None, None, :] < rawscores.nvalid.to(s.device)[:, None, None]
+    if nvalid is not None:          # padding columns must not take part in the row softmax
+        col = torch.arange(s.shape[-1], device=s.device)[None, None, :] < nvalid.to(s.device)[:, None, None]
         s = s.masked_fill(~col, float('-inf'))
-    cost = (-torch.log_softmax(s, -1)).cpu().numpy()
-    acc, total, all_acc = 0, 0, []
-    for b, n in enumerate(sizes):
-        _, preds = linear_sum_assignment(cost[b, :n, :n])
-        hit = int(np.sum(preds == np.arange(n)))
-        acc += hit
-        total += n
-        all_acc.append(hit / n)
-    return (acc, total) if aggregate_score else all_acc
+    cost = (-torch.log_softmax(s.float(), -1)).contiguous()
+    B, N, _ = cost.shape
+    correct = torch.empty(B, dtype=torch.int32, device=s.device)
+    nv32 = nvalid.to(device=s.device, dtype=torch.int32).contiguous() if nvalid is not None else None
+    _lib.call('fgnn_lsap_accuracy', _lib.ptr(cost), N * N, N, _lib.ptr(nv32), B, N, _lib.ptr(correct), None, _lib.stream_ptr())
+    if aggregate_score:
+        return int(correct.sum().item()), int(sizes.sum().item())
+    return (correct.to(torch.float64) / sizes.to(torch.float64).to(correct.device)).tolist()

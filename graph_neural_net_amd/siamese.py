@@ -53,9 +53,9 @@ class Siamese_Node_Exp(nn.Module):
     def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
                  metric=None, precision='fp32'):
         """Same positional signature as the reference (models/trainers.py:21).  Two keyword-only extras:
-        metric: None -> the reference's default, the Hungarian matching accuracy (`accuracy_linear_assignment`, host-side
-                SciPy like the reference: trainers.py:52, metrics.py:92-116); 'max' -> the device-side arg-max accuracy
-                (`accuracy_max`, metrics.py:118-141: no device->host copy of the scores per step); or any callable.
+        metric: None -> the reference's default, the Hungarian matching accuracy (`accuracy_linear_assignment`: trainers.py:52,
+                metrics.py:92-116; SciPy's assignment computed on the device, csrc/lsap.hip); 'max' -> the arg-max accuracy
+                (`accuracy_max`, metrics.py:118-141); or any callable.  Neither copies the scores to the host.
         precision: 'fp32' (default) or 'bf16' (the bf16 engine; what `node_embedder.half()` also selects)."""
         super().__init__()
         node_emb = dict(node_emb)

@@ -329,6 +329,15 @@ int fgnn_adam_step_dev(float *params, const float *grads, float *exp_avg, float 
 /* accuracy_max (toolbox/metrics.py:119-141): correct[b] = #{i < n_b : argmax_j scores[b,i,j] == i},
  * first maximum on ties (np.argmax); int32, bit-exact.                                              */
 int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int *correct, void *stream);
+/* accuracy_linear_assignment (toolbox/metrics.py:92-116): per graph b the minimum-cost perfect matching of the n_b x n_b corner
+ * of cost[b] (= -log_softmax(scores[b]); row pitch ld, graphs bstride apart), correct[b] = #{i : matched column of row i == i};
+ * assign (optional, (B, N) int32) receives the matched column of every row (-1 in the padding).  The algorithm, arithmetic
+ * (fp64) and tie rules are those of scipy.optimize.linear_sum_assignment (Crouse's shortest augmenting paths), so the
+ * ASSIGNMENT equals SciPy's, ties included (tests/test_gpu_lsap.py).  A cost matrix without a finite matching (SciPy raises)
+ * yields correct[b] = 0 and assign = -1.  No device->host copy, no host loop over the graphs.                          */
+#define FGNN_LSAP_MAX_N 512
+int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, const int *nvalid, int B, int N, int *correct,
+                       int *assign /* optional */, void *stream);
 
 /* Input expansion (loaders/data_generator.py:118-125): bits (G, N, ceil(N/32)) uint32, bit j of row i =
  * W[i][j]  ->  x (G, 2, N, N) fp32 with x[g,0] = W, x[g,1] = diag(row sums); exact 0/1/integer values. */

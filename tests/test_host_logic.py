@@ -166,26 +166,13 @@ def test_bucket_by_size_partitions_and_orders():
     assert sorted(i for _, idx in b for i in idx) == list(range(len(sizes)))
 
 
-def test_accuracy_linear_assignment_host_metric():
-    """Hungarian metric (toolbox/metrics.py:92-116): identity-dominant scores are fully matched, a permuted
-    optimum is counted against the identity, and the ragged form ignores the padding."""
-    from scipy.optimize import linear_sum_assignment
-    from graph_neural_net_amd.metrics import accuracy_linear_assignment
-    g = torch.Generator().manual_seed(0)
-    s = torch.randn(3, 6, 6, generator=g)
-    ref = 0
-    for b in range(3):
-        _, p = linear_sum_assignment(-torch.log_softmax(s[b], -1).numpy())
-        ref += int((p == np.arange(6)).sum())
-    assert accuracy_linear_assignment(s) == (ref, 18)
-    assert accuracy_linear_assignment(torch.eye(5)[None] * 10.0) == (5, 5)
-    assert accuracy_linear_assignment(torch.eye(4)[None].flip(-1) * 10.0) == (0, 4)
-    pad = torch.zeros(2, 5, 5)
-    pad[0, :3, :3] = torch.eye(3) * 8
-    pad[1] = torch.eye(5) * 8
-    mt = MaskedTensor(pad, torch.tensor([3, 5]), (1, 2))
-    assert accuracy_linear_assignment(mt) == (8, 8)
-    assert accuracy_linear_assignment(mt, aggregate_score=False) == [1.0, 1.0]
+def test_metrics_have_no_cpu_path():
+    """both matching accuracies run on the device only (csrc/pool_score.hip, csrc/lsap.hip): CPU scores are refused, loudly"""
+    from graph_neural_net_amd.metrics import accuracy_linear_assignment, accuracy_max
+    s = torch.randn(2, 5, 5)
+    for fn in (accuracy_linear_assignment, accuracy_max):
+        with pytest.raises(RuntimeError, match='no CPU path'):
+            fn(s)
 
 
 def test_bench_algorithmic_model_matches_survey_figures():
