@@ -32,3 +32,19 @@ for B, N in ((32, 50), (8, 200), (64, 120)):
             fn()
         torch.cuda.synchronize()
         print('B = %2d  N = %3d  %-22s %8.3f ms per call' % (B, N, name, (time.perf_counter() - t0) * 100))
+
+# the kernel alone (cost already formed), event-timed
+from graph_neural_net_amd import _lib
+for B, N in ((32, 50), (8, 200), (64, 120)):
+    cost = (-torch.log_softmax(torch.randn(B, N, N, device=dev) * 3, -1)).contiguous()
+    correct = torch.empty(B, dtype=torch.int32, device=dev)
+    st = _lib.stream_ptr()
+    f = lambda: _lib.call('fgnn_lsap_accuracy', _lib.ptr(cost), N * N, N, None, B, N, _lib.ptr(correct), None, st)
+    f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    print('B = %2d  N = %3d  fgnn_lsap_accuracy alone %8.3f ms' % (B, N, e0.elapsed_time(e1) / 10))
