@@ -116,18 +116,27 @@ class Siamese_Node_Exp(nn.Module):
         kernels but pays ~40 host launches and the autograd bookkeeping per step).
         Afterwards every trainable parameter's `.grad` is the gradient of this batch (views of one flat buffer, OVERWRITTEN
         per call like after `zero_grad()`), so any torch optimizer / scheduler steps as usual.
-        Constant-size batches (tensors or {'input': T} dicts) of the standard node_embedding graph; equal-size graphs make
-        both loss reductions the same number (toolbox/losses.py:27-34).  Returns (loss, raw scores (bs, n, n)): device
+        Constant-size batches (tensors or {'input': T} dicts).  The standard node_embedding graph runs the fused engine; widths /
+        depths the engine is not built for (in_features > 32, depth_of_mlp != 3 ...) run the module path's own per-layer launch
+        sequence, captured the same way (`_captured_module_step`); models that run zero-padded on the engine are refused.
+        Equal-size graphs make both loss reductions the same number (toolbox/losses.py:27-34).  Returns (loss, raw scores (bs, n, n)): device
         tensors that the NEXT call of the same shape overwrites."""
         x1, x2 = _unwrap_input(x1), _unwrap_input(x2)
         net = self.node_embedder
         lay = net._standard_layout()
-        if isinstance(x1, MaskedTensor) or lay is None or net._pad is not None:
-            raise RuntimeError('fused_step covers constant-size batches of the standard node_embedding graph '
-                               '(original_features_num 2 or 32, in_features = out_features = 32); use the module path '
-                               '`loss = model.loss(model(x1, x2)); loss.backward()` for everything else')
+        if isinstance(x1, MaskedTensor):
+            raise RuntimeError('fused_step covers constant-size batches; use the module path '
+                               '`loss = model.loss(model(x1, x2)); loss.backward()` for MaskedTensor batches')
         if not x1.is_cuda:
             raise RuntimeError('graph_neural_net_amd only runs on the GPU (input is on %s)' % (x1.device,))
+        if lay is None:
+            # widths / depths the fused engine is not built for: the module path's own launch sequence (per-layer kernels,
+            # csrc/conv.hip), captured once per batch shape and replayed
+            return self._captured_module_step(x1, x2, capture)
+        if net._pad is not None:
+            raise RuntimeError('fused_step: this model runs zero-padded on the fused engine (widths below 32 / '
+                               'original_features_num other than 2 or 32); use the module path '
+                               '`loss = model.loss(model(x1, x2)); loss.backward()`')
         net._bind_flat()
         B, N = x1.shape[0], x1.shape[-1]
         eng = net._engine_for_shape(2 * B, N, False, x1.device, 'step')
@@ -159,6 +168,57 @@ class Siamese_Node_Exp(nn.Module):
             if p.requires_grad:
                 p.grad = v
         return loss.reshape(()), scores
+
+    def _captured_module_step(self, x1, x2, capture):
+        """forward + loss + backward of the eager module path (models/trainers.py:60-76) as ONE replayed HIP graph per batch
+        shape: the ~400 launches of a non-standard model cost the host nothing on replay.  Same contract as fused_step:
+        every p.grad is overwritten per call, the returned tensors are overwritten by the next call of the same shape."""
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        params = [p for _, p in named]
+
+        def run(a, b):
+            # The step differentiates fresh leaves that alias the parameters' storage, not the parameters themselves: a
+            # parameter's AccumulateGrad node lives as long as ANY autograd graph that reached it (e.g. the caller's previous
+            # `loss`), belongs to the stream it was created on, and the autograd engine synchronises with that stream --
+            # which is not allowed inside a capture (the capture then dies in hipStreamEndCapture).
+            leaves = {n: p.detach().requires_grad_(True) for n, p in named}
+            scores = torch.func.functional_call(self, leaves, (a, b))
+            loss = self.loss(scores)
+            grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+            return loss.detach().reshape(()), scores.detach(), grads
+
+        if not capture:
+            loss, scores, grads = run(x1, x2)
+            for p, gr in zip(params, grads):
+                p.grad = gr
+            return loss, scores
+        steps = self.__dict__.setdefault('_module_steps', {})
+        key = (tuple(x1.shape), tuple(x2.shape), x1.dtype, x1.device, tuple(id(p) for p in params))
+        st = steps.get(key)
+        if st is None:
+            if len(steps) >= 4:                         # a handful of batch shapes; each holds a graph's private memory pool
+                steps.pop(next(iter(steps)))
+            st = steps[key] = {'x1': torch.empty_like(x1), 'x2': torch.empty_like(x2), 'graph': None}
+        st['x1'].copy_(x1)
+        st['x2'].copy_(x2)
+        if st['graph'] is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):               # allocations, kernel attributes, autograd's first-use set-up
+                for _ in range(3):
+                    run(st['x1'], st['x2'])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, scores, grads = run(st['x1'], st['x2'])
+            if all(gr is None for gr in grads):
+                raise RuntimeError('fused_step: no parameter received a gradient from the captured module step')
+            st['out'], st['grads'], st['graph'] = (loss, scores), grads, g
+        st['graph'].replay()
+        for p, gr in zip(params, st['grads']):
+            p.grad = gr
+        return st['out']
 
     # -- the step methods of the reference's LightningModule (models/trainers.py:70-90); `log` is a no-op
     #    here and is overridden by whatever training shell wraps the module

@@ -396,3 +396,52 @@ def test_conv1x1_with_padded_strides():
     dw_ref = torch.einsum('gmp,gkp->mk', dy.double(), x.double())
     assert rel(flat[:M * K].view(M, K).cpu(), dw_ref) < 1e-5
     assert rel(flat[M * K:].cpu(), dy.double().sum((0, 2))) < 1e-5
+
+
+def test_fused_step_on_a_non_standard_width_is_the_captured_module_path():
+    """Siamese_Node_Exp.fused_step on a model the fused engine is not built for (in = out = 64): the eager module path's launch
+    sequence captured in one HIP graph -- loss, scores and every gradient equal the eager run bit for bit, replay after replay,
+    and an optimizer step between replays is seen by the next one."""
+    from graph_neural_net_amd.siamese import Siamese_Node_Exp
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=64,
+              out_features=64, depth_of_mlp=3)
+    torch.manual_seed(3)
+    model = Siamese_Node_Exp(2, ne, metric='max').to(DEV)
+    g = torch.Generator().manual_seed(4)
+    B, N = 3, 20
+    x1 = torch.randn(B, 2, N, N, generator=g).to(DEV)
+    x2 = torch.randn(B, 2, N, N, generator=g).to(DEV)
+    scores = model(x1, x2)
+    loss = model.loss(scores)
+    loss.backward()
+    eager = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for rep in range(3):
+        for p in model.parameters():
+            p.grad = None
+        l2, s2 = model.fused_step(x1, x2)
+        assert torch.equal(s2, scores.detach()) and torch.equal(l2, loss.detach().reshape(()))
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, eager[n]), (rep, n)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    opt.step()
+    l3, _ = model.fused_step(x1, x2)
+    with torch.no_grad():
+        l_eager = model.loss(model(x1, x2))
+    assert torch.equal(l3, l_eager.reshape(())) and l3.item() != loss.item()
+    # another batch shape gets its own graph; the first one still replays
+    y1, y2 = x1[:2].contiguous(), x2[:2].contiguous()
+    l4, s4 = model.fused_step(y1, y2)
+    with torch.no_grad():
+        assert torch.equal(s4, model(y1, y2))
+    l5, _ = model.fused_step(x1, x2)
+    assert torch.equal(l5, l3)
+
+
+def test_fused_step_refuses_models_that_run_zero_padded_on_the_engine():
+    from graph_neural_net_amd.siamese import Siamese_Node_Exp
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=16,
+              out_features=16, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne, metric='max').to(DEV)
+    x = torch.randn(2, 2, 10, 10, device=DEV)
+    with pytest.raises(RuntimeError, match='zero-padded'):
+        model.fused_step(x, x)
