@@ -114,6 +114,8 @@ _SIGNATURES = {
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_gn_plane_fwd': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _LL, _LL, _VP, _VP],
+    'fgnn_gn_plane_bwd': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP, _VP, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_apply': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_ragged_tile_ranges': [_VP, _I, _I, _VP, _VP],

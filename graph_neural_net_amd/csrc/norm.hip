@@ -479,6 +479,140 @@ extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const f
                                0, stream);
 }
 
+// ---- GraphNorm of a dense (G, C, ld) tensor with ONE workgroup per (g, c) plane (N*N <= 4096): the plane is read once into
+// registers, reduced in the workgroup (fixed order) and normalised from the registers -- statistics + apply in one pass over
+// the tensor and one launch instead of two passes and two launches (three and three in the backward).
+namespace {
+constexpr int PLANE_EPT = 16, PLANE_THREADS = 256, PLANE_MAX = PLANE_EPT * PLANE_THREADS;
+
+DEVI float plane_sum(float v, float *sm, int tid) {      // every thread gets the total; fixed order
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) sm[tid >> 6] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+// validity of element p of the plane (dense planes need no index arithmetic)
+DEVI bool plane_valid(int p, int P, int N, int nv) {
+    if (p >= P) return false;
+    if (nv == N) return true;
+    const int i = p / N, j = p - i * N;
+    return i < nv && j < nv;
+}
+
+__global__ __launch_bounds__(PLANE_THREADS) void gn_plane_fwd_kernel(const float *x, long long gs, long long ld, const float *gw,
+                                                                     const float *beta, const int *nvalid, int C, int N, float eps,
+                                                                     float *y, long long yg, long long ldy, float *nrm) {
+    __shared__ float sm[4];
+    const int gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
+    const int nv = nvalid_of(nvalid, g, N), P = N * N;
+    const float *xp = x + (long long)g * gs + (long long)c * ld;
+    float v[PLANE_EPT];
+    unsigned ok = 0;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        const int p = tid + PLANE_THREADS * k;
+        const bool val = plane_valid(p, P, N, nv);
+        ok |= (val ? 1u : 0u) << k;
+        v[k] = xp[p < P ? p : 0];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) s += ((ok >> k) & 1u) ? v[k] : 0.f;
+    const float m = (float)nv * (float)nv;
+    s = plane_sum(s, sm, tid);
+    const float mean = m > 0.f ? s / m : 0.f;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        const float d = ((ok >> k) & 1u) ? v[k] - mean : 0.f;
+        s2 += d * d;
+    }
+    s2 = plane_sum(s2, sm, tid);
+    const float4 rec = nrm_record(mean, s2, m, (float)nv, gw ? gw[c] : 1.f, eps);
+    if (tid == 0) reinterpret_cast<float4 *>(nrm)[gc] = rec;
+    const float be = beta ? beta[c] : 0.f;
+    float *yp = y + (long long)g * yg + (long long)c * ldy;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        const int p = tid + PLANE_THREADS * k;
+        if (p < P) yp[p] = ((ok >> k) & 1u) ? (v[k] - rec.x) * rec.y + be : 0.f;
+    }
+}
+
+// dz = ca*dy + cb*(z - mean) + cc with the coefficients of gn_bwd_coef_kernel formed from this plane's own S1 / S2
+__global__ __launch_bounds__(PLANE_THREADS) void gn_plane_bwd_kernel(const float *dy, long long dg, long long ldd, const float *z,
+                                                                     long long zg, long long ldz, const float *nrm,
+                                                                     const int *nvalid, int C, int N, float *dz, long long og,
+                                                                     long long ldo, float *s12) {
+    __shared__ float sm[4];
+    const int gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
+    const int nv = nvalid_of(nvalid, g, N), P = N * N;
+    const float4 n = reinterpret_cast<const float4 *>(nrm)[gc];
+    const float *dp = dy + (long long)g * dg + (long long)c * ldd;
+    const float *zp = z + (long long)g * zg + (long long)c * ldz;
+    float d[PLANE_EPT], u[PLANE_EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        const int p = tid + PLANE_THREADS * k;
+        const bool val = plane_valid(p, P, N, nv);
+        const float dv = dp[p < P ? p : 0], zv = zp[p < P ? p : 0];
+        d[k] = val ? dv : 0.f;
+        u[k] = val ? zv - n.x : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        s1 += d[k];
+        s2 += d[k] * u[k];
+    }
+    s1 = plane_sum(s1, sm, tid);
+    s2 = plane_sum(s2, sm, tid);
+    if (tid == 0) {
+        s12[(long long)gc * 2] = s1;
+        s12[(long long)gc * 2 + 1] = s2;
+    }
+    const float m = (float)nv * (float)nv;
+    const float ca = n.y, cb = m > 0.f ? -n.y * s2 * n.w / m : 0.f, cc = m > 0.f ? -n.y * s1 / m : 0.f;
+    float *op = dz + (long long)g * og + (long long)c * ldo;
+#pragma unroll
+    for (int k = 0; k < PLANE_EPT; ++k) {
+        const int p = tid + PLANE_THREADS * k;
+        if (p < P) op[p] = plane_valid(p, P, N, nv) ? ca * d[k] + cb * u[k] + cc : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int fgnn_gn_plane_supported(int N) { return (long long)N * N <= PLANE_MAX ? 1 : 0; }
+
+extern "C" int fgnn_gn_plane_fwd(const float *x, long long gstride, long long ldp, const float *gn_weight, const float *beta,
+                                 const int *nvalid, int G, int C, int N, float eps, float *y, long long ygstride, long long ldy,
+                                 float *nrm, void *stream) {
+    FGNN_CHECK(x && y && nrm && G > 0 && C > 0 && N > 0 && ldp >= (long long)N * N && ldy >= (long long)N * N,
+               "fgnn_gn_plane_fwd: bad arguments");
+    FGNN_CHECK(fgnn_gn_plane_supported(N), "fgnn_gn_plane_fwd: N*N = %d > %d (use fgnn_gn_stats + fgnn_gn_apply)", N * N, PLANE_MAX);
+    hipLaunchKernelGGL(gn_plane_fwd_kernel, dim3(G * C), dim3(PLANE_THREADS), 0, (hipStream_t)stream, x, gstride, ldp, gn_weight,
+                       beta, nvalid, C, N, eps, y, ygstride, ldy, nrm);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_gn_plane_bwd(const float *dy, long long dgstride, long long ldd, const float *z, long long zgstride,
+                                 long long ldz, const float *nrm, const int *nvalid, int G, int C, int N, float *dz,
+                                 long long ogstride, long long ldo, float *s12, float *dgn_w, float *dgn_b, void *stream) {
+    FGNN_CHECK(dy && z && nrm && dz && s12 && G > 0 && C > 0 && N > 0, "fgnn_gn_plane_bwd: bad arguments");
+    FGNN_CHECK(fgnn_gn_plane_supported(N), "fgnn_gn_plane_bwd: N*N = %d > %d (use fgnn_gn_bwd_stats / _coef / _apply)", N * N,
+               PLANE_MAX);
+    hipLaunchKernelGGL(gn_plane_bwd_kernel, dim3(G * C), dim3(PLANE_THREADS), 0, (hipStream_t)stream, dy, dgstride, ldd, z, zgstride,
+                       ldz, nrm, nvalid, C, N, dz, ogstride, ldo, s12);
+    FGNN_LAUNCH_CHECK();
+    if (dgn_w || dgn_b) {
+        hipLaunchKernelGGL(gn_bwd_affine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s12, nrm, G, C, dgn_w, dgn_b);
+        FGNN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 extern "C" int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float *gn_weight,
                              const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream) {
     FGNN_CHECK(x && nrm && G > 0 && C > 0 && N > 0 && ldp >= (long long)N * N, "fgnn_gn_stats: bad arguments");

@@ -235,10 +235,14 @@ class _GraphNormFn(torch.autograd.Function):
         nrm = torch.empty(G * Cc * 4, dtype=torch.float32, device=x.device)
         y = torch.empty_like(x)
         st = _lib.stream_ptr()
-        _lib.call('fgnn_gn_stats', _lib.ptr(x), Cc * P, P, _lib.ptr(gn_w), _nv(nvalid), G, Cc, N, float(eps),
-                  _lib.ptr(nrm), st)
-        _lib.call('fgnn_gn_apply', _lib.ptr(x), Cc * P, P, _lib.ptr(nrm), _lib.ptr(gn_b), _nv(nvalid), G, Cc, N,
-                  _lib.ptr(y), Cc * P, P, st)
+        if _lib.load().fgnn_gn_plane_supported(N):      # one pass, one launch: a (g, c) plane fits a workgroup's registers
+            _lib.call('fgnn_gn_plane_fwd', _lib.ptr(x), Cc * P, P, _lib.ptr(gn_w), _lib.ptr(gn_b), _nv(nvalid), G, Cc, N,
+                      float(eps), _lib.ptr(y), Cc * P, P, _lib.ptr(nrm), st)
+        else:
+            _lib.call('fgnn_gn_stats', _lib.ptr(x), Cc * P, P, _lib.ptr(gn_w), _nv(nvalid), G, Cc, N, float(eps),
+                      _lib.ptr(nrm), st)
+            _lib.call('fgnn_gn_apply', _lib.ptr(x), Cc * P, P, _lib.ptr(nrm), _lib.ptr(gn_b), _nv(nvalid), G, Cc, N,
+                      _lib.ptr(y), Cc * P, P, st)
         ctx.save_for_backward(x, nrm, nvalid, gn_w, gn_b)
         return y
 
@@ -256,12 +260,16 @@ class _GraphNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         st = _lib.stream_ptr()
         gs = Cc * P
-        _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(nrm), _nv(nvalid), G, Cc, N,
-                  _lib.ptr(s12), st)
-        _lib.call('fgnn_gn_bwd_coef', _lib.ptr(s12), _lib.ptr(nrm), _nv(nvalid), G, Cc, N, _lib.ptr(coef),
-                  _lib.ptr(dgw), _lib.ptr(dgb), st)
-        _lib.call('fgnn_gn_bwd_apply', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(coef), _nv(nvalid), G, Cc, N,
-                  _lib.ptr(dx), gs, P, st)
+        if _lib.load().fgnn_gn_plane_supported(N):
+            _lib.call('fgnn_gn_plane_bwd', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(nrm), _nv(nvalid), G, Cc, N,
+                      _lib.ptr(dx), gs, P, _lib.ptr(s12), _lib.ptr(dgw), _lib.ptr(dgb), st)
+        else:
+            _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(nrm), _nv(nvalid), G, Cc, N,
+                      _lib.ptr(s12), st)
+            _lib.call('fgnn_gn_bwd_coef', _lib.ptr(s12), _lib.ptr(nrm), _nv(nvalid), G, Cc, N, _lib.ptr(coef),
+                      _lib.ptr(dgw), _lib.ptr(dgb), st)
+            _lib.call('fgnn_gn_bwd_apply', _lib.ptr(dy), gs, P, _lib.ptr(x), gs, P, _lib.ptr(coef), _nv(nvalid), G, Cc, N,
+                      _lib.ptr(dx), gs, P, st)
         return (dx, None, None, dgw.view(1, Cc, 1, 1) if dgw is not None else None,
                 dgb.view(1, Cc, 1, 1) if dgb is not None else None)
 

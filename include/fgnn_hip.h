@@ -137,6 +137,18 @@ int fgnn_gn_stats(const float *x, long long gstride, long long ldp, const float 
 int fgnn_gn_apply(const float *z, long long zgstride, long long ldz, const float *nrm, const float *beta /* (C) or NULL=0 */,
                   const int *nvalid, int G, int C, int N, float *y, long long ygstride, long long ldy, void *stream);
 
+/* GraphNorm.forward (models/layers.py:47-80) of a dense tensor in ONE pass and ONE launch when a plane fits a workgroup's
+ * registers (N*N <= 4096): statistics record (nrm, as fgnn_gn_stats) + y = (x - mean) a + beta (as fgnn_gn_apply).
+ * fgnn_gn_plane_bwd: its autograd -- S1 / S2 of the plane (written to s12), dz = ca dy + cb (z - mean) + cc, and the affine
+ * gradients d gn_weight / d gn_bias (fixed order over the graphs) -- replacing fgnn_gn_bwd_stats + _coef + _apply.        */
+int fgnn_gn_plane_supported(int N);
+int fgnn_gn_plane_fwd(const float *x, long long gstride, long long ldp, const float *gn_weight, const float *beta /* NULL = 0 */,
+                      const int *nvalid, int G, int C, int N, float eps, float *y, long long ygstride, long long ldy,
+                      float *nrm /* (G*C*4) */, void *stream);
+int fgnn_gn_plane_bwd(const float *dy, long long dgstride, long long ldd, const float *z, long long zgstride, long long ldz,
+                      const float *nrm, const int *nvalid, int G, int C, int N, float *dz, long long ogstride, long long ldo,
+                      float *s12 /* (G*C*2) */, float *dgn_w /* (C) or NULL */, float *dgn_b /* (C) or NULL */, void *stream);
+
 /* ---- generic-width 1x1 convolution (conv.hip) ------------------------------------------
  * One layer of MlpBlock_Real.forward, `out = activation(conv_layer(out))` (models/layers.py:125-131: nn.Conv2d(k=1, bias=True)
  * + F.relu), for channel widths the fused 32-wide fgnn_mlp_fwd / fgnn_mlp_bwd are not built for (any Cin = K and Cout = M up

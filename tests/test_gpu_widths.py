@@ -445,3 +445,60 @@ def test_fused_step_refuses_models_that_run_zero_padded_on_the_engine():
     x = torch.randn(2, 2, 10, 10, device=DEV)
     with pytest.raises(RuntimeError, match='zero-padded'):
         model.fused_step(x, x)
+
+
+@pytest.mark.parametrize('N,ragged', [(7, False), (50, False), (64, True), (33, True)])
+def test_graphnorm_plane_kernels_equal_the_two_pass_kernels(N, ragged):
+    """fgnn_gn_plane_fwd / _bwd (one workgroup per (g, c) plane, one pass) against the statistics / apply kernels they replace
+    and against the fp64 definition (models/layers.py:47-80 and its autograd)."""
+    G, Cc = 3, 5
+    g = torch.Generator().manual_seed(N)
+    nv = torch.tensor([N, max(1, N // 2), N - 1], dtype=torch.int32) if ragged else None
+    mask = _valid_mask(G, N, nv)
+    x = (torch.randn(G, Cc, N, N, generator=g).double() * mask).float() * 2 + 0.5 * mask.float()
+    dy = (torch.randn(G, Cc, N, N, generator=g).double() * mask).float()
+    gw, gb = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    xd, dyd, gwd, gbd = x.to(DEV), dy.to(DEV), gw.to(DEV), gb.to(DEV)
+    nvd = nv.to(DEV) if ragged else None
+    nvp = _lib.ptr(nvd) if ragged else None
+    P, st = N * N, _lib.stream_ptr()
+    f32 = dict(dtype=torch.float32, device=DEV)
+    y1, y2 = torch.full_like(xd, float('nan')), torch.full_like(xd, float('nan'))
+    n1, n2 = torch.empty(G * Cc * 4, **f32), torch.empty(G * Cc * 4, **f32)
+    _lib.call('fgnn_gn_plane_fwd', _lib.ptr(xd), Cc * P, P, _lib.ptr(gwd), _lib.ptr(gbd), nvp, G, Cc, N, 1e-5, _lib.ptr(y1),
+              Cc * P, P, _lib.ptr(n1), st)
+    _lib.call('fgnn_gn_stats', _lib.ptr(xd), Cc * P, P, _lib.ptr(gwd), nvp, G, Cc, N, 1e-5, _lib.ptr(n2), st)
+    _lib.call('fgnn_gn_apply', _lib.ptr(xd), Cc * P, P, _lib.ptr(n2), _lib.ptr(gbd), nvp, G, Cc, N, _lib.ptr(y2), Cc * P, P, st)
+    assert rel(n1.cpu(), n2.cpu()) < 1e-5 and rel(y1.cpu(), y2.cpu()) < 1e-5
+    assert (y1.cpu().double() * (1 - mask)).abs().max() == 0
+    # fp64 definition
+    xr = x.double().requires_grad_(True)
+    gwr, gbr = gw.double().requires_grad_(True), gb.double().requires_grad_(True)
+    ys = []
+    for b in range(G):
+        n = N if nv is None else int(nv[b])
+        xb = xr[b, :, :n, :n]
+        mean = xb.mean((-1, -2), keepdim=True)
+        var = ((xb - mean) ** 2).mean((-1, -2), keepdim=True)
+        yb = gwr[:, None, None] * (xb - mean) / (2 * torch.sqrt(n * (var + 1e-5))) + gbr[:, None, None]
+        ys.append(torch.nn.functional.pad(yb, (0, N - n, 0, N - n)))
+    yr = torch.stack(ys)
+    yr.backward(dy.double())
+    assert rel(y1.cpu(), yr.detach()) < 1e-5
+    dz1, dz2 = torch.full_like(xd, float('nan')), torch.full_like(xd, float('nan'))
+    s1, s2, coef = torch.empty(G * Cc * 2, **f32), torch.empty(G * Cc * 2, **f32), torch.empty(G * Cc * 4, **f32)
+    dw1, db1, dw2, db2 = (torch.empty(Cc, **f32) for _ in range(4))
+    _lib.call('fgnn_gn_plane_bwd', _lib.ptr(dyd), Cc * P, P, _lib.ptr(xd), Cc * P, P, _lib.ptr(n1), nvp, G, Cc, N, _lib.ptr(dz1),
+              Cc * P, P, _lib.ptr(s1), _lib.ptr(dw1), _lib.ptr(db1), st)
+    _lib.call('fgnn_gn_bwd_stats', _lib.ptr(dyd), Cc * P, P, _lib.ptr(xd), Cc * P, P, _lib.ptr(n2), nvp, G, Cc, N, _lib.ptr(s2), st)
+    _lib.call('fgnn_gn_bwd_coef', _lib.ptr(s2), _lib.ptr(n2), nvp, G, Cc, N, _lib.ptr(coef), _lib.ptr(dw2), _lib.ptr(db2), st)
+    _lib.call('fgnn_gn_bwd_apply', _lib.ptr(dyd), Cc * P, P, _lib.ptr(xd), Cc * P, P, _lib.ptr(coef), nvp, G, Cc, N, _lib.ptr(dz2),
+              Cc * P, P, st)
+    assert rel(dz1.cpu(), dz2.cpu()) < 2e-5 and rel(dw1.cpu(), dw2.cpu()) < 2e-5 and rel(db1.cpu(), db2.cpu()) < 2e-5
+    assert rel(dz1.cpu(), xr.grad) < 2e-5 and rel(dw1.cpu(), gwr.grad) < 2e-5 and rel(db1.cpu(), gbr.grad) < 2e-5
+    assert (dz1.cpu().double() * (1 - mask)).abs().max() == 0
+    # bit-reproducible
+    dz3, s3 = torch.empty_like(xd), torch.empty_like(s1)
+    _lib.call('fgnn_gn_plane_bwd', _lib.ptr(dyd), Cc * P, P, _lib.ptr(xd), Cc * P, P, _lib.ptr(n1), nvp, G, Cc, N, _lib.ptr(dz3),
+              Cc * P, P, _lib.ptr(s3), None, None, st)
+    assert torch.equal(dz3, dz1) and torch.equal(s3, s1)
