@@ -16,8 +16,7 @@
 
 namespace {
 
-constexpr int LSAP_MAX = FGNN_LSAP_MAX_N;
-constexpr size_t LSAP_STAGE_BYTES = 144 * 1024;        // next to 15 KB of solver state (160 KB per workgroup)
+constexpr size_t LSAP_LDS_BYTES = 160 * 1024;          // solver state (29 bytes per vertex) + as many cost rows as fit
 
 // lanes of the wave exchange values through LDS: order the accesses for the compiler (LDS itself is in order per wave)
 DEVI void wsync() {
@@ -72,17 +71,20 @@ DEVI int wave_max_i32(int v) {
 // NC = columns per lane (lane l owns columns l, l + 64, ...: their dual v, path cost, predecessor, matched row and position
 // in SciPy's `remaining` list live in registers); the row-indexed state (u, col4row, SR) and what the pointer walk of the
 // augmentation needs (path, row4col) are in LDS, and so are the first `rows_staged` rows of the n x n cost corner (all of
-// them up to n = 192; row pitch n): a row scan then reads LDS instead of paying a global-memory round trip per step.
+// them up to n = 198; row pitch n): a row scan then reads LDS instead of paying a global-memory round trip per step.
 // The list is never materialised: a column knows its position, the minimum / first / last-unassigned positions are wave
 // reductions, the column at the chosen position identifies itself, and the compaction "move the last entry into the freed
 // slot" is the lane that sits at the last position rewriting its own position.
 template <int NC>
 __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, long long bstride, int ld, const int *nvalid, int B, int N,
                                                   int *correct, int *assign, int stage_floats) {
-    extern __shared__ float cl[];
-    __shared__ double u[LSAP_MAX], spc_l[LSAP_MAX];
-    __shared__ int path_l[LSAP_MAX], col4row[LSAP_MAX], row4col[LSAP_MAX];
-    __shared__ unsigned char SR[LSAP_MAX];
+    // dynamic LDS: solver state sized for N, then the staged cost rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsap_lds[];
+    const int NA = (N + 3) & ~3;
+    double *u = reinterpret_cast<double *>(lsap_lds), *spc_l = u + NA;
+    int *path_l = reinterpret_cast<int *>(spc_l + NA), *col4row = path_l + NA, *row4col = col4row + NA;
+    unsigned char *SR = reinterpret_cast<unsigned char *>(row4col + NA);
+    float *cl = reinterpret_cast<float *>(SR + NA);
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = nvalid_of(nvalid, b, N);
     const float *cb = cost + (long long)b * bstride;
@@ -157,12 +159,12 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, long long b
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const bool chosen = pos[c] == index, last = pos[c] == num_remaining;
-                who = chosen ? ((lane + 64 * c) | ((r4c[c] + 1) << 10)) : who;
+                who = chosen ? ((lane + 64 * c) | ((r4c[c] + 1) << 12)) : who;
                 SC[c] = SC[c] || chosen;
                 pos[c] = chosen ? -1 : (last ? index : pos[c]);     // remaining[index] = remaining[--num_remaining]
             }
             who = wave_max_i32(who);
-            const int j = who & 1023, r4 = (who >> 10) - 1;
+            const int j = who & 4095, r4 = (who >> 12) - 1;
             if (r4 == -1) sink = j;
             else i = r4;
         }
@@ -213,8 +215,10 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, long long b
 template <int NC>
 int launch_lsap(const float *cost, long long bstride, int ld, const int *nvalid, int B, int N, int *correct, int *assign,
                 hipStream_t st) {
-    size_t lds = (size_t)N * N * sizeof(float);
-    if (lds > LSAP_STAGE_BYTES) lds = LSAP_STAGE_BYTES;
+    const size_t state = (size_t)((N + 3) & ~3) * (8 + 8 + 4 + 4 + 4 + 1);
+    size_t stage = (size_t)N * N * sizeof(float);
+    if (state + stage > LSAP_LDS_BYTES) stage = (LSAP_LDS_BYTES - state) & ~(size_t)15;
+    const size_t lds = state + stage;
     static size_t attr = 0;
     if (lds > attr) {
         FGNN_CHECK(hipFuncSetAttribute((const void *)lsap_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
@@ -222,7 +226,7 @@ int launch_lsap(const float *cost, long long bstride, int ld, const int *nvalid,
         attr = lds;
     }
     hipLaunchKernelGGL((lsap_kernel<NC>), dim3(B), dim3(64), lds, st, cost, bstride, ld, nvalid, B, N, correct, assign,
-                       (int)(lds / sizeof(float)));
+                       (int)(stage / sizeof(float)));
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -238,5 +242,7 @@ extern "C" int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, 
     if (N <= 64) return launch_lsap<1>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
     if (N <= 128) return launch_lsap<2>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
     if (N <= 256) return launch_lsap<4>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
-    return launch_lsap<8>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
+    if (N <= 512) return launch_lsap<8>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
+    if (N <= 1024) return launch_lsap<16>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
+    return launch_lsap<32>(cost, bstride, ld, nvalid, B, N, correct, assign, st);
 }

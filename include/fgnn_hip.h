@@ -347,7 +347,7 @@ int fgnn_accuracy_max(const float *scores, const int *nvalid, int B, int N, int 
  * (fp64) and tie rules are those of scipy.optimize.linear_sum_assignment (Crouse's shortest augmenting paths), so the
  * ASSIGNMENT equals SciPy's, ties included (tests/test_gpu_lsap.py).  A cost matrix without a finite matching (SciPy raises)
  * yields correct[b] = 0 and assign = -1.  No device->host copy, no host loop over the graphs.                          */
-#define FGNN_LSAP_MAX_N 512
+#define FGNN_LSAP_MAX_N 2048
 int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, const int *nvalid, int B, int N, int *correct,
                        int *assign /* optional */, void *stream);
 

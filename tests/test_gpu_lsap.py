@@ -26,12 +26,12 @@ def _solve(cost, nv=None):
     return correct.cpu().numpy(), assign.cpu().numpy()
 
 
-@pytest.mark.parametrize('N', [1, 2, 7, 50, 64, 65, 120, 200])
+@pytest.mark.parametrize('N', [1, 2, 7, 50, 64, 65, 120, 200, 300, 700, 1100])
 def test_matching_equals_scipy_random_costs(N):
     rng = np.random.default_rng(N)
-    B = 5
+    B = 5 if N <= 300 else 2
     cost = rng.standard_normal((B, N, N)).astype(np.float32)
-    nv = np.array([N, max(1, N // 2), max(1, N - 1), 1, N])
+    nv = np.array([N, max(1, N // 2), max(1, N - 1), 1, N])[:B]
     correct, assign = _solve(cost, nv)
     for b in range(B):
         n = int(nv[b])
