@@ -114,6 +114,7 @@ _SIGNATURES = {
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_gn_plane_supported': [_I],
     'fgnn_gn_plane_fwd': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _LL, _LL, _VP, _VP],
     'fgnn_gn_plane_bwd': [_VP, _LL, _LL, _VP, _LL, _LL, _VP, _VP, _I, _I, _I, _VP, _LL, _LL, _VP, _VP, _VP, _VP],
     'fgnn_gn_stats': [_VP, _LL, _LL, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
