@@ -177,6 +177,162 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void conv1x1_pre_kernel(
     }
 }
 
+// ---- chain of up to three 1x1 convolutions, intermediates in registers (fgnn_conv_chain) ------------------------------------
+// Layer 0 reads its input like conv1x1_pre_kernel (lane = pixel, half h, channel 2u + h).  A layer's output is a set of
+// 32-channel D fragments (lane = pixel, register r = channel ch_of(r, h) of the group); used as the next layer's B operand,
+// k-step (ig, r) contracts channels 32 ig + ch_of(r, 0 / 1) -- the operand image of that layer is laid out accordingly, so the
+// activations never move.  LDS: [image 0 | image 1 | image 2 | biases], image 0 = [og][k][32 o], image l >= 1 =
+// [og][ig][r][h][32 o].  MAXG = 32-channel groups a layer's output may have (2 or 4).
+struct ChainDev {
+    const float *W[3];
+    long long w_so[3], w_sk[3];
+    const float *bias[3];
+    int M[3], K[3], relu[3];
+    const float *mask[3];
+    float *out[3];
+    long long o_gs[3], o_ld;
+};
+
+template <int MAXG>
+struct Frags {
+    f32x16 f[MAXG];
+};
+
+// one layer l >= 1: in = prev fragments (IG groups), out -> cur fragments
+template <int MAXG, bool FULL>
+DEVI void chain_hidden(Frags<MAXG> &cur, const Frags<MAXG> &prev, const float *wl, const float *bl, int OG, int IG, int col, int h) {
+#pragma unroll
+    for (int og = 0; og < MAXG; ++og) {
+        if (FULL || og < OG) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bl[og * 32 + ch_of(r, h)];
+#pragma unroll
+            for (int ig = 0; ig < MAXG; ++ig) {
+                if (FULL || ig < IG) {
+                    const float *wp = wl + ((og * (FULL ? MAXG : IG) + ig) * 16) * 64 + h * 32 + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc = mfma32(wp[r * 64], prev.f[ig][r], acc);
+                }
+            }
+            cur.f[og] = acc;
+        }
+    }
+}
+// activation, mask, validity, store of one layer's fragments
+template <int MAXG, bool FULL>
+DEVI void chain_post(Frags<MAXG> &cur, int OG, int M, int relu, const float *mask, float *out, long long o_gs, long long o_ld, int G,
+                     const TileCtx &c, int h) {
+    const View ov = make_view(out ? out : mask, o_gs, o_ld, G);         // (only dereferenced when the pointer exists)
+    const View mv = make_view(mask ? mask : out, o_gs, o_ld, G);
+    // the graph / half / pixel part of the address in the VGPR offset, the channel rows (shared by all layers: one channel
+    // stride) in the scalar offset
+    const int vo = c.inb ? c.g * ov.gs4 + 4 * h * ov.ld4 + c.p * 4 : OOB_OFF;
+#pragma unroll
+    for (int og = 0; og < MAXG; ++og) {
+        if (FULL || og < OG) {
+            // channel bound of the group: a full group (every width that is a multiple of 32) needs no per-row predicate
+            const bool full = FULL || M - og * 32 >= 32;
+            float m[16];
+            if (mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ob = og * 32 + (r & 3) + 8 * (r >> 2);
+                    m[r] = buf_load(mv, (full || ob + 4 * h < M) ? vo : OOB_OFF, ob * ov.ld4);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = cur.f[og][r];
+                if (relu) v = relu1(v);
+                if (mask) v = m[r] > 0.f ? v : 0.f;
+                v = c.ok ? v : 0.f;
+                cur.f[og][r] = v;
+                if (out) {
+                    const int ob = og * 32 + (r & 3) + 8 * (r >> 2);
+                    buf_store(v, ov, (full || ob + 4 * h < M) ? vo : OOB_OFF, ob * ov.ld4);
+                }
+            }
+        }
+    }
+}
+
+// FULL: K_0 = 2 KH and every layer has exactly MAXG full output groups (the 64-wide model): no bounds inside the tile loop
+template <int KH, int MAXG, bool FULL>
+__global__ __launch_bounds__(64 * CONV_WAVES, MAXG == 2 ? 2 : 1) void conv_chain_kernel(const float *xp, long long x_gs, long long x_ld, int depth,
+                                                                     const ChainDev L, const int *nvalid, int G, int N, int tpg,
+                                                                     int ntiles) {
+    extern __shared__ float wl[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
+    const int K2 = (L.K[0] + 1) / 2;
+    int OGs[3], off[3];
+    int tot = 0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        OGs[l] = l < depth ? (L.M[l] + 31) / 32 : 0;
+        off[l] = tot;
+        if (l < depth) tot += l == 0 ? OGs[0] * K2 * 64 : OGs[l] * OGs[l - 1] * 1024;
+    }
+    float *bl = wl + tot;                       // [layer][128]
+    const View xv = make_view(xp, x_gs, x_ld, G);
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t_begin = blockIdx.x * per, t_end = min(ntiles, t_begin + per);
+    ConvTile<KH> A;
+    int t = t_begin + wv;
+    if (t < t_end) conv_request<KH>(A, t, xv, xv, false, tpg, N, nvalid, L.K[0], K2, col, h);      // in flight under the image copy
+    // operand images
+    for (int e = tid; e < OGs[0] * K2 * 64; e += 64 * CONV_WAVES) {
+        const int og = e / (K2 * 64), rem = e - og * (K2 * 64);
+        const int k = rem >> 5, o = og * 32 + (rem & 31);
+        wl[e] = (k < L.K[0] && o < L.M[0]) ? L.W[0][o * L.w_so[0] + k * L.w_sk[0]] : 0.f;
+    }
+#pragma unroll
+    for (int l = 1; l < 3; ++l) {
+        if (l < depth) {
+            const int IG = OGs[l - 1];
+            for (int e = tid; e < OGs[l] * IG * 1024; e += 64 * CONV_WAVES) {
+                const int o = e & 31, hh = (e >> 5) & 1, r = (e >> 6) & 15, gi = e >> 10;       // gi = og * IG + ig
+                const int og = gi / IG, ig = gi - og * IG;
+                const int oc = og * 32 + o, kc = ig * 32 + ch_of(r, hh);
+                wl[off[l] + e] = (oc < L.M[l] && kc < L.K[l]) ? L.W[l][oc * L.w_so[l] + kc * L.w_sk[l]] : 0.f;
+            }
+        }
+    }
+    for (int e = tid; e < 3 * 128; e += 64 * CONV_WAVES) {
+        const int l = e >> 7, o = e & 127;
+        bl[e] = (l < depth && L.bias[l] && o < L.M[l]) ? L.bias[l][o] : 0.f;
+    }
+    __syncthreads();
+    for (; t < t_end; t += CONV_WAVES) {
+        if (t != t_begin + wv) conv_request<KH>(A, t, xv, xv, false, tpg, N, nvalid, L.K[0], K2, col, h);
+        Frags<MAXG> fa, fb;
+        // layer 0: from the channel-pair registers
+#pragma unroll
+        for (int og = 0; og < MAXG; ++og) {
+            if (FULL || og < OGs[0]) {
+                const float *wg = wl + og * (FULL ? KH : K2) * 64 + h * 32 + col;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bl[og * 32 + ch_of(r, h)];
+#pragma unroll
+                for (int u = 0; u < KH; ++u) {
+                    if (FULL || u < K2) acc = mfma32(wg[u * 64], A.b[u], acc);
+                }
+                fa.f[og] = acc;
+            }
+        }
+        chain_post<MAXG, FULL>(fa, OGs[0], L.M[0], L.relu[0], L.mask[0], L.out[0], L.o_gs[0], L.o_ld, G, A.c, h);
+        if (depth > 1) {
+            chain_hidden<MAXG, FULL>(fb, fa, wl + off[1], bl + 128, OGs[1], OGs[0], col, h);
+            chain_post<MAXG, FULL>(fb, OGs[1], L.M[1], L.relu[1], L.mask[1], L.out[1], L.o_gs[1], L.o_ld, G, A.c, h);
+        }
+        if (depth > 2) {
+            chain_hidden<MAXG, FULL>(fa, fb, wl + off[2], bl + 256, OGs[2], OGs[1], col, h);
+            chain_post<MAXG, FULL>(fa, OGs[2], L.M[2], L.relu[2], L.mask[2], L.out[2], L.o_gs[2], L.o_ld, G, A.c, h);
+        }
+    }
+}
+
 // grid (chunks, sets): workgroup (chunk, set) accumulates a 2 x 2 set of 32 x 32 blocks of dW -- output groups og0, og0 + 1
 // times input groups cg0, cg0 + 1 -- over its chunk of tiles; groups past M / K load nothing and their blocks are not stored.
 constexpr int DW_TILES = 4;         // LDS transposing tiles per wave: dz of two output groups, x of two input groups
@@ -369,6 +525,78 @@ extern "C" int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d
     }
     hipLaunchKernelGGL(conv1x1_dw_kernel, dim3(chunks, sets), dim3(64 * DW_WAVES), DW_LDS_BYTES, (hipStream_t)stream, dy,
                        d_gstride, d_ld, relu_mask, x, x_gstride, x_ld, nvalid, G, N, M, K, wpart, tpg, ntiles);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_conv_chain_supported(int depth, int K0, const int *M) {
+    if (depth < 1 || depth > 3 || K0 < 1 || K0 > 128 || !M) return 0;
+    for (int l = 0; l < depth; ++l) {
+        if (M[l] < 1 || M[l] > 128) return 0;
+        if (l < depth - 1 && M[l] > 64) return 0;       // hidden activations: at most two fragment groups feed the next layer
+    }
+    return 1;
+}
+
+extern "C" int fgnn_conv_chain(const fgnn_chain_args *a, void *stream) {
+    FGNN_CHECK(a && a->x && a->G > 0 && a->N > 0, "fgnn_conv_chain: bad arguments");
+    int Ms[3] = {0, 0, 0};
+    for (int l = 0; l < a->depth && l < 3; ++l) Ms[l] = a->layer[l].M;
+    FGNN_CHECK(fgnn_conv_chain_supported(a->depth, a->layer[0].K, Ms),
+               "fgnn_conv_chain: depth %d, widths %d -> %d -> %d -> %d are outside the chain kernel (use fgnn_conv1x1 per layer)",
+               a->depth, a->layer[0].K, Ms[0], Ms[1], Ms[2]);
+    const long long P = (long long)a->N * a->N, lim = (1ll << 31) / 4;
+    FGNN_CHECK(a->x_ld >= P && a->x_gstride >= a->layer[0].K * a->x_ld && a->G * a->x_gstride < lim,
+               "fgnn_conv_chain: input strides smaller than the tensor, or 2 GiB or more");
+    ChainDev L = {};
+    L.o_ld = a->o_ld;
+    size_t floats = 0;
+    int maxg = 1;
+    for (int l = 0; l < a->depth; ++l) {
+        const fgnn_chain_layer &y = a->layer[l];
+        FGNN_CHECK(y.W && y.M > 0 && y.K == (l == 0 ? y.K : a->layer[l - 1].M), "fgnn_conv_chain: layer %d does not chain (K = %d)", l, y.K);
+        FGNN_CHECK(!(y.out || y.mask) || (a->o_ld >= P && y.o_gstride >= y.M * a->o_ld && a->G * y.o_gstride < lim),
+                   "fgnn_conv_chain: layer %d output strides smaller than the tensor, or 2 GiB or more", l);
+        L.W[l] = y.W; L.w_so[l] = y.w_ostride; L.w_sk[l] = y.w_kstride; L.bias[l] = y.bias; L.M[l] = y.M; L.K[l] = y.K;
+        L.relu[l] = y.relu; L.mask[l] = y.mask; L.out[l] = y.out; L.o_gs[l] = y.o_gstride;
+        const int og = (y.M + 31) / 32;
+        maxg = og > maxg ? og : maxg;
+        floats += l == 0 ? (size_t)og * ((y.K + 1) / 2) * 64 : (size_t)og * ((a->layer[l - 1].M + 31) / 32) * 1024;
+    }
+    FGNN_CHECK(a->layer[a->depth - 1].out, "fgnn_conv_chain: the last layer needs an output");
+    const size_t lds = (floats + 3 * 128) * sizeof(float);
+    FGNN_CHECK(lds <= 160 * 1024, "fgnn_conv_chain: %zu bytes of operand images exceed the LDS", lds);
+    int tpg;
+    const int ntiles = conv_tiles(a->G, a->N, &tpg);
+    int grid = (ntiles + 2 * CONV_WAVES - 1) / (2 * CONV_WAVES);
+    if (grid > 1024) grid = 1024;
+    const int K2 = (a->layer[0].K + 1) / 2;
+#define FGNN_CHAIN_(KH, MG, FL)                                                                                               \
+    {                                                                                                                      \
+        static size_t attr = 0;                                                                                            \
+        if (lds > attr) {                                                                                                  \
+            FGNN_CHECK(hipFuncSetAttribute((const void *)conv_chain_kernel<KH, MG, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)lds) == hipSuccess, "fgnn_conv_chain: %zu bytes of LDS refused", lds);      \
+            attr = lds;                                                                                                    \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((conv_chain_kernel<KH, MG, FL>), dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, a->x,  \
+                           a->x_gstride, a->x_ld, a->depth, L, a->nvalid, a->G, a->N, tpg, ntiles);                        \
+    }
+    // (the FULL = true instantiations -- no bounds inside the tile loop -- measured SLOWER: with the uniform branches gone the
+    //  scheduler hoists the operand reads of a whole layer, 238 instead of 149 registers, 117 against 93 us at 64 -> 64 -> 64 -> 64)
+#define FGNN_CHAIN(KH, MG) FGNN_CHAIN_(KH, MG, false)
+    if (maxg <= 2) {
+        if (K2 <= 4) FGNN_CHAIN(4, 2)
+        else if (K2 <= 16) FGNN_CHAIN(16, 2)
+        else if (K2 <= 32) FGNN_CHAIN(32, 2)
+        else FGNN_CHAIN(64, 2)
+    } else {
+        if (K2 <= 16) FGNN_CHAIN(16, 4)
+        else if (K2 <= 32) FGNN_CHAIN(32, 4)
+        else FGNN_CHAIN(64, 4)
+    }
+#undef FGNN_CHAIN
+#undef FGNN_CHAIN_
     FGNN_LAUNCH_CHECK();
     return 0;
 }

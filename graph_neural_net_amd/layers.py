@@ -222,6 +222,113 @@ class _ConvFn(torch.autograd.Function):
         return dx, None, dw, db, None
 
 
+def _chain_supported(cin, widths):
+    arr = (C.c_int * len(widths))(*widths)
+    return len(widths) <= 3 and bool(_lib.load().fgnn_conv_chain_supported(len(widths), cin, arr))
+
+
+class _ConvChainFn(torch.autograd.Function):
+    """The conv stack of MlpBlock_Real (models/layers.py:125-131: conv, ReLU, ..., conv) outside the fused 32-wide kernels as
+    ONE launch forward (csrc/conv.hip `conv_chain_kernel`: the hidden activations stay in registers and are written once, for
+    the backward) and ONE launch for the whole input-gradient chain; the weight gradients take the d(pre-activation) tensors
+    that chain leaves behind (fgnn_conv1x1_dw, no mask to re-read)."""
+
+    @staticmethod
+    def forward(ctx, x, nvalid, *wb):
+        _check(x, 'MlpBlock_Real')
+        x = x.contiguous()
+        G, K0, N, _ = x.shape
+        P = N * N
+        depth = len(wb) // 2
+        ws = [wb[2 * l].contiguous() for l in range(depth)]
+        bs = [wb[2 * l + 1] for l in range(depth)]
+        acts = []
+        args = _lib.ChainArgs()
+        args.x, args.x_gstride, args.x_ld, args.depth = x.data_ptr(), K0 * P, P, depth
+        args.o_ld, args.G, args.N = P, G, N
+        args.nvalid = nvalid.data_ptr() if nvalid is not None else None
+        k = K0
+        for l in range(depth):
+            M = ws[l].shape[0]
+            if ws[l].shape[1] != k:
+                raise RuntimeError('MlpBlock_Real: conv %d expects %d input channels, gets %d' % (l, ws[l].shape[1], k))
+            a = torch.empty(G, M, N, N, dtype=torch.float32, device=x.device)
+            acts.append(a)
+            L = args.layer[l]
+            L.W, L.w_ostride, L.w_kstride = ws[l].data_ptr(), k, 1
+            L.bias = bs[l].data_ptr() if bs[l] is not None else None
+            L.M, L.K, L.relu = M, k, int(l < depth - 1)
+            L.mask, L.out, L.o_gstride = None, a.data_ptr(), M * P
+            k = M
+        _lib.call('fgnn_conv_chain', C.byref(args), _lib.stream_ptr())
+        ctx.save_for_backward(x, nvalid, *acts, *ws)
+        ctx.depth, ctx.has_bias = depth, [b is not None for b in bs]
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dz):
+        depth = ctx.depth
+        x, nvalid = ctx.saved_tensors[:2]
+        acts = ctx.saved_tensors[2:2 + depth]
+        ws = ctx.saved_tensors[2 + depth:]
+        dz = dz.contiguous()
+        G, K0, N, _ = x.shape
+        P = N * N
+        st = _lib.stream_ptr()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        need_dx = ctx.needs_input_grad[0]
+        # input-gradient chain: layer j of the chain is conv (depth-1-j) transposed; its output is d(pre-activation) of conv
+        # (depth-2-j) -- masked by that conv's saved post-ReLU output -- or, for the last one, dx
+        # (a last chain layer of more than 64 outputs -- dx of a block's mlp3, whose input is the 128-channel cat -- needs four
+        #  fragment groups per wave: one wave per SIMD, 238 us against 60 for the plain kernel; it stays a launch of its own)
+        split_dx = need_dx and ws[0].shape[1] > 64
+        nchain = depth if (need_dx and not split_dx) else depth - 1
+        dpre = [None] * depth           # dpre[l] = gradient at the output of conv l (before its ReLU mask for l = depth-1: none)
+        dpre[depth - 1] = dz
+        dx = None
+        if nchain > 0:
+            args = _lib.ChainArgs()
+            args.x, args.x_gstride, args.x_ld, args.depth = dz.data_ptr(), ws[depth - 1].shape[0] * P, P, nchain
+            args.o_ld, args.G, args.N = P, G, N
+            args.nvalid = nvalid.data_ptr() if nvalid is not None else None
+            for j in range(nchain):
+                l = depth - 1 - j                       # the conv being transposed: M_l outputs -> K_l inputs
+                Ml, Kl = ws[l].shape[0], ws[l].shape[1]
+                out = torch.empty(G, Kl, N, N, **f32)
+                L = args.layer[j]
+                L.W, L.w_ostride, L.w_kstride, L.bias = ws[l].data_ptr(), 1, Kl, None
+                L.M, L.K, L.relu = Kl, Ml, 0
+                L.mask = acts[l - 1].data_ptr() if l > 0 else None
+                L.out, L.o_gstride = out.data_ptr(), Kl * P
+                if l > 0:
+                    dpre[l - 1] = out
+                else:
+                    dx = out
+            _lib.call('fgnn_conv_chain', C.byref(args), st)
+        if split_dx:
+            M0, K0w = ws[0].shape[0], ws[0].shape[1]
+            dx = torch.empty(G, K0w, N, N, **f32)
+            _lib.call('fgnn_conv1x1', _lib.ptr(dpre[0]), M0 * P, P, None, _lib.ptr(ws[0]), 1, K0w, None, 0, _nv(nvalid), G, N, K0w, M0,
+                      _lib.ptr(dx), K0w * P, P, st)
+        grads = []
+        chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
+        for l in range(depth):
+            gw = gb = None
+            if ctx.needs_input_grad[2 + 2 * l] or (ctx.has_bias[l] and ctx.needs_input_grad[3 + 2 * l]):
+                Ml, Kl = ws[l].shape[0], ws[l].shape[1]
+                cnt = Ml * Kl + Ml
+                wpart = torch.empty(chunks * cnt, **f32)
+                flat = torch.empty(cnt, **f32)
+                inp = acts[l - 1] if l > 0 else x
+                _lib.call('fgnn_conv1x1_dw', _lib.ptr(dpre[l]), Ml * P, P, None, _lib.ptr(inp), Kl * P, P, _nv(nvalid), G, N, Ml, Kl,
+                          _lib.ptr(wpart), st)
+                _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat), st)
+                gw = flat[:Ml * Kl].view(Ml, Kl, 1, 1)
+                gb = flat[Ml * Kl:] if ctx.has_bias[l] else None
+            grads += [gw, gb]
+        return (dx, None, *grads)
+
+
 # --------------------------------------------------------------------------------------
 # GraphNorm / normalize on an arbitrary (G, C, N, N) tensor
 # --------------------------------------------------------------------------------------
@@ -343,11 +450,17 @@ class MlpBlock_Real(nn.Module):
             for conv in self.convs:
                 wb += [conv.weight, conv.bias]
             y = _MlpGnFn.apply(x, nvalid, self.gn.eps, self.gn.weight, self.gn.bias, *wb)
-        else:       # any other widths: one conv.hip launch per layer, then GraphNorm on the (G, C, N, N) tensor
-            y = x
-            last = len(self.convs) - 1
-            for l, conv in enumerate(self.convs):
-                y = _ConvFn.apply(y, nvalid, conv.weight, conv.bias, l < last)
+        else:       # any other widths (csrc/conv.hip), then GraphNorm on the (G, C, N, N) tensor
+            if _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
+                wb = []
+                for conv in self.convs:
+                    wb += [conv.weight, conv.bias]
+                y = _ConvChainFn.apply(x, nvalid, *wb)         # the whole conv stack in one launch per direction
+            else:
+                y = x
+                last = len(self.convs) - 1
+                for l, conv in enumerate(self.convs):
+                    y = _ConvFn.apply(y, nvalid, conv.weight, conv.bias, l < last)
             y = _GraphNormFn.apply(y, nvalid, self.gn.eps, self.gn.weight, self.gn.bias)
         return _wrap(y, inputs)
 

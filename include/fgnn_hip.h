@@ -171,6 +171,37 @@ int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d_ld, const 
                     long long x_gstride, long long x_ld, const int *nvalid, int G, int N, int M, int K, float *wpart,
                     void *stream);
 
+/* A chain of up to three 1x1 convolutions in ONE launch, the intermediate activations never leaving the register file
+ * (channel widths the fused 32-wide kernels are not built for; conv.hip).  Layer l maps K_l -> M_l channels (K_{l+1} = M_l):
+ *     t_l = W_l in_l + bias_l;   t_l = relu(t_l) if relu;   t_l = t_l where mask_l > 0 else 0 if mask_l;   out_l = t_l
+ * in_0 = x, in_{l+1} = t_l; padding pixels of ragged graphs are exact zeros in every out_l.  Two uses:
+ *   forward of MlpBlock_Real's conv stack (models/layers.py:125-131): relu on all but the last layer, every out_l kept for
+ *     the backward;
+ *   its input-gradient chain: layers in reverse with W^T given by strides, no bias, mask_l = the saved post-ReLU activation
+ *     the gradient flows into, out_l = d(pre-activation) of that layer (what fgnn_conv1x1_dw then takes with relu_mask = NULL).
+ * Limits (fgnn_conv_chain_supported): depth <= 3, K_0 <= 128, every M_l <= 128, hidden widths (M_l, l < depth-1) <= 64.   */
+typedef struct {
+    const float *W;                         /* element (o, k) at W[o * w_ostride + k * w_kstride]                        */
+    long long w_ostride, w_kstride;
+    const float *bias;                      /* (M) or NULL                                                               */
+    int M, K;
+    int relu;
+    const float *mask;                      /* optional (G, M, N*N) with the strides of `out`                            */
+    float *out;                             /* optional (G, M, N*N)                                                      */
+    long long o_gstride;                    /* graph stride of mask / out (their channel stride is fgnn_chain_args.o_ld)   */
+} fgnn_chain_layer;
+typedef struct {
+    const float *x;
+    long long x_gstride, x_ld;
+    int depth;
+    fgnn_chain_layer layer[3];
+    long long o_ld;                         /* channel stride of every layer's mask / out                                */
+    const int *nvalid;
+    int G, N;
+} fgnn_chain_args;
+int fgnn_conv_chain_supported(int depth, int K0, const int *M /* depth widths */);
+int fgnn_conv_chain(const fgnn_chain_args *args, void *stream);
+
 /* ---- Matmul.forward: per (g,c) N x N product (models/layers.py:161-162) --------------
  * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
 int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,

@@ -502,3 +502,60 @@ def test_graphnorm_plane_kernels_equal_the_two_pass_kernels(N, ragged):
     _lib.call('fgnn_gn_plane_bwd', _lib.ptr(dyd), Cc * P, P, _lib.ptr(xd), Cc * P, P, _lib.ptr(n1), nvp, G, Cc, N, _lib.ptr(dz3),
               Cc * P, P, _lib.ptr(s3), None, None, st)
     assert torch.equal(dz3, dz1) and torch.equal(s3, s1)
+
+
+@pytest.mark.parametrize('cin,widths', [(64, (64, 64, 64)), (128, (64, 64, 64)), (2, (64, 64, 64)), (19, (48, 24)), (33, (40, 40, 70)),
+                                        (7, (16,)), (64, (33, 64, 128))])
+@pytest.mark.parametrize('ragged', [False, True])
+def test_conv_chain_equals_the_per_layer_kernels(cin, widths, ragged):
+    """_ConvChainFn (the whole conv stack of an MlpBlock_Real in one launch per direction, csrc/conv.hip conv_chain_kernel)
+    against the per-layer _ConvFn launches it replaces and the fp64 ATen definition: output, input gradient and every
+    parameter gradient; exact zeros in the padding of ragged graphs."""
+    from graph_neural_net_amd.layers import _ConvChainFn, _ConvFn, _chain_supported
+    assert _chain_supported(cin, list(widths))
+    G, N = 3, 13
+    g = torch.Generator().manual_seed(cin * 7 + len(widths))
+    nv = torch.tensor([N, 6, N - 1], dtype=torch.int32) if ragged else None
+    mask = _valid_mask(G, N, nv)
+    x = (torch.randn(G, cin, N, N, generator=g).double() * mask).float()
+    ws, bs, k = [], [], cin
+    for m in widths:
+        ws.append(torch.randn(m, k, 1, 1, generator=g) / k ** 0.5)
+        bs.append(0.3 * torch.randn(m, generator=g))
+        k = m
+    dy = (torch.randn(G, widths[-1], N, N, generator=g).double() * mask).float()
+    nvd = nv.to(DEV) if ragged else None
+
+    def run(fn_kind):
+        xd = x.to(DEV).requires_grad_(True)
+        wd = [w.to(DEV).requires_grad_(True) for w in ws]
+        bd = [b.to(DEV).requires_grad_(True) for b in bs]
+        if fn_kind == 'chain':
+            wb = []
+            for w, b in zip(wd, bd):
+                wb += [w, b]
+            y = _ConvChainFn.apply(xd, nvd, *wb)
+        else:
+            y = xd
+            for l, (w, b) in enumerate(zip(wd, bd)):
+                y = _ConvFn.apply(y, nvd, w, b, l < len(wd) - 1)
+        y.backward(dy.to(DEV))
+        return [y.detach().cpu(), xd.grad.cpu()] + [w.grad.cpu() for w in wd] + [b.grad.cpu() for b in bd]
+
+    got, ref = run('chain'), run('layers')
+    # fp64 definition with the MaskedTensor semantics (re-mask after every op)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    yr = xr
+    for l, (w, b) in enumerate(zip(wr, br)):
+        yr = F.conv2d(yr, w, b)
+        if l < len(wr) - 1:
+            yr = F.relu(yr)
+        yr = yr * mask
+    yr.backward(dy.double())
+    truth = [yr.detach(), xr.grad] + [w.grad for w in wr] + [b.grad for b in br]
+    for a, b_, t in zip(got, ref, truth):
+        assert rel(a, t) < 2e-5, (rel(a, t), rel(b_, t))
+        assert rel(a, b_) < 2e-5
+    assert (got[0].double() * (1 - mask)).abs().max() == 0 and (got[1].double() * (1 - mask)).abs().max() == 0
