@@ -382,14 +382,15 @@ __global__ __launch_bounds__(256, 4) void chan_matmul_fwd1_kernel(const fgnn_sla
     }
 }
 
-__global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
+// Two LDS tiles, not three: Ya waits in registers while dA = dM Yb^T runs and takes Yb's tile afterwards -- 35 KB instead of
+// 52 KB per workgroup, i.e. four workgroups per CU instead of three (same MFMA sequence: results bit-identical).
+__global__ __launch_bounds__(256, 4) void chan_matmul_bwd1_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                const float *dm, long long dmg, long long ldm,
                                                                const int *nvalid, int N, int M, float *da, float *db,
                                                                long long ogstride, long long ldo, float *s12a,
                                                                float *s12b) {
-    __shared__ float As[TM * LDS_LD];
-    __shared__ float Bs[TM * LDS_LD];
-    __shared__ float Ds[TM * LDS_LD];
+    __shared__ float Bs[TM * LDS_LD];        // Yb, then Ya, then dB on its way out
+    __shared__ float Ds[TM * LDS_LD];        // dM, then dA on its way out
     __shared__ float red[4][4];
     const int C = ya.C;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -411,13 +412,12 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
         load_tile_raw(xd, vD, g * vD.gs4 + c * vD.ld4, N, nv, tid);
         const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
         const int o_off = g * vOA.gs4 + c * vOA.ld4;
-        float ua[16], ub[16];
+        float ua[16], ub[16], va[16];
+        finish_tile<true>(va, ua, xa, nv, na, tid);
         {
-            float va[16], vb[16], vd[16];
-            finish_tile<true>(va, ua, xa, nv, na, tid);
+            float vb[16], vd[16];
             finish_tile<true>(vb, ub, xb, nv, nb, tid);
             finish_tile<false>(vd, dummy, xd, nv, none, tid);
-            store_tile_lds(As, va, tid);
             store_tile_lds(Bs, vb, tid);
             store_tile_lds(Ds, vd, tid);
         }
@@ -431,26 +431,27 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
         }
         if (live) {
             // dA[i][k] = sum_j dM[i][j] Yb[k][j]
-            {
-                const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
-                const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
-                for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
-            }
-            // dB[k][j] = sum_i Ya[i][k] dM[i][j]
-            {
-                const float *ap = As + h * LDS_LD + 32 * qi + j;
-                const float *bp = Ds + h * LDS_LD + 32 * qj + j;
-                for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
-            }
+            const float *ap = Ds + (32 * qi + j) * LDS_LD + h;
+            const float *bp = Bs + (32 * qj + j) * LDS_LD + h;
+            for (int k = 0; k < N; k += 2) accA = mfma32(ap[k], bp[k], accA);
         }
-        __syncthreads();                                   // all products done: As / Bs are free
-        frag_to_lds(Bs, 32 * qi, 32 * qj, accA, lane);     // dA -> Bs
-        frag_to_lds(As, 32 * qi, 32 * qj, accB, lane);     // dB -> As
+        __syncthreads();                                   // Yb consumed: its tile takes Ya
+        store_tile_lds(Bs, va, tid);
+        __syncthreads();
+        if (live) {
+            // dB[k][j] = sum_i Ya[i][k] dM[i][j]
+            const float *ap = Bs + h * LDS_LD + 32 * qi + j;
+            const float *bp = Ds + h * LDS_LD + 32 * qj + j;
+            for (int k = 0; k < N; k += 2) accB = mfma32(ap[k * LDS_LD], bp[k * LDS_LD], accB);
+        }
+        __syncthreads();                                   // all products done: both tiles are free
+        frag_to_lds(Ds, 32 * qi, 32 * qj, accA, lane);     // dA -> Ds
+        frag_to_lds(Bs, 32 * qi, 32 * qj, accB, lane);     // dB -> Bs
         __syncthreads();
         float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
         if (s12a) {
-            tile_to_global<true>(vOA, o_off, Bs, N, ua, sa1, sa2, tid);
-            tile_to_global<true>(vOB, o_off, As, N, ub, sb1, sb2, tid);
+            tile_to_global<true>(vOA, o_off, Ds, N, ua, sa1, sa2, tid);
+            tile_to_global<true>(vOB, o_off, Bs, N, ub, sb1, sb2, tid);
             sa1 = wave_sum(sa1);
             sa2 = wave_sum(sa2);
             sb1 = wave_sum(sb1);
@@ -468,8 +469,8 @@ __global__ __launch_bounds__(256, 3) void chan_matmul_bwd1_kernel(const fgnn_sla
                 *dst = v;
             }
         } else {
-            tile_to_global<false>(vOA, o_off, Bs, N, dummy, sa1, sa2, tid);
-            tile_to_global<false>(vOB, o_off, As, N, dummy, sb1, sb2, tid);
+            tile_to_global<false>(vOA, o_off, Ds, N, dummy, sa1, sa2, tid);
+            tile_to_global<false>(vOB, o_off, Bs, N, dummy, sb1, sb2, tid);
         }
     }
 }
