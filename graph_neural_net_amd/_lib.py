@@ -40,6 +40,11 @@ class MlpFwdArgs(C.Structure):
                 ('ranges', C.c_void_p), ('cu_share', C.c_int)]
 
 
+class DwJob(C.Structure):
+    _fields_ = [('dy', C.c_void_p), ('d_gstride', C.c_longlong), ('d_ld', C.c_longlong), ('relu_mask', C.c_void_p),
+                ('x', C.c_void_p), ('x_gstride', C.c_longlong), ('x_ld', C.c_longlong), ('M', C.c_int), ('K', C.c_int)]
+
+
 class ChainLayer(C.Structure):
     _fields_ = [('W', C.c_void_p), ('w_ostride', C.c_longlong), ('w_kstride', C.c_longlong), ('bias', C.c_void_p),
                 ('M', C.c_int), ('K', C.c_int), ('relu', C.c_int), ('mask', C.c_void_p), ('out', C.c_void_p),
@@ -133,6 +138,7 @@ _SIGNATURES = {
     'fgnn_ragged_tile_ranges': [_VP, _I, _I, _VP, _VP],
     'fgnn_ragged_tile_ranges_order': [_VP, _I, _I, _VP, _VP, _VP],
     'fgnn_ragged_tile_ranges16': [_VP, _I, _I, _I, _VP, _VP],
+    'fgnn_conv1x1_dw_multi': [C.POINTER(DwJob), _I, _VP, _I, _I, _VP, _VP],
     'fgnn_conv_chain_supported': [_I, _I, C.POINTER(C.c_int)],
     'fgnn_conv_chain': [C.POINTER(ChainArgs), _VP],
     'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],

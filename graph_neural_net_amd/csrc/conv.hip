@@ -337,13 +337,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES, MAXG == 2 ? 2 : 1) void conv_chain
 // times input groups cg0, cg0 + 1 -- over its chunk of tiles; groups past M / K load nothing and their blocks are not stored.
 constexpr int DW_TILES = 4;         // LDS transposing tiles per wave: dz of two output groups, x of two input groups
 constexpr int DW_WAVES = 8;         // 135 KB of LDS: one workgroup per CU, two waves per SIMD
-__global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_kernel(
-    const float *dyp, long long d_gs, long long d_ld, const float *mp, const float *xp, long long x_gs, long long x_ld,
-    const int *nvalid, int G, int N, int M, int K, float *wpart, int tpg, int ntiles) {
+// `set` = which 2 x 2 set of blocks, `out` = this chunk's partial record [dW (M, K) | db (M)]
+DEVI void conv1x1_dw_body(const float *dyp, long long d_gs, long long d_ld, const float *mp, const float *xp, long long x_gs,
+                          long long x_ld, const int *nvalid, int G, int N, int M, int K, float *out, int set, int tpg, int ntiles) {
     extern __shared__ float dw_lds[];       // [wave][4 tiles][32 * CONV_TLD]; reused for the final reduction
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
     const int KS = ((K + 31) / 32 + 1) / 2;
-    const int os = blockIdx.y / KS, cs = blockIdx.y - os * KS;
+    const int os = set / KS, cs = set - os * KS;
     const int o0 = os * 64, c0 = cs * 64;                       // first output / input channel of the set
     float *tl = dw_lds + wv * DW_TILES * 32 * CONV_TLD;
     const View dv = make_view(dyp, d_gs, d_ld, G), xv = make_view(xp, x_gs, x_ld, G);
@@ -424,8 +424,6 @@ __global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_kernel(
     redb[wv * 128 + lane] = bsum[0];
     redb[wv * 128 + 64 + lane] = bsum[1];
     __syncthreads();
-    const long long cnt = (long long)M * K + M;
-    float *out = wpart + blockIdx.x * cnt;
     for (int e = tid; e < 4 * 1024; e += 64 * DW_WAVES) {
         const int q = e >> 10, f = e & 1023, r = f >> 6, l = f & 63;
         float s = 0.f;
@@ -441,6 +439,27 @@ __global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_kernel(
         const int o = o0 + 32 * q + oc;
         if (o < M) out[(long long)M * K + o] = s;
     }
+}
+__global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_kernel(
+    const float *dyp, long long d_gs, long long d_ld, const float *mp, const float *xp, long long x_gs, long long x_ld,
+    const int *nvalid, int G, int N, int M, int K, float *wpart, int tpg, int ntiles) {
+    conv1x1_dw_body(dyp, d_gs, d_ld, mp, xp, x_gs, x_ld, nvalid, G, N, M, K, wpart + blockIdx.x * ((long long)M * K + M),
+                    blockIdx.y, tpg, ntiles);
+}
+// several layers in one launch (the three convs of an MlpBlock_Real): blockIdx.y walks the sets of all jobs; a chunk's
+// record is the concatenation of the jobs' records, so ONE fgnn_reduce_partials finishes all of them
+struct DwJobs {
+    const float *dy[FGNN_DW_MAX_JOBS], *mask[FGNN_DW_MAX_JOBS], *x[FGNN_DW_MAX_JOBS];
+    long long d_gs[FGNN_DW_MAX_JOBS], d_ld[FGNN_DW_MAX_JOBS], x_gs[FGNN_DW_MAX_JOBS], x_ld[FGNN_DW_MAX_JOBS];
+    int M[FGNN_DW_MAX_JOBS], K[FGNN_DW_MAX_JOBS], set0[FGNN_DW_MAX_JOBS + 1];
+    long long off[FGNN_DW_MAX_JOBS + 1];
+};
+__global__ __launch_bounds__(64 * DW_WAVES) void conv1x1_dw_multi_kernel(const DwJobs J, int njobs, const int *nvalid, int G, int N,
+                                                                         float *wpart, int tpg, int ntiles) {
+    int j = 0;
+    while (j + 1 < njobs && (int)blockIdx.y >= J.set0[j + 1]) ++j;
+    conv1x1_dw_body(J.dy[j], J.d_gs[j], J.d_ld[j], J.mask[j], J.x[j], J.x_gs[j], J.x_ld[j], nvalid, G, N, J.M[j], J.K[j],
+                    wpart + blockIdx.x * J.off[njobs] + J.off[j], blockIdx.y - J.set0[j], tpg, ntiles);
 }
 constexpr int DW_LDS_BYTES = DW_WAVES * DW_TILES * 32 * CONV_TLD * 4;
 static_assert(DW_LDS_BYTES >= DW_WAVES * 4 * 1024 * 4 + DW_WAVES * 128 * 4, "dw LDS: the reduction image must fit");
@@ -597,6 +616,44 @@ extern "C" int fgnn_conv_chain(const fgnn_chain_args *a, void *stream) {
     }
 #undef FGNN_CHAIN
 #undef FGNN_CHAIN_
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int fgnn_conv1x1_dw_multi(const fgnn_dw_job *jobs, int njobs, const int *nvalid, int G, int N, float *wpart,
+                                     void *stream) {
+    FGNN_CHECK(jobs && wpart && njobs >= 1 && njobs <= FGNN_DW_MAX_JOBS && G > 0 && N > 0, "fgnn_conv1x1_dw_multi: bad arguments");
+    const long long P = (long long)N * N, lim = (1ll << 31) / 4;
+    DwJobs J = {};
+    int sets = 0;
+    long long off = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const fgnn_dw_job &b = jobs[j];
+        FGNN_CHECK(b.dy && b.x && b.M > 0 && b.K > 0 && b.M <= FGNN_CONV_MAX_CH && b.K <= FGNN_CONV_MAX_CH,
+                   "fgnn_conv1x1_dw_multi: job %d: bad tensors or more than %d channels", j, FGNN_CONV_MAX_CH);
+        FGNN_CHECK(b.x_ld >= P && b.d_ld >= P && b.x_gstride >= b.K * b.x_ld && b.d_gstride >= b.M * b.d_ld &&
+                       G * b.x_gstride < lim && G * b.d_gstride < lim,
+                   "fgnn_conv1x1_dw_multi: job %d: strides smaller than the tensors, or 2 GiB or more", j);
+        J.dy[j] = b.dy; J.mask[j] = b.relu_mask; J.x[j] = b.x;
+        J.d_gs[j] = b.d_gstride; J.d_ld[j] = b.d_ld; J.x_gs[j] = b.x_gstride; J.x_ld[j] = b.x_ld;
+        J.M[j] = b.M; J.K[j] = b.K; J.set0[j] = sets; J.off[j] = off;
+        sets += (((b.M + 31) / 32 + 1) / 2) * (((b.K + 31) / 32 + 1) / 2);
+        off += (long long)b.M * b.K + b.M;
+    }
+    J.set0[njobs] = sets;
+    J.off[njobs] = off;
+    FGNN_CHECK((long long)G * ((P + CONV_T - 1) / CONV_T) < (1ll << 30), "fgnn_conv1x1_dw_multi: too many tiles");
+    int tpg;
+    const int ntiles = conv_tiles(G, N, &tpg);
+    const int chunks = fgnn_conv1x1_dw_chunks(G, N);
+    static bool attr = false;
+    if (!attr) {
+        FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_dw_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       DW_LDS_BYTES) == hipSuccess, "fgnn_conv1x1_dw_multi: %d bytes of LDS refused", DW_LDS_BYTES);
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv1x1_dw_multi_kernel, dim3(chunks, sets), dim3(64 * DW_WAVES), DW_LDS_BYTES, (hipStream_t)stream, J, njobs,
+                       nvalid, G, N, wpart, tpg, ntiles);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

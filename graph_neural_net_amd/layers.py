@@ -310,22 +310,31 @@ class _ConvChainFn(torch.autograd.Function):
             dx = torch.empty(G, K0w, N, N, **f32)
             _lib.call('fgnn_conv1x1', _lib.ptr(dpre[0]), M0 * P, P, None, _lib.ptr(ws[0]), 1, K0w, None, 0, _nv(nvalid), G, N, K0w, M0,
                       _lib.ptr(dx), K0w * P, P, st)
-        grads = []
-        chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
-        for l in range(depth):
-            gw = gb = None
-            if ctx.needs_input_grad[2 + 2 * l] or (ctx.has_bias[l] and ctx.needs_input_grad[3 + 2 * l]):
+        # weight / bias gradients of every layer: one launch, one reduction (a chunk's record = the layers' records in a row)
+        want = [ctx.needs_input_grad[2 + 2 * l] or (ctx.has_bias[l] and ctx.needs_input_grad[3 + 2 * l]) for l in range(depth)]
+        grads = [None] * (2 * depth)
+        todo = [l for l in range(depth) if want[l]]
+        if todo:
+            chunks = _lib.load().fgnn_conv1x1_dw_chunks(G, N)
+            jobs = (_lib.DwJob * len(todo))()
+            offs, total = [], 0
+            for i, l in enumerate(todo):
                 Ml, Kl = ws[l].shape[0], ws[l].shape[1]
-                cnt = Ml * Kl + Ml
-                wpart = torch.empty(chunks * cnt, **f32)
-                flat = torch.empty(cnt, **f32)
                 inp = acts[l - 1] if l > 0 else x
-                _lib.call('fgnn_conv1x1_dw', _lib.ptr(dpre[l]), Ml * P, P, None, _lib.ptr(inp), Kl * P, P, _nv(nvalid), G, N, Ml, Kl,
-                          _lib.ptr(wpart), st)
-                _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, cnt, _lib.ptr(flat), st)
-                gw = flat[:Ml * Kl].view(Ml, Kl, 1, 1)
-                gb = flat[Ml * Kl:] if ctx.has_bias[l] else None
-            grads += [gw, gb]
+                jb = jobs[i]
+                jb.dy, jb.d_gstride, jb.d_ld, jb.relu_mask = dpre[l].data_ptr(), Ml * P, P, None
+                jb.x, jb.x_gstride, jb.x_ld, jb.M, jb.K = inp.data_ptr(), Kl * P, P, Ml, Kl
+                offs.append(total)
+                total += Ml * Kl + Ml
+            wpart = torch.empty(chunks * total, **f32)
+            flat = torch.empty(total, **f32)
+            _lib.call('fgnn_conv1x1_dw_multi', jobs, len(todo), _nv(nvalid), G, N, _lib.ptr(wpart), st)
+            _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), chunks, total, _lib.ptr(flat), st)
+            for i, l in enumerate(todo):
+                Ml, Kl = ws[l].shape[0], ws[l].shape[1]
+                grads[2 * l] = flat[offs[i]:offs[i] + Ml * Kl].view(Ml, Kl, 1, 1)
+                if ctx.has_bias[l]:
+                    grads[2 * l + 1] = flat[offs[i] + Ml * Kl:offs[i] + Ml * Kl + Ml]
         return (dx, None, *grads)
 
 

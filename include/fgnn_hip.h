@@ -171,6 +171,18 @@ int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d_ld, const 
                     long long x_gstride, long long x_ld, const int *nvalid, int G, int N, int M, int K, float *wpart,
                     void *stream);
 
+/* the same for up to FGNN_DW_MAX_JOBS layers in one launch (the convs of one MlpBlock_Real): a chunk's partial record is the
+ * concatenation of the jobs' records [dW_0 | db_0 | dW_1 | db_1 | ...], so one fgnn_reduce_partials(wpart, chunks, sum of the
+ * counts, out) finishes all of them */
+#define FGNN_DW_MAX_JOBS 4
+typedef struct {
+    const float *dy; long long d_gstride, d_ld;
+    const float *relu_mask;                 /* optional */
+    const float *x; long long x_gstride, x_ld;
+    int M, K;
+} fgnn_dw_job;
+int fgnn_conv1x1_dw_multi(const fgnn_dw_job *jobs, int njobs, const int *nvalid, int G, int N, float *wpart, void *stream);
+
 /* A chain of up to three 1x1 convolutions in ONE launch, the intermediate activations never leaving the register file
  * (channel widths the fused 32-wide kernels are not built for; conv.hip).  Layer l maps K_l -> M_l channels (K_{l+1} = M_l):
  *     t_l = W_l in_l + bias_l;   t_l = relu(t_l) if relu;   t_l = t_l where mask_l > 0 else 0 if mask_l;   out_l = t_l
