@@ -1,5 +1,5 @@
 """End-to-end sanity run: train the default model on fresh synthetic regular-graph pairs with the fused HIP
-step + fused Adam and print the loss / arg-max accuracy trend.  usage: python tools/train_demo.py [steps] [B] [N]
+step + fused Adam and print the loss / arg-max and Hungarian accuracy trend.  usage: python tools/train_demo.py [steps] [B] [N]
 (FGNN_CAPTURE=0: eager launches; FGNN_PRECISION=bf16: the 16-bit kernel set)"""
 import os, sys, time
 import torch
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from graph_neural_net_amd import synthetic
 from graph_neural_net_amd.engine import ParamLayout
-from graph_neural_net_amd.metrics import accuracy_max
+from graph_neural_net_amd.metrics import accuracy_linear_assignment, accuracy_max
 from graph_neural_net_amd.trainer import FgnnTrainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -26,6 +26,7 @@ for s in range(steps):
     loss, scores = tr.train_step(x1, x2)
     if s % 25 == 0 or s == steps - 1:
         acc, n = accuracy_max(scores)
-        print('step %4d  loss %.4f  acc_max %.3f' % (s, loss.item(), acc / n), flush=True)
+        hun, _ = accuracy_linear_assignment(scores)          # the reference's per-step metric (toolbox/metrics.py:92-116), on the device
+        print('step %4d  loss %.4f  acc_max %.3f  acc_linear_assignment %.3f' % (s, loss.item(), acc / n, hun / n), flush=True)
 torch.cuda.synchronize()
 print('%.1f steps/s (%s, %s, incl. Adam)' % (steps / (time.time() - t0), precision, 'HIP graph replay' if capture else 'eager launches'))
