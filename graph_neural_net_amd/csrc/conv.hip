@@ -216,6 +216,7 @@ DEVI void chain_hidden(Frags<MAXG> &cur, const Frags<MAXG> &prev, const float *w
                 }
             }
             cur.f[og] = acc;
+            __builtin_amdgcn_sched_barrier(0);                  // (keeps the next group's operand reads from being hoisted)
         }
     }
 }
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, MAXG == 2 ? 2 : 1) void conv_chain
                     if (FULL || u < K2) acc = mfma32(wg[u * 64], A.b[u], acc);
                 }
                 fa.f[og] = acc;
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         chain_post<MAXG, FULL>(fa, OGs[0], L.M[0], L.relu[0], L.mask[0], L.out[0], L.o_gs[0], L.o_ld, G, A.c, h);
@@ -601,9 +603,13 @@ extern "C" int fgnn_conv_chain(const fgnn_chain_args *a, void *stream) {
         hipLaunchKernelGGL((conv_chain_kernel<KH, MG, FL>), dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, a->x,  \
                            a->x_gstride, a->x_ld, a->depth, L, a->nvalid, a->G, a->N, tpg, ntiles);                        \
     }
-    // (the FULL = true instantiations -- no bounds inside the tile loop -- measured SLOWER: with the uniform branches gone the
-    //  scheduler hoists the operand reads of a whole layer, 238 instead of 149 registers, 117 against 93 us at 64 -> 64 -> 64 -> 64)
-#define FGNN_CHAIN(KH, MG) FGNN_CHAIN_(KH, MG, false)
+    bool full_all = true;           // every layer exactly `maxg` full groups, K_0 = 2 KH for the instantiated KH
+    for (int l = 0; l < a->depth; ++l) full_all = full_all && a->layer[l].M == 32 * maxg;
+#define FGNN_CHAIN(KH, MG)                                      \
+    {                                                           \
+        if (full_all && a->layer[0].K == 2 * KH) FGNN_CHAIN_(KH, MG, true) \
+        else FGNN_CHAIN_(KH, MG, false)                         \
+    }
     if (maxg <= 2) {
         if (K2 <= 4) FGNN_CHAIN(4, 2)
         else if (K2 <= 16) FGNN_CHAIN(16, 2)
