@@ -33,7 +33,7 @@ __device__ int g_phase_sel = 0;       // CA * 100 + CB of the variant that recor
 #define PH_FLUSH if (g_phase_buf && g_phase_sel == CA * 100 + CB && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; ++k_) g_phase_buf[((long long)blockIdx.x * NW + wv) * 16 + k_] = ph_[k_]; }
 #else
 #define PH_DECL
-#define PH(k)
+#define PH(k) __builtin_amdgcn_sched_barrier(0);        // phase boundaries double as scheduling barriers: <32,32,3> 256 VGPRs + 2 spilled -> 251, none spilled (same time)
 #define PH_FLUSH
 #endif
 
