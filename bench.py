@@ -16,7 +16,11 @@ import os
 import sys
 import time
 
-import torch
+# the host driver of this pool only supports dmabuf IPC: RCCL (and any sharing of device tensors across processes) needs this
+# before the first HIP call; the image exports it, a bare environment might not
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch                                                      # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
