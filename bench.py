@@ -448,11 +448,13 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
         try:   # HBM traffic of that kernel from the committed PMC passes (same workload), if present
             with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
                 tr = json.load(f)
-            key = dom if not bf16 else 'cfg4:' + dom
-            if key in tr and (B, N) == ((8, 200) if bf16 else (32, 50)) and bf16 == dense_er:
-                dom_key = key
+            if ragged:      # cfg5: the PMC passes ran on exactly this batch (seed 5000, 8 pairs, n in [30, 120], fp32, one rank)
+                key = 'cfg5:' + dom
+                ok = (B, args.n or 120) == (8, 120) and not bf16 and rank == 0
             else:
-                dom_key = None
+                key = dom if not bf16 else 'cfg4:' + dom
+                ok = (B, N) == ((8, 200) if bf16 else (32, 50)) and bf16 == dense_er
+            dom_key = key if (key in tr and ok) else None
             if dom_key is not None:
                 roofline['traffic'] = tr[dom_key]['bytes']
                 roofline['traffic_source'] = tr.get('_source')

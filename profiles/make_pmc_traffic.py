@@ -1,7 +1,9 @@
 """profiles/<tag>_pmc_per_kernel.txt -> profiles/pmc_traffic.json (HBM bytes per launch of the main kernels,
 read by bench.py for roofline.traffic).
-usage: python profiles/make_pmc_traffic.py profiles/r02_cfg2_x_pmc_per_kernel.txt [profiles/r02_cfg4_x_pmc_per_kernel.txt]
-The second file is the bf16 N=200 workload (bench.py --config cfg4); its kernels are stored under 'cfg4:<tag>'."""
+usage: python profiles/make_pmc_traffic.py profiles/r02_cfg2_x_pmc_per_kernel.txt [profiles/r02_cfg4_x_pmc_per_kernel.txt
+                                            [profiles/r03_cfg5_x_pmc_per_kernel.txt]]
+The second file is the bf16 N=200 workload (bench.py --config cfg4); its kernels are stored under 'cfg4:<tag>'.  The third is
+the ragged fp32 workload (--config cfg5, 8 pairs, the batch of bench.py's seed); its kernels are stored under 'cfg5:<tag>'."""
 import json, os, re, sys
 
 TAGS = {
@@ -20,14 +22,17 @@ TAGS16 = {
     'mlp_fwd16_kernel<2, 0, 2, 3>': 'mlp_fwd16[cin=2,nmlp=2]', 'mlp_fwd16_kernel<32, 2, 1, 3>': 'mlp_fwd16[cin=34,nmlp=1]',
     'chan_matmul_bwd16_kernel<8, 7, 2>': 'fgnn_chan_matmul_bwd16', 'chan_matmul_fwd16_kernel<8, 7, true>': 'fgnn_chan_matmul_fwd16',
 }
+# ragged batches run the SKIP = true instantiations (the ', false' of the packed-input flag is stripped below)
+TAGS5 = {k.replace('>', ', true>') if k.startswith(('mlp_', )) else k: v for k, v in TAGS.items()}
+TAGS5.update({'chan_matmul_bwd_big_kernel<4>': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd_big_kernel<4>': 'fgnn_chan_matmul_fwd'})
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rel = lambda f: os.path.relpath(f, root)
 out = {'_note': 'HBM traffic per launch from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, '
-                'profiles/pmc_passes.sh); bench workloads cfg2 (B=32 N=50 fp32) and, under cfg4:<kernel>, cfg4 (B=8 N=200 bf16); '
+                'profiles/pmc_passes.sh); bench workloads cfg2 (B=32 N=50 fp32) and, under cfg4:<kernel> / cfg5:<kernel>, cfg4 (B=8 N=200 bf16) / cfg5 (8 ragged pairs, fp32); '
                 'bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is '
                 'doubled as prescribed for gfx950 in MI355X_MICROARCH.md (HBM section); WRITE_SIZE is uncalibrated there '
                 'and used as reported.',
-       '_source': ' + '.join(rel(f) for f in sys.argv[1:3])}
+       '_source': ' + '.join(rel(f) for f in sys.argv[1:4])}
 
 
 def collect(src, tags, prefix):
@@ -51,6 +56,8 @@ def collect(src, tags, prefix):
 collect(sys.argv[1], TAGS, '')
 if len(sys.argv) > 2:
     collect(sys.argv[2], TAGS16, 'cfg4:')
+if len(sys.argv) > 3:
+    collect(sys.argv[3], TAGS5, 'cfg5:')
 for k, v in out.items():
     if isinstance(v, dict) and 'fetch_kib' in v and 'write_kib' in v:
         v['bytes'] = (2 * v['fetch_kib'] + v['write_kib']) * 1024
