@@ -197,12 +197,41 @@ def self_launch(n):
                    FGNN_BENCH_CHILD='1')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode('utf-8', 'replace'))
+    # rank 0's stdout is drained by a thread (a full pipe would block it); ALL children are polled: when one dies with a
+    # non-zero code (bad device index, RCCL init failure) the others -- stuck in the rendezvous or a barrier until the
+    # distributed timeout -- are terminated and the parent reports at once
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            sys.stderr.write('bench.py: rank %d exited with code %d; stopping the other ranks\n' % (failed, rcs[failed]))
+            for r, p in enumerate(procs):           # exactly the processes started above, by handle
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(chunks).decode('utf-8', 'replace'))
     sys.stdout.flush()
-    worst = max(rcs, key=abs)
-    raise SystemExit(worst)
+    if failed is not None:
+        raise SystemExit(rcs[failed] if rcs[failed] > 0 else 1)
+    raise SystemExit(max(rcs, key=abs))
 
 
 def parse_args():
@@ -355,40 +384,44 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
     graph = None
     model_work()                                  # allocates the backward workspace, sets kernel attributes
     torch.cuda.synchronize()
+    comm = grads if path == 'engine' else model.node_embedder._flat_grad
+    # the ONE collective of a step: recorded into the step's HIP graph when the backend can be captured (RCCL), so a step is one
+    # replay with no host launch on its critical path; otherwise (gloo, --no-graph, module path) an eager call after the model work
+    ar_in_graph = world > 1 and not no_graph and dp.collective_captures()
+    if world > 1:
+        dp.warm_up_collective(dev)                # communicator set-up: not inside a capture, not inside the timed region
     if not no_graph:
-        try:
+        def capture(with_collective):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 model_work()
+                if with_collective:
+                    dp.allreduce_sum_(comm)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
                 model_work()
+                if with_collective:
+                    dp.allreduce_sum_(comm)
+            return g
+        try:
+            graph = capture(ar_in_graph)
         except Exception as exc:                  # capture unsupported -> eager launches (still the HIP path)
             graph = None
+            ar_in_graph = False
             if rank == 0:
                 print('bench.py: HIP graph capture failed (%s); running eager' % (exc,), file=sys.stderr)
             torch.cuda.synchronize()
 
-    comm = grads if path == 'engine' else model.node_embedder._flat_grad
-    ar_events = []                                # (start, stop) around the collective of the timed steps, rank 0's stream
-
-    def step(timed=False):
+    def step():
         if graph is not None:
             graph.replay()
         else:
             model_work()
-        if world > 1:
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                dp.allreduce_sum_(comm)
-                e1.record()
-                ar_events.append((e0, e1))
-            else:
-                dp.allreduce_sum_(comm)
+        if world > 1 and not ar_in_graph:
+            dp.allreduce_sum_(comm)
 
     # Settling (untimed, part of the set-up like the capture runs above): the first ~20 replays after the set-up phase run
     # ~4 % slower than steady state (clocks, TLBs; `--steps 20 --warmup 5` gave 0.945 ms against 0.905 ms for any longer
@@ -407,15 +440,24 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(timed=True)
+            step()
         torch.cuda.synchronize()
         dp.barrier()
         torch.cuda.synchronize()
         window_s.append(dp.max_over_ranks(time.perf_counter() - t0, dev))
     elapsed = sorted(window_s)[len(window_s) // 2]
+    # the collective on its own (outside the timed windows: events inside them would cost the step two host calls each):
+    # 20 back-to-back eager all-reduces of the same buffer on every rank, event-timed on rank 0's stream
     allreduce_ms = None
-    if world > 1 and ar_events:
-        allreduce_ms = sum(a.elapsed_time(b) for a, b in ar_events) / len(ar_events)
+    if world > 1:
+        dp.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dp.allreduce_sum_(comm)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 20
 
     # ---- roofline leg: per-kernel durations from events on the launch stream (eager launches) ----
     roofline = None
@@ -512,7 +554,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
-                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'path': path, 'settle_steps': args.settle,
+                       'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'allreduce_in_graph': bool(ar_in_graph), 'path': path, 'settle_steps': args.settle,
                        'chains': 2 if dual else 1,
                        'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
                                            ('mlp1 / mlp2: 3 x bf16 split operands (8 / 6 partial products, fp32 accumulation) on '

@@ -17,6 +17,7 @@ FGNN_H = 32
 FGNN_TILE = 32
 FGNN_MAX_DEPTH = 3
 FGNN_RANGE_WG = 256          # include/fgnn_hip.h
+FGNN_LSAP_MAX_N = 2048       # include/fgnn_hip.h: largest graph of fgnn_lsap_accuracy
 FGNN_SCORE_SPLIT = 4
 
 c_float_p = C.c_void_p   # device pointers travel as integers

@@ -493,12 +493,8 @@ extern "C" int fgnn_conv1x1(const float *x, long long x_gstride, long long x_ld,
         const size_t lds = ((size_t)MG * K2 * 64 + MG * 32) * sizeof(float);
 #define FGNN_CONV_PRE(KH)                                                                                              \
     {                                                                                                                  \
-        static size_t attr = 0;                                                                                        \
-        if (lds > attr) {                                                                                              \
-            FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_pre_kernel<KH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                           (int)lds) == hipSuccess, "fgnn_conv1x1: %zu bytes of LDS refused", lds);     \
-            attr = lds;                                                                                                \
-        }                                                                                                              \
+        static LdsAttrCache attr_cache;                                                                                \
+        FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)conv1x1_pre_kernel<KH>, lds), "fgnn_conv1x1: %zu bytes of LDS refused", lds); \
         hipLaunchKernelGGL(conv1x1_pre_kernel<KH>, dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, x,      \
                            x_gstride, x_ld, relu_mask, W, w_ostride, w_kstride, bias, relu, nvalid, G, N, M, K, y,     \
                            y_gstride, y_ld, tpg, ntiles);                                                              \
@@ -538,12 +534,8 @@ extern "C" int fgnn_conv1x1_dw(const float *dy, long long d_gstride, long long d
     const int ntiles = conv_tiles(G, N, &tpg);
     const int chunks = fgnn_conv1x1_dw_chunks(G, N);
     const int sets = (((M + 31) / 32 + 1) / 2) * (((K + 31) / 32 + 1) / 2);
-    static bool attr = false;
-    if (!attr) {
-        FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       DW_LDS_BYTES) == hipSuccess, "fgnn_conv1x1_dw: %d bytes of LDS refused", DW_LDS_BYTES);
-        attr = true;
-    }
+    static LdsAttrCache attr_cache;
+    FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)conv1x1_dw_kernel, DW_LDS_BYTES), "fgnn_conv1x1_dw: %d bytes of LDS refused", DW_LDS_BYTES);
     hipLaunchKernelGGL(conv1x1_dw_kernel, dim3(chunks, sets), dim3(64 * DW_WAVES), DW_LDS_BYTES, (hipStream_t)stream, dy,
                        d_gstride, d_ld, relu_mask, x, x_gstride, x_ld, nvalid, G, N, M, K, wpart, tpg, ntiles);
     FGNN_LAUNCH_CHECK();
@@ -594,12 +586,8 @@ extern "C" int fgnn_conv_chain(const fgnn_chain_args *a, void *stream) {
     const int K2 = (a->layer[0].K + 1) / 2;
 #define FGNN_CHAIN_(KH, MG, FL)                                                                                               \
     {                                                                                                                      \
-        static size_t attr = 0;                                                                                            \
-        if (lds > attr) {                                                                                                  \
-            FGNN_CHECK(hipFuncSetAttribute((const void *)conv_chain_kernel<KH, MG, FL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                           (int)lds) == hipSuccess, "fgnn_conv_chain: %zu bytes of LDS refused", lds);      \
-            attr = lds;                                                                                                    \
-        }                                                                                                                  \
+        static LdsAttrCache attr_cache;                                                                                \
+        FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)conv_chain_kernel<KH, MG, FL>, lds), "fgnn_conv_chain: %zu bytes of LDS refused", lds); \
         hipLaunchKernelGGL((conv_chain_kernel<KH, MG, FL>), dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, a->x,  \
                            a->x_gstride, a->x_ld, a->depth, L, a->nvalid, a->G, a->N, tpg, ntiles);                        \
     }
@@ -652,12 +640,8 @@ extern "C" int fgnn_conv1x1_dw_multi(const fgnn_dw_job *jobs, int njobs, const i
     int tpg;
     const int ntiles = conv_tiles(G, N, &tpg);
     const int chunks = fgnn_conv1x1_dw_chunks(G, N);
-    static bool attr = false;
-    if (!attr) {
-        FGNN_CHECK(hipFuncSetAttribute((const void *)conv1x1_dw_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       DW_LDS_BYTES) == hipSuccess, "fgnn_conv1x1_dw_multi: %d bytes of LDS refused", DW_LDS_BYTES);
-        attr = true;
-    }
+    static LdsAttrCache attr_cache;
+    FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)conv1x1_dw_multi_kernel, DW_LDS_BYTES), "fgnn_conv1x1_dw_multi: %d bytes of LDS refused", DW_LDS_BYTES);
     hipLaunchKernelGGL(conv1x1_dw_multi_kernel, dim3(chunks, sets), dim3(64 * DW_WAVES), DW_LDS_BYTES, (hipStream_t)stream, J, njobs,
                        nvalid, G, N, wpart, tpg, ntiles);
     FGNN_LAUNCH_CHECK();

@@ -146,6 +146,22 @@ DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *n
     return next_live_tile_p(t, t_end, step, tpg, FGNN_TILE, N, nvalid);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: what has been raised is remembered per
+// (launcher, device), so a process that drives a second GPU raises it there as well.
+struct LdsAttrCache {
+    size_t raised[32] = {};
+};
+inline bool fgnn_raise_lds(LdsAttrCache &c, const void *kernel, size_t lds) {
+    if (lds <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32)
+        return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (lds <= c.raised[dev]) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    c.raised[dev] = lds;
+    return true;
+}
+
 // error plumbing shared by the launchers
 void fgnn_set_error(const char *fmt, ...);
 #define FGNN_CHECK(cond, ...)                       \

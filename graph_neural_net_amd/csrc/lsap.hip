@@ -219,12 +219,8 @@ int launch_lsap(const float *cost, long long bstride, int ld, const int *nvalid,
     size_t stage = (size_t)N * N * sizeof(float);
     if (state + stage > LSAP_LDS_BYTES) stage = (LSAP_LDS_BYTES - state) & ~(size_t)15;
     const size_t lds = state + stage;
-    static size_t attr = 0;
-    if (lds > attr) {
-        FGNN_CHECK(hipFuncSetAttribute((const void *)lsap_kernel<NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
-                       hipSuccess, "fgnn_lsap_accuracy: %zu bytes of LDS refused", lds);
-        attr = lds;
-    }
+    static LdsAttrCache attr_cache;
+    FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)lsap_kernel<NC>, lds), "fgnn_lsap_accuracy: %zu bytes of LDS refused", lds);
     hipLaunchKernelGGL((lsap_kernel<NC>), dim3(B), dim3(64), lds, st, cost, bstride, ld, nvalid, B, N, correct, assign,
                        (int)(stage / sizeof(float)));
     FGNN_LAUNCH_CHECK();

@@ -1037,12 +1037,8 @@ extern "C" int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb
                    "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
 #define FGNN_BIG_FWD(MT)                                                                                              \
     {                                                                                                                 \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)chan_matmul_fwd_big_kernel<MT>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<MT>::LDS_BYTES);             \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        static LdsAttrCache attr_cache;                                                                           \
+        (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_fwd_big_kernel<MT>, BigCfg<MT>::LDS_BYTES);                   \
         hipLaunchKernelGGL(chan_matmul_fwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
                            (hipStream_t)stream, *ya, *yb, nvalid, N, G, out, ogstride, ldo, order);                   \
     }
@@ -1126,12 +1122,8 @@ extern "C" int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb
                    "fgnn_chan_matmul_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
 #define FGNN_BIG_BWD(MT)                                                                                              \
     {                                                                                                                 \
-        static bool attr = false;                                                                                     \
-        if (!attr) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)chan_matmul_bwd_big_kernel<MT>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, BigCfg<MT>::LDS_BYTES);             \
-            attr = true;                                                                                              \
-        }                                                                                                             \
+        static LdsAttrCache attr_cache;                                                                           \
+        (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_bwd_big_kernel<MT>, BigCfg<MT>::LDS_BYTES);                   \
         hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C * (split ? 2 : 1)), dim3(BIG_THREADS),      \
                            BigCfg<MT>::LDS_BYTES, (hipStream_t)stream, *ya, *yb, dm, dmgstride, ldm, nvalid, N, G, da, \
                            db, ogstride, ldo, s12a, s12b, order, split);                                              \

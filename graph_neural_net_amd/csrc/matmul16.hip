@@ -773,12 +773,8 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
 template <int NT, int NCOL, bool FIN>
 int launch_fwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const int *nvalid, int G, int N, int ldr, void *out,
                       long long ogstride, long long ldo, const FinArgs16 &F, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)chan_matmul_fwd16_kernel<NT, NCOL, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  MMCfg<NT>::LDS_BYTES);
-        attr = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_fwd16_kernel<NT, NCOL, FIN>, MMCfg<NT>::LDS_BYTES);
     hipLaunchKernelGGL((chan_matmul_fwd16_kernel<NT, NCOL, FIN>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya,
                        *yb, nvalid, N, ldr, G, out, ogstride, ldo, F);
     FGNN_LAUNCH_CHECK();
@@ -797,12 +793,8 @@ template <int NT, int NCOL, int STATS>
 int launch_bwd16_impl(const fgnn_slab16 *ya, const fgnn_slab16 *yb, const void *dm, long long dmg, long long ldm, const int *nvalid,
                       int G, int N, int ldr, void *da, void *db, long long ogstride, long long ldo, float *s12a, float *s12b,
                       const float *tpart, int tpg, hipStream_t st, CoefOut co) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)chan_matmul_bwd16_kernel<NT, NCOL, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  MMCfg<NT>::LDS_BYTES);
-        attr = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_bwd16_kernel<NT, NCOL, STATS>, MMCfg<NT>::LDS_BYTES);
     hipLaunchKernelGGL((chan_matmul_bwd16_kernel<NT, NCOL, STATS>), dim3(G * ya->C), dim3(MM_THREADS), MMCfg<NT>::LDS_BYTES, st, *ya,
                        *yb, dm, dmg, ldm, nvalid, N, ldr, G, da, db, ogstride, ldo, s12a, s12b, tpart, tpg, co.a, co.b);
     FGNN_LAUNCH_CHECK();

@@ -765,11 +765,8 @@ template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false>
 int launch_bwd_impl(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = BwdLayout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>, LDS);
     // BWD_WG workgroups = rows of the partials buffer (fgnn_grad_finalize); cu_share == 2: half of the CUs, half the rows
     hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>), dim3(a->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st,
                        *a, tpg, total);

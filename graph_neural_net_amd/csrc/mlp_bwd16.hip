@@ -556,11 +556,8 @@ template <int CA, int CB, int DEPTH, bool SKIP>
 int launch_bwd16_impl(const fgnn_mlp_bwd16_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = Bwd16Layout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd16_kernel<CA, CB, DEPTH, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd16_kernel<CA, CB, DEPTH, SKIP>, LDS);
     hipLaunchKernelGGL((mlp_bwd16_kernel<CA, CB, DEPTH, SKIP>), dim3(BWD16_WG), dim3(64 * NWB), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;

@@ -573,11 +573,8 @@ template <int CA>
 int launch_pair16(const fgnn_mlp_bwd16_args *a1, const fgnn_mlp_bwd16_args *a2, int tpg, int total, hipStream_t st) {
     constexpr int LDS = Bwd16Layout<CA, 0, 3>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd16_pair_kernel<CA>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd16_pair_kernel<CA>, LDS);
     Pair16Args P;
     P.m[0] = *a1;
     P.m[1] = *a2;

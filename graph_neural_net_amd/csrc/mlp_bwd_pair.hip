@@ -482,11 +482,8 @@ template <int CA, bool PK, bool SKIP>
 int launch_pair_impl(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
     constexpr int LDS = PairLayout<CA>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_pair_kernel<CA, PK, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_pair_kernel<CA, PK, SKIP>, LDS);
     PairArgs P;
     P.m[0] = *a1;
     P.m[1] = *a2;

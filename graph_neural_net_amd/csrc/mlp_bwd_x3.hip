@@ -582,11 +582,8 @@ int launch_bwd_x3(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st
     constexpr int LDS = BwdX3Layout<CA, CB, NWT>::LDS_F * 4;
     constexpr int NW = NWT;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_bwd_x3_kernel<CA, CB, PK, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_x3_kernel<CA, CB, PK, NWT>, LDS);
     hipLaunchKernelGGL((mlp_bwd_x3_kernel<CA, CB, PK, NWT>), dim3(a->cu_share == 2 ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st, *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;

@@ -397,12 +397,8 @@ int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t 
     constexpr int NW = L::NW;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>, LDS);
     int grid = (total + NW - 1) / NW;
     const int cap = a->cu_share == 2 ? 128 : 256;      // 2: half of the CUs (two launches on two streams side by side)
     if (grid > cap) grid = cap;

@@ -286,12 +286,8 @@ int launch_fwd16_impl(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStrea
     using L = Fwd16Layout<CA, CB, NMLP, DEPTH>;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd16_kernel<CA, CB, NMLP, DEPTH, SKIP>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd16_kernel<CA, CB, NMLP, DEPTH, SKIP>, LDS);
     int grid = (total + NWF - 1) / NWF;
     if (grid > 256) grid = 256;
     if (SKIP) grid = FGNN_RANGE_WG;

@@ -213,11 +213,8 @@ int launch_fwd_x3(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st
     using L = FwdX3Layout<CA, CB, NMLP, NWT>;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set && LDS > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void *)mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>, LDS);
     int grid = (total + NWT - 1) / NWT;
     const int cap = a->cu_share == 2 ? 128 : 256;
     if (grid > cap) grid = cap;

@@ -57,11 +57,43 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
-def allreduce_sum_(flat):
-    """In-place sum of a flat buffer over all ranks (single call, single bucket)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+def allreduce_sum_(flat, force=False):
+    """In-place sum of a flat buffer over all ranks (single call, single bucket).
+    force: issue the collective also with ONE rank (tests of the RCCL path on a one-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def backend():
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
+def collective_captures():
+    """Can the gradient all-reduce be recorded into a HIP graph together with the kernels around it?  RCCL ('nccl') enqueues
+    its kernels on the current stream and supports stream capture; gloo stages through the host and does not.
+    FGNN_ALLREDUCE_IN_GRAPH=0 forces the eager call."""
+    return backend() == 'nccl' and os.environ.get('FGNN_ALLREDUCE_IN_GRAPH', '1') != '0'
+
+
+def pick_backend(world):
+    """Backend and device index of this rank for a `world`-rank job on this node: one GPU per rank over RCCL when the node has
+    at least `world` GPUs, else all ranks on cuda:0 over gloo (RCCL refuses two ranks on one device) -- the functional form the
+    one-GPU test box can run.  torch.cuda.device_count() does not initialise the GPU."""
+    _, local_rank, _ = env_rank()
+    if world > 1 and torch.cuda.device_count() >= world:
+        return 'nccl', local_rank
+    return ('gloo' if world > 1 else None), 0
+
+
+def warm_up_collective(device, force=False):
+    """The first collective of a process group creates the communicator (RCCL: rings over xGMI, IPC handles) -- seconds, and
+    not something to do inside a stream capture or a timed step.  Called once at set-up, outside any step."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
+        t = torch.zeros(8, dtype=torch.float32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if t.is_cuda:
+            torch.cuda.synchronize(device)
 
 
 def barrier():

@@ -165,7 +165,7 @@ class FgnnEngine:
 
     def __init__(self, layout, G, N, device, ragged=False, cu_share=0, mfma=None):
         """cu_share=2: the persistent MLP kernels take half of the CUs (fgnn_mlp_fwd_args.cu_share), for engines that run
-        next to another one on a second stream (FgnnEngineDual).
+        next to another one on a second stream (FgnnEngineDual).  Ragged engines with tile ranges ignore it (full grid).
         mfma: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); 'x3' = the bf16 matrix cores through the exact
         three-way operand split of csrc/fgnn_x3.h (fp32 tensors, fp32 accumulation, error of an fp32 rounding per product;
         built for depth 3 and constant-size batches -- other cases use 'f32')."""
@@ -415,7 +415,9 @@ class FgnnEngine:
         f32 = dict(dtype=torch.float32, device=self.device)
         act = lambda: torch.empty(self.G * 32 * self.ldp, **f32)
         nwg = _lib.load().fgnn_mlp_bwd_num_workgroups()
-        if self.cu_share == 2:          # half of the CUs: half the workgroups, half the partial rows
+        # cu_share = 2: half of the CUs = half the workgroups = half the partial rows -- but only for constant-size batches:
+        # with `ranges` (ragged engines) the kernels ignore cu_share and run the full grid, one row of wpart per workgroup
+        if self.cu_share == 2 and self.ranges is None:
             nwg //= 2
         L = self.layout
         keys = [(k, j) for k in range(1, L.num_blocks + 1) for j in (1, 2, 3)]

@@ -6,7 +6,9 @@ end-of-kernel imbalance and its reduction.  Graph pairs are independent (models/
 meet in the per-pair score matrix), so ``FgnnEngineDual`` splits the batch into two chains of pairs -- each a complete
 ``FgnnEngine`` (forward, loss, backward) on its own stream -- whose persistent MLP kernels take half of the CUs each
 (``cu_share = 2``: at most 128 workgroups).  The two chains then run side by side on disjoint CUs and one chain's ramps
-fall under the other chain's streaming.  Captured in a HIP graph the fork / join become graph edges.
+fall under the other chain's streaming.  Captured in a HIP graph the fork / join become graph edges.  (Ragged batches:
+the work-balanced tile ranges are cut for the full grid, so the MLP kernels of a ragged chain ignore ``cu_share`` and run 256
+workgroups; the two chains then overlap like any two kernels on two streams, not on disjoint CUs.)
 
 Measured (tools/gpu_dual_probe.py, 1 x MI355X, B = 32): 0.894 -> 0.877 ms per step, i.e. 2 % -- every kernel still takes
 what its per-CU work takes, only the HBM idle time of the ramps is shared -- which is why the single engine stays the

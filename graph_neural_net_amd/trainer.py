@@ -15,10 +15,12 @@ from .optim import FlatAdam
 class FgnnTrainer:
     ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU); 288 GB HBM leave room to raise it
 
-    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32'):
-        """capture=True: constant-shape steps are captured in a HIP graph (model work + fused Adam; the gradient
-        all-reduce, when there is more than one rank, stays an eager RCCL call between two captured halves) and
-        replayed -- the launch overhead of ~40 kernels per step disappears.
+    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32', collective='auto'):
+        """capture=True: constant-shape steps are captured in a HIP graph and replayed -- the launch overhead of ~40 kernels
+        per step disappears.  With more than one rank the gradient all-reduce is recorded INSIDE that graph when the backend
+        can be captured (RCCL: model work -> all-reduce -> fused Adam is one replay, no host launch on the critical path;
+        `allreduce_in_graph` says which form is in use); with gloo it stays an eager call between two captured halves.
+        collective='always': issue the all-reduce with a single rank as well (exercises the RCCL path on a one-GPU box).
         precision='bf16': the model work runs on the bf16 kernel set (engine16; the reference's
         pl.Trainer(precision=16), commander_explore.py:120-122); parameters, gradients, Adam state and the collective
         stay fp32."""
@@ -37,6 +39,14 @@ class FgnnTrainer:
         self.capture = capture
         self._engines = EngineCache(self.ENGINE_CACHE_BYTES)
         self._graphs = {}
+        if collective not in ('auto', 'always'):
+            raise ValueError("collective must be 'auto' or 'always' (got %r)" % (collective,))
+        self._force_collective = collective == 'always'
+        self.allreduce_in_graph = False
+        if dp.world_size() > 1 or self._force_collective:
+            # communicator set-up (RCCL: rings over xGMI) happens at the first collective: here, not inside a step or a capture
+            dp.warm_up_collective(params_flat.device, force=self._force_collective)
+            self.allreduce_in_graph = bool(capture) and dp.collective_captures()
 
     @classmethod
     def from_module(cls, model, lr=None, capture=True):
@@ -73,7 +83,7 @@ class FgnnTrainer:
     def _reduce_and_update(self, opt_graph=None):
         """all-reduce [grads | loss sum | nodes], then Adam with grad_scale = 1 / global nodes (device side).
         Returns the loss of the global batch as a fresh device scalar."""
-        dp.allreduce_sum_(self.comm)
+        dp.allreduce_sum_(self.comm, force=self._force_collective)
         self.opt.sync_hyper_parameters(grad_scale=None)
         self.opt.set_grad_scale_reciprocal(self._nodes)
         if opt_graph is not None:
@@ -179,12 +189,16 @@ class FgnnTrainer:
             torch.cuda.synchronize()
             t0 = self.opt.t
             g_model, g_opt = torch.cuda.CUDAGraph(), None
+            exchange = world > 1 or self._force_collective
             with torch.cuda.graph(g_model):
                 scores, _ = eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
-                if world == 1:                            # nothing to exchange: the whole step is one graph
+                if not exchange or self.allreduce_in_graph:
+                    # nothing to exchange, or the ONE collective rides in the graph: the whole step is one replay
+                    if exchange:
+                        dp.allreduce_sum_(self.comm, force=self._force_collective)
                     self.opt.set_grad_scale_reciprocal(self._nodes)
                     self.opt.step_dev(self.grads)
-            if world > 1:
+            if exchange and not self.allreduce_in_graph:
                 g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_opt):
                     self.opt.step_dev(self.grads)

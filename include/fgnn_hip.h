@@ -102,7 +102,9 @@ typedef struct {
     int cu_share;                           /* 0 / 1: the whole GPU (up to 256 persistent workgroups).  2: HALF of the CUs (at most 128
                                                workgroups): two launches on different streams -- independent half-batches, see
                                                engine_dual.py -- run side by side on disjoint CUs, one chain's ramps under the
-                                               other's streaming.  Results do not depend on it. */
+                                               other's streaming.  Results do not depend on it.  IGNORED when `ranges` is given:
+                                               the range table has one entry per workgroup of the full grid, so a ragged launch
+                                               always runs FGNN_RANGE_WG workgroups */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
 
@@ -329,7 +331,8 @@ typedef struct {
     const int *ranges;                       /* optional work-balanced tile bounds + padding-tile skipping, as in the forward
                                                 arguments; cannot be combined with s12tiles                                  */
     int cu_share;                            /* as in fgnn_mlp_fwd_args; 2 = fgnn_mlp_bwd_num_workgroups() / 2 workgroups and rows of
-                                                wpart (never with `ranges`) */
+                                                wpart.  IGNORED when `ranges` is given: a ragged launch always runs the full grid
+                                                and writes fgnn_mlp_bwd_num_workgroups() rows of wpart -- size wpart for that */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 int fgnn_mlp_bwd_x3(const fgnn_mlp_bwd_args *args, void *stream);   /* the x3 form (see fgnn_mlp_fwd_x3): image of kind 1 from

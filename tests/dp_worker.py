@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Worker of tests/test_00_gpu_two_ranks.py: one rank of a data-parallel FgnnTrainer run (gloo rendezvous on 127.0.0.1,
-all ranks share cuda:0), or the single-process run on the concatenated batch (WORLD_SIZE=1).  Writes the parameters after
-each mode's steps and the per-step losses to <out>.pt.   usage: dp_worker.py <out-prefix>"""
+"""Worker of tests/test_00_gpu_two_ranks.py: one rank of a data-parallel FgnnTrainer run, or the single-process run on the
+concatenated batch (WORLD_SIZE=1).  Backend and device follow the node (graph_neural_net_amd.dp.pick_backend): with at least
+WORLD_SIZE GPUs every rank takes cuda:LOCAL_RANK over RCCL ('nccl') -- the form the 8-GPU run uses; on a one-GPU box all ranks
+share cuda:0 over gloo (RCCL refuses two ranks on one device).  FGNN_TEST_BACKEND overrides.  Writes the parameters after each
+mode's steps and the per-step losses to <out>.pt.   usage: dp_worker.py <out-prefix>"""
 import os
 import sys
 
@@ -44,10 +46,15 @@ def _counted(fn, *a, **k):
 
 def main():
     out = sys.argv[1]
-    rank, _, world = dp.init_process_group('gloo')
+    world = dp.env_rank()[2]
+    backend, index = dp.pick_backend(world)               # device_count() only: the GPU is not initialised yet
+    backend = os.environ.get('FGNN_TEST_BACKEND') or backend
+    if backend == 'gloo':
+        index = 0
+    torch.cuda.set_device(index)
+    rank, _, world = dp.init_process_group(backend)
     _count_collectives()
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda:0')
+    dev = torch.device('cuda', index)
     lay = ParamLayout(2, 2, 32, 32, 3)
     p0 = lay.init_flat(11, dev)
     res = {}
@@ -66,6 +73,9 @@ def main():
             if s == 0:
                 res[mode + '_comm'] = tr.comm.cpu().clone()      # [summed gradients | loss sum | node count] after the all-reduce
         res[mode] = (tr.params.cpu().clone(), losses, tr.opt.t)
+        res[mode + '_in_graph'] = tr.allreduce_in_graph
+    res['backend'] = dp.backend()
+    res['device_index'] = index
     # ---- ragged: 6 pairs with different sizes, ranks hold different node counts ----
     tr = FgnnTrainer(lay, p0.clone(), lr=2e-3)
     losses = []

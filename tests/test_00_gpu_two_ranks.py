@@ -1,5 +1,6 @@
-"""GPU: the HIP trainer with MORE THAN ONE RANK.  Two fresh child processes (gloo rendezvous on 127.0.0.1, both on
-cuda:0) run FgnnTrainer.train_step -- eager, HIP-graph-captured, size-bucketed ragged and padded ragged -- on their shards
+"""GPU: the HIP trainer with MORE THAN ONE RANK.  Two fresh child processes (rendezvous on 127.0.0.1; one GPU per rank
+over RCCL when the node has two GPUs, else both on cuda:0 over gloo -- graph_neural_net_amd.dp.pick_backend) run
+FgnnTrainer.train_step -- eager, HIP-graph-captured, size-bucketed ragged and padded ragged -- on their shards
 of a global batch; the parameters after three optimizer steps must equal the single-process run on the concatenated batch
 ("equals the single-process batch"; normaliser toolbox/losses.py:27-34), and every step must issue
 exactly ONE collective.
@@ -88,29 +89,37 @@ def test_one_collective_per_step(tmp_path):
     tmp = str(tmp_path)
     _launch(2, os.path.join(tmp, 'count'), tmp)
     two = torch.load(os.path.join(tmp, 'count.pt'))
+    assert two['backend'] == ('nccl' if torch.cuda.device_count() >= 2 else 'gloo')
     for mode in ('eager', 'capture', 'ragged', 'padded'):
         per_step = two[mode + '_collectives']
         assert len(per_step) == 3
+        if mode == 'capture' and two['capture_in_graph']:
+            # RCCL: the collective was recorded into the step's graph -- ONE call while capturing, none from the host after
+            assert per_step == [['all_reduce'], [], []], per_step
+            continue
         for calls in per_step:
             assert calls == ['all_reduce'], (mode, per_step)
 
 
 def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` without a launcher: the parent (which never touches the GPU) starts two rank processes,
-    relays rank 0's JSON line and exits 0.  gloo backend: both ranks share cuda:0 on a one-GPU box; with the default backend
-    (nccl = RCCL) the same command is the 1/2/4/8-GPU scaling run."""
+    relays rank 0's JSON line and exits 0.  On a node with two GPUs this IS the 2-GPU scaling run (default backend nccl =
+    RCCL, the all-reduce inside the replayed graph); on a one-GPU box both ranks share cuda:0 over gloo."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '3', '--warmup', '1',
-                        '--windows', '2', '--settle', '4', '--no-cpu-baseline', '--profile-steps', '0'], env=env, capture_output=True, text=True,
-                       timeout=900)
+    multi = torch.cuda.device_count() >= 2          # (device_count does not initialise the GPU)
+    backend = 'nccl' if multi else 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--windows', '2',
+                        '--settle', '4', '--no-cpu-baseline', '--profile-steps', '0'] + ([] if multi else ['--backend', 'gloo']),
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == 'gloo'
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['backend'] == backend
+    assert out['config']['allreduce_in_graph'] == multi
     assert out['config']['global_batch'] == 64 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
     assert out['allreduce_ms'] is not None and out['allreduce_ms'] > 0
     assert out['value'] > 0 and abs(out['value'] - 64 / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
@@ -140,3 +149,46 @@ def test_rccl_all_reduce_on_the_gradient_buffer(tmp_path):
         env.pop(k, None)
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'RCCL_OK backend=nccl' in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_rccl_all_reduce_inside_the_captured_step(tmp_path):
+    """The RCCL all-reduce recorded INTO the trainer's HIP graph (model work -> all-reduce -> fused Adam = one replay), with the
+    one rank a one-GPU box can host (collective='always' issues the collective although there is nothing to sum): three
+    replayed steps must leave bit-identical parameters to the trainer without a collective, the host must have issued the
+    collective exactly once (while capturing), and replays must not call into torch.distributed at all."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from graph_neural_net_amd import dp, synthetic\n"
+        "from graph_neural_net_amd.engine import ParamLayout\n"
+        "from graph_neural_net_amd.trainer import FgnnTrainer\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1)\n"
+        "calls = []\n"
+        "orig = dist.all_reduce\n"
+        "dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]\n"
+        "dev = torch.device('cuda:0')\n"
+        "lay = ParamLayout(2, 2, 32, 32, 3)\n"
+        "p0 = lay.init_flat(11, dev)\n"
+        "batches = [synthetic.make_batch(7100 + s, 4, 18, 'ErdosRenyi', 0.3, 0.05) for s in range(3)]\n"
+        "out = []\n"
+        "for coll in ('auto', 'always'):\n"
+        "    tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, capture=True, collective=coll)\n"
+        "    n0 = len(calls); per = []; losses = []\n"
+        "    for x1, x2 in batches:\n"
+        "        m0 = len(calls)\n"
+        "        loss, _ = tr.train_step(x1.to(dev), x2.to(dev))\n"
+        "        losses.append(loss.item()); per.append(len(calls) - m0)\n"
+        "    torch.cuda.synchronize()\n"
+        "    out.append((tr.params.clone(), losses, per, tr.allreduce_in_graph))\n"
+        "(pa, la, ca, ga), (pb, lb, cb, gb) = out\n"
+        "assert not ga and ca == [0, 0, 0], (ga, ca)\n"
+        "assert gb and cb == [1, 0, 0], (gb, cb)\n"
+        "assert torch.equal(pa, pb) and la == lb, (la, lb)\n"
+        "print('RCCL_IN_GRAPH_OK')\n"
+        "dist.destroy_process_group()\n") % (ROOT,)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_IN_GRAPH_OK' in r.stdout, (r.stdout + r.stderr)[-3000:]

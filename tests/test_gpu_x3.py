@@ -125,3 +125,32 @@ def test_dual_chains_equal_the_single_engine(mode):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(grads, eager)
+
+
+def test_dual_chains_on_a_ragged_batch_equal_the_single_engine():
+    """with tile ranges the MLP kernels ignore cu_share and run the full grid, so a ragged chain writes 256 rows
+    of weight-gradient partials -- the dual engine must size and reduce them as such.  Scores bit-identical to the single
+    ragged engine, gradients equal up to the association of the partial sums, reproducible run to run."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    xs, ys = synthetic.make_ragged_batch(5100, 6, 20, 70)
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    nvd = torch.cat([nv, nv]).to(DEV)
+    out = []
+    for cls in (FgnnEngine, FgnnEngineDual, FgnnEngineDual):
+        eng = cls(lay, x.shape[0], x.shape[-1], DEV, ragged=True)
+        grads = torch.zeros_like(params)
+        scores, loss = eng.step(params, grads, x, nvalid=nvd)
+        torch.cuda.synchronize()
+        out.append((scores.cpu().clone(), loss.item(), lay.unflatten(grads.cpu().clone())))
+    (s1, l1, g1), (s2, l2, g2), (s3, l3, g3) = out
+    assert torch.equal(s1, s2) and torch.equal(s2, s3)
+    assert abs(l1 - l2) <= 1e-6 * abs(l1) and l2 == l3
+    for k in g1:
+        assert torch.isfinite(g2[k]).all(), k
+        assert torch.equal(g2[k], g3[k]), k
+        if not is_zero_grad(k):
+            assert rel(g2[k], g1[k]) < 1e-5, (k, rel(g2[k], g1[k]))

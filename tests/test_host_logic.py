@@ -166,13 +166,28 @@ def test_bucket_by_size_partitions_and_orders():
     assert sorted(i for _, idx in b for i in idx) == list(range(len(sizes)))
 
 
-def test_metrics_have_no_cpu_path():
-    """both matching accuracies run on the device only (csrc/pool_score.hip, csrc/lsap.hip): CPU scores are refused, loudly"""
+def test_metrics_on_host_scores_take_the_reference_route():
+    """Scores that live on the host (saved scores, evaluation scripts) are handled the reference's way -- per-graph SciPy
+    assignment / arg-max (toolbox/metrics.py:92-141) -- dense and MaskedTensor; scores on the GPU never take this route
+    (tests/test_gpu_lsap.py: the device kernel, and a missing library raises)."""
+    from scipy.optimize import linear_sum_assignment
+    from graph_neural_net_amd.masked import from_list
     from graph_neural_net_amd.metrics import accuracy_linear_assignment, accuracy_max
-    s = torch.randn(2, 5, 5)
-    for fn in (accuracy_linear_assignment, accuracy_max):
-        with pytest.raises(RuntimeError, match='no CPU path'):
-            fn(s)
+    g = torch.Generator().manual_seed(4)
+    s = torch.randn(3, 7, 7, generator=g)
+    want = 0
+    for b in range(3):
+        r, c = linear_sum_assignment((-torch.log_softmax(s[b], -1)).numpy())
+        want += int((r == c).sum())
+    assert accuracy_linear_assignment(s) == (want, 21)
+    assert accuracy_max(s) == (int((s.argmax(-1) == torch.arange(7)).sum()), 21)
+    lst = [torch.randn(n, n, generator=g) for n in (4, 6)]
+    mt = from_list(lst, dims=(0, 1))
+    per = accuracy_linear_assignment(mt, aggregate_score=False)
+    for t, a in zip(lst, per):
+        r, c = linear_sum_assignment((-torch.log_softmax(t, -1)).numpy())
+        assert a == int((r == c).sum()) / t.shape[0]
+    assert accuracy_max(mt) == (sum(int((t.argmax(-1) == torch.arange(t.shape[0])).sum()) for t in lst), 10)
 
 
 def test_bench_algorithmic_model_matches_survey_figures():
