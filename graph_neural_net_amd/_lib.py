@@ -169,6 +169,7 @@ _SIGNATURES = {
     'fgnn_mlp_bwd_x3': [C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_pair': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_pair_supported': [_I, _I],
+    'fgnn_mlp_bwd_pair_x3': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],

@@ -141,3 +141,63 @@ DEVI f32x16 gemm_x3_rr(f32x16 acc, const X3 &a, const X3 &b) {
     }
     return acc;
 }
+
+// Transposed operand of a weight-gradient GEMM (contraction over the tile's 32 pixels) WITHOUT LDS: each bf16 part of a
+// normal-form operand (lane = pixel, slots = channels) goes through the matrix pipe against -I (two MFMAs, exact: every
+// product is x * -1 or x * 0), the fp32 result (lane = channel, register r <-> pixel ch_of(r, h)) is re-packed (exact: the
+// values are bf16 numbers).  The result is the NEGATED transposed operand; a GEMM of two such operands is the product of the
+// un-negated ones.  WITH_SUM: nsum += (-1) x the sum of the lane's 16 pixels over the three parts = the lane's share of a
+// bias gradient (rows of the operand summed over the pixels), in a fixed order.
+template <bool WITH_SUM>
+DEVI void transpose_x3(X3 &t, const X3 &x, const F16 &negI, float &nsum) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ts = 0.f;                                        // this tile's sum: parts smallest first, then into the running sum
+#pragma unroll
+    for (int q = 2; q >= 0; --q) {
+        f32x16 a = mfma16(step_of(x.p[q], 0), step_of(negI, 0), zero);
+        a = mfma16(step_of(x.p[q], 1), step_of(negI, 1), a);
+        if constexpr (WITH_SUM) {
+            const float s0 = (a[0] + a[1]) + (a[2] + a[3]), s1 = (a[4] + a[5]) + (a[6] + a[7]);
+            const float s2 = (a[8] + a[9]) + (a[10] + a[11]), s3 = (a[12] + a[13]) + (a[14] + a[15]);
+            ts += (s0 + s1) + (s2 + s3);
+        }
+        pack_acc(t.p[q], a);
+    }
+    if constexpr (WITH_SUM) nsum += ts;
+}
+
+// Weight-gradient GEMM with the second operand streamed: acc += A (x) B over the tile's pixels, A = an already transposed
+// operand (three parts), B = the fp32 values v in normal form (lane = pixel, slots = channels).  Part q of B is split off, sent
+// through the matrix-pipe transposer and consumed by its products at once (b0: a2 b0, a1 b0, a0 b0; b1: a1 b1, a0 b1; b2: a0 b2
+// -- the six products of weight >= 2^-16), so beside A only ONE 8-register part of B exists at a time, in either form.
+DEVI f32x16 wgrad_stream_x3(f32x16 acc, const X3 &a, const f32x16 &v, const F16 &negI) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 r = v;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        F16 p;
+        pack_acc(p, r);
+        if (q < 2) {                                        // residual for the next part: r - p, exact
+            r = mfma16(step_of(negI, 0), step_of(p, 0), r);
+            r = mfma16(step_of(negI, 1), step_of(p, 1), r);
+        }
+        f32x16 t = mfma16(step_of(p, 0), step_of(negI, 0), zero);
+        t = mfma16(step_of(p, 1), step_of(negI, 1), t);
+        F16 b;
+        pack_acc(b, t);                                     // (negated, like A: the product of the two is not)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const i32x4 bs = step_of(b, s);
+            if (q == 0) acc = mfma16(step_of(a.p[2], s), bs, acc);
+            if (q <= 1) acc = mfma16(step_of(a.p[1], s), bs, acc);
+            acc = mfma16(step_of(a.p[0], s), bs, acc);
+        }
+    }
+    return acc;
+}
+DEVI f32x16 wgrad_stream_x3(f32x16 acc, const X3 &a, const float (&v)[16], const F16 &negI) {
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = v[r];
+    return wgrad_stream_x3(acc, a, x, negI);
+}

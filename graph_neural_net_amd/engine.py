@@ -453,12 +453,13 @@ class FgnnEngine:
                                                 (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 
     def _mlp_bwd_pair(self, params, k, sin, din, emit):
-        """mlp1 + mlp2 of block k in ONE launch (csrc/mlp_bwd_pair.hip): the two waves of a SIMD take one MLP each and sum the
-        gradient of the shared input in LDS; d_in is bit-identical to the two accumulating launches it replaces."""
+        """mlp1 + mlp2 of block k in ONE launch (csrc/mlp_bwd_pair.hip; with mfma='x3' csrc/mlp_bwd_pair_x3.hip): the two waves of a
+        SIMD take one MLP each and sum the gradient of the shared input in LDS; d_in is bit-identical to the two accumulating
+        launches it replaces."""
         W = self._bwd
         a1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], None, None, None, False, False, False, None)
         a2 = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit, None)
-        _lib.call('fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
+        _lib.call('fgnn_mlp_bwd_pair_x3' if self.x3 else 'fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
                   tag='mlp_bwd_pair[cin=%d,dx=%d]' % (sin.C, sin.C if din is not None else 0))
 
     def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides):
@@ -560,7 +561,7 @@ class FgnnEngine:
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
                       _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_bwd')
-            if self.PAIR_BWD and not self.x3 and dxs is None and L.depth == 3 and sin.C in (2, 32):
+            if self.PAIR_BWD and dxs is None and L.depth == 3 and sin.C in (2, 32):
                 self._mlp_bwd_pair(params, k, sin, din, emit=not first)
             else:
                 self._mlp_bwd(params, k, 1, sin, None, W['dy1'], None, din, None, True, False, dx_strides=dxs)

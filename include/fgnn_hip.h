@@ -343,6 +343,11 @@ int fgnn_mlp_bwd_x3(const fgnn_mlp_bwd_args *args, void *stream);   /* the x3 fo
  * the two accumulating launches.  Depth 3, one slab of 2 or 32 channels, constant-size batches, both operand images. */
 int fgnn_mlp_bwd_pair_supported(int ca, int depth);
 int fgnn_mlp_bwd_pair(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
+/* The same launch with every contraction on the bf16 matrix cores through the exact three-way operand split (the arithmetic of
+ * fgnn_mlp_bwd_x3 / fgnn_mlp_fwd_x3: the recompute reproduces the x3 forward bit for bit): both images are of kind 1 from
+ * fgnn_pack_x3_operands; the weight-gradient operands are transposed on the matrix pipe instead of through LDS tiles
+ * (csrc/mlp_bwd_pair_x3.hip).  d_in is bit-identical to two accumulating fgnn_mlp_bwd_x3 launches.  No `ranges`. */
+int fgnn_mlp_bwd_pair_x3(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
 int fgnn_mlp_bwd_coef_tiles_supported(int G, int N);   /* s12tiles usable: a workgroup spans <= FGNN_BWD_COEF_GRAPHS graphs */
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:

@@ -154,3 +154,34 @@ def test_dual_chains_on_a_ragged_batch_equal_the_single_engine():
         assert torch.equal(g2[k], g3[k]), k
         if not is_zero_grad(k):
             assert rel(g2[k], g1[k]) < 1e-5, (k, rel(g2[k], g1[k]))
+
+
+@pytest.mark.parametrize('B,N,bits', [(3, 33, False), (4, 50, True), (4, 50, False), (2, 64, False), (16, 50, False)])
+def test_x3_pair_backward_equals_the_two_x3_launches_it_replaces(B, N, bits):
+    """fgnn_mlp_bwd_pair_x3 (mlp1 + mlp2 of a block in one launch on the bf16 matrix cores, weight-gradient operands transposed
+    on the matrix pipe): the block-input gradient slabs are bit-identical to those of the two accumulating fgnn_mlp_bwd_x3
+    launches -- same split, same partial products, (d_in3 + dx1) + dx2 in both -- and every parameter gradient agrees up to the
+    association of the per-wave partial sums (the transposed operands are the same bf16 parts either way: exact)."""
+    import numpy as np
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x1, x2 = synthetic.make_batch(600 + N, B, N, 'ErdosRenyi', 0.3, 0.1)
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    packed = torch.from_numpy(synthetic.pack_adjacency(torch.cat([x1, x2])[:, 0].numpy()).astype('int32')).to(DEV) if bits else None
+    out = []
+    for pair in (False, True):
+        eng = FgnnEngine(lay, 2 * B, N, DEV, mfma='x3')
+        eng.PAIR_BWD = pair
+        g = torch.zeros_like(params)
+        sc, loss = eng.step(params, g, None if bits else x, bits=packed)
+        torch.cuda.synchronize()
+        out.append((sc.clone(), loss.clone(), g.clone(), eng.unpadded(eng._bwd['dy'][0]), eng.unpadded(eng._bwd['dy'][1])))
+        g2 = torch.zeros_like(params)
+        eng.step(params, g2, None if bits else x, bits=packed)
+        torch.cuda.synchronize()
+        assert torch.equal(g, g2)                                    # run-to-run bit-reproducible
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6, ((a[2] - b[2]).norm() / a[2].norm()).item()
