@@ -557,8 +557,8 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
                        'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'allreduce_in_graph': bool(ar_in_graph), 'path': path, 'settle_steps': args.settle,
                        'chains': 2 if dual else 1,
                        'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
-                                           ('mlp1 / mlp2: 3 x bf16 split operands (8 / 6 partial products, fp32 accumulation) on '
-                                            'v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)
+                                           ('mlp1 / mlp2 (forward, and the pair backward fgnn_mlp_bwd_pair_x3): 3 x bf16 split operands (8 / 6 partial '
+                                            'products, fp32 accumulation) on v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)
                                             else 'v_mfma_f32_32x32x2_f32')),
                        'grad_allreduce': ('%s sum of %d fp32 per step' % (torch.distributed.get_backend(), layout.total)) if world > 1 else 'none'},
             'ranks_seen': dp.world_size(), 'backend': torch.distributed.get_backend() if world > 1 else None, 'allreduce_ms': allreduce_ms,

@@ -22,6 +22,18 @@
 
 namespace {
 
+#ifdef FGNN_PHASES
+// Debug build only (make phases): per-wave cycle stamps of the tile phases, summed over the wave's tiles (tools/gpu_phases_px3.py)
+__device__ unsigned long long *g_px3_phase_buf = nullptr;
+#define PH_DECL unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = __builtin_amdgcn_s_memtime();
+#define PH(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_last_; ph_last_ = t_; }
+#define PH_FLUSH if (g_px3_phase_buf && CA == 32 && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; ++k_) g_px3_phase_buf[((long long)blockIdx.x * NW + wv) * 16 + k_] = ph_[k_]; }
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_FLUSH
+#endif
+
 constexpr int BWD_WG = 256;          // persistent workgroups (one per CU) = rows of each wpart
 constexpr int NW = 8;                // waves per workgroup: 4 pairs
 constexpr int NP = 4;
@@ -98,7 +110,7 @@ DEVI void load_rows16_to_lds(float *dst, const View &v, int voff, int g) {
     const int s0 = g * v.gs4;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v.r, (__attribute__((address_space(3))) void *)(unsigned)(unsigned long long)(dst + r * 64), 4,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v.r, (__attribute__((address_space(3))) void *)(unsigned long long)(unsigned)(unsigned long long)(dst + r * 64), 4,
                                                  voff, s0 + ((r & 3) + 8 * (r >> 2)) * v.ld4, 0, 0);
 }
 
@@ -153,6 +165,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
     const bool emit = (CA == 32) && role == 1 && normA && has_dx && P.m[1].s12part != nullptr;
     const bool rmw = has_dx && P.m[1].accumulate_a;
 
+    PH_DECL
     // Prologue = ONE memory round trip: both operand images (into registers), the first tile, the per-graph records
     // (the two images are separate buffers: see mlp_bwd_pair.hip)
     constexpr int N4 = L::WEIGHT_F / 4, N4PAD = (N4 + 63) & ~63, IMG_PER = (N4PAD + N4 + 64 * NW - 1) / (64 * NW);
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
 
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const F16 negI = make_neg_identity(lane);
+    PH(9)
     int tnext = 0, prev_tile = -1;
     for (int tile = first; tile < T1; tile = tnext) {
         tnext = tile + NP;
@@ -244,6 +258,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
             }
         }
 
+        PH(0)               // records, consumed-wait, LDS-direct request
         // ---- forward recompute of the hidden activations: the arithmetic of mlp_fwd_x3.hip ----
         f32x16 acc;
         load_bias16(acc, wl + L::BIAS_F, 0, h);
@@ -254,6 +269,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
             split_slab<SA>(X, ya, h, negI);
             acc = gemm_x3<L::STEPS_A, X3_FWD_TERMS>(acc, wl, L::PD, L::OFF_W0A, X, lane);
         }
+        PH(1)               // x arrival, normalise, split, layer-0 products issued
         // this tile's dy / z fly behind the recompute
         load_rows16_at(dyr, vdy, voff16, c.g);
         load_rows16_at(zr, vz, voff16, c.g);
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
         for (int r = 0; r < 16; ++r) h2[r] = relu1(acc[r]);
         __builtin_amdgcn_sched_barrier(0);
 
+        PH(2)               // h1, h2
         // ---- dz from (dy, z, coef) ----
         float dpre[16];
         {
@@ -282,6 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
                 dpre[r] = (k.y * dyr[r] + k.z * (zr[r] - k.x) + k.w) * vf;
             }
         }
+        PH(3)               // dz (waits for dy, z)
         // ---- layer 2: dgrad W_2^T dz, mask with h2, weight gradient dz (x) h2 from the matrix-pipe transposes ----
         // (the order below keeps at most three 24-register operands alive at a time; the barriers pin it)
         {
@@ -297,6 +315,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
             wgrad_parked(PARK + 1024, TD, h2, negI, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        PH(4)
         // ---- layer 1 ----
         {
             X3 D;
@@ -311,6 +330,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
             wgrad_parked(PARK, TD, h1, negI, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
+        PH(5)
         // ---- layer 0: input gradient first (hand-over / store / emission), then the weight gradient ----
         {
             X3 D;
@@ -321,6 +341,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
                 const TileCtx cn = decode_tile(tnext, tnext < T1, tpg, A.N, P2, j);
                 load_slab<SA, PK>(nxa, va, ps, cn, h);
             }
+            PH(6)           // split D0, next slab requested
             if constexpr (CA == 32) {
                 if (has_dx) {
                     const f32x16 dx = gemm_x3<2, X3_BWD_TERMS>(zero, wl, L::PD, L::OFF_WT0A, D, lane);
@@ -384,6 +405,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            PH(7)           // dx products, hand-over (flag waits), store, emission
             X3 TD;
             transpose_x3<true>(TD, D, negI, ndb[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
             for (int s_ = 0; s_ < (SA > 0 ? SA : 1); ++s_) xa[s_] = nxa[s_];
         }
         prev_tile = tile;
+        PH(8)               // layer-0 weight gradient
     }
 
     // ---- workgroup reduction: each MLP's partial = fixed-order sum of its four waves ----
@@ -424,7 +447,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
         dWh[0][r] = PARK[r * 64 + lane];
         dWh[1][r] = PARK[1024 + r * 64 + lane];
     }
+    PH(12)
     __syncthreads();                       // everyone done with the operand images, the pair slots and the parked accumulators
+    PH(10)
     {
         float *red = smem + wv * PCOUNT;
 #pragma unroll
@@ -460,6 +485,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
         }
         reinterpret_cast<float4 *>(P.m[m].wpart + (long long)blockIdx.x * PCOUNT)[ee] = a;
     }
+    PH(11)
+    PH_FLUSH
 }
 
 template <int CA, bool PK>
@@ -477,6 +504,12 @@ int launch_pair_x3(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int
 }
 
 }  // namespace
+
+#ifdef FGNN_PHASES
+extern "C" int fgnn_debug_phase_buffer_px3(void *p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_px3_phase_buf), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int fgnn_mlp_bwd_pair_x3(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, void *stream) {
     FGNN_CHECK(a1 && a2, "fgnn_mlp_bwd_pair_x3: null args");
