@@ -259,6 +259,12 @@ def parse_args():
     ap.add_argument('--mfma', default=None, choices=('f32', 'x3'),
                     help="contraction of the fp32 MLP kernels: 'f32' (default) = v_mfma_f32_32x32x2_f32, 'x3' = bf16 matrix cores "
                          'through the exact three-way operand split (csrc/fgnn_x3.h)')
+    ap.add_argument('--input', default=None, choices=('dense', 'bits'),
+                    help="how the batch is handed to the engine: 'dense' = the (2B, 2, N, N) fp32 tensor representation, 'bits' = the "
+                         'bit-packed adjacency (block 1 expands it itself: SURVEY 8 row f3).  Default: bits with --block1 structured, else dense')
+    ap.add_argument('--block1', default=None, choices=('generic', 'structured'),
+                    help="block 1 on bit-packed inputs: 'structured' = csrc/block1_struct.hip (class tables + closed-form per-channel "
+                         "product; constant-size batches, N <= 64, fp32 engine), 'generic' = the kernels every block uses")
     ap.add_argument('--settle', type=int, default=64, help='untimed replays before the warm-up steps (clock / TLB settling)')
     ap.add_argument('--windows', type=int, default=5,
                     help='the K-step timed window is repeated this many times; ms_per_step / value are the MEDIAN window, '
@@ -285,6 +291,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     out = run_config(args, args.config, rank, world, dev, cpu_leg=(world == 1 and not args.no_cpu_baseline))
+    if rank == 0 and world == 1 and out['config'].get('block1', 'generic') != 'generic' and not args.no_extra_configs:
+        # the same step on the DENSE tensor representation through the generic block-1 kernels, reported beside the headline
+        sub = run_config(args, args.config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), block1='generic', input_form='dense')
+        out['dense_input'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'],
+                              'ms_per_step_min': sub['ms_per_step_min'], 'ms_per_step_max': sub['ms_per_step_max'],
+                              'input': sub['config']['input'], 'block1': sub['config']['block1'],
+                              'roofline': {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')
+                                           if sub['roofline'] and k in sub['roofline']}}
     if rank == 0 and world == 1 and args.config == 'cfg2' and args.precision is None and args.path == 'engine' \
             and not args.no_extra_configs and args.batch is None and args.n is None:
         # BASELINE configs 4 and 5 (per-GPU shard) under the same K / W protocol, outside the headline's timed region
@@ -306,9 +320,10 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
+def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=None, input_form=None):
     """One measurement: build the workload of `config`, capture the step, settle, warm up, time `windows` windows of
-    exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0)."""
+    exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0).
+    block1 / input_form: override --block1 / --input (the dense-input line reported beside the headline)."""
     windows = args.windows if windows is None else windows
     precision = args.precision if config == args.config else None
     dense_er = config == 'cfg4'                   # the workload
@@ -346,15 +361,30 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
             from graph_neural_net_amd.engine_dual import FgnnEngineDual
             eng = FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
         else:
-            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
+            # The headline line (cfg2, fp32 engine) hands the batch over as bit-packed adjacency and runs block 1 on its structured
+            # form unless told otherwise; `dense_input` in the JSON is the same step on the dense tensor through the generic kernels
+            b1 = block1 if block1 is not None else (args.block1 if same else None)
+            if b1 is None:
+                b1 = 'structured' if (config == 'cfg2' and same and args.input != 'dense' and path == 'engine') else 'generic'
+            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma, block1=b1)
     x = torch.cat([x1, x2]).contiguous().to(dev)
+    struct1 = bool(getattr(eng, 'struct1', False))
+    want = input_form if input_form is not None else (args.input if same else None)
+    use_bits = (not bf16 and path == 'engine' and not hasattr(eng, 'stage_inputs') and ((want == 'bits') if want is not None else struct1))
+    xbits = None
+    if use_bits:     # the same batch as 32-bit words of adjacency rows (synthetic.pack_adjacency), resident in HBM like x
+        import numpy as np
+        xbits = torch.from_numpy(synthetic.pack_adjacency(torch.cat([x1, x2])[:, 0].numpy()).view(np.int32)).to(dev)
     dual = hasattr(eng, 'stage_inputs')
     if dual:
         eng.stage_inputs(x, nvalid)        # loader work, like the cat above: the chains' input buffers are resident before the timed region
     total_nodes = float((sum(sizes) if ragged else B * N) * world)      # loss normaliser of the concatenated global batch
 
     def model_work():
-        eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
+        if xbits is not None:
+            eng.step(params, grads, None, nvalid=nvalid, total_nodes=total_nodes, bits=xbits)
+        else:
+            eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
 
     model = None
     if path == 'module':
@@ -556,6 +586,9 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None):
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
                        'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'allreduce_in_graph': bool(ar_in_graph), 'path': path, 'settle_steps': args.settle,
                        'chains': 2 if dual else 1,
+                       'input': 'bit-packed adjacency (N x ceil(N/32) words per graph)' if xbits is not None else 'dense (2, N, N) fp32 tensor representation',
+                       'block1': ('structured: class tables + closed-form per-channel product (csrc/block1_struct.hip)'
+                                  if (struct1 and xbits is not None) else 'generic'),
                        'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
                                            ('mlp1 / mlp2 (forward, and the pair backward fgnn_mlp_bwd_pair_x3): 3 x bf16 split operands (8 / 6 partial '
                                             'products, fp32 accumulation) on v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)

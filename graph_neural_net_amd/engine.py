@@ -163,7 +163,12 @@ class FgnnEngine:
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
 
-    def __init__(self, layout, G, N, device, ragged=False, cu_share=0, mfma=None):
+    # block 1 on bit-packed inputs: 'generic' = the MLP / per-channel-product kernels every block uses (bit-identical to the
+    # dense-input step); 'structured' = csrc/block1_struct.hip (class tables, closed-form product, class sums in the backward:
+    # same function, results equal to fp32 rounding).  FGNN_BLOCK1 overrides the default.
+    BLOCK1 = os.environ.get('FGNN_BLOCK1', 'generic')
+
+    def __init__(self, layout, G, N, device, ragged=False, cu_share=0, mfma=None, block1=None):
         """cu_share=2: the persistent MLP kernels take half of the CUs (fgnn_mlp_fwd_args.cu_share), for engines that run
         next to another one on a second stream (FgnnEngineDual).  Ragged engines with tile ranges ignore it (full grid).
         mfma: 'f32' = v_mfma_f32_32x32x2_f32 (exact fp32 fma chain); 'x3' = the bf16 matrix cores through the exact
@@ -175,6 +180,14 @@ class FgnnEngine:
         if mfma not in ('f32', 'x3'):
             raise ValueError("mfma must be 'f32' or 'x3' (got %r)" % (mfma,))
         self.x3 = (mfma == 'x3' and not ragged and layout.depth == 3 and layout.c0 in (2, 32))
+        block1 = self.BLOCK1 if block1 is None else block1
+        if block1 not in ('generic', 'structured'):
+            raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
+        # the structured block 1 applies to bit-packed inputs of constant-size batches (embed(bits=...)); anything else runs generic
+        self.struct1 = (block1 == 'structured' and not ragged and cu_share == 0
+                        and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0))
+                        and G <= _lib.load().fgnn_mlp_bwd_num_workgroups())
+        self._struct = None
         self.layout = layout
         self.G, self.N = G, N
         self.P = N * N
@@ -349,7 +362,8 @@ class FgnnEngine:
             if self.xdeg is None:
                 self.xdeg = torch.empty(self.G * self.N, dtype=torch.float32, device=self.device)
             self.x, self.xbits = None, bits
-            _lib.call('fgnn_adjacency_degree', _lib.ptr(bits), self._nv(), self.G, self.N, _lib.ptr(self.xdeg), st)
+            if not self.struct1:        # (the structured block 1 writes the row sums itself: one launch less)
+                _lib.call('fgnn_adjacency_degree', _lib.ptr(bits), self._nv(), self.G, self.N, _lib.ptr(self.xdeg), st)
         else:
             if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
                 raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
@@ -359,6 +373,11 @@ class FgnnEngine:
             self.pack_operands(params)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
+            if k == 1 and self.struct1 and self.xbits is not None:
+                self._struct_fwd(params)
+                pool_fin = L.num_blocks == 1 and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
+                self._mlp_fwd(params, 1, (3,), self._slab_raw(self.mult[1]), sin, finalize=not pool_fin)
+                continue
             # finalize-in-prologue lengthens every matmul workgroup by ~2 us: it beats the separate finalize launch
             # (~6 us) only while the matmul runs a few workgroup rounds (measured cross-over: B ~ 64-128 pairs at N = 50)
             fin = bool(_lib.load().fgnn_chan_matmul_fwd_fin_supported(self.N)) and self.G * 32 <= 4096
@@ -386,6 +405,49 @@ class FgnnEngine:
         else:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
+
+    # ------------------------------------------------------------------ block 1 on its structured input (csrc/block1_struct.hip)
+    def _struct_ws(self):
+        if self._struct is None:
+            lib = _lib.load()
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._struct = {'tab': torch.empty(lib.fgnn_block1_struct_table_floats(self.N), **f32),
+                            'csum': torch.empty(lib.fgnn_block1_struct_csum_floats(self.G), **f32)}
+        return self._struct
+
+    def _w3(self, params, j):
+        rec = self.layout.mlp[(1, j)]
+        return ((C.c_void_p * 3)(*[self._w(params, o) for o in rec['w']]), (C.c_void_p * 3)(*[self._w(params, o) for o in rec['b']]))
+
+    def _struct_fwd(self, params):
+        """mlp1 + mlp2 + mult of block 1 from the class tables: two small launches instead of fgnn_mlp_fwd + fgnn_chan_matmul_fwd."""
+        S = self._struct_ws()
+        st = _lib.stream_ptr()
+        (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
+        r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
+        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, _lib.ptr(S['tab']), st)
+        _lib.call('fgnn_block1_struct_fwd', _lib.ptr(self.xbits), self.G, self.N, _lib.ptr(S['tab']),
+                  C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
+                  C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
+                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
+                  _lib.ptr(self.xdeg), st)
+
+    def _struct_bwd(self, params):
+        """... and in the backward direction: class sums of d(mult), then the per-class GraphNorm / conv backward, instead of
+        fgnn_chan_matmul_bwd + fgnn_mlp_bwd_pair.  Leaves wpart / s12 of mlp1 and mlp2 for fgnn_grad_finalize."""
+        S, W = self._struct_ws(), self._bwd
+        if not W.get('struct_rows_clean', True):        # a dense-input step on this engine has filled all rows in between
+            W['wpart'][(1, 1)].zero_()
+            W['wpart'][(1, 2)].zero_()
+        W['struct_rows_clean'] = True
+        (w1, _), (w2, _) = self._w3(params, 1), self._w3(params, 2)
+        r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
+        _lib.call('fgnn_block1_struct_bwd', _lib.ptr(self.xbits), self.G, self.N, _lib.ptr(S['tab']), w1, w2,
+                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]),
+                  C.c_void_p(self._w(params, r1['gn_b'])), C.c_void_p(self._w(params, r2['gn_b'])),
+                  _lib.ptr(W['dmult']), 32 * self.ldp, self.ldp, _lib.ptr(S['csum']),
+                  _lib.ptr(W['wpart'][(1, 1)]), _lib.ptr(W['wpart'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
+                  _lib.stream_ptr())
 
     def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None, pack=True):
         """Siamese forward on the stacked batch x = cat(x1, x2) (or its bit-packed adjacency, see embed): returns
@@ -428,7 +490,9 @@ class FgnnEngine:
             # per-MLP GraphNorm-backward sums and workgroup partials live until the final
             # fgnn_grad_finalize launch
             's12': {kj: torch.empty(self.G * 32 * 2, **f32) for kj in keys},
-            'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32) for kj in keys},
+            # (the structured block 1 writes one row per graph: the other rows of its two buffers stay zero)
+            'wpart': {kj: (torch.zeros if (self.struct1 and kj in ((1, 1), (1, 2))) else torch.empty)(nwg * L.mlp[kj]['count'], **f32)
+                      for kj in keys},
             's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
             'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
             'nwg': nwg,
@@ -556,11 +620,17 @@ class FgnnEngine:
             # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
                           None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False, dx_strides=dxs)
+            if first and self.struct1 and self.xbits is not None and dxs is None:
+                self._struct_bwd(params)
+                dy = din
+                continue
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
                       _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_bwd')
+            if first and self.struct1:
+                W['struct_rows_clean'] = False
             if self.PAIR_BWD and dxs is None and L.depth == 3 and sin.C in (2, 32):
                 self._mlp_bwd_pair(params, k, sin, din, emit=not first)
             else:

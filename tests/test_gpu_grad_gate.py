@@ -17,7 +17,11 @@ E2E_FWD_TOL = 3e-5
 
 
 def run_cases(mode, groups=None, pair_bwd=None):
-    """-> (err, terr, score_err) dicts per group for the engine variant `mode`."""
+    """-> (err, terr, score_err) dicts per group for the engine variant `mode`: 'f32' / 'x3' = the contraction of the MLP kernels
+    on dense inputs; a trailing 's' ('f32s', 'x3s') = bit-packed inputs with block 1 on its structured form
+    (csrc/block1_struct.hip; N <= 64, larger cases run the generic block 1)."""
+    struct = mode.endswith('s')
+    mfma = mode[:-1] if struct else mode
     groups = GG.load_groups() if groups is None else groups
     sds = {'A': sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/'),
            'B': {k: torch.from_numpy(v) for k, v in groups['B']['sd'].items()}}
@@ -38,12 +42,16 @@ def run_cases(mode, groups=None, pair_bwd=None):
             x1 = unpack_pairs(torch.from_numpy(g['bits'][i, 0:1, :n, :w].copy()), n)
             x2 = unpack_pairs(torch.from_numpy(g['bits'][i, 1:2, :n, :w].copy()), n)
             if n not in engines:
-                engines[n] = FgnnEngine(lay, 2, n, DEV, mfma=mode)
+                engines[n] = FgnnEngine(lay, 2, n, DEV, mfma=mfma, block1='structured' if struct else 'generic')
                 if pair_bwd is not None:
                     engines[n].PAIR_BWD = pair_bwd
             eng = engines[n]
             grads = torch.zeros_like(params)
-            scores, loss = eng.step(params, grads, torch.cat([x1, x2]).contiguous().to(DEV))
+            if struct:
+                packed = torch.from_numpy(np.ascontiguousarray(g['bits'][i, :, :n, :w]).view(np.int32)).to(DEV)
+                scores, loss = eng.step(params, grads, None, bits=packed)
+            else:
+                scores, loss = eng.step(params, grads, torch.cat([x1, x2]).contiguous().to(DEV))
             torch.cuda.synchronize()
             got = grads.cpu().double()
             ref = torch.from_numpy(g['g64'][i]).double()
@@ -68,7 +76,7 @@ def run_cases(mode, groups=None, pair_bwd=None):
     return err, terr, serr
 
 
-@pytest.mark.parametrize('mode', ['f32', 'x3'])
+@pytest.mark.parametrize('mode', ['f32', 'x3', 'f32s', 'x3s'])
 def test_gradient_gate(mode):
     groups = GG.load_groups()
     err, terr, serr = run_cases(mode, groups)
