@@ -229,6 +229,14 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits
     const int g = pl / FGNN_H, c = pl - g * FGNN_H;
     GraphBits &B = B4[wv];
     float *T = plane[wv];
+    // ONE memory round trip: the plane (lane = column), the two GraphNorm records and the bit rows are requested together
+    const float *src = dm + (long long)g * gstride + (long long)c * ldp;
+    float v[SB_MAXN];
+#pragma unroll
+    for (int i = 0; i < SB_MAXN; ++i) v[i] = (lane < N && i < N) ? src[i * N + lane] : 0.f;
+    const float4 ra = reinterpret_cast<const float4 *>(nrm1)[(long long)g * FGNN_H + c];
+    const float4 rb = reinterpret_cast<const float4 *>(nrm2)[(long long)g * FGNN_H + c];
+    const float ba = gnb1[c], bb = gnb2[c];
     // (wave-private LDS: in-order within the wave, no barrier needed; __syncthreads keeps the compiler honest about visibility)
     sb_bits_rows(B, bits, g, lane, N);
     __syncthreads();
@@ -237,11 +245,8 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits
     const int NC = sb_classes(N);
     const bool on = lane < N;
     // the class values of this channel in both models, from the forward's records
-    const float4 ra = reinterpret_cast<const float4 *>(nrm1)[(long long)g * FGNN_H + c];
-    const float4 rb = reinterpret_cast<const float4 *>(nrm2)[(long long)g * FGNN_H + c];
     const float *ta = tab, *tb = tab + (long long)NC * SB_TAB;
     const int cl = B.cls[on ? lane : 0];
-    const float ba = gnb1[c], bb = gnb2[c];
     const float u0 = (ta[2 * FGNN_H + c] - ra.x) * ra.y + ba, u1 = (ta[SB_TAB + 2 * FGNN_H + c] - ra.x) * ra.y + ba;
     const float v0 = (tb[2 * FGNN_H + c] - rb.x) * rb.y + bb, v1 = (tb[SB_TAB + 2 * FGNN_H + c] - rb.x) * rb.y + bb;
     const float p = u1 - u0, r = v1 - v0;
@@ -249,13 +254,9 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits
     const float q = on ? ((ta[cl * SB_TAB + 2 * FGNN_H + c] - ra.x) * ra.y + ba) - u0 - p * wii : 0.f;
     const float s = on ? ((tb[cl * SB_TAB + 2 * FGNN_H + c] - rb.x) * rb.y + bb) - v0 - r * wii : 0.f;
     // pass 1, lane = column j: column sums C, masked column sums Qm, <dM, W^2> share, diagonal; the plane goes to LDS
-    const float *src = dm + (long long)g * gstride + (long long)c * ldp;
     const u64 cj = B.col[lane];
     float C = 0.f, Qm = 0.f, U = 0.f, dg = 0.f;
     {
-        float v[SB_MAXN];                 // the whole plane in flight: one memory round trip
-#pragma unroll
-        for (int i = 0; i < SB_MAXN; ++i) v[i] = (on && i < N) ? src[i * N + lane] : 0.f;
 #pragma unroll
         for (int i = 0; i < SB_MAXN; ++i) {
             if (i < N) {
@@ -312,6 +313,12 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits
     o2[2 + lane] = d2;
 }
 
+#ifdef SB_STAMPS
+__device__ unsigned long long *g_sb_stamps = nullptr;
+#define SB_STAMP(i) if (threadIdx.x == 0 && g_sb_stamps) g_sb_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define SB_STAMP(i)
+#endif
 #ifdef SB_STOP
 #define SB_STOP_AT(k) if (SB_STOP == k) return;
 #else
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
     const int g = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
     const int NC = sb_classes(N), K = N + 2;
     const float *tm = tab + (long long)m * NC * SB_TAB;
+    SB_STAMP(0)
     // Everything this workgroup reads from memory is requested up front in explicitly unrolled batches (a rolled staging loop
     // pays one memory round trip per iteration: DESIGN.md section 7, "Rolled staging loops")
     sb_bits_rows(B, bits, g, tid, N);
@@ -366,7 +374,9 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
             if (e < CSN) CS[e / SB_CS][e % SB_CS] = v[q];
         }
     }
+    SB_STAMP(1)
     __syncthreads();
+    SB_STAMP(2)
     SB_STOP_AT(1)
     if (tid < SB_MAXN) {
         sb_bits_vertex(B, tid);
@@ -379,6 +389,7 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
         cnt[2 + tid] = 1.f;
     }
     __syncthreads();
+    SB_STAMP(3)
     SB_STOP_AT(2)
     {
         // h1 | h2 | z of every instance's class: (instance, channel) pairs, KMAX * 32 / 256 per thread and array, loads first
@@ -405,7 +416,9 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
             }
         }
     }
+    SB_STAMP(4)
     __syncthreads();
+    SB_STAMP(5)
     {
         // S1 = sum_k S_k, S2 = sum_k S_k (z_k - mean): 8 threads per channel, fixed partition and tree
         const int c = tid >> 3, s8 = tid & 7;
@@ -430,6 +443,7 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
         }
     }
     __syncthreads();
+    SB_STAMP(6)
     SB_STOP_AT(3)
     // dz summed over the pixels of an instance: ca S_k + n_k (cb (z_k - mean) + cc)
     for (int e = tid; e < K * FGNN_H; e += 256) {
@@ -437,6 +451,7 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
         DZ[k][c] = coef[c][0] * CS[c][k] + cnt[k] * (coef[c][1] * ZV[k][c] + coef[c][2]);
     }
     __syncthreads();
+    SB_STAMP(7)
     // dpre2 = (W2^T dz) masked by h2, then dpre1 = (W1^T dpre2) masked by h1, every instance at once: thread (k mod 8, c) keeps
     // column c of the transposed weight in registers and reads an instance's vector with 128-bit broadcast loads
     {
@@ -457,6 +472,7 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
             }
             D2[k][c] = HB[k][FGNN_H + c] > 0.f ? a : 0.f;
         }
+        SB_STAMP(8)
         __syncthreads();
 #pragma unroll
         for (int oo = 0; oo < FGNN_H; ++oo) wc[oo] = Wt[0][oo * FGNN_H + c];
@@ -486,53 +502,83 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits
         return;
     }
 #endif
+    SB_STAMP(9)
     SB_STOP_AT(4)
-    // gradients: thread t owns row o, columns 4 c4 .. 4 c4 + 3 of each 32 x 32 matrix; sums over the instances in index order
-    const int o = tid >> 3, c4 = tid & 7;
-    float4 dW2 = make_float4(0.f, 0.f, 0.f, 0.f), dW1 = dW2;
-    for (int kb = 0; kb < K; kb += 4) {                  // four instances per LDS round trip (rows >= K hold zeros: see below)
-        float dz[4], d2[4];
-        float4 h2[4], h1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = kb + u < K ? kb + u : 0;
-            dz[u] = kb + u < K ? DZ[k][o] : 0.f;
-            d2[u] = kb + u < K ? D2[k][o] : 0.f;
-            h2[u] = reinterpret_cast<const float4 *>(HB[k] + FGNN_H)[c4];
-            h1[u] = reinterpret_cast<const float4 *>(HB[k])[c4];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            dW2.x = fmaf(dz[u], h2[u].x, dW2.x);
-            dW2.y = fmaf(dz[u], h2[u].y, dW2.y);
-            dW2.z = fmaf(dz[u], h2[u].z, dW2.z);
-            dW2.w = fmaf(dz[u], h2[u].w, dW2.w);
-            dW1.x = fmaf(d2[u], h1[u].x, dW1.x);
-            dW1.y = fmaf(d2[u], h1[u].y, dW1.y);
-            dW1.z = fmaf(d2[u], h1[u].z, dW1.z);
-            dW1.w = fmaf(d2[u], h1[u].w, dW1.w);
-        }
-    }
+    // Gradients = sums over the instances.  Wave 0: dW2 = sum_k dz_k (x) h2_k and wave 1: dW1 = sum_k dpre2_k (x) h1_k as 32 x 32 x K
+    // products on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains in instance order; lane (j, h) supplies row k = 2 s + h of both
+    // operands, an odd K is padded with a zero row); waves 2, 3: the 2-column dW0 and the three bias gradients, eight instances
+    // per LDS round trip.
     constexpr int PC = 32 * 2 + 32 + 2 * (32 * 32 + 32);
     float *row = A.wpart[m] + (long long)g * PC;
-    if (tid < 64) {                                      // dW0[tid >> 1][tid & 1] = sum_k dpre1_k x_k
-        float a = 0.f;
-        for (int k = 0; k < K; ++k) {
-            const float x = k == 0 ? 0.f : (k == 1 ? (tid & 1 ? 0.f : 1.f) : (tid & 1 ? B.degr[k - 2] : (float)B.wii[k - 2]));
-            a = fmaf(D1[k][tid >> 1], x, a);
+    const int wv = tid >> 6, lane = tid & 63, jj = lane & 31, hh = lane >> 5;
+    if (wv < 2) {
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float (*L)[FGNN_H + 4] = wv == 0 ? DZ : D2;
+        const int hoff = wv == 0 ? FGNN_H : 0;
+        constexpr int SMAX = KMAX / 2;                   // k-steps of two instances; every operand is requested before the first product
+        float av[SMAX], bv[SMAX];
+#pragma unroll
+        for (int u = 0; u < SMAX; ++u) {
+            const int k = 2 * u + hh;
+            const bool ok = k < K;
+            av[u] = ok ? L[ok ? k : 0][jj] : 0.f;
+            bv[u] = ok ? HB[ok ? k : 0][hoff + jj] : 0.f;
         }
-        row[tid] = a;
-    } else if (tid < 160) {                              // biases: l = 0: dpre1 (b0), 1: dpre2 (b1), 2: dz (b2)
-        const int l = (tid - 64) >> 5, cc2 = (tid - 64) & 31;
+#pragma unroll
+        for (int u = 0; u < SMAX; ++u)
+            if (2 * u < K) acc = mfma32(av[u], bv[u], acc);
+        float *dst = row + (wv == 0 ? 96 + 1024 + 32 : 96);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[ch_of(r, hh) * FGNN_H + jj] = acc[r];
+    } else if (tid < 128 + 64) {                         // dW0[t >> 1][t & 1] = sum_k dpre1_k x_k,  t = tid - 128
+        const int t = tid - 128;
         float a = 0.f;
-        for (int k = 0; k < K; ++k) a += l == 0 ? D1[k][cc2] : (l == 1 ? D2[k][cc2] : DZ[k][cc2]);
-        row[l == 0 ? 64 + cc2 : (l == 1 ? 96 + 1024 + cc2 : 96 + 1024 + 32 + 1024 + cc2)] = a;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float d[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                const bool ok = k < K;
+                d[u] = ok ? D1[ok ? k : 0][t >> 1] : 0.f;
+                x[u] = (!ok || k == 0) ? 0.f : (k == 1 ? (t & 1 ? 0.f : 1.f) : (t & 1 ? B.degr[k - 2] : (float)B.wii[k - 2]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(d[u], x[u], a);
+        }
+        row[t] = a;
+    } else {                                             // threads 192 .. 255: b0 = sum_k dpre1_k, b1 = sum_k dpre2_k
+        const int t = tid - 192, l = t >> 5, cc2 = t & 31;
+        const float (*V)[FGNN_H + 4] = l == 0 ? D1 : D2;
+        float a = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = k0 + u < K ? V[k0 + u < K ? k0 + u : 0][cc2] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += d[u];
+        }
+        row[l == 0 ? 64 + cc2 : 96 + 1024 + cc2] = a;
     }
-    reinterpret_cast<float4 *>(row + 96 + o * FGNN_H)[c4] = dW1;
-    reinterpret_cast<float4 *>(row + 96 + 1024 + 32 + o * FGNN_H)[c4] = dW2;
+    SB_STAMP(10)
+    if (wv == 0 && lane < 32) {                           // b2 = sum_k dz_k (wave 0, after its product)
+        float a = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = k0 + u < K ? DZ[k0 + u < K ? k0 + u : 0][lane] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += d[u];
+        }
+        row[96 + 1024 + 32 + 1024 + lane] = a;
+    }
+    SB_STAMP(11)
 }
 
 }  // namespace
+
+#ifdef SB_STAMPS
+extern "C" int fgnn_debug_sb_stamps(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sb_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
+#endif
 
 extern "C" int fgnn_block1_struct_supported(int N, int depth, int c0) { return (N >= 1 && N <= SB_MAXN && depth == 3 && c0 == 2) ? 1 : 0; }
 extern "C" int fgnn_block1_struct_table_floats(int N) { return 2 * (2 + 2 * (N + 1)) * SB_TAB; }
