@@ -12,6 +12,8 @@ TAGS = {
     'mlp_fwd_kernel<32, 0, 2, 3>': 'mlp_fwd[cin=32,nmlp=2]', 'mlp_fwd_kernel<32, 32, 1, 3>': 'mlp_fwd[cin=64,nmlp=1]',
     'mlp_fwd_kernel<2, 0, 2, 3>': 'mlp_fwd[cin=2,nmlp=2]', 'mlp_fwd_kernel<32, 2, 1, 3>': 'mlp_fwd[cin=34,nmlp=1]',
     'mlp_bwd_pair_kernel<32>': 'mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_pair_kernel<2>': 'mlp_bwd_pair[cin=2,dx=0]',
+    'mlp_bwd_pair_x3_kernel<32>': 'x3:mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_pair_x3_kernel<2>': 'x3:mlp_bwd_pair[cin=2,dx=0]',
+    'sb_fwd_kernel': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel': 'fgnn_block1_struct_bwd',
     'chan_matmul_bwd1_kernel': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd1_kernel': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_w_kernel<7, true>': 'fgnn_chan_matmul_fwd',
 }
 TAGS16 = {
