@@ -249,9 +249,11 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU (default: the config\'s)')
     ap.add_argument('--n', type=int, default=None, help='vertices per graph (default: the config\'s)')
     ap.add_argument('--blocks', type=int, default=4)
-    ap.add_argument('--path', default='engine', choices=('engine', 'module'),
+    ap.add_argument('--path', default='engine', choices=('engine', 'module', 'fused_step'),
                     help="'engine': FgnnEngine.step (the fused launch sequence, the headline); 'module': the same batch through "
-                         'the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward()')
+                         "the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward(), eager launches; "
+                         "'fused_step': Siamese_Node_Exp.fused_step on the loader's batch (tensors or MaskedTensors): the module "
+                         "surface with the step as ONE replayed graph")
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--chains', type=int, default=None, choices=(1, 2),
                     help='2: the batch runs as two half-batch chains on two streams / disjoint halves of the CUs (FgnnEngineDual: '
@@ -387,7 +389,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
             eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
 
     model = None
-    if path == 'module':
+    if path in ('module', 'fused_step'):
         # the surface a user of the reference calls (models/trainers.py:60-76): same weights, same batch, eager launches
         from graph_neural_net_amd.siamese import Siamese_Node_Exp
         node_emb = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=args.blocks,
@@ -406,6 +408,9 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         no_graph = True
 
         def model_work():                      # noqa: F811
+            if path == 'fused_step':
+                model.fused_step({'input': xa}, {'input': xb})
+                return
             for p in model.parameters():
                 p.grad = None
             loss = model.loss(model({'input': xa}, {'input': xb})) * ((sum(sizes) if ragged else B * N) / total_nodes)

@@ -568,16 +568,22 @@ class FgnnEngine:
             args.s12part = W['s12part'].data_ptr()
         return args
 
-    def backward(self, params, grads, grad_scale=1.0, finalize=True):
+    def backward(self, params, grads, grad_scale=1.0, finalize=True, gscale_dev=None):
         """Backward of loss*grad_scale after forward(); fills the flat `grads` buffer (finalize=False: everything but the
-        last launch, see backward_from_dE)."""
+        last launch, see backward_from_dE).
+        gscale_dev: a 1-element fp32 DEVICE tensor that holds grad_scale / total_nodes (replaces both): the normaliser of a ragged
+        batch then never visits the host, and a captured step stays valid when the next batch has another node count."""
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
-        gs = grad_scale / self.total_nodes
-        if W.get('gscale_value') != gs:        # a 1-element fill kernel per step otherwise
-            W['gscale'].fill_(gs)
-            W['gscale_value'] = gs
+        if gscale_dev is not None:
+            W['gscale'].copy_(gscale_dev.reshape(1))
+            W['gscale_value'] = None
+        else:
+            gs = grad_scale / self.total_nodes
+            if W.get('gscale_value') != gs:        # a 1-element fill kernel per step otherwise
+                W['gscale'].fill_(gs)
+                W['gscale_value'] = gs
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)

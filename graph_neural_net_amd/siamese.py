@@ -109,65 +109,130 @@ class Siamese_Node_Exp(nn.Module):
             return MaskedTensor(scores, nvalid, (1, 2), x1.base_name)
         return scores
 
-    def fused_step(self, x1, x2, capture=True):
-        """Forward of both branches + scoring + `triplet_loss` + the full backward as the fused launch sequence of
-        engine.FgnnEngine -- with capture=True ONE replayed HIP graph per batch shape, the step `bench.py` measures (the
-        eager module path `loss = model.loss(model(x1, x2)); loss.backward()` of models/trainers.py:60-76 issues the same
-        kernels but pays ~40 host launches and the autograd bookkeeping per step).
+    def fused_step(self, x1, x2, capture=True, metric=False):
+        """Forward of both branches + scoring + `triplet_loss` + the full backward (+ the step's metric, models/trainers.py:70-76)
+        as the fused launch sequence of engine.FgnnEngine -- with capture=True ONE replayed HIP graph per (padded) batch shape,
+        the step `bench.py` measures (the eager module path `loss = model.loss(model(x1, x2)); loss.backward()` of
+        models/trainers.py:60-76 issues the same kernels but pays ~40 host launches and the autograd bookkeeping per step).
         Afterwards every trainable parameter's `.grad` is the gradient of this batch (views of one flat buffer, OVERWRITTEN
         per call like after `zero_grad()`), so any torch optimizer / scheduler steps as usual.
-        Constant-size batches (tensors or {'input': T} dicts).  The standard node_embedding graph runs the fused engine; widths /
-        depths the engine is not built for (in_features > 32, depth_of_mlp != 3 ...) run the module path's own per-layer launch
-        sequence, captured the same way (`_captured_module_step`); models that run zero-padded on the engine are refused.
-        Equal-size graphs make both loss reductions the same number (toolbox/losses.py:27-34).  Returns (loss, raw scores (bs, n, n)): device
-        tensors that the NEXT call of the same shape overwrites."""
+
+        Takes whatever the reference's loaders yield (loaders/loaders.py:5-15): tensors or {'input': T} dicts of constant-size
+        batches, and MaskedTensor batches (both sides sharing the per-pair vertex counts).  A ragged batch runs zero-padded to its
+        largest graph rounded up to a multiple of 16 (so batches of nearby sizes replay the same graph); the vertex counts and
+        the loss normaliser 1 / sum(n) (toolbox/losses.py:27-34) live in device buffers that each call overwrites -- nothing
+        about a batch is baked into the captured graph but its padded shape.  Models narrower than the engine (widths below 32,
+        1 or 3..31 input channels) run on zero-padded parameters (Network._padded_layout): the scatter of the parameters and the
+        gather of their gradients are part of the graph.  Widths / depths the engine is not built for (in_features > 32,
+        depth_of_mlp > 3 ...) run the module path's own per-layer launch sequence, captured the same way.
+
+        metric=True appends the model's matching accuracy (the default Hungarian accuracy or 'max', both device kernels) to the
+        step: returns (loss, scores, (n_correct, n_vertices)) with the counts as DEVICE tensors -- no host synchronisation
+        unless the caller reads them.  Returns (loss, raw scores) otherwise; scores are (bs, n, n) or a MaskedTensor; all outputs
+        are device tensors that the NEXT call of the same shape overwrites."""
         x1, x2 = _unwrap_input(x1), _unwrap_input(x2)
         net = self.node_embedder
         lay = net._standard_layout()
-        if isinstance(x1, MaskedTensor):
-            raise RuntimeError('fused_step covers constant-size batches; use the module path '
-                               '`loss = model.loss(model(x1, x2)); loss.backward()` for MaskedTensor batches')
-        if not x1.is_cuda:
-            raise RuntimeError('graph_neural_net_amd only runs on the GPU (input is on %s)' % (x1.device,))
-        if lay is None:
-            # widths / depths the fused engine is not built for: the module path's own launch sequence (per-layer kernels,
-            # csrc/conv.hip), captured once per batch shape and replayed
-            return self._captured_module_step(x1, x2, capture)
-        if net._pad is not None:
-            raise RuntimeError('fused_step: this model runs zero-padded on the fused engine (widths below 32 / '
-                               'original_features_num other than 2 or 32); use the module path '
-                               '`loss = model.loss(model(x1, x2)); loss.backward()`')
+        ragged = isinstance(x1, MaskedTensor)
+        t1, t2 = (x1.tensor.rename(None), x2.tensor.rename(None)) if ragged else (x1, x2)
+        if not t1.is_cuda:
+            raise RuntimeError('graph_neural_net_amd only runs on the GPU (input is on %s)' % (t1.device,))
+        builtin_metric = self.metric is accuracy_linear_assignment or self.metric is accuracy_max
+        if lay is None or (ragged and self.loss.loss_reduction != 'mean'):
+            # widths / depths the fused engine is not built for (or a per-graph loss weighting the engine's scoring kernel does not
+            # have): the module path's own launch sequence, captured once per batch shape and replayed (constant-size batches)
+            if ragged:
+                raise RuntimeError('fused_step: MaskedTensor batches need the standard node_embedding graph and loss_reduction="mean"; '
+                                   'use the module path `loss = model.loss(model(x1, x2)); loss.backward()`')
+            out = self._captured_module_step(t1, t2, capture)
+            if metric:
+                acc, n = self.metric(out[1])
+                return out + ((acc, n),)
+            return out
         net._bind_flat()
-        B, N = x1.shape[0], x1.shape[-1]
-        eng = net._engine_for_shape(2 * B, N, False, x1.device, 'step')
+        dev = t1.device
+        B, nmax = t1.shape[0], t1.shape[-1]
+        N = -(-nmax // 16) * 16 if ragged else nmax
+        pad = net._pad
+        c0e = pad['c0p'] if pad is not None else t1.shape[1]
+        eng = net._engine_for_shape(2 * B, N, ragged, dev, 'step')
         st = getattr(eng, '_step_state', None)
         if st is None:
-            st = eng._step_state = {'x': torch.empty(2 * B, x1.shape[1], N, N, dtype=torch.float32, device=x1.device), 'graph': None}
-        st['x'][:B].copy_(x1)
-        st['x'][B:].copy_(x2)
+            st = eng._step_state = {'x': torch.zeros(2 * B, c0e, N, N, dtype=torch.float32, device=dev), 'graph': {},
+                                    'nv': torch.zeros(2 * B, dtype=torch.int32, device=dev) if ragged else None,
+                                    'inv': torch.ones(1, dtype=torch.float32, device=dev),
+                                    'correct': torch.zeros(B, dtype=torch.int32, device=dev), 'nmax': N}
+        c0 = t1.shape[1]
+        if ragged:
+            if nmax < st['nmax']:                        # a smaller batch in the same workspace: the old values are padding now
+                st['x'].zero_()
+            st['nmax'] = nmax
+            st['x'][:B, :c0, :nmax, :nmax].copy_(t1)
+            st['x'][B:, :c0, :nmax, :nmax].copy_(t2)
+            st['nv'][:B].copy_(x1.nvalid)
+            st['nv'][B:].copy_(x1.nvalid)
+        else:
+            st['x'][:B, :c0].copy_(t1)
+            st['x'][B:, :c0].copy_(t2)
         if st.get('flat') is not net._flat:             # (re)bound parameters: a captured graph holds the old addresses
-            st['graph'], st['flat'] = None, net._flat
-        if capture and st['graph'] is None:
+            st['graph'], st['flat'] = {}, net._flat
+
+        def work():
+            params = net._engine_params()                # the bound flat buffer, or its zero-padded image (an index_copy_)
+            grads = net._flat_grad if pad is None else pad['pgrad']
+            if ragged:
+                # 1 / sum(n) on the device; the engine back-propagates sum-of-pair-losses * gscale and leaves the un-normalised loss
+                torch.reciprocal(st['nv'][:B].sum().to(torch.float32).reshape(1), out=st['inv'])
+                scores, loss = eng.forward(params, st['x'], nvalid=st['nv'], total_nodes=1.0, defer_loss=True)
+                eng.backward(params, grads, gscale_dev=st['inv'])
+                loss.mul_(st['inv'])
+            else:
+                scores, loss = eng.step(params, grads, st['x'])
+            if pad is not None:
+                torch.index_select(pad['pgrad'], 0, pad['idx'], out=net._flat_grad)
+            if metric and builtin_metric:
+                nvp = _lib.ptr(st['nv']) if ragged else None
+                if self.metric is accuracy_max:
+                    _lib.call('fgnn_accuracy_max', _lib.ptr(scores), nvp, B, N, _lib.ptr(st['correct']), _lib.stream_ptr())
+                else:               # -log_softmax over the valid columns, then SciPy's assignment on the device (metrics.py)
+                    s = scores
+                    if ragged:
+                        col = torch.arange(N, device=dev)[None, None, :] < st['nv'][:B, None, None]
+                        s = s.masked_fill(~col, float('-inf'))
+                    cost = (-torch.log_softmax(s, -1)).contiguous()
+                    _lib.call('fgnn_lsap_accuracy', _lib.ptr(cost), N * N, N, nvp, B, N, _lib.ptr(st['correct']), None, _lib.stream_ptr())
+            return scores, loss
+
+        key = bool(metric and builtin_metric)
+        if capture and st['graph'].get(key) is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):               # allocations, kernel attributes
                 for _ in range(2):
-                    eng.step(net._flat, net._flat_grad, st['x'])
+                    work()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                st['out'] = eng.step(net._flat, net._flat_grad, st['x'])
-            st['graph'] = g
+                st['out', key] = work()
+            st['graph'][key] = g
         if capture:
-            st['graph'].replay()
-            scores, loss = st['out']
+            st['graph'][key].replay()
+            scores, loss = st['out', key]
         else:
-            scores, loss = eng.step(net._flat, net._flat_grad, st['x'])
+            scores, loss = work()
         for p, v in zip(net._param_list, net._grad_views):
             if p.requires_grad:
                 p.grad = v
-        return loss.reshape(()), scores
+        if ragged:
+            scores = MaskedTensor(scores, x1.nvalid, (1, 2), x1.base_name)
+        if not metric:
+            return loss.reshape(()), scores
+        if builtin_metric:
+            total = st['nv'][:B].sum() if ragged else torch.tensor(B * N, device=dev)
+            return loss.reshape(()), scores, (st['correct'].sum(), total)
+        acc, n = self.metric(scores)
+        return loss.reshape(()), scores, (acc, n)
 
     def _captured_module_step(self, x1, x2, capture):
         """forward + loss + backward of the eager module path (models/trainers.py:60-76) as ONE replayed HIP graph per batch

@@ -1,6 +1,7 @@
 """GPU: the reference's module surface on top of the HIP kernels.  These read like the
 reference's own tests (maskedtensors/test_maskedtensor.py): masked batch == list of
 per-graph dense results, atol 1e-5; expected values come from the oracle / golden vectors."""
+import numpy as np
 import pytest
 import torch
 
@@ -471,3 +472,48 @@ def test_fused_step_equals_the_eager_module_path_and_trains_in_place():
     with torch.no_grad():                                                       # the module's eager forward sees the trained weights
         l_eager = model.loss(model(x1, x2)).item()
     assert l_eager < losses[0]
+
+
+def test_fused_step_on_masked_tensor_batches_with_the_metric_in_the_graph():
+    """Siamese_Node_Exp.fused_step on what the reference's loader yields for ragged graphs (MaskedTensor pairs,
+    loaders/loaders.py:5-10): one captured graph per padded shape, vertex counts and the loss normaliser in device buffers --
+    three batches of different sizes replay the SAME graph and each matches the eager module path; the step's metric
+    (models/trainers.py:74) rides in the graph and equals the eager metric on the same scores."""
+    from graph_neural_net_amd.masked import from_list
+    from graph_neural_net_amd.metrics import accuracy_linear_assignment, accuracy_max
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=32,
+              out_features=32, depth_of_mlp=3, constant_n_vertices=False)
+    for metric_name, metric_fn in ((None, accuracy_linear_assignment), ('max', accuracy_max)):
+        torch.manual_seed(3)
+        model = Siamese_Node_Exp(2, dict(ne), metric=metric_name).to(DEV)
+        graphs_seen = set()
+        for seed, sizes in ((1, (9, 14, 11)), (2, (13, 7, 15)), (3, (16, 16, 10))):       # all pad to N = 16
+            xs, ys = [], []
+            rng = np.random.default_rng(seed)
+            for n in sizes:
+                a, b = synthetic.make_pair(rng, n, 'ErdosRenyi', 0.4, 0.1)
+                xs.append(torch.from_numpy(a).to(DEV))
+                ys.append(torch.from_numpy(b).to(DEV))
+            m1, m2 = from_list(xs, dims=(1, 2), base_name='N'), from_list(ys, dims=(1, 2), base_name='M')
+            for p in model.parameters():
+                p.grad = None
+            scores = model(m1, m2)
+            loss = model.loss(scores)
+            loss.backward()
+            eager = {n: p.grad.clone() for n, p in model.named_parameters()}
+            for p in model.parameters():
+                p.grad = None
+            l2, s2, (acc, tot) = model.fused_step(m1, m2, metric=True)
+            assert abs(l2.item() - loss.item()) <= 2e-6 * abs(loss.item()), (l2.item(), loss.item())
+            for i, n in enumerate(sizes):         # the same kernels on another padded geometry: equal to fp32 rounding
+                assert rel(s2.tensor[i, :n, :n], scores.tensor[i, :n, :n].detach()) < 1e-5
+            # the in-graph metric == the eager metric ON THE SAME SCORES (on an untrained model the eager path's scores, equal to
+            # 1e-6, may already give another assignment among near-tied costs)
+            acc_e, n_e = metric_fn(s2)
+            assert int(tot.item()) == n_e == sum(sizes) and int(acc.item()) == acc_e
+            for name, p in model.named_parameters():
+                if not name.endswith('convs.2.bias'):
+                    assert rel(p.grad, eager[name]) < 1e-4, (name, rel(p.grad, eager[name]))
+            eng = next(e for e in model.node_embedder._engines.values() if getattr(e, '_step_state', None) is not None)
+            graphs_seen.add(id(eng._step_state['graph'][True]))
+        assert len(graphs_seen) == 1                       # one capture served all three batches

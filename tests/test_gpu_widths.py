@@ -437,14 +437,28 @@ def test_fused_step_on_a_non_standard_width_is_the_captured_module_path():
     assert torch.equal(l5, l3)
 
 
-def test_fused_step_refuses_models_that_run_zero_padded_on_the_engine():
+def test_fused_step_on_models_that_run_zero_padded_on_the_engine():
+    """Widths below 32 / 3 input channels: fused_step runs the 32-wide engine on zero-padded parameters inside ONE replayed graph
+    (parameter scatter, step, gradient gather) and leaves the same loss, scores and p.grad as the eager module path."""
     from graph_neural_net_amd.siamese import Siamese_Node_Exp
-    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=16,
-              out_features=16, depth_of_mlp=3)
-    model = Siamese_Node_Exp(2, ne, metric='max').to(DEV)
-    x = torch.randn(2, 2, 10, 10, device=DEV)
-    with pytest.raises(RuntimeError, match='zero-padded'):
-        model.fused_step(x, x)
+    for c0, win, wout in ((2, 16, 16), (3, 16, 24)):
+        torch.manual_seed(5)
+        ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=win,
+                  out_features=wout, depth_of_mlp=3)
+        model = Siamese_Node_Exp(c0, ne, metric='max').to(DEV)
+        g = torch.Generator().manual_seed(6)
+        x1, x2 = torch.randn(3, c0, 12, 12, generator=g).to(DEV), torch.randn(3, c0, 12, 12, generator=g).to(DEV)
+        scores = model(x1, x2)
+        loss = model.loss(scores)
+        loss.backward()
+        eager = {n: p.grad.clone() for n, p in model.named_parameters()}
+        for cap in (False, True, True):
+            for p in model.parameters():
+                p.grad = None
+            l2, s2 = model.fused_step(x1, x2, capture=cap)
+            assert torch.equal(s2, scores.detach()) and abs(l2.item() - loss.item()) <= 1e-6 * abs(loss.item())
+            for n, p in model.named_parameters():
+                assert torch.equal(p.grad, eager[n]), (c0, win, wout, cap, n)
 
 
 @pytest.mark.parametrize('N,ragged', [(7, False), (50, False), (64, True), (33, True)])
