@@ -18,7 +18,13 @@ from util import is_zero_grad, load_golden, rel, sub, unpack_pairs
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-BIG_FLAT, BIG_TENSOR = 4.0, 10.0     # batch-level gradient gates of the large fixtures (see test_cfg2_full_batch_against_golden)
+# Batch-level gradient gates of the large fixtures (see test_cfg2_full_batch_against_golden), derived from the multi-seed fixture
+# (tests/golden/gradgate_single_pairs.npz, group A = the 32 pairs of the benchmarked batch; tests/gradgate.py): the error of a
+# batch gradient is the rms of its pairs' errors, and between two equally valid fp32 evaluations of the reference (8 threads /
+# 1 thread, and the two HIP engines judged the same way) the rms over 32 resampled pairs differs by 1.9 x at the 90th, 3.2 x at
+# the 99th and 4.4 x at the 99.9th percentile (20 000 bootstrap batches) -> BIG_FLAT = 4; per tensor, the reference's own two
+# runs differ by up to 10.3 x at batch level (rms over the pairs; median 1.4 x, 90 % 2.9 x) -> BIG_TENSOR = 10.
+BIG_FLAT, BIG_TENSOR = 4.0, 10.0
 OP_TOL = 1e-5          # per-block forward / scores at small depth
 E2E_FWD_TOL = 3e-5     # block-4 activations / scores after 4 blocks (reference fp32-vs-fp64: 1.6e-5 / 1.4e-5)
 

@@ -55,5 +55,7 @@ def l2rel(a, b):
 
 
 # bf16 results are compared with the reference's own all-bf16 run as the yard-stick: same error class = within this
-# factor of the reference-bf16 distance to the fp64 truth (see tests/test_oracle_bf16.py for the measured spread)
-BF16_CLASS = 2.0
+# factor of the reference-bf16 distance to the fp64 truth.  Measured after four blocks on the N = 200 fixture (round 4,
+# tests/diag/gpu_bf16_ratios.py): scores 0.061 vs 0.054 (1.13 x), flat gradient 0.574 vs 0.493 (1.16 x); the same-point bf16
+# oracle 1.0 - 1.2 x (tests/test_oracle_bf16.py).  The ONE-block fixtures are gated at <= 1.0 x (one_block_gates).
+BF16_CLASS = 1.5
