@@ -369,11 +369,12 @@ class FgnnEngine:
                 raise RuntimeError('FgnnEngine.embed: expected contiguous fp32 %s, got %s %s'
                                    % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
             self.x, self.xbits = x, None
-        if pack:                # (FgnnEngineDual packs once for both of its engines)
-            self.pack_operands(params)
+        struct_now = self.struct1 and self.xbits is not None
+        if pack:                # (FgnnEngineDual packs once for both of its engines.  Running this launch on a second stream beside the
+            self.pack_operands(params)          # structured block 1, which reads no operand image, was measured: +20 us per step)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
-            if k == 1 and self.struct1 and self.xbits is not None:
+            if k == 1 and struct_now:
                 self._struct_fwd(params)
                 pool_fin = L.num_blocks == 1 and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
                 self._mlp_fwd(params, 1, (3,), self._slab_raw(self.mult[1]), sin, finalize=not pool_fin)

@@ -218,38 +218,12 @@ def test_cfg2_full_batch_against_golden():
     # that hold a ReLU / arg-max decision within rounding distance of a tie, and the two fp32 evaluations hit different
     # pairs.  A batch figure -- of EITHER implementation -- is set by the two or three unlucky pairs it happens to hold, so
     # the batch-level gates against one realisation of the reference are looser (BIG_*) than the small-case gates (2x / 4x),
-    # and the per-pair distribution test below is the sharp statement.
+    # and the per-case distribution gate of tests/test_gpu_grad_gate.py is the sharp statement.
     _check_grads(grads, d, BIG_FLAT, BIG_TENSOR)
 
 
-def test_gradient_error_is_the_same_class_as_the_reference_per_pair():
-    """Per-pair gradients of ten pairs of the benchmarked batch against the fp64 truth, next to the oracle's (= the
-    reference's) own fp32 error on the same pair.  The fp32 error of a pair is bimodal -- ~1e-5 when no ReLU / arg-max
-    decision sits within rounding distance of a tie, ~1e-3 when one does -- and the two fp32 evaluations hit different
-    pairs (measured on these pairs: ours 1.2e-5 ... 8.8e-3, reference 1.6e-5 ... 1.9e-3, each worse on about half).  So the
-    gate is on the distribution: the median ratio ours / reference is at most 1.5, and we are not the outlier (> 3x worse)
-    on clearly more pairs than the reference is."""
-    d = load_golden('cfg2_reg_n50_b32_4blk.npz')
-    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
-    sd64 = {k: v.double() for k, v in sd.items()}
-    n = int(d['n'])
-    x1, x2 = unpack_pairs(d['bits1'], n), unpack_pairs(d['bits2'], n)
-    keys = [k for k in sub(d, 'grad/') if not is_zero_grad(k)]
-    flat = lambda g: torch.cat([g[k].reshape(-1).double() for k in keys])
-    ratios = []
-    for b in range(10):
-        _, _, _, _, _, got = _run_engine(sd, x1[b:b + 1], x2[b:b + 1], 4)
-        _, _, g64 = O.step_fwd_bwd(x1[b:b + 1].double(), x2[b:b + 1].double(), sd64)
-        _, _, g32 = O.step_fwd_bwd(x1[b:b + 1], x2[b:b + 1], sd)
-        f64 = flat(g64)
-        ours = ((flat(got) - f64).norm() / f64.norm()).item()
-        theirs = ((flat(g32) - f64).norm() / f64.norm()).item()
-        assert ours < 2e-2, (b, ours)                    # even an unlucky pair stays far below 1e-2 ... 2e-2
-        ratios.append(ours / theirs)
-    ratios.sort()
-    median = 0.5 * (ratios[4] + ratios[5])
-    assert median <= 1.5, ratios
-    assert sum(r > 3 for r in ratios) <= sum(r < 1 / 3 for r in ratios) + 2, ratios
+# (The per-pair statement -- the error distribution over single pairs matches the reference's, for ALL 32 pairs of the benchmarked
+# batch and 116 more cases, with the reference's own flipped decisions and margins on record -- is tests/test_gpu_grad_gate.py.)
 
 
 def test_cfg4_shape_n200_dense_er_fp32_golden():
