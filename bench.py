@@ -366,8 +366,8 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
             # The headline line (cfg2, fp32 engine) hands the batch over as bit-packed adjacency and runs block 1 on its structured
             # form unless told otherwise; `dense_input` in the JSON is the same step on the dense tensor through the generic kernels
             b1 = block1 if block1 is not None else (args.block1 if same else None)
-            if b1 is None:
-                b1 = 'structured' if (config == 'cfg2' and same and args.input != 'dense' and path == 'engine') else 'generic'
+            if b1 is None:      # cfg2 and cfg5 (fp32 engine, N <= 128): structured unless the dense input was asked for
+                b1 = 'structured' if (config in ('cfg2', 'cfg5') and not (same and args.input == 'dense') and path == 'engine') else 'generic'
             eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma, block1=b1)
     x = torch.cat([x1, x2]).contiguous().to(dev)
     struct1 = bool(getattr(eng, 'struct1', False))

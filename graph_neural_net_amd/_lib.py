@@ -172,10 +172,10 @@ _SIGNATURES = {
     'fgnn_mlp_bwd_pair_x3': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_block1_struct_supported': [_I, _I, _I],
     'fgnn_block1_struct_table_floats': [_I],
-    'fgnn_block1_struct_csum_floats': [_I],
+    'fgnn_block1_struct_csum_floats': [_I, _I],
     'fgnn_block1_struct_tables': [_VP, _VP, _VP, _VP, _I, _VP, _VP],
-    'fgnn_block1_struct_fwd': [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP],
-    'fgnn_block1_struct_bwd': [_VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
+    'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP],
+    'fgnn_block1_struct_bwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],

@@ -143,7 +143,6 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
     const int j = lane & 31, h = lane >> 5;
     const int PP = A.N * A.ldr;
     const View16 va = make_view16(A.a.ptr, A.a.gstride, A.a.ldp, A.G);
-    const View16 vb = make_view16(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
     const View16 vdy = make_view16(A.dy, A.dgstride, A.ldd, A.G);
     const View16 vz = make_view16(A.z, A.zgstride, A.ldz, A.G);
     const View16 vdxa = make_view16(P.m[1].dxa, P.m[1].dxa_gstride, P.m[1].dxa_ld, P.m[1].G);
