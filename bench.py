@@ -355,7 +355,11 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
     if bf16:
         from graph_neural_net_amd.engine16 import FgnnEngineBF16
-        eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged)
+        # cfg4 (16-bit engine) takes the same default as the fp32 lines: bit-packed adjacency + structured block 1
+        b1 = block1 if block1 is not None else (args.block1 if same else None)
+        if b1 is None:
+            b1 = 'structured' if (not (same and args.input == 'dense') and path == 'engine') else 'generic'
+        eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged, block1=b1)
     else:
         chains = args.chains if (same and args.chains is not None) else 1
         mfma = args.mfma if (same and args.mfma is not None) else None
@@ -372,7 +376,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     x = torch.cat([x1, x2]).contiguous().to(dev)
     struct1 = bool(getattr(eng, 'struct1', False))
     want = input_form if input_form is not None else (args.input if same else None)
-    use_bits = (not bf16 and path == 'engine' and not hasattr(eng, 'stage_inputs') and ((want == 'bits') if want is not None else struct1))
+    use_bits = (path == 'engine' and not hasattr(eng, 'stage_inputs') and ((want == 'bits' and (struct1 or not bf16)) if want is not None else struct1))
     xbits = None
     if use_bits:     # the same batch as 32-bit words of adjacency rows (synthetic.pack_adjacency), resident in HBM like x
         import numpy as np

@@ -172,10 +172,13 @@ _SIGNATURES = {
     'fgnn_mlp_bwd_pair_x3': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_block1_struct_supported': [_I, _I, _I],
     'fgnn_block1_struct_table_floats': [_I],
-    'fgnn_block1_struct_csum_floats': [_I, _I],
-    'fgnn_block1_struct_tables': [_VP, _VP, _VP, _VP, _I, _VP, _VP],
-    'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP],
+    'fgnn_block1_struct_ws_floats': [_I, _I],
+    'fgnn_block1_struct_rows': [_I, _I],
+    'fgnn_block1_struct_tables': [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP],
+    'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
     'fgnn_block1_struct_bwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
+    'fgnn_block1_struct_fwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
+    'fgnn_block1_struct_bwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
@@ -212,7 +215,7 @@ _SIGNATURES = {
     'fgnn_mlp_bwd16': [C.POINTER(MlpBwd16Args), _VP],
     'fgnn_mlp_bwd16_pair': [C.POINTER(MlpBwd16Args), C.POINTER(MlpBwd16Args), _VP],
 }
-_RESTYPES = {'fgnn_last_error': C.c_char_p}
+_RESTYPES = {'fgnn_last_error': C.c_char_p, 'fgnn_block1_struct_ws_floats': C.c_longlong}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

@@ -1,4 +1,4 @@
-// Block 1 of the 2-FGNN on its STRUCTURED input (bit-packed adjacency; constant-size and ragged batches, N <= 128).
+// Block 1 of the 2-FGNN on its STRUCTURED input (bit-packed adjacency; constant-size and ragged batches, N <= 256).
 //
 // The reference feeds block 1 the tensor representation of a graph (loaders/data_generator.py:118-125): channel 0 = the 0/1
 // adjacency W, channel 1 = diag(row sums).  So the input pixel (i, j) takes one of few values -- off the diagonal (w_ij, 0)
@@ -9,7 +9,7 @@
 // and the per-channel product mult_c = Y1_c Y2_c (models/layers.py:161-162) has the closed form
 //     mult_c[i][j] = u0 v0 n + u0 r degc_j + u0 s_j + p v0 degr_i + p r (W^2)_ij + p w_ij s_j + v0 q_i + r q_i w_ij + [i = j] q_i s_i
 // with (W^2)_ij = popcount(row_i & column_j) on the bit rows: ONE integer product per pixel instead of 32 N x N products per
-// graph.  GraphNorm statistics (models/layers.py:68-80) follow from the class counts.  In the backward direction the gradient
+// graph, formed once per graph (sb_graph_kernel: a 16-bit code plane (W^2)_ij | w_ij << 15 plus per-vertex records).  GraphNorm statistics (models/layers.py:68-80) follow from the class counts.  In the backward direction the gradient
 // reaches the parameters of mlp1 / mlp2 only through the class values, so what is needed of dY1_c = dM_c Y2_c^T and dY2_c =
 // Y1_c^T dM_c are their CLASS SUMS, which reduce to row / column / diagonal / masked sums of dM_c and <dM_c, W^2>: one pass
 // over d(mult).  The GraphNorm backward and the conv / ReLU chain then run per class (the ReLU masks are class constants, the
@@ -20,16 +20,19 @@
 // with the generic kernels to fp32 rounding (tests/test_gpu_struct.py), not bit for bit.
 // Ragged batches: graph g has nv = nvalid[g] vertices inside the N x N padded planes; everything below runs on the valid corner
 // (rows / bits >= nv are cleared on load, class counts and the GraphNorm n use nv), mult is written as 0 outside it.
-// The kernels are instantiated for bit rows of one (N <= 64) and two (N <= 128) 64-bit words.
+// The kernels are instantiated for bit rows of one (N <= 64), two (N <= 128) and four (N <= 256) 64-bit words, and for fp32 slabs
+// (row pitch N) as well as the bf16 slabs of the 16-bit engine (row pitch ldr, values rounded to nearest even on store).
 #include "fgnn_common.h"
 #include "fgnn_norm.h"
+#include "fgnn_bf16.h"
 
 namespace {
 
 constexpr int SB_CG = 8;                 // channel groups of the forward kernel (4 channels each)
 constexpr int SB_CPG = FGNN_H / SB_CG;   // channels per group
-constexpr int SB_TAB = 3 * FGNN_H;       // floats per table row: h1 | h2 | z
-constexpr int SB_NMAX = 128;
+constexpr int SB_TAB = 4 * FGNN_H;       // floats per table row: h1 | h2 | z (fp32, for the statistics) | z as stored (bf16 scheme: R(z))
+constexpr int SB_NMAX = 256;
+constexpr int SB_KC = 32;                // class instances per round of the class-algebra kernel
 
 // class of a pixel's input value: 0 = off-diagonal, w = 0; 1 = off-diagonal, w = 1; 2 + 2 deg + w_ii = diagonal
 DEVI int sb_classes(int N) { return 2 + 2 * (N + 1); }
@@ -41,7 +44,9 @@ struct TabArgs {
     const float *W[2][3];
     const float *b[2][3];
 };
-__global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const int N, float *tab) {
+// bf: the 16-bit scheme of engine16 (oracle/fgnn_oracle_bf16.py): matrix-core operands R(W), R(relu(.)) and the stored R(z)
+DEVI float sb_r(float v, int bf) { return bf ? bf_lo(cvt_pk(v, 0.f)) : v; }
+__global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const int N, float *tab, const int bf) {
     __shared__ float hbuf[2][FGNN_H];
     const int cls = blockIdx.x, m = blockIdx.y, o = threadIdx.x;
     float x0, x1;
@@ -56,9 +61,9 @@ __global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const in
     if (o < FGNN_H) {
         const float *W0 = A.W[m][0];
         float a = A.b[m][0][o];
-        a = fmaf(W0[o * 2 + 0], x0, a);
-        a = fmaf(W0[o * 2 + 1], x1, a);
-        a = fmaxf(a, 0.f);
+        a = fmaf(sb_r(W0[o * 2 + 0], bf), x0, a);
+        a = fmaf(sb_r(W0[o * 2 + 1], bf), x1, a);
+        a = sb_r(fmaxf(a, 0.f), bf);
         hbuf[0][o] = a;
         out[o] = a;
     }
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const in
         const float *W1 = A.W[m][1] + o * FGNN_H;
         float a = A.b[m][1][o];
 #pragma unroll
-        for (int c = 0; c < FGNN_H; ++c) a = fmaf(W1[c], hbuf[0][c], a);
-        a = fmaxf(a, 0.f);
+        for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W1[c], bf), hbuf[0][c], a);
+        a = sb_r(fmaxf(a, 0.f), bf);
         hbuf[1][o] = a;
         out[FGNN_H + o] = a;
     }
@@ -77,8 +82,9 @@ __global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const in
         const float *W2 = A.W[m][2] + o * FGNN_H;
         float a = A.b[m][2][o];
 #pragma unroll
-        for (int c = 0; c < FGNN_H; ++c) a = fmaf(W2[c], hbuf[1][c], a);
+        for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W2[c], bf), hbuf[1][c], a);
         out[2 * FGNN_H + o] = a;
+        out[3 * FGNN_H + o] = sb_r(a, bf);
     }
 }
 
@@ -119,28 +125,35 @@ DEVI void sb_bits_vertex(GraphBits<NWD> &B, int t) {           // what needs the
     B.wii[t] = wself;
     B.cls[t] = 2 + 2 * dr + wself;
 }
+// column t of the bit matrix from the rows in LDS: 32 rows per group, every shift a compile-time constant (one 32-bit LDS read,
+// one bit-field extract and one shift-or per bit; a wave instruction costs 4 cycles, so the 64-bit / dynamic-index form of this
+// loop was the longest phase of every kernel that called it)
 template <int NWD>
 DEVI void sb_bits_cols(GraphBits<NWD> &B, int t, int nv) {
     if (t < 64 * NWD) {
-        u64 c[NWD];
+        const unsigned *rows32 = reinterpret_cast<const unsigned *>(&B.row[0][0]);      // [64 NWD][2 NWD] dwords
+        const int dw = t >> 5, sh = t & 31;
+        unsigned c32[2 * NWD];
 #pragma unroll
-        for (int w = 0; w < NWD; ++w) c[w] = 0ull;
-        const int tw = t >> 6, tb = t & 63;
-        for (int i0 = 0; i0 < nv; i0 += 8) {              // eight rows per LDS round trip (rows >= nv are empty)
-            u64 r[8];
+        for (int h = 0; h < 2 * NWD; ++h) {              // rows 32 h .. 32 h + 31 (rows >= nv are empty)
+            unsigned acc = 0u;
+            if (32 * h < nv) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) r[k] = B.row[(i0 + k) & (64 * NWD - 1)][tw];
+                for (int k8 = 0; k8 < 32; k8 += 8) {
+                    unsigned r[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = (i0 + k) & (64 * NWD - 1);
-                c[NWD == 1 ? 0 : (i >> 6)] |= ((r[k] >> tb) & 1ull) << (i & 63);
+                    for (int k = 0; k < 8; ++k) r[k] = rows32[(32 * h + k8 + k) * 2 * NWD + dw];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc |= ((r[k] >> sh) & 1u) << (k8 + k);
+                }
             }
+            c32[h] = acc;
         }
         int dc = 0;
 #pragma unroll
         for (int w = 0; w < NWD; ++w) {
-            B.col[t][w] = c[w];
-            dc += __popcll(c[w]);
+            B.col[t][w] = (u64)c32[2 * w] | ((u64)c32[2 * w + 1] << 32);
+            dc += __popc(c32[2 * w]) + __popc(c32[2 * w + 1]);
         }
         B.degc[t] = (float)dc;
         sb_bits_vertex(B, t);
@@ -156,27 +169,154 @@ DEVI int sb_w2(const GraphBits<NWD> &B, int i, int j) {        // (W^2)_ij = |{k
 template <int NWD>
 DEVI bool sb_w(const GraphBits<NWD> &B, int i, int j) { return (B.row[i][j >> 6] >> (j & 63)) & 1ull; }
 
-// The normalised class values of channel c of one model in one graph.  The 64 lanes of a wave call this together; lane l
-// owns the vertices l + 64 k.  Statistics from the class counts (two-pass: mean, then squared deviations), record as
-// fgnn_norm.h, y = (z - mean) a + beta as every consumer of a slab evaluates it.
+// The normalised class values of channel c of one model in one graph: Y = u0 J + p W + diag(q)
 template <int NWD>
 struct ClassVals {
     float u0, p, q[NWD];     // Y = u0 J + p W + diag(q): q[k] belongs to vertex lane + 64 k
     float4 rec;              // GraphNorm record of (g, c)
 };
+// The per-step kernels touch the bit matrix ONCE per graph: sb_graph_kernel turns it into a 16-bit code plane, code[g][i][j] =
+// (W^2)_ij | w_ij << 15, plus per-vertex {row sum, column sum, w_ii, class} records; the forward kernel, the class-sum kernel
+// and the class algebra read those (L2-resident: N^2 x 2 bytes per graph against the 32 N^2 values of a slab).  (A first form
+// that re-derived the popcounts from LDS bit rows in every (graph, channel group) workgroup cost 105 / 100 / 51 us at N = 200,
+// 16 graphs, against 22 / 24 / 9 us now: profiles/r04_cfg4_struct_timelines.txt.)
+// Workspace of one step (fwd fills, bwd reads):
+struct WsLayout {
+    long long csum, coef, vinfo, gones, code, total;      // offsets in floats
+    int cp, CS;
+};
+static WsLayout sb_ws_layout(int G, int N) {
+    const int MAXN = N <= 64 ? 64 : (N <= 128 ? 128 : 256);
+    WsLayout L;
+    L.CS = 2 + MAXN;
+    L.cp = (N + 7) & ~7;
+    long long o = 0;
+    L.csum = o;
+    o += 2LL * G * FGNN_H * L.CS;
+    o = (o + 3) & ~3LL;
+    L.coef = o;
+    o += 2LL * G * FGNN_H * 4;
+    L.vinfo = o;
+    o += 4LL * G * N;
+    L.gones = o;
+    o += (G + 3) & ~3;
+    L.code = o;
+    o += ((long long)G * N * L.cp / 2 + 3) & ~3LL;
+    L.total = o;
+    return L;
+}
+
+// NWD consecutive 16-bit values at p as one load / store (p is 2 NWD-byte aligned)
 template <int NWD>
-DEVI ClassVals<NWD> sb_class_values(const float *tab_m, const GraphBits<NWD> &B, int nv, int c, float gnw, float beta, float eps, int lane) {
+DEVI void sb_load16(const unsigned short *p, unsigned (&o)[NWD]) {
+    if constexpr (NWD == 4) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        o[0] = v.x & 0xffffu;
+        o[1] = v.x >> 16;
+        o[2] = v.y & 0xffffu;
+        o[3] = v.y >> 16;
+    } else if constexpr (NWD == 2) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(p);
+        o[0] = v & 0xffffu;
+        o[1] = v >> 16;
+    } else {
+        o[0] = *p;
+    }
+}
+template <int NWD>
+DEVI void sb_store16(unsigned short *p, const unsigned (&o)[NWD]) {
+    if constexpr (NWD == 4) *reinterpret_cast<uint2 *>(p) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    else if constexpr (NWD == 2) *reinterpret_cast<unsigned *>(p) = o[0] | (o[1] << 16);
+    else *p = (unsigned short)o[0];
+}
+
+// ---- KG: code plane + vertex records (+ the input slabs the other kernels of block 1 read) -------------------------------------
+// grid (G, ny): every workgroup builds the bit rows / columns of its graph and codes a band of rows
+template <int NWD>
+__global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, const int *nvalid, const int N, const int cp, unsigned *code,
+                                                       float4 *vinfo, float *gones, float *xdeg, void *x16, const long long ldp16,
+                                                       const int pitch16) {
+    __shared__ GraphBits<NWD> B;
+    __shared__ float red[4];
+    const int g = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x;
+    const int nv = nvalid_of(nvalid, g, N);
+    sb_bits_rows(B, bits, g, tid, N, nv);
+    __syncthreads();
+    sb_bits_cols(B, tid, nv);
+    __syncthreads();
+    if (y == 0) {
+        float on1 = 0.f;
+        if (tid < N) {
+            const bool on = tid < nv;
+            const float dr = on ? B.degr[tid] : 0.f;
+            const int ws = on ? B.wii[tid] : 0;
+            vinfo[(long long)g * N + tid] = make_float4(dr, on ? B.degc[tid] : 0.f, __int_as_float(ws), __int_as_float(on ? B.cls[tid] : 0));
+            if (xdeg) xdeg[(long long)g * N + tid] = dr;                  // what fgnn_adjacency_degree would write
+            on1 = dr - (float)ws;
+        }
+        on1 = wave_sum(on1);
+        if ((tid & 63) == 0) red[tid >> 6] = on1;
+        __syncthreads();
+        if (tid == 0) gones[g] = (red[0] + red[1]) + (red[2] + red[3]);   // off-diagonal ones of the valid corner
+    }
+    // band of rows of this workgroup: wave <-> row, lane <-> the NWD consecutive columns NWD lane + t, whose column words stay in
+    // registers (the row words are wave-uniform LDS broadcasts): no bank conflicts, one vector store per row and plane
+    const int rpc = (N + ny - 1) / ny, r0 = y * rpc, r1 = min(N, r0 + rpc);
+    const int lane = tid & 63, wv = tid >> 6, j0 = NWD * lane;
+    u64 cw[NWD][NWD];
+#pragma unroll
+    for (int t = 0; t < NWD; ++t)
+#pragma unroll
+        for (int w = 0; w < NWD; ++w) cw[t][w] = B.col[j0 + t][w];                 // j0 + t < 64 NWD
+    unsigned short *code16 = reinterpret_cast<unsigned short *>(code) + (long long)g * N * cp;
+    unsigned short *xa = reinterpret_cast<unsigned short *>(x16) + (long long)g * 2 * ldp16, *xb = xa + ldp16;
+    for (int i = r0 + wv; i < r1; i += 4) {
+        u64 rw[NWD];
+#pragma unroll
+        for (int w = 0; w < NWD; ++w) rw[w] = B.row[i][w];                         // empty for i >= nv
+        const float dr = B.degr[i];
+        unsigned cdv[NWD], wv16[NWD], dg16[NWD];
+#pragma unroll
+        for (int t = 0; t < NWD; ++t) {
+            int w2 = 0;
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) w2 += __popcll(rw[w] & cw[t][w]);
+            const int j = j0 + t;
+            const bool wb = (rw[NWD == 1 ? 0 : (j >> 6)] >> (j & 63)) & 1ull;      // bits >= nv are cleared
+            cdv[t] = (i < nv && j < nv) ? ((unsigned)w2 | (wb ? 0x8000u : 0u)) : 0u;
+            wv16[t] = wb ? 0x3F80u : 0u;                                           // bf16 1.0
+            dg16[t] = (j == i && i < nv) ? (cvt_pk(dr, 0.f) & 0xffffu) : 0u;
+        }
+        if (j0 < cp) sb_store16<NWD>(code16 + (long long)i * cp + j0, cdv);
+        if (x16 && j0 < pitch16) {
+            sb_store16<NWD>(xa + (long long)i * pitch16 + j0, wv16);
+            sb_store16<NWD>(xb + (long long)i * pitch16 + j0, dg16);
+        }
+    }
+    if (x16 && y == ny - 1) {
+        // tail of the channel stride of the 2-channel input slab of the 16-bit engine (mlp3 reads the slab as its skip connection)
+        unsigned *x0 = reinterpret_cast<unsigned *>(xa), *x1 = reinterpret_cast<unsigned *>(xb);
+        for (int e = N * pitch16 / 2 + tid; e < (int)(ldp16 / 2); e += 256) x0[e] = x1[e] = 0u;
+    }
+}
+
+// class values of channel c of one model from the vertex records.  The 64 lanes of a wave call this together; lane l owns the
+// vertices l + 64 k.  Statistics from the class counts (two-pass: mean, then squared deviations), record as fgnn_norm.h,
+// y = (z - mean) a + beta as every consumer of a slab evaluates it
+template <int NWD>
+DEVI ClassVals<NWD> sb_class_values(const float *tab_m, const float4 (&vi)[NWD], float ones, int nv, int c, float gnw, float beta, float eps, int lane,
+                                     int bf) {
     const float z0 = tab_m[0 * SB_TAB + 2 * FGNN_H + c], z1 = tab_m[1 * SB_TAB + 2 * FGNN_H + c];
-    float zd[NWD], on1 = 0.f, szd = 0.f;
+    const float y0 = tab_m[0 * SB_TAB + 3 * FGNN_H + c], y1 = tab_m[1 * SB_TAB + 3 * FGNN_H + c];          // as stored
+    float zd[NWD], yd[NWD], szd = 0.f;
 #pragma unroll
     for (int k = 0; k < NWD; ++k) {
-        const int v = lane + 64 * k;
-        const bool on = v < nv;
-        zd[k] = on ? tab_m[B.cls[on ? v : 0] * SB_TAB + 2 * FGNN_H + c] : 0.f;
-        on1 += on ? B.degr[v] - (float)B.wii[v] : 0.f;
+        const bool on = lane + 64 * k < nv;
+        const int cl = on ? __float_as_int(vi[k].w) : 0;
+        zd[k] = on ? tab_m[cl * SB_TAB + 2 * FGNN_H + c] : 0.f;
+        yd[k] = on ? tab_m[cl * SB_TAB + 3 * FGNN_H + c] : 0.f;
         szd += zd[k];
     }
-    const float ones = wave_sum(on1);                                    // off-diagonal ones
     const float fN = (float)nv, m = fN * fN;
     const float n1 = ones, n0 = m - fN - ones;
     const float mean = m > 0.f ? (n0 * z0 + n1 * z1 + wave_sum(szd)) / m : 0.f;
@@ -190,43 +330,49 @@ DEVI ClassVals<NWD> sb_class_values(const float *tab_m, const GraphBits<NWD> &B,
     const float m2 = n0 * d0 * d0 + n1 * d1 * d1 + wave_sum(sdd);
     ClassVals<NWD> v;
     v.rec = nrm_record(mean, m2, m, fN, gnw, eps);
-    const float u0 = (z0 - mean) * v.rec.y + beta, u1 = (z1 - mean) * v.rec.y + beta;
+    const float u0 = sb_r((y0 - mean) * v.rec.y + beta, bf), u1 = sb_r((y1 - mean) * v.rec.y + beta, bf);
     v.u0 = u0;
     v.p = u1 - u0;
 #pragma unroll
     for (int k = 0; k < NWD; ++k) {
-        const int vx = lane + 64 * k;
-        const float e = (zd[k] - mean) * v.rec.y + beta;
-        v.q[k] = vx < nv ? e - u0 - v.p * (float)B.wii[vx] : 0.f;
+        const float e = sb_r((yd[k] - mean) * v.rec.y + beta, bf);
+        v.q[k] = lane + 64 * k < nv ? e - u0 - v.p * (float)__float_as_int(vi[k].z) : 0.f;
     }
     return v;
 }
 
-// ---- K1: GraphNorm records of mlp1 / mlp2 + mult = Y1 Y2 in closed form ---------------------------------------------------
-// grid (G, SB_CG), 256 threads: a workgroup writes SB_CPG channels of one graph
-template <int NWD>
-__global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned *bits, const int *nvalid, const int N, const float *tab, const float *gnw1,
-                                                     const float *gnb1, const float *gnw2, const float *gnb2, const float eps, float *nrm1,
-                                                     float *nrm2, float *mult, const long long gstride, const long long ldp, float *xdeg) {
+// ---- K1: GraphNorm records of mlp1 / mlp2 + mult = Y1 Y2 in closed form, row by row ------------------------------
+// grid (G, SB_CG, parts), 256 threads: a workgroup writes SB_CPG channels; wave w takes the rows w + 4 part, + 4 parts, ...; a
+// lane owns fixed columns and keeps their per-channel terms in registers, the row terms are wave-uniform:
+//     mult_c[i][j] = [k0 + k2 degr_i + v0 q_i] + [k1 degc_j + u0 s_j] + k3 (W^2)_ij + w_ij (p s_j + r q_i) + [i = j] q_i s_i
+// fp32 slabs: lane <-> columns lane + 64 t; bf16 slabs: lane <-> column pairs 2 lane + 128 t (one dword per store)
+template <int NWD, bool BF>
+__global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code, const float4 *vinfo, const float *gones, const int *nvalid,
+                                                      const int N, const int cp, const float *tab, const float *gnw1, const float *gnb1,
+                                                      const float *gnw2, const float *gnb2, const float eps, float *nrm1, float *nrm2, void *mult,
+                                                      const long long gstride, const long long ldp, const int pitch) {
     constexpr int MAXN = 64 * NWD;
-    __shared__ GraphBits<NWD> B;
-    __shared__ float sc[SB_CPG][8];                    // u0, p, v0, r per channel
+    constexpr int NT = BF ? (NWD >= 2 ? NWD / 2 : 1) : NWD;      // column slots per lane
+    constexpr int CW = BF ? 2 : 1;                               // columns per slot
+    __shared__ float sc[SB_CPG][4];                              // u0, p, v0, r per channel
     __shared__ float Q[SB_CPG][MAXN], S[SB_CPG][MAXN];
-    const int g = blockIdx.x, cg = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ float DR[MAXN], DC[MAXN];
+    const int g = blockIdx.x, cg = blockIdx.y, part = blockIdx.z, nparts = gridDim.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N);
-    sb_bits_rows(B, bits, g, tid, N, nv);
-    __syncthreads();
-    sb_bits_cols(B, tid, nv);
-    __syncthreads();
-    if (xdeg && cg == 0 && tid < N) xdeg[(long long)g * N + tid] = tid < MAXN ? B.degr[tid] : 0.f;      // what fgnn_adjacency_degree would write
     const int NC = sb_classes(N);
     {   // wave wv owns channel cg * SB_CPG + wv of both models
+        float4 vi[NWD];
+#pragma unroll
+        for (int k = 0; k < NWD; ++k) vi[k] = lane + 64 * k < nv ? vinfo[(long long)g * N + lane + 64 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ones = gones[g];
         const int c = cg * SB_CPG + wv;
-        const ClassVals<NWD> a = sb_class_values(tab, B, nv, c, gnw1[c], gnb1[c], eps, lane);
-        const ClassVals<NWD> b = sb_class_values(tab + (long long)NC * SB_TAB, B, nv, c, gnw2[c], gnb2[c], eps, lane);
-        if (lane == 0) {
+        const ClassVals<NWD> a = sb_class_values(tab, vi, ones, nv, c, gnw1[c], gnb1[c], eps, lane, BF ? 1 : 0);
+        const ClassVals<NWD> b = sb_class_values(tab + (long long)NC * SB_TAB, vi, ones, nv, c, gnw2[c], gnb2[c], eps, lane, BF ? 1 : 0);
+        if (lane == 0 && part == 0) {
             reinterpret_cast<float4 *>(nrm1)[(long long)g * FGNN_H + c] = a.rec;
             reinterpret_cast<float4 *>(nrm2)[(long long)g * FGNN_H + c] = b.rec;
+        }
+        if (lane == 0) {
             sc[wv][0] = a.u0;
             sc[wv][1] = a.p;
             sc[wv][2] = b.u0;
@@ -236,100 +382,201 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned *bits, const
         for (int k = 0; k < NWD; ++k) {
             Q[wv][lane + 64 * k] = a.q[k];
             S[wv][lane + 64 * k] = b.q[k];
+            if (wv == 0) {
+                DR[lane + 64 * k] = vi[k].x;
+                DC[lane + 64 * k] = vi[k].y;
+            }
         }
     }
     __syncthreads();
-    const int P = N * N;
     const float fN = (float)nv;
-    float k0[SB_CPG], k1[SB_CPG], k2[SB_CPG], k3[SB_CPG], u0[SB_CPG], pp[SB_CPG], v0[SB_CPG], rr[SB_CPG];
+    float k0[SB_CPG], k2[SB_CPG], k3[SB_CPG], v0[SB_CPG], rr[SB_CPG];
+    float colc[SB_CPG][NT * CW], psv[SB_CPG][NT * CW], sv[SB_CPG][NT * CW];
+    int col[NT * CW];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int h = 0; h < CW; ++h) col[t * CW + h] = BF ? 2 * lane + 128 * t + h : lane + 64 * t;
 #pragma unroll
     for (int k = 0; k < SB_CPG; ++k) {
-        u0[k] = sc[k][0];
-        pp[k] = sc[k][1];
+        const float u0 = sc[k][0], pp = sc[k][1];
         v0[k] = sc[k][2];
         rr[k] = sc[k][3];
-        k0[k] = u0[k] * v0[k] * fN;
-        k1[k] = u0[k] * rr[k];
-        k2[k] = pp[k] * v0[k];
-        k3[k] = pp[k] * rr[k];
+        k0[k] = u0 * v0[k] * fN;
+        k2[k] = pp * v0[k];
+        k3[k] = pp * rr[k];
+        const float k1 = u0 * rr[k];
+#pragma unroll
+        for (int e = 0; e < NT * CW; ++e) {
+            const int j = col[e] < MAXN ? col[e] : 0;
+            sv[k][e] = S[k][j];
+            colc[k][e] = k1 * DC[j] + u0 * sv[k][e];
+            psv[k][e] = pp * sv[k][e];
+        }
     }
-    float *out = mult + (long long)g * gstride + (long long)cg * SB_CPG * ldp;
-    for (int p = tid; p < P; p += 256) {
-        const int i = p / N, j = p - i * N;
-        if (i < nv && j < nv) {
-            const float w = sb_w(B, i, j) ? 1.f : 0.f;
-            const float w2 = (float)sb_w2(B, i, j);
-            const float dc = B.degc[j], dr = B.degr[i];
-            const bool dg = i == j;
+    const unsigned short *cg16 = code + (long long)g * N * cp;
+    float *out32 = reinterpret_cast<float *>(mult) + (BF ? 0 : (long long)g * gstride + (long long)cg * SB_CPG * ldp);
+    unsigned *out16 = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(mult) + (BF ? (long long)g * gstride + (long long)cg * SB_CPG * ldp : 0));
+    constexpr int RU = 2;                                        // rows in flight per wave
+    for (int i0 = part * 4 + wv; i0 < N; i0 += 4 * nparts * RU) {
+        unsigned cd[RU][NT];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + 4 * nparts * u;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int j = col[t * CW];
+                if constexpr (BF) cd[u][t] = (i < nv && j < cp) ? *reinterpret_cast<const unsigned *>(cg16 + (long long)i * cp + j) : 0u;
+                else cd[u][t] = (i < nv && j < nv) ? (unsigned)cg16[(long long)i * cp + j] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + 4 * nparts * u;
+            if (i >= N) break;
+            const bool rowon = i < nv;
+            const int ii = rowon ? i : 0;
+            const float dr = DR[ii];
+            float rowc[SB_CPG], rq[SB_CPG], qk[SB_CPG];
 #pragma unroll
             for (int k = 0; k < SB_CPG; ++k) {
-                const float q = Q[k][i], s = S[k][j];
-                float v = k0[k] + k1[k] * dc + u0[k] * s + k2[k] * dr + k3[k] * w2 + v0[k] * q;
-                v += w * (pp[k] * s + rr[k] * q);
-                if (dg) v += q * s;
-                out[(long long)k * ldp + p] = v;
+                qk[k] = Q[k][ii];
+                rowc[k] = k0[k] + k2[k] * dr + v0[k] * qk[k];
+                rq[k] = rr[k] * qk[k];
             }
-        } else {                      // padding of a ragged graph: exact zeros, as the generic product leaves them
 #pragma unroll
-            for (int k = 0; k < SB_CPG; ++k) out[(long long)k * ldp + p] = 0.f;
+            for (int t = 0; t < NT; ++t) {
+                float val[SB_CPG][CW];
+#pragma unroll
+                for (int h = 0; h < CW; ++h) {
+                    const int e = t * CW + h, j = col[e];
+                    const unsigned c16 = (cd[u][t] >> (16 * h)) & 0xffffu;
+                    const float w2f = (float)(c16 & 0x7fffu);
+                    const bool w = c16 >> 15, on = rowon && j < nv;
+#pragma unroll
+                    for (int k = 0; k < SB_CPG; ++k) {
+                        float v = rowc[k] + colc[k][e];
+                        v = fmaf(k3[k], w2f, v);
+                        if (w) v += psv[k][e] + rq[k];
+                        if (j == i) v = fmaf(qk[k], sv[k][e], v);
+                        val[k][h] = on ? v : 0.f;
+                    }
+                }
+                const int j = col[t * CW];
+                if constexpr (BF) {
+                    if (j < pitch)
+#pragma unroll
+                        for (int k = 0; k < SB_CPG; ++k) out16[((long long)k * ldp + (long long)i * pitch + j) / 2] = cvt_pk(val[k][0], val[k][1]);
+                } else {
+                    if (j < N)
+#pragma unroll
+                        for (int k = 0; k < SB_CPG; ++k) out32[(long long)k * ldp + (long long)i * N + j] = val[k][0];
+                }
+            }
         }
+    }
+    if constexpr (BF) {
+        if (part == 0)                                           // tail of the channel stride
+            for (int e = N * pitch / 2 + tid; e < (int)(ldp / 2); e += 256)
+#pragma unroll
+                for (int k = 0; k < SB_CPG; ++k) out16[((long long)k * ldp) / 2 + e] = 0u;
     }
 }
 
-// ---- K2: class sums of dY1 = dM Y2^T and dY2 = Y1^T dM from one pass over dM = d(mult) ------------------------------------
-// One 256-thread workgroup per (g, c) plane.  Wave w takes rows w, w + 4, ...: lanes = columns (lane + 64 k), the row sums are
-// wave reductions, the column sums stay per lane and are combined over the four waves in a fixed order.  csum[m][g][c][0] =
-// off-diagonal w = 0, [1] = off-diagonal w = 1, [2 + i] = (i, i).
+// ---- K2: class sums of dY1 = dM Y2^T and dY2 = Y1^T dM from one pass over dM, + the GraphNorm-backward sums ------
+// One workgroup of 4 (N <= 128) or 8 waves per (g, c) plane (wave w: rows w, w + waves, ...; lane: NWD consecutive columns, one load per row
+// and operand); the masks and (W^2)_ij come from the code plane.  The last
+// wave also forms S1 = sum dY, S2 = sum dY (z - mean) of both models (s12, for fgnn_grad_finalize) and the coefficients of
+// dz_p = ca dy_p + cb (z_p - mean) + cc   the class algebra applies: coef[m][g][c] = {ca, cb, cc, mean}
+// NWD consecutive floats at a 4-byte aligned address as one load
 template <int NWD>
-__global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits, const int *nvalid, const int G, const int N, const float *tab,
-                                                            const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
-                                                            const float *dm, const long long gstride, const long long ldp, float *csum) {
-    constexpr int MAXN = 64 * NWD, CS = 2 + MAXN;
-    __shared__ GraphBits<NWD> B;
-    __shared__ float colp[4][3][MAXN];                  // per wave: C, Qm, U per column
+struct __attribute__((packed, aligned(4))) SbFloats {
+    float v[NWD];
+};
+// (NWD + 1) / 2 dwords holding NWD consecutive 16-bit values
+template <int NWD>
+DEVI void sb_load16_packed(const unsigned short *p, unsigned (&o)[(NWD + 1) / 2]) {
+    if constexpr (NWD == 4) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        o[0] = v.x;
+        o[1] = v.y;
+    } else if constexpr (NWD == 2) {
+        o[0] = *reinterpret_cast<const unsigned *>(p);
+    } else {
+        o[0] = *p;
+    }
+}
+template <int NWD>
+constexpr int sb_reduce_waves() { return NWD == 4 ? 8 : 4; }      // (8 waves measured slower for N <= 128)
+template <int NWD, bool BF>
+__global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_kernel(
+    const unsigned short *code, const float4 *vinfo, const int *nvalid, const int G, const int N, const int cp, const float *tab, const float *nrm1,
+    const float *nrm2, const float *gnb1, const float *gnb2, const void *dm, const long long gstride, const long long ldp, const int pitch, float *csum,
+    float *s12_1, float *s12_2, float4 *coef) {
+    constexpr int MAXN = 64 * NWD, CS = 2 + MAXN, NW = sb_reduce_waves<NWD>();
+    __shared__ float colp[NW][3][MAXN];                 // per wave: C, Qm, U per column
     __shared__ float Rs[MAXN], Ps[MAXN], Dg[MAXN];      // per row: sum, W-masked sum, diagonal entry
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int pl = blockIdx.x, g = pl / FGNN_H, c = pl - g * FGNN_H;
     const int nv = nvalid_of(nvalid, g, N);
-    // the records and class rows this plane needs are requested before the bit rows are processed
     const float4 ra = reinterpret_cast<const float4 *>(nrm1)[(long long)g * FGNN_H + c];
     const float4 rb = reinterpret_cast<const float4 *>(nrm2)[(long long)g * FGNN_H + c];
     const float ba = gnb1[c], bb = gnb2[c];
-    sb_bits_rows(B, bits, g, tid, N, nv);
-    __syncthreads();
-    sb_bits_cols(B, tid, nv);
-    __syncthreads();
-    const float *src = dm + (long long)g * gstride + (long long)c * ldp;
+    const float *src = reinterpret_cast<const float *>(dm) + (BF ? 0 : (long long)g * gstride + (long long)c * ldp);
+    const unsigned short *src16 = reinterpret_cast<const unsigned short *>(dm) + (BF ? (long long)g * gstride + (long long)c * ldp : 0);
+    const unsigned short *cg16 = code + (long long)g * N * cp;
+    // lane <-> the NWD consecutive columns NWD lane + t: one load per row and operand
+    const int j0 = NWD * lane;
+    const bool lane_on = j0 < nv;
     float C[NWD], Qm[NWD], U[NWD];
 #pragma unroll
     for (int k = 0; k < NWD; ++k) C[k] = Qm[k] = U[k] = 0.f;
-    for (int i0 = wv; i0 < nv; i0 += 16) {               // four rows of this wave per memory round trip
-        float v[4][NWD];
+    constexpr int RU = NWD == 4 ? 8 : 4;                 // rows of this wave per memory round trip
+    constexpr int XW = BF ? (NWD + 1) / 2 : NWD;         // dwords of a lane's row segment of d(mult)
+    for (int i0 = wv; i0 < nv; i0 += NW * RU) {
+        unsigned xr[RU][XW], cr[RU][(NWD + 1) / 2];      // kept packed until used
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + NW * u;
 #pragma unroll
-            for (int k = 0; k < NWD; ++k) {
-                const int i = i0 + 4 * u, j = lane + 64 * k;
-                v[u][k] = (i < nv && j < nv) ? src[i * N + j] : 0.f;
+            for (int k = 0; k < XW; ++k) xr[u][k] = 0u;
+#pragma unroll
+            for (int k = 0; k < (NWD + 1) / 2; ++k) cr[u][k] = 0u;
+            if (i < nv && lane_on) {
+                sb_load16_packed<NWD>(cg16 + (long long)i * cp + j0, cr[u]);     // cp is a multiple of 8: the vector stays inside the row
+                if constexpr (BF) {
+                    sb_load16_packed<NWD>(src16 + (long long)i * pitch + j0, xr[u]);      // pitch is a multiple of 8
+                } else if (i < N - 1) {                  // (wave-uniform) a lane's vector may run into the next row of the plane, not past it
+                    const SbFloats<NWD> f = *reinterpret_cast<const SbFloats<NWD> *>(src + (long long)i * pitch + j0);
+#pragma unroll
+                    for (int k = 0; k < NWD; ++k) xr[u][k] = __float_as_uint(f.v[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NWD; ++k) xr[u][k] = j0 + k < N ? __float_as_uint(src[(long long)i * pitch + j0 + k]) : 0u;
+                }
             }
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 4 * u;
+        for (int u = 0; u < RU; ++u) {
+            const int i = i0 + NW * u;
             if (i < nv) {
                 float rs = 0.f, rm = 0.f;
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) {
-                    const int j = lane + 64 * k;
-                    const float x = v[u][k];
-                    const bool wij = (B.row[i][k] >> lane) & 1ull;
+                    const bool on = j0 + k < nv;
+                    const unsigned cd = on ? (cr[u][k >> 1] >> (16 * (k & 1))) & 0xffffu : 0u;
+                    float x;
+                    if constexpr (BF) x = __uint_as_float((xr[u][k >> 1] >> (16 * (k & 1))) << 16);
+                    else x = __uint_as_float(xr[u][k]);
+                    x = on ? x : 0.f;
                     C[k] += x;
                     rs += x;
-                    if (wij) {
+                    if (cd >> 15) {
                         Qm[k] += x;
                         rm += x;
                     }
-                    U[k] += x * (float)sb_w2(B, i, j < MAXN ? j : 0);
-                    if (j == i) Dg[i] = x;
+                    U[k] = fmaf(x, (float)(cd & 0x7fffu), U[k]);
+                    if (j0 + k == i) Dg[i] = x;
                 }
                 rs = wave_sum(rs);
                 rm = wave_sum(rm);
@@ -342,350 +589,286 @@ __global__ __launch_bounds__(256) void sb_bwd_reduce_kernel(const unsigned *bits
     }
 #pragma unroll
     for (int k = 0; k < NWD; ++k) {
-        colp[wv][0][lane + 64 * k] = C[k];
-        colp[wv][1][lane + 64 * k] = Qm[k];
-        colp[wv][2][lane + 64 * k] = U[k];
+        colp[wv][0][j0 + k] = C[k];
+        colp[wv][1][j0 + k] = Qm[k];
+        colp[wv][2][j0 + k] = U[k];
     }
     __syncthreads();
-    if (wv != 0) return;
-    // wave 0: lane l owns the vertices l + 64 k
+    // wave k < NWD: lane l owns vertex l + 64 k; the partial sums of the NWD waves meet in LDS (fixed order), wave 0 finishes
+    __shared__ float fin[NWD][16];
     const int NC = sb_classes(N);
     const float *ta = tab, *tb = tab + (long long)NC * SB_TAB;
-    const float u0 = (ta[2 * FGNN_H + c] - ra.x) * ra.y + ba, u1 = (ta[SB_TAB + 2 * FGNN_H + c] - ra.x) * ra.y + ba;
-    const float v0 = (tb[2 * FGNN_H + c] - rb.x) * rb.y + bb, v1 = (tb[SB_TAB + 2 * FGNN_H + c] - rb.x) * rb.y + bb;
+    constexpr int bf = BF ? 1 : 0;
+    const float za0 = ta[3 * FGNN_H + c] - ra.x, za1 = ta[SB_TAB + 3 * FGNN_H + c] - ra.x;           // z (as stored) - mean
+    const float zb0 = tb[3 * FGNN_H + c] - rb.x, zb1 = tb[SB_TAB + 3 * FGNN_H + c] - rb.x;
+    const float u0 = sb_r(za0 * ra.y + ba, bf), u1 = sb_r(za1 * ra.y + ba, bf);
+    const float v0 = sb_r(zb0 * rb.y + bb, bf), v1 = sb_r(zb1 * rb.y + bb, bf);
     const float p = u1 - u0, r = v1 - v0;
     const float fN = (float)nv;
-    float sC = 0.f, sU = 0.f, sCdc = 0.f, sCs = 0.f, sRdr = 0.f, sQs = 0.f, sqR = 0.f, sqP = 0.f, sd1 = 0.f, swd1 = 0.f, sd2 = 0.f, swd2 = 0.f;
-    float d1[NWD], d2[NWD];
-#pragma unroll
-    for (int k = 0; k < NWD; ++k) {
-        const int vx = lane + 64 * k;
-        const bool on = vx < nv;
-        const int cl = B.cls[on ? vx : 0];
-        const float wii = on ? (float)B.wii[vx] : 0.f;
-        const float q = on ? ((ta[cl * SB_TAB + 2 * FGNN_H + c] - ra.x) * ra.y + ba) - u0 - p * wii : 0.f;
-        const float s = on ? ((tb[cl * SB_TAB + 2 * FGNN_H + c] - rb.x) * rb.y + bb) - v0 - r * wii : 0.f;
-        const float Cj = (colp[0][0][vx] + colp[1][0][vx]) + (colp[2][0][vx] + colp[3][0][vx]);
-        const float Qj = (colp[0][1][vx] + colp[1][1][vx]) + (colp[2][1][vx] + colp[3][1][vx]);
-        const float Uj = (colp[0][2][vx] + colp[1][2][vx]) + (colp[2][2][vx] + colp[3][2][vx]);
-        const float R = on ? Rs[vx] : 0.f, Pm = on ? Ps[vx] : 0.f, dg = on ? Dg[vx] : 0.f;
-        const float degr = on ? B.degr[vx] : 0.f, degc = on ? B.degc[vx] : 0.f;
-        sC += Cj;
-        sU += Uj;
-        sCdc += Cj * degc;
-        sCs += Cj * s;
-        sRdr += R * degr;
-        sQs += Qj * s;
-        sqR += q * R;
-        sqP += q * Pm;
-        d1[k] = on ? v0 * R + r * Pm + dg * s : 0.f;             // dA_ii = v0 R_i + r (dM W^T)_ii + dM_ii s_i
-        d2[k] = on ? u0 * Cj + p * Qj + q * dg : 0.f;            // dB_ii = u0 C_i + p (W^T dM)_ii + q_i dM_ii
-        sd1 += d1[k];
-        swd1 += wii * d1[k];
-        sd2 += d2[k];
-        swd2 += wii * d2[k];
-    }
-    const float Tt = wave_sum(sC), Ut = wave_sum(sU);
-    sCdc = wave_sum(sCdc);
-    sRdr = wave_sum(sRdr);
-    // mlp1: dA = dM Y2^T,  dA_ij = v0 R_i + r (dM W^T)_ij + dM_ij s_j
-    const float tot1 = v0 * fN * Tt + r * sCdc + wave_sum(sCs);
-    const float sw1 = v0 * sRdr + r * Ut + wave_sum(sQs);
-    sd1 = wave_sum(sd1);
-    swd1 = wave_sum(swd1);
-    // mlp2: dB = Y1^T dM,  dB_ij = u0 C_j + p (W^T dM)_ij + q_i dM_ij
-    const float tot2 = u0 * fN * Tt + p * sRdr + wave_sum(sqR);
-    const float sw2 = u0 * sCdc + p * Ut + wave_sum(sqP);
-    sd2 = wave_sum(sd2);
-    swd2 = wave_sum(swd2);
     float *o1 = csum + ((long long)g * FGNN_H + c) * CS;
     float *o2 = csum + (((long long)G + g) * FGNN_H + c) * CS;
-    if (lane == 0) {
-        const float off11 = sw1 - swd1, off12 = sw2 - swd2;
-        o1[0] = tot1 - sd1 - off11;
-        o1[1] = off11;
-        o2[0] = tot2 - sd2 - off12;
-        o2[1] = off12;
-    }
+    float t[14];
+    if (wv < NWD) {
+        const int vx = lane + 64 * wv;
+        const bool on = vx < nv;
+        const float4 vi = on ? vinfo[(long long)g * N + vx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cl = __float_as_int(vi.w);
+        const float wii = (float)__float_as_int(vi.z);
+        const float za = on ? ta[cl * SB_TAB + 3 * FGNN_H + c] - ra.x : 0.f, zb = on ? tb[cl * SB_TAB + 3 * FGNN_H + c] - rb.x : 0.f;
+        const float q = on ? sb_r(za * ra.y + ba, bf) - u0 - p * wii : 0.f;
+        const float s = on ? sb_r(zb * rb.y + bb, bf) - v0 - r * wii : 0.f;
+        float Cj = (colp[0][0][vx] + colp[1][0][vx]) + (colp[2][0][vx] + colp[3][0][vx]);
+        float Qj = (colp[0][1][vx] + colp[1][1][vx]) + (colp[2][1][vx] + colp[3][1][vx]);
+        float Uj = (colp[0][2][vx] + colp[1][2][vx]) + (colp[2][2][vx] + colp[3][2][vx]);
+        if constexpr (NW == 8) {
+            Cj += (colp[4][0][vx] + colp[5][0][vx]) + (colp[6][0][vx] + colp[7][0][vx]);
+            Qj += (colp[4][1][vx] + colp[5][1][vx]) + (colp[6][1][vx] + colp[7][1][vx]);
+            Uj += (colp[4][2][vx] + colp[5][2][vx]) + (colp[6][2][vx] + colp[7][2][vx]);
+        }
+        const float R = on ? Rs[vx] : 0.f, Pm = on ? Ps[vx] : 0.f, dg = on ? Dg[vx] : 0.f;
+        const float degr = vi.x, degc = vi.y;
+        const float d1 = on ? v0 * R + r * Pm + dg * s : 0.f;             // dA_ii = v0 R_i + r (dM W^T)_ii + dM_ii s_i
+        const float d2 = on ? u0 * Cj + p * Qj + q * dg : 0.f;            // dB_ii = u0 C_i + p (W^T dM)_ii + q_i dM_ii
+        o1[2 + vx] = d1;
+        o2[2 + vx] = d2;
+        const float part[14] = {Cj, Uj, Cj * degc, Cj * s, R * degr, Qj * s, q * R, q * Pm, d1, wii * d1, d2, wii * d2, d1 * za, d2 * zb};
 #pragma unroll
-    for (int k = 0; k < NWD; ++k) {
-        o1[2 + lane + 64 * k] = d1[k];
-        o2[2 + lane + 64 * k] = d2[k];
+        for (int e = 0; e < 14; ++e) {
+            t[e] = wave_sum(part[e]);
+            if (NWD > 1 && lane == 0) fin[wv][e] = t[e];
+        }
+    }
+    if constexpr (NWD > 1) {
+        __syncthreads();
+        if (wv != 0) return;
+#pragma unroll
+        for (int e = 0; e < 14; ++e) {
+            t[e] = fin[0][e];
+#pragma unroll
+            for (int w = 1; w < NWD; ++w) t[e] += fin[w][e];
+        }
+    } else if (wv != 0) {
+        return;
+    }
+    if (lane == 0) {
+        const float Tt = t[0], Ut = t[1], sCdc = t[2], sCs = t[3], sRdr = t[4], sQs = t[5], sqR = t[6], sqP = t[7];
+        const float sd1 = t[8], swd1 = t[9], sd2 = t[10], swd2 = t[11], sz1 = t[12], sz2 = t[13];
+        // mlp1: dA = dM Y2^T,  dA_ij = v0 R_i + r (dM W^T)_ij + dM_ij s_j
+        const float tot1 = v0 * fN * Tt + r * sCdc + sCs;
+        const float sw1 = v0 * sRdr + r * Ut + sQs;
+        // mlp2: dB = Y1^T dM,  dB_ij = u0 C_j + p (W^T dM)_ij + q_i dM_ij
+        const float tot2 = u0 * fN * Tt + p * sRdr + sqR;
+        const float sw2 = u0 * sCdc + p * Ut + sqP;
+        const float off11 = sw1 - swd1, off12 = sw2 - swd2;
+        const float off01 = tot1 - sd1 - off11, off02 = tot2 - sd2 - off12;
+        o1[0] = off01;
+        o1[1] = off11;
+        o2[0] = off02;
+        o2[1] = off12;
+        const float s1a = (off01 + off11) + sd1, s2a = (off01 * za0 + off11 * za1) + sz1;
+        const float s1b = (off02 + off12) + sd2, s2b = (off02 * zb0 + off12 * zb1) + sz2;
+        const float mm = fN * fN;
+        reinterpret_cast<float2 *>(s12_1)[(long long)g * FGNN_H + c] = make_float2(s1a, s2a);
+        reinterpret_cast<float2 *>(s12_2)[(long long)g * FGNN_H + c] = make_float2(s1b, s2b);
+        coef[(long long)g * FGNN_H + c] = make_float4(ra.y, mm > 0.f ? -ra.y * s2a * ra.w / mm : 0.f, mm > 0.f ? -ra.y * s1a / mm : 0.f, ra.x);
+        coef[((long long)G + g) * FGNN_H + c] = make_float4(rb.y, mm > 0.f ? -rb.y * s2b * rb.w / mm : 0.f, mm > 0.f ? -rb.y * s1b / mm : 0.f, rb.x);
     }
 }
 
-#ifdef SB_STAMPS
-__device__ unsigned long long *g_sb_stamps = nullptr;
-#define SB_STAMP(i) if (threadIdx.x == 0 && g_sb_stamps) g_sb_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime();
-#else
-#define SB_STAMP(i)
-#endif
-// ---- K3: per graph and model, class sums -> GraphNorm backward -> conv / ReLU chain per class -> parameter gradients --------
-// grid (G, 2), 256 threads; writes row g of wpart[m] ([W0 (32x2) | b0 | W1 | b1 | W2 | b2], the layout of fgnn_mlp_bwd) and
-// s12[m][g][c] = {S1, S2} (the GraphNorm-backward sums fgnn_grad_finalize turns into the affine gradients)
+// ---- K3: the class algebra, KC instances per round, the rounds of a graph spread over wpg workgroups --------------
+// grid (G wpg, 2), 256 threads: workgroup (g, w) of model m takes the instance chunks w, w + wpg, ... of graph g (instance 0 / 1 =
+// the off-diagonal classes, 2 + v = vertex v) and writes row g wpg + w of wpart[m]
 struct ParArgs {
     const float *W[2][3];
     float *wpart[2];
-    float *s12[2];
-    const float *nrm[2];
+    int bf;
 };
-template <int NWD>
-__global__ __launch_bounds__(256) void sb_bwd_params_kernel(const unsigned *bits, const int *nvalid, const int G, const int N, const float *tab,
-                                                            const float *csum, const ParArgs A) {
-    constexpr int MAXN = 64 * NWD, CS = 2 + MAXN;
-    constexpr int KMAX = MAXN + 2;                      // class instances of a graph: the two off-diagonal classes + one per vertex
-    extern __shared__ __attribute__((aligned(16))) float sb_lds[];
-    __shared__ GraphBits<NWD> B;
-    __shared__ float coef[FGNN_H][4];                   // ca, cb, cc per channel
-    __shared__ float cnt[KMAX];                         // pixels per instance
-    float *Wt = sb_lds;                                 // [2][32 * 32]: W1, W2 of this model
-    float (*CSs)[CS + 1] = reinterpret_cast<float (*)[CS + 1]>(Wt + 2 * FGNN_H * FGNN_H);           // [32][CS + 1]: class sums [channel][instance]
-    float (*ZV)[FGNN_H] = reinterpret_cast<float (*)[FGNN_H]>(&CSs[FGNN_H][0]);                      // [KMAX][32]: z - mean of the instance's class
-    float (*HB)[2 * FGNN_H] = reinterpret_cast<float (*)[2 * FGNN_H]>(&ZV[KMAX][0]);                 // [KMAX][64]: h1 | h2
-    float (*DZ)[FGNN_H + 4] = reinterpret_cast<float (*)[FGNN_H + 4]>(&HB[KMAX][0]);                 // [KMAX][36] each: rows 16-byte aligned
-    float (*D2)[FGNN_H + 4] = DZ + KMAX;
-    float (*D1)[FGNN_H + 4] = D2 + KMAX;
-    const int g = blockIdx.x, m = blockIdx.y, tid = threadIdx.x;
+template <int KC>
+__global__ __launch_bounds__(256) void sb_bwd_params_kernel(const float4 *vinfo, const float *gones, const int *nvalid, const int G, const int N,
+                                                             const int CS, const float *tab, const float *csum, const float4 *coef,
+                                                             const ParArgs A, const int wpg) {
+    static_assert(KC % 8 == 0 && KC * FGNN_H % 256 == 0, "chunk size");
+    __shared__ __attribute__((aligned(16))) float Wt[2][FGNN_H * FGNN_H];      // W1, W2 of this model
+    __shared__ float CSs[FGNN_H][KC + 1];                                       // class sums [channel][instance]
+    __shared__ __attribute__((aligned(16))) float HB[KC][2 * FGNN_H];           // h1 | h2
+    __shared__ __attribute__((aligned(16))) float DZ[KC][FGNN_H + 4], D2[KC][FGNN_H + 4], D1[KC][FGNN_H + 4];
+    __shared__ float XI[KC][2];                                                 // the instance's input value (w, degree)
+    const int g = blockIdx.x / wpg, widx = blockIdx.x - g * wpg, m = blockIdx.y, tid = threadIdx.x;
     const int nv = nvalid_of(nvalid, g, N);
     const int NC = sb_classes(N), K = nv + 2;
     const float *tm = tab + (long long)m * NC * SB_TAB;
-    SB_STAMP(0)
-    // Everything this workgroup reads from memory is requested up front in explicitly unrolled batches (a rolled staging loop
-    // pays one memory round trip per iteration: DESIGN.md section 7, "Rolled staging loops")
-    sb_bits_rows(B, bits, g, tid, N, nv);
+    const int c = tid & 31, kq = tid >> 5;
     {
         float w[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            w[q] = A.W[m][1][tid + 256 * q];
-            w[4 + q] = A.W[m][2][tid + 256 * q];
+            w[q] = sb_r(A.W[m][1][tid + 256 * q], A.bf);
+            w[4 + q] = sb_r(A.W[m][2][tid + 256 * q], A.bf);
         }
-        constexpr int CSN = FGNN_H * CS, CSI = (CSN + 255) / 256;       // the (model, graph) block of csum is contiguous
-        const float *cs = csum + ((long long)m * G + g) * CSN;
-        float v[CSI];
-#pragma unroll
-        for (int q = 0; q < CSI; ++q) v[q] = cs[min(tid + 256 * q, CSN - 1)];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            Wt[tid + 256 * q] = w[q];
-            Wt[FGNN_H * FGNN_H + tid + 256 * q] = w[4 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < CSI; ++q) {
-            const int e = tid + 256 * q;
-            if (e < CSN) CSs[e / CS][e % CS] = v[q];
+            Wt[0][tid + 256 * q] = w[q];
+            Wt[1][tid + 256 * q] = w[4 + q];
         }
     }
-    SB_STAMP(1)
-    __syncthreads();
-    SB_STAMP(2)
-    if (tid < MAXN) {
-        sb_bits_vertex(B, tid);
-        cnt[2 + tid] = 1.f;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float on1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NWD; ++k) on1 += tid + 64 * k < nv ? B.degr[tid + 64 * k] - (float)B.wii[tid + 64 * k] : 0.f;
-        const float ones = wave_sum(on1);      // off-diagonal ones (threads 0..63 = wave 0)
-        const float fN = (float)nv;
-        if (tid == 0) {
-            cnt[0] = fN * fN - fN - ones;
-            cnt[1] = ones;
-        }
-    }
-    SB_STAMP(3)
-    {
-        // h1 | h2 | z of every instance's class: (instance, channel) pairs, KMAX * 32 / 256 per thread and array, loads first
-        constexpr int IT = (KMAX * FGNN_H + 255) / 256;
-        float v[3][IT];
-        const int c = tid & 31;
-        const float mean = reinterpret_cast<const float4 *>(A.nrm[m])[(long long)g * FGNN_H + c].x;
-#pragma unroll
-        for (int q = 0; q < IT; ++q) {
-            const int k = (tid >> 5) + 8 * q;
-            const int cl = k < 2 ? k : B.cls[k - 2 < nv ? k - 2 : 0];
-            const float *row = tm + (long long)cl * SB_TAB + c;
-            v[0][q] = row[0];
-            v[1][q] = row[FGNN_H];
-            v[2][q] = row[2 * FGNN_H];
-        }
-#pragma unroll
-        for (int q = 0; q < IT; ++q) {
-            const int k = (tid >> 5) + 8 * q;
-            if (k < K) {
-                HB[k][c] = v[0][q];
-                HB[k][FGNN_H + c] = v[1][q];
-                ZV[k][c] = v[2][q] - mean;
-            }
-        }
-    }
-    SB_STAMP(4)
-    __syncthreads();
-    SB_STAMP(5)
-    {
-        // S1 = sum_k S_k, S2 = sum_k S_k (z_k - mean): 8 threads per channel, fixed partition and tree
-        const int c = tid >> 3, s8 = tid & 7;
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = s8; k < K; k += 8) {
-            s1 += CSs[c][k];
-            s2 += CSs[c][k] * ZV[k][c];
-        }
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
-            s1 += __shfl_xor(s1, d);
-            s2 += __shfl_xor(s2, d);
-        }
-        if (s8 == 0) {
-            const float4 rec = reinterpret_cast<const float4 *>(A.nrm[m])[(long long)g * FGNN_H + c];
-            const float fN = (float)nv, mm = fN * fN;
-            reinterpret_cast<float2 *>(A.s12[m])[(long long)g * FGNN_H + c] = make_float2(s1, s2);
-            // dz_p = ca dy_p + cb (z_p - mean) + cc  
-            coef[c][0] = rec.y;
-            coef[c][1] = mm > 0.f ? -rec.y * s2 * rec.w / mm : 0.f;
-            coef[c][2] = mm > 0.f ? -rec.y * s1 / mm : 0.f;
-        }
-    }
-    __syncthreads();
-    SB_STAMP(6)
-    // dz summed over the pixels of an instance: ca S_k + n_k (cb (z_k - mean) + cc)
-    for (int e = tid; e < K * FGNN_H; e += 256) {
-        const int k = e >> 5, c = e & 31;
-        DZ[k][c] = coef[c][0] * CSs[c][k] + cnt[k] * (coef[c][1] * ZV[k][c] + coef[c][2]);
-    }
-    __syncthreads();
-    SB_STAMP(7)
-    // dpre2 = (W2^T dz) masked by h2, then dpre1 = (W1^T dpre2) masked by h1, every instance at once: thread (k mod 8, c) keeps
-    // column c of the transposed weight in registers and reads an instance's vector with 128-bit broadcast loads
-    {
-        const int c = tid & 31, k0 = tid >> 5;
-        float wc[FGNN_H];
-#pragma unroll
-        for (int oo = 0; oo < FGNN_H; ++oo) wc[oo] = Wt[FGNN_H * FGNN_H + oo * FGNN_H + c];
-        for (int k = k0; k < K; k += 8) {
-            const float4 *dz = reinterpret_cast<const float4 *>(DZ[k]);
-            float a = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = dz[q];
-                a = fmaf(wc[4 * q + 0], v.x, a);
-                a = fmaf(wc[4 * q + 1], v.y, a);
-                a = fmaf(wc[4 * q + 2], v.z, a);
-                a = fmaf(wc[4 * q + 3], v.w, a);
-            }
-            D2[k][c] = HB[k][FGNN_H + c] > 0.f ? a : 0.f;
-        }
-        SB_STAMP(8)
-        __syncthreads();
-#pragma unroll
-        for (int oo = 0; oo < FGNN_H; ++oo) wc[oo] = Wt[oo * FGNN_H + c];
-        for (int k = k0; k < K; k += 8) {
-            const float4 *d2 = reinterpret_cast<const float4 *>(D2[k]);
-            float a = 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = d2[q];
-                a = fmaf(wc[4 * q + 0], v.x, a);
-                a = fmaf(wc[4 * q + 1], v.y, a);
-                a = fmaf(wc[4 * q + 2], v.z, a);
-                a = fmaf(wc[4 * q + 3], v.w, a);
-            }
-            D1[k][c] = HB[k][c] > 0.f ? a : 0.f;
-        }
-    }
-    __syncthreads();
-    SB_STAMP(9)
-    // Gradients = sums over the instances.  Wave 0: dW2 = sum_k dz_k (x) h2_k and wave 1: dW1 = sum_k dpre2_k (x) h1_k as 32 x 32 x K
-    // products on v_mfma_f32_32x32x2_f32 (exact fp32 fma chains in instance order; lane (j, h) supplies row k = 2 s + h of both
-    // operands, an odd K is padded with a zero row); waves 2, 3: the 2-column dW0 and two of the bias gradients, eight instances
-    // per LDS round trip; the third bias gradient after wave 0's product.
-    constexpr int PC = 32 * 2 + 32 + 2 * (32 * 32 + 32);
-    float *row = A.wpart[m] + (long long)g * PC;
+    const float4 cf = coef[((long long)m * G + g) * FGNN_H + c];              // ca, cb, cc, mean of channel c
+    const float ones = gones[g], fN = (float)nv;
+    const float cnt0 = fN * fN - fN - ones, cnt1 = ones;
     const int wv = tid >> 6, lane = tid & 63, jj = lane & 31, hh = lane >> 5;
-    if (wv < 2) {
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float (*L)[FGNN_H + 4] = wv == 0 ? DZ : D2;
-        const int hoff = wv == 0 ? FGNN_H : 0;
-        constexpr int SB8 = 8;                           // k-steps requested per LDS round trip
-        for (int s0 = 0; 2 * s0 < K; s0 += SB8) {
-            float av[SB8], bv[SB8];
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f, ab2 = 0.f;
+    const float *cs = csum + ((long long)m * G + g) * FGNN_H * CS;
+#pragma unroll 1
+    for (int ch = widx; ch * KC < K; ch += wpg) {
+        const int kb = ch * KC, kn = min(KC, K - kb);
+        constexpr int IT = KC / 8;
+        float csv[IT], h1[IT], h2[IT], zv[IT], cntk[IT];
 #pragma unroll
-            for (int u = 0; u < SB8; ++u) {
-                const int k = 2 * (s0 + u) + hh;
-                const bool ok = k < K;
-                av[u] = ok ? L[ok ? k : 0][jj] : 0.f;
-                bv[u] = ok ? HB[ok ? k : 0][hoff + jj] : 0.f;
+        for (int q = 0; q < IT; ++q) {
+            {   // class sums: (channel, instance) = (e / KC, e % KC), contiguous over the instances of a channel
+                const int e = tid + 256 * q, c2 = e / KC, kl = e - c2 * KC;
+                csv[q] = kl < kn ? cs[(long long)c2 * CS + kb + kl] : 0.f;
+            }
+            const int kl = kq + 8 * q, k = kb + kl;
+            int cl = k;
+            float x0 = k == 1 ? 1.f : 0.f, x1 = 0.f;
+            cntk[q] = k == 0 ? cnt0 : (k == 1 ? cnt1 : 1.f);
+            if (k >= 2) {
+                const float4 vi = vinfo[(long long)g * N + (k < K ? k - 2 : 0)];
+                cl = __float_as_int(vi.w);
+                x0 = (float)__float_as_int(vi.z);
+                x1 = vi.x;
+            }
+            const float *row = tm + (long long)(k < K ? cl : 0) * SB_TAB + c;
+            h1[q] = row[0];
+            h2[q] = row[FGNN_H];
+            zv[q] = row[3 * FGNN_H] - cf.w;           // z as stored - mean
+            if (c == 0 && kl < kn) {
+                XI[kl][0] = x0;
+                XI[kl][1] = x1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int e = tid + 256 * q, c2 = e / KC, kl = e - c2 * KC;
+            CSs[c2][kl] = csv[q];
+            const int kl2 = kq + 8 * q;
+            HB[kl2][c] = h1[q];
+            HB[kl2][FGNN_H + c] = h2[q];
+        }
+        __syncthreads();
+        // dz summed over the pixels of an instance: ca S_k + n_k (cb (z_k - mean) + cc)
+#pragma unroll
+        for (int q = 0; q < IT; ++q) {
+            const int kl = kq + 8 * q;
+            DZ[kl][c] = kl < kn ? cf.x * CSs[c][kl] + cntk[q] * (cf.y * zv[q] + cf.z) : 0.f;
+        }
+        __syncthreads();
+        // dpre2 = (W2^T dz) masked by h2, then dpre1 = (W1^T dpre2) masked by h1: thread (k mod 8, c) keeps column c of the transposed
+        // weight in registers and reads an instance's vector with 128-bit broadcast loads
+        {
+            float wc[FGNN_H];
+#pragma unroll
+            for (int oo = 0; oo < FGNN_H; ++oo) wc[oo] = Wt[1][oo * FGNN_H + c];
+#pragma unroll
+            for (int q = 0; q < IT; ++q) {
+                const int k = kq + 8 * q;
+                const float4 *dz = reinterpret_cast<const float4 *>(DZ[k]);
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 v = dz[r];
+                    a = fmaf(wc[4 * r + 0], v.x, a);
+                    a = fmaf(wc[4 * r + 1], v.y, a);
+                    a = fmaf(wc[4 * r + 2], v.z, a);
+                    a = fmaf(wc[4 * r + 3], v.w, a);
+                }
+                D2[k][c] = (k < kn && h2[q] > 0.f) ? a : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int oo = 0; oo < FGNN_H; ++oo) wc[oo] = Wt[0][oo * FGNN_H + c];
+#pragma unroll
+            for (int q = 0; q < IT; ++q) {
+                const int k = kq + 8 * q;
+                const float4 *d2 = reinterpret_cast<const float4 *>(D2[k]);
+                float a = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 v = d2[r];
+                    a = fmaf(wc[4 * r + 0], v.x, a);
+                    a = fmaf(wc[4 * r + 1], v.y, a);
+                    a = fmaf(wc[4 * r + 2], v.z, a);
+                    a = fmaf(wc[4 * r + 3], v.w, a);
+                }
+                D1[k][c] = (k < kn && h1[q] > 0.f) ? a : 0.f;
+            }
+        }
+        __syncthreads();
+        // Gradients = sums over the instances (rows kn .. KC - 1 of DZ / D2 / D1 are zero).  Wave 0: dW2 += dz_k (x) h2_k, wave 1:
+        // dW1 += dpre2_k (x) h1_k on v_mfma_f32_32x32x2_f32 (lane (j, h) supplies row k = 2 s + h of both operands); waves 2, 3: the
+        // 2-column dW0 and two bias gradients; the third bias gradient by wave 0 after its product
+        if (wv < 2) {
+            const float (*L)[FGNN_H + 4] = wv == 0 ? DZ : D2;
+            const int hoff = wv == 0 ? FGNN_H : 0;
+            float av[KC / 2], bv[KC / 2];
+#pragma unroll
+            for (int u = 0; u < KC / 2; ++u) {
+                av[u] = L[2 * u + hh][jj];
+                bv[u] = 2 * u + hh < kn ? HB[2 * u + hh][hoff + jj] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < SB8; ++u)
-                if (2 * (s0 + u) < K) acc = mfma32(av[u], bv[u], acc);
+            for (int u = 0; u < KC / 2; ++u) acc = mfma32(av[u], bv[u], acc);
+            if (wv == 0 && lane < 32) {
+#pragma unroll
+                for (int u = 0; u < KC; ++u) ab2 += DZ[u][lane];
+            }
+        } else if (tid < 128 + 64) {                         // dW0[t >> 1][t & 1] += dpre1_k x_k,  t = tid - 128
+            const int t = tid - 128;
+            float d[KC], x[KC];
+#pragma unroll
+            for (int u = 0; u < KC; ++u) {
+                d[u] = D1[u][t >> 1];
+                x[u] = u < kn ? XI[u][t & 1] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < KC; ++u) asum = fmaf(d[u], x[u], asum);
+        } else {                                             // threads 192 .. 255: b0 += dpre1_k, b1 += dpre2_k
+            const int t = tid - 192, l = t >> 5, cc2 = t & 31;
+            const float (*V)[FGNN_H + 4] = l == 0 ? D1 : D2;
+#pragma unroll
+            for (int u = 0; u < KC; ++u) asum += V[u][cc2];
         }
+        __syncthreads();                                      // the next round overwrites the arrays
+    }
+    constexpr int PC = 32 * 2 + 32 + 2 * (32 * 32 + 32);
+    float *row = A.wpart[m] + ((long long)g * wpg + widx) * PC;
+    if (wv < 2) {
         float *dst = row + (wv == 0 ? 96 + 1024 + 32 : 96);
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[ch_of(r, hh) * FGNN_H + jj] = acc[r];
-    } else if (tid < 128 + 64) {                         // dW0[t >> 1][t & 1] = sum_k dpre1_k x_k,  t = tid - 128
-        const int t = tid - 128;
-        float a = 0.f;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float d[8], x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u;
-                const bool ok = k < K;
-                d[u] = ok ? D1[ok ? k : 0][t >> 1] : 0.f;
-                x[u] = (!ok || k == 0) ? 0.f : (k == 1 ? (t & 1 ? 0.f : 1.f) : (t & 1 ? B.degr[k - 2] : (float)B.wii[k - 2]));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a = fmaf(d[u], x[u], a);
-        }
-        row[t] = a;
-    } else {                                             // threads 192 .. 255: b0 = sum_k dpre1_k, b1 = sum_k dpre2_k
-        const int t = tid - 192, l = t >> 5, cc2 = t & 31;
-        const float (*V)[FGNN_H + 4] = l == 0 ? D1 : D2;
-        float a = 0.f;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float d[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) d[u] = k0 + u < K ? V[k0 + u < K ? k0 + u : 0][cc2] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a += d[u];
-        }
-        row[l == 0 ? 64 + cc2 : 96 + 1024 + cc2] = a;
+        if (wv == 0 && lane < 32) row[96 + 1024 + 32 + 1024 + lane] = ab2;
+    } else if (tid < 128 + 64) {
+        row[tid - 128] = asum;
+    } else {
+        const int t = tid - 192;
+        row[(t >> 5) == 0 ? 64 + (t & 31) : 96 + 1024 + (t & 31)] = asum;
     }
-    SB_STAMP(10)
-    if (wv == 0 && lane < 32) {                           // b2 = sum_k dz_k (wave 0, after its product)
-        float a = 0.f;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float d[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) d[u] = k0 + u < K ? DZ[k0 + u < K ? k0 + u : 0][lane] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) a += d[u];
-        }
-        row[96 + 1024 + 32 + 1024 + lane] = a;
-    }
-    SB_STAMP(11)
-}
-
-template <int NWD>
-constexpr int sb_params_lds_bytes() {
-    constexpr int MAXN = 64 * NWD, CS = 2 + MAXN, KMAX = MAXN + 2;
-    return 4 * (2 * FGNN_H * FGNN_H + FGNN_H * (CS + 1) + KMAX * FGNN_H + KMAX * 2 * FGNN_H + 3 * KMAX * (FGNN_H + 4));
 }
 
 }  // namespace
 
-#ifdef SB_STAMPS
-extern "C" int fgnn_debug_sb_stamps(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sb_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
-#endif
-
 extern "C" int fgnn_block1_struct_supported(int N, int depth, int c0) { return (N >= 1 && N <= SB_NMAX && depth == 3 && c0 == 2) ? 1 : 0; }
 extern "C" int fgnn_block1_struct_table_floats(int N) { return 2 * (2 + 2 * (N + 1)) * SB_TAB; }
-extern "C" int fgnn_block1_struct_csum_floats(int G, int N) { return 2 * G * FGNN_H * (2 + (N <= 64 ? 64 : 128)); }
+extern "C" long long fgnn_block1_struct_ws_floats(int G, int N) { return sb_ws_layout(G, N).total; }
+extern "C" int fgnn_block1_struct_rows(int G, int N) {          // rows of wpart the backward pass writes (the caller keeps the others zero)
+    const int chunks = (N + 2 + SB_KC - 1) / SB_KC, fit = fgnn_mlp_bwd_num_workgroups() / (G > 0 ? G : 1);
+    const int wpg = chunks < fit ? chunks : fit;
+    return G * (wpg < 1 ? 1 : wpg);
+}
 
 extern "C" int fgnn_block1_struct_tables(const float *const *W1, const float *const *b1, const float *const *W2, const float *const *b2, int N,
-                                         float *tables, void *stream) {
+                                         int bf16_scheme, float *tables, void *stream) {
     FGNN_CHECK(W1 && b1 && W2 && b2 && tables && N >= 1 && N <= SB_NMAX, "fgnn_block1_struct_tables: bad arguments (N=%d)", N);
     TabArgs A;
     for (int l = 0; l < 3; ++l) {
@@ -695,66 +878,138 @@ extern "C" int fgnn_block1_struct_tables(const float *const *W1, const float *co
         A.b[1][l] = b2[l];
         FGNN_CHECK(W1[l] && b1[l] && W2[l] && b2[l], "fgnn_block1_struct_tables: layer %d missing", l);
     }
-    hipLaunchKernelGGL(sb_tables_kernel, dim3(2 + 2 * (N + 1), 2), dim3(64), 0, (hipStream_t)stream, A, N, tables);
-    FGNN_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1,
-                                      const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult,
-                                      long long gstride, long long ldp, float *xdeg, void *stream) {
-    FGNN_CHECK(bits && tables && gnw1 && gnb1 && gnw2 && gnb2 && nrm1 && nrm2 && mult && G > 0, "fgnn_block1_struct_fwd: bad arguments");
-    FGNN_CHECK(N >= 1 && N <= SB_NMAX, "fgnn_block1_struct_fwd: N = %d (built for N <= %d)", N, SB_NMAX);
-    FGNN_CHECK(ldp >= (long long)N * N && gstride >= FGNN_H * ldp, "fgnn_block1_struct_fwd: strides smaller than the planes");
-    hipStream_t st = (hipStream_t)stream;
-    if (N <= 64)
-        hipLaunchKernelGGL(sb_fwd_kernel<1>, dim3(G, SB_CG), dim3(256), 0, st, bits, nvalid, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult,
-                           gstride, ldp, xdeg);
-    else
-        hipLaunchKernelGGL(sb_fwd_kernel<2>, dim3(G, SB_CG), dim3(256), 0, st, bits, nvalid, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult,
-                           gstride, ldp, xdeg);
+    hipLaunchKernelGGL(sb_tables_kernel, dim3(2 + 2 * (N + 1), 2), dim3(64), 0, (hipStream_t)stream, A, N, tables, bf16_scheme ? 1 : 0);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 
 namespace {
-template <int NWD>
-int sb_bwd_launch(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const ParArgs &A, const float *gnb1, const float *gnb2,
-                  const float *dmult, long long gstride, long long ldp, float *csum, hipStream_t st) {
-    hipLaunchKernelGGL(sb_bwd_reduce_kernel<NWD>, dim3(G * FGNN_H), dim3(256), 0, st, bits, nvalid, G, N, tables, A.nrm[0], A.nrm[1], gnb1, gnb2, dmult,
-                       gstride, ldp, csum);
+struct FwdCall {
+    const unsigned *bits;
+    const int *nvalid;
+    int G, N;
+    const float *tables, *gnw1, *gnb1, *gnw2, *gnb2;
+    float eps;
+    float *nrm1, *nrm2;
+    void *mult;
+    long long gstride, ldp;
+    int pitch;
+    float *xdeg;
+    void *x16;
+    float *ws;
+    hipStream_t st;
+};
+template <int NWD, bool BF>
+int sb_fwd_launch(const FwdCall &c) {
+    const int parts0 = (1024 + c.G * SB_CG - 1) / (c.G * SB_CG), parts = parts0 > 8 ? 8 : parts0;      // four workgroups per CU
+    const WsLayout L = sb_ws_layout(c.G, c.N);
+    const int ny0 = (512 + c.G - 1) / c.G, ny = ny0 > (c.N + 3) / 4 ? (c.N + 3) / 4 : ny0;      // two workgroups per CU, at least one row per wave
+    unsigned short *code = reinterpret_cast<unsigned short *>(c.ws + L.code);
+    float4 *vinfo = reinterpret_cast<float4 *>(c.ws + L.vinfo);
+    hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(c.G, ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code), vinfo,
+                       c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch);
     FGNN_LAUNCH_CHECK();
-    constexpr int LDS = sb_params_lds_bytes<NWD>();
-    static_assert(LDS <= 150 * 1024, "LDS budget of the class-algebra kernel");
-    static LdsAttrCache attr_cache;
-    FGNN_CHECK(fgnn_raise_lds(attr_cache, (const void *)sb_bwd_params_kernel<NWD>, LDS), "fgnn_block1_struct_bwd: %d bytes of LDS refused", LDS);
-    hipLaunchKernelGGL(sb_bwd_params_kernel<NWD>, dim3(G, 2), dim3(256), LDS, st, bits, nvalid, G, N, tables, csum, A);
+    hipLaunchKernelGGL((sb_fwd_kernel<NWD, BF>), dim3(c.G, SB_CG, parts), dim3(256), 0, c.st, code, vinfo, c.ws + L.gones, c.nvalid, c.N, L.cp, c.tables,
+                       c.gnw1, c.gnb1, c.gnw2, c.gnb2, c.eps, c.nrm1, c.nrm2, c.mult, c.gstride, c.ldp, c.pitch);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+template <bool BF>
+int sb_fwd_dispatch(const FwdCall &c) {
+    FGNN_CHECK(c.bits && c.tables && c.gnw1 && c.gnb1 && c.gnw2 && c.gnb2 && c.nrm1 && c.nrm2 && c.mult && c.ws && c.G > 0,
+               "fgnn_block1_struct_fwd: bad arguments");
+    FGNN_CHECK(c.N >= 1 && c.N <= SB_NMAX, "fgnn_block1_struct_fwd: N = %d (built for N <= %d)", c.N, SB_NMAX);
+    FGNN_CHECK((reinterpret_cast<uintptr_t>(c.ws) & 15) == 0, "fgnn_block1_struct_fwd: workspace not 16-byte aligned");
+    if (c.N <= 64) return sb_fwd_launch<1, BF>(c);
+    if (c.N <= 128) return sb_fwd_launch<2, BF>(c);
+    return sb_fwd_launch<4, BF>(c);
+}
+}  // namespace
+
+extern "C" int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1,
+                                      const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult,
+                                      long long gstride, long long ldp, float *xdeg, float *ws, void *stream) {
+    FGNN_CHECK(ldp >= (long long)N * N && gstride >= FGNN_H * ldp, "fgnn_block1_struct_fwd: strides smaller than the planes");
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, N, xdeg, nullptr, ws, (hipStream_t)stream};
+    return sb_fwd_dispatch<false>(c);
+}
+
+extern "C" int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
+                                        const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, void *mult,
+                                        long long gstride, long long ldp, void *x16, float *ws, void *stream) {
+    FGNN_CHECK(ldr >= N && ldr % 8 == 0 && ldp >= (long long)N * ldr && ldp % 2 == 0 && gstride >= FGNN_H * ldp && gstride % 2 == 0,
+               "fgnn_block1_struct_fwd16: pitches (ldr = %d, ldp = %lld, gstride = %lld)", ldr, ldp, gstride);
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, (hipStream_t)stream};
+    return sb_fwd_dispatch<true>(c);
+}
+
+namespace {
+struct BwdCall {
+    const unsigned *bits;
+    const int *nvalid;
+    int G, N;
+    const float *tables;
+    const float *const *W1, *const *W2;
+    const float *nrm1, *nrm2, *gnb1, *gnb2;
+    const void *dmult;
+    long long gstride, ldp;
+    int pitch;
+    float *ws, *wpart1, *wpart2, *s12_1, *s12_2;
+    hipStream_t st;
+};
+template <int NWD, bool BF>
+int sb_bwd_launch(const BwdCall &c) {
+    const WsLayout L = sb_ws_layout(c.G, c.N);
+    float *csum = c.ws + L.csum;
+    const unsigned short *code = reinterpret_cast<const unsigned short *>(c.ws + L.code);
+    const float4 *vinfo = reinterpret_cast<const float4 *>(c.ws + L.vinfo);
+    float4 *coef = reinterpret_cast<float4 *>(c.ws + L.coef);
+    hipLaunchKernelGGL((sb_bwd_reduce_kernel<NWD, BF>), dim3(c.G * FGNN_H), dim3(64 * sb_reduce_waves<NWD>()), 0, c.st, code, vinfo, c.nvalid, c.G, c.N, L.cp, c.tables, c.nrm1,
+                       c.nrm2, c.gnb1, c.gnb2, c.dmult, c.gstride, c.ldp, c.pitch, csum, c.s12_1, c.s12_2, coef);
+    FGNN_LAUNCH_CHECK();
+    ParArgs A;
+    for (int l = 0; l < 3; ++l) {
+        A.W[0][l] = c.W1[l];
+        A.W[1][l] = c.W2[l];
+    }
+    A.wpart[0] = c.wpart1;
+    A.wpart[1] = c.wpart2;
+    A.bf = BF ? 1 : 0;
+    const int wpg = fgnn_block1_struct_rows(c.G, c.N) / c.G;
+    hipLaunchKernelGGL((sb_bwd_params_kernel<SB_KC>), dim3(c.G * wpg, 2), dim3(256), 0, c.st, vinfo, c.ws + L.gones, c.nvalid, c.G, c.N, L.CS, c.tables, csum,
+                       coef, A, wpg);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+template <bool BF>
+int sb_bwd_dispatch(const BwdCall &c) {
+    FGNN_CHECK(c.bits && c.tables && c.W1 && c.W2 && c.nrm1 && c.nrm2 && c.gnb1 && c.gnb2 && c.dmult && c.ws && c.wpart1 && c.wpart2 && c.s12_1 &&
+                   c.s12_2 && c.G > 0,
+               "fgnn_block1_struct_bwd: bad arguments");
+    FGNN_CHECK(c.N >= 1 && c.N <= SB_NMAX, "fgnn_block1_struct_bwd: N = %d (built for N <= %d)", c.N, SB_NMAX);
+    FGNN_CHECK(c.G <= fgnn_mlp_bwd_num_workgroups(), "fgnn_block1_struct_bwd: one partial row per graph: G = %d exceeds the %d rows of wpart", c.G,
+               fgnn_mlp_bwd_num_workgroups());
+    if (c.N <= 64) return sb_bwd_launch<1, BF>(c);
+    if (c.N <= 128) return sb_bwd_launch<2, BF>(c);
+    return sb_bwd_launch<4, BF>(c);
 }
 }  // namespace
 
 extern "C" int fgnn_block1_struct_bwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *const *W1,
                                       const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
-                                      const float *dmult, long long gstride, long long ldp, float *csum, float *wpart1, float *wpart2,
+                                      const float *dmult, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2,
                                       float *s12_1, float *s12_2, void *stream) {
-    FGNN_CHECK(bits && tables && W1 && W2 && nrm1 && nrm2 && gnb1 && gnb2 && dmult && csum && wpart1 && wpart2 && s12_1 && s12_2 && G > 0,
-               "fgnn_block1_struct_bwd: bad arguments");
-    FGNN_CHECK(N >= 1 && N <= SB_NMAX, "fgnn_block1_struct_bwd: N = %d (built for N <= %d)", N, SB_NMAX);
-    FGNN_CHECK(G <= fgnn_mlp_bwd_num_workgroups(), "fgnn_block1_struct_bwd: one partial row per graph: G = %d exceeds the %d rows of wpart", G,
-               fgnn_mlp_bwd_num_workgroups());
-    ParArgs A;
-    for (int l = 0; l < 3; ++l) {
-        A.W[0][l] = W1[l];
-        A.W[1][l] = W2[l];
-    }
-    A.wpart[0] = wpart1;
-    A.wpart[1] = wpart2;
-    A.s12[0] = s12_1;
-    A.s12[1] = s12_2;
-    A.nrm[0] = nrm1;
-    A.nrm[1] = nrm2;
-    hipStream_t st = (hipStream_t)stream;
-    if (N <= 64) return sb_bwd_launch<1>(bits, nvalid, G, N, tables, A, gnb1, gnb2, dmult, gstride, ldp, csum, st);
-    return sb_bwd_launch<2>(bits, nvalid, G, N, tables, A, gnb1, gnb2, dmult, gstride, ldp, csum, st);
+    const BwdCall c = {bits, nvalid, G, N, tables, W1, W2, nrm1, nrm2, gnb1, gnb2, dmult, gstride, ldp, N, ws, wpart1, wpart2, s12_1, s12_2,
+                       (hipStream_t)stream};
+    return sb_bwd_dispatch<false>(c);
+}
+
+extern "C" int fgnn_block1_struct_bwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *const *W1,
+                                        const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
+                                        const void *dmult, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2,
+                                        float *s12_1, float *s12_2, void *stream) {
+    FGNN_CHECK(ldr >= N && ldr % 8 == 0 && ldp >= (long long)N * ldr, "fgnn_block1_struct_bwd16: pitches (ldr = %d, ldp = %lld)", ldr, ldp);
+    const BwdCall c = {bits, nvalid, G, N, tables, W1, W2, nrm1, nrm2, gnb1, gnb2, dmult, gstride, ldp, ldr, ws, wpart1, wpart2, s12_1, s12_2,
+                       (hipStream_t)stream};
+    return sb_bwd_dispatch<true>(c);
 }

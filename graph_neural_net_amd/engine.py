@@ -183,7 +183,7 @@ class FgnnEngine:
         block1 = self.BLOCK1 if block1 is None else block1
         if block1 not in ('generic', 'structured'):
             raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
-        # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged, N <= 128; anything else runs generic
+        # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged, N <= 256; anything else runs generic
         self.struct1 = (block1 == 'structured' and cu_share == 0
                         and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0))
                         and G <= _lib.load().fgnn_mlp_bwd_num_workgroups())
@@ -413,7 +413,7 @@ class FgnnEngine:
             lib = _lib.load()
             f32 = dict(dtype=torch.float32, device=self.device)
             self._struct = {'tab': torch.empty(lib.fgnn_block1_struct_table_floats(self.N), **f32),
-                            'csum': torch.empty(lib.fgnn_block1_struct_csum_floats(self.G, self.N), **f32)}
+                            'ws': torch.empty(lib.fgnn_block1_struct_ws_floats(self.G, self.N), **f32)}
         return self._struct
 
     def _w3(self, params, j):
@@ -426,12 +426,12 @@ class FgnnEngine:
         st = _lib.stream_ptr()
         (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
-        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, _lib.ptr(S['tab']), st)
+        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, 0, _lib.ptr(S['tab']), st)
         _lib.call('fgnn_block1_struct_fwd', _lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']),
                   C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
                   C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
                   _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
-                  _lib.ptr(self.xdeg), st)
+                  _lib.ptr(self.xdeg), _lib.ptr(S['ws']), st)
 
     def _struct_bwd(self, params):
         """... and in the backward direction: class sums of d(mult), then the per-class GraphNorm / conv backward, instead of
@@ -446,7 +446,7 @@ class FgnnEngine:
         _lib.call('fgnn_block1_struct_bwd', _lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']), w1, w2,
                   _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]),
                   C.c_void_p(self._w(params, r1['gn_b'])), C.c_void_p(self._w(params, r2['gn_b'])),
-                  _lib.ptr(W['dmult']), 32 * self.ldp, self.ldp, _lib.ptr(S['csum']),
+                  _lib.ptr(W['dmult']), 32 * self.ldp, self.ldp, _lib.ptr(S['ws']),
                   _lib.ptr(W['wpart'][(1, 1)]), _lib.ptr(W['wpart'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
                   _lib.stream_ptr())
 

@@ -11,6 +11,7 @@ same flat fp32 buffers as in the fp32 engine (one all-reduce per step).
 Rounding points are spelled out in ``oracle/fgnn_oracle_bf16.py`` (test infrastructure; never imported here).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -22,9 +23,18 @@ class FgnnEngineBF16:
     """Workspace + launch sequence for a fixed (G, N) problem on the current device, bf16 storage."""
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges16 + tile skipping in fgnn_mlp_fwd16 / fgnn_mlp_bwd16
     PAIR_BWD = True               # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd16_pair), constant-size batches
+    BLOCK1 = os.environ.get('FGNN_BLOCK1', 'generic')      # 'structured': csrc/block1_struct.hip for bit-packed inputs
 
-    def __init__(self, layout, G, N, device, ragged=False):
+    def __init__(self, layout, G, N, device, ragged=False, block1=None):
         lib = _lib.load()
+        block1 = self.BLOCK1 if block1 is None else block1
+        if block1 not in ('generic', 'structured'):
+            raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
+        # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged; dense inputs run generic
+        self.struct1 = (block1 == 'structured' and bool(lib.fgnn_block1_struct_supported(N, layout.depth, layout.c0))
+                        and G <= lib.fgnn_mlp_bwd_num_workgroups())
+        self._struct = None
+        self.xbits = None
         if layout.depth != 3:
             raise RuntimeError('the bf16 kernels are built for depth_of_mlp = 3 (got %d)' % layout.depth)
         if layout.c0 != 2:
@@ -143,25 +153,43 @@ class FgnnEngineBF16:
                       _lib.ptr(self.nrm[(k, js[0])]), st)
 
     # ------------------------------------------------------------------ forward
-    def embed(self, params, x, nvalid=None):
-        """x: (G, 2, N, N) contiguous fp32 device tensor (0/1 adjacency + degrees: exact in bf16 for N <= 256)."""
+    def embed(self, params, x, nvalid=None, bits=None):
+        """x: (G, 2, N, N) contiguous fp32 device tensor (0/1 adjacency + degrees: exact in bf16 for N <= 256) -- or bits:
+        (G, N, ceil(N/32)) int32 words of the bit-packed adjacency (the input form of FgnnEngine.embed(bits=...)); with
+        block1='structured' block 1 then runs on the class tables (csrc/block1_struct.hip)."""
         L = self.layout
-        if x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
-            raise RuntimeError('FgnnEngineBF16.embed: expected contiguous fp32 %s, got %s %s'
-                               % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
         if (nvalid is None) != (self.nvalid is None):
             raise RuntimeError('FgnnEngineBF16: ragged flag and nvalid argument disagree')
+        if bits is not None:
+            words = (self.N + 31) // 32
+            if x is not None:
+                raise RuntimeError('FgnnEngineBF16.embed: pass x or bits, not both')
+            if tuple(bits.shape) != (self.G, self.N, words) or bits.dtype not in (torch.int32, torch.uint32) \
+                    or not bits.is_contiguous() or bits.device.type != 'cuda':
+                raise RuntimeError('FgnnEngineBF16.embed: expected contiguous int32 device bits %s, got %s %s'
+                                   % ((self.G, self.N, words), tuple(bits.shape), bits.dtype))
+            if not self.struct1:
+                raise RuntimeError("FgnnEngineBF16.embed: bits= needs block1='structured' (N <= 256, depth 3, 2 input channels)")
+        elif x.shape != (self.G, L.c0, self.N, self.N) or not x.is_contiguous() or x.dtype != torch.float32:
+            raise RuntimeError('FgnnEngineBF16.embed: expected contiguous fp32 %s, got %s %s'
+                               % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
+        self.xbits = bits
         if nvalid is not None:
             self.nvalid.copy_(nvalid.to(torch.int32))
         st = _lib.stream_ptr()
         if self.ranges is not None:
             _lib.call('fgnn_ragged_tile_ranges16', _lib.ptr(self.nvalid), self.G, self.N, self.ldr, _lib.ptr(self.ranges), st)
-        _lib.call('fgnn_to_bf16', _lib.ptr(x), self._nv(), self.G, 2, self.N, self.ldr, _lib.ptr(self.x16),
-                  2 * self.ldp, self.ldp, st)
+        if bits is None:
+            _lib.call('fgnn_to_bf16', _lib.ptr(x), self._nv(), self.G, 2, self.N, self.ldr, _lib.ptr(self.x16),
+                      2 * self.ldp, self.ldp, st)
         self.pack_operands(params)
         gs = 32 * self.ldp
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
+            if k == 1 and bits is not None:
+                self._struct_fwd(params)           # mlp1 + mlp2 + mult of block 1 from the class tables; also writes x16
+                self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
+                continue
             # mlp1 / mlp2's GraphNorm records are finalized by the matmul that consumes them (one launch less per block)
             self._mlp_fwd(params, k, (1, 2), sin, None, finalize=False)
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
@@ -176,8 +204,48 @@ class FgnnEngineBF16:
                   _lib.ptr(self.idx), st)
         return self.E
 
-    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None):
-        self.embed(params, x, nvalid)
+    # ------------------------------------------------------------------ block 1 on its structured input (csrc/block1_struct.hip)
+    def _struct_ws(self):
+        if self._struct is None:
+            lib = _lib.load()
+            f32 = dict(dtype=torch.float32, device=self.device)
+            self._struct = {'tab': torch.empty(lib.fgnn_block1_struct_table_floats(self.N), **f32),
+                            'ws': torch.empty(lib.fgnn_block1_struct_ws_floats(self.G, self.N), **f32)}
+        return self._struct
+
+    def _w3(self, params, j):
+        rec = self.layout.mlp[(1, j)]
+        return ((C.c_void_p * 3)(*[self._w(params, o) for o in rec['w']]), (C.c_void_p * 3)(*[self._w(params, o) for o in rec['b']]))
+
+    def _struct_fwd(self, params):
+        S = self._struct_ws()
+        st = _lib.stream_ptr()
+        (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
+        r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
+        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, 1, _lib.ptr(S['tab']), st)
+        _lib.call('fgnn_block1_struct_fwd16', _lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']),
+                  C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
+                  C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
+                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
+                  _lib.ptr(self.x16), _lib.ptr(S['ws']), st)
+
+    def _struct_bwd(self, params):
+        S, W = self._struct_ws(), self._bwd
+        if not W.get('struct_rows_clean', False):       # one partial row per graph: the other rows stay zero
+            W['wpart'][(1, 1)].zero_()
+            W['wpart'][(1, 2)].zero_()
+        W['struct_rows_clean'] = True
+        (w1, _), (w2, _) = self._w3(params, 1), self._w3(params, 2)
+        r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
+        _lib.call('fgnn_block1_struct_bwd16', _lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']), w1, w2,
+                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]),
+                  C.c_void_p(self._w(params, r1['gn_b'])), C.c_void_p(self._w(params, r2['gn_b'])),
+                  _lib.ptr(W['dmult']), 32 * self.ldp, self.ldp, _lib.ptr(S['ws']),
+                  _lib.ptr(W['wpart'][(1, 1)]), _lib.ptr(W['wpart'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
+                  _lib.stream_ptr())
+
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None):
+        self.embed(params, x, nvalid, bits=bits)
         B, N = self.B, self.N
         st = _lib.stream_ptr()
         e1, e2 = self.E[:B], self.E[B:]
@@ -300,6 +368,11 @@ class FgnnEngineBF16:
             # its outputs from it instead of re-reading the two raw operand slabs
             self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy, coef3, W['dmult'], din, False, False, emit=True)
             hook('mlp3_bwd', k)
+            if first and self.xbits is not None:
+                self._struct_bwd(params)
+                break
+            if first:
+                W['struct_rows_clean'] = False          # the generic kernels fill every partial row of block 1
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd16_tc', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       _lib.ptr(W['s12part']), self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']),
@@ -345,8 +418,8 @@ class FgnnEngineBF16:
             _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
         return grads
 
-    def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None):
-        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out)
+    def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits)
         self.backward(params, grads)
         return scores, loss
 

@@ -407,26 +407,41 @@ int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, const int *
  * 0/1 adjacency, channel 1 = diag(row sums)), so mlp1 / mlp2 of block 1 (models/blocks_emb.py:16-27, models/layers.py:126-131)
  * take one value per input class -- off-diagonal w = 0 / 1, diagonal (w_ii, deg_i) -- and their per-channel product
  * (models/layers.py:161-162) has a closed form in W, W^2, the degrees and the class values.  For bit-packed inputs of
- * batches (constant-size or ragged) with N <= 128, depth 3, these entry points replace fgnn_mlp_fwd (mlp1 + mlp2) + fgnn_chan_matmul_fwd
+ * batches (constant-size or ragged) with N <= 256, depth 3, these entry points replace fgnn_mlp_fwd (mlp1 + mlp2) + fgnn_chan_matmul_fwd
  * and fgnn_chan_matmul_bwd + fgnn_mlp_bwd_pair of block 1: same function, another evaluation order (equal to fp32 rounding).
- *   tables : (2 models, 2 + 2 (N + 1) classes, {h1, h2, z}, 32) floats, graph independent: once per step
+ *   tables : (2 models, 2 + 2 (N + 1) classes, {h1, h2, z, z as stored}, 32) floats, graph independent: once per step.
+ *            bf16_scheme != 0: the arithmetic of the 16-bit engine (matrix-core operands R(W), R(relu(.)), stored R(z))
  *   fwd    : GraphNorm records nrm1 / nrm2 (G, 32, 4) of mlp1 / mlp2 and the raw slab mult (G, 32, ldp)
  *   bwd    : from d(mult): row g of wpart1 / wpart2 (the partial layout of fgnn_mlp_bwd, one row per graph -- the caller keeps
- *            the other rows zero) and s12_1 / s12_2 (G, 32, 2), ready for fgnn_grad_finalize; csum is workspace             */
-int fgnn_block1_struct_supported(int N, int depth, int original_features_num);      /* N <= 128, depth 3, 2 input channels */
+ *            the other rows zero) and s12_1 / s12_2 (G, 32, 2), ready for fgnn_grad_finalize; csum is workspace
+ * The ...16 forms take the bf16 slabs of the 16-bit engine (row pitch ldr elements, channel stride ldp, tables built with
+ * bf16_scheme = 1): mult is rounded to nearest even on store, the statistics stay fp32 and the class sums of the backward pass
+ * are formed in fp32 from the bf16 d(mult) (the generic 16-bit kernels round every pixel of dY1 / dY2 / dz instead).          */
+int fgnn_block1_struct_supported(int N, int depth, int original_features_num);      /* N <= 256, depth 3, 2 input channels */
 int fgnn_block1_struct_table_floats(int N);
-int fgnn_block1_struct_csum_floats(int G, int N);
+long long fgnn_block1_struct_ws_floats(int G, int N);       /* workspace shared by fwd and bwd of one step (16-byte aligned) */
+int fgnn_block1_struct_rows(int G, int N);                  /* bwd writes rows 0 .. rows-1 of wpart1 / wpart2 (<= fgnn_mlp_bwd_num_workgroups()) */
 int fgnn_block1_struct_tables(const float *const *W1, const float *const *b1, const float *const *W2, const float *const *b2, int N,
-                              float *tables, void *stream);
+                              int bf16_scheme, float *tables, void *stream);
 /* nvalid: optional per-graph vertex counts (ragged batches: the N x N planes are padded; mult is written as 0 outside the valid
- * corner, class counts and the GraphNorm n use nvalid[g]) */
+ * corner, class counts and the GraphNorm n use nvalid[g]).  fwd fills ws (16-bit code plane (W^2)_ij | w_ij << 15, per-vertex
+ * {row sum, column sum, w_ii, class}); bwd of the same step reads it. */
 int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1, const float *gnb1,
                            const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult, long long gstride,
-                           long long ldp, float *xdeg /* optional: (G, N) row sums, as fgnn_adjacency_degree writes them */, void *stream);
+                           long long ldp, float *xdeg /* optional: (G, N) row sums, as fgnn_adjacency_degree writes them */, float *ws,
+                           void *stream);
 int fgnn_block1_struct_bwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *const *W1,
                            const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
-                           const float *dmult, long long gstride, long long ldp, float *csum, float *wpart1, float *wpart2, float *s12_1,
+                           const float *dmult, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2, float *s12_1,
                            float *s12_2, void *stream);
+/* x16 (optional): the (G, 2, ldp) bf16 input slab (channel 0 = W, channel 1 = diag(row sums)) the later kernels of block 1 read */
+int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
+                             const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2,
+                             void *mult /* bf16 */, long long gstride, long long ldp, void *x16 /* bf16, optional */, float *ws, void *stream);
+int fgnn_block1_struct_bwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *const *W1,
+                             const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
+                             const void *dmult /* bf16 */, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2,
+                             float *s12_1, float *s12_2, void *stream);
 
 /* Input expansion (loaders/data_generator.py:118-125): bits (G, N, ceil(N/32)) uint32, bit j of row i =
  * W[i][j]  ->  x (G, 2, N, N) fp32 with x[g,0] = W, x[g,1] = diag(row sums); exact 0/1/integer values. */

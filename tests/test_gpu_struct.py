@@ -90,8 +90,8 @@ def test_structured_block1_against_the_oracle_four_blocks():
 
 def test_structured_block1_falls_back_where_it_does_not_apply():
     lay = ParamLayout(2, 2, 32, 32, 3)
-    assert not FgnnEngine(lay, 4, 129, DEV, block1='structured').struct1           # N > 128
-    assert FgnnEngine(lay, 4, 128, DEV, block1='structured').struct1
+    assert not FgnnEngine(lay, 4, 257, DEV, block1='structured').struct1           # N > 256
+    assert FgnnEngine(lay, 4, 256, DEV, block1='structured').struct1
     assert FgnnEngine(lay, 4, 20, DEV, ragged=True, block1='structured').struct1
     eng = FgnnEngine(lay, 4, 20, DEV, block1='structured')
     assert eng.struct1

@@ -1,0 +1,227 @@
+"""GPU: block 1 on its structured input in the 16-bit engine (FgnnEngineBF16(block1='structured') with bit-packed adjacency:
+fgnn_block1_struct_fwd16 / _bwd16) and the four-word bit rows (128 < N <= 256) of both engines.
+
+Forward: the class tables follow the rounding points of oracle/fgnn_oracle_bf16.py (operands R(W), R(relu(.)), stored R(z),
+statistics from the un-rounded z, normalised operands R(.), mult = R(.)), so mult / the GraphNorm records / the input slab must
+equal the generic 16-bit kernels' up to isolated one-ulp flips, exactly like tests/test_gpu_bf16.py demands of those.
+Backward: the class sums are formed in fp32 from the bf16 d(mult) -- the generic kernels round every pixel of dY1 / dY2 / dz to
+bf16 first -- so the gradients of mlp1 / mlp2 of block 1 are a DIFFERENT (less rounded) evaluation of the same bf16 scheme; the
+gates are the statistical ones of tests/test_gpu_bf16.py, unchanged."""
+import numpy as np
+import pytest
+import torch
+
+from graph_neural_net_amd import synthetic
+from graph_neural_net_amd.engine import FgnnEngine, ParamLayout
+from graph_neural_net_amd.engine16 import FgnnEngineBF16
+from oracle import fgnn_oracle as O, fgnn_oracle_bf16 as OB
+from util import BF16_CLASS, flat_of, is_zero_grad, l2rel, load_golden, rel, sub, unpack_pairs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+SAME_POINT = 0.5
+ULP = 2.0 ** -7
+
+
+def _bits(x):
+    return torch.from_numpy(synthetic.pack_adjacency(x[:, 0].numpy()).view(np.int32)).to(DEV)
+
+
+def _run(sd, x1, x2, nblk, block1, nvalid=None):
+    lay = ParamLayout(2, nblk, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    grads = torch.zeros_like(params)
+    eng = FgnnEngineBF16(lay, 2 * x1.shape[0], x1.shape[-1], DEV, ragged=nvalid is not None, block1=block1)
+    x = torch.cat([x1, x2]).contiguous()
+    nv = None if nvalid is None else torch.cat([nvalid, nvalid]).to(DEV)
+    if block1 == 'structured':
+        assert eng.struct1
+        scores, loss = eng.step(params, grads, None, nvalid=nv, bits=_bits(x))
+    else:
+        scores, loss = eng.step(params, grads, x.to(DEV), nvalid=nv)
+    torch.cuda.synchronize()
+    return eng, lay, scores.cpu(), loss.item(), lay.unflatten(grads.cpu())
+
+
+def _ulp_close(got, ref, max_frac, flips=1e-3):
+    """Element-wise agreement of two evaluations of the same bf16 scheme.  An element may differ by one bf16 ulp of its value, or --
+    where an N-term sum cancels to something far smaller than its terms -- by the fp32 rounding of the terms (4e-6 of the largest
+    magnitude).  Beyond that, at most `flips` of the elements may be off, and by no more than one ulp of the LARGEST magnitude: a
+    normalised operand R((z - mean) a + beta) that sits on a bf16 rounding boundary rounds the other way when the statistics
+    differ in their last fp32 bit, and every product sum that uses it moves by (one ulp of the operand) x (the other operand).
+    At most max_frac of the elements differ at all."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    diff = (got - ref).abs()
+    top = ref.abs().max()
+    bad = diff > ULP * ref.abs() + 4e-6 * top
+    assert bad.float().mean().item() <= flips, (int(bad.sum()), bad.numel())
+    assert (diff <= ULP * top).all(), (diff.max().item(), top.item())
+    frac = (diff > 0).float().mean().item()
+    assert frac <= max_frac, frac
+
+
+@pytest.mark.parametrize('N,B', [(20, 2), (50, 2), (37, 1), (64, 2), (100, 1), (200, 1), (256, 1)])
+def test_structured_first_block_in_16_bit(N, B):
+    """One block: the input slab is bit-identical, mult and the records equal the oracle's / the generic kernels' up to one-ulp
+    flips, scores / loss / gradients sit inside the gates of test_first_block_is_exact_up_to_rounding_flips."""
+    torch.manual_seed(10 + N)
+    sd = O.init_state_dict(num_blocks=1)
+    g = torch.Generator().manual_seed(11 + N)
+    for k, v in sd.items():
+        if k.endswith('.bias') and v.dim() == 1:
+            v.add_(0.1 * torch.randn(v.shape, generator=g))
+        elif k.endswith('gn.weight'):
+            v.mul_(1 + 0.2 * torch.randn(v.shape, generator=g))
+        elif k.endswith('gn.bias'):
+            v.add_(0.05 * torch.randn(v.shape, generator=g))
+    x1, x2 = synthetic.make_batch(N, B, N, 'ErdosRenyi', 0.3 if N < 100 else 0.5, 0.1)
+    keep = {}
+    s_ref, l_ref, g_ref = OB.step_fwd_bwd(x1, x2, sd, keep=keep)
+    eg, _, sg, lg, gg = _run(sd, x1, x2, 1, 'generic')
+    es, _, ss, ls, gs = _run(sd, x1, x2, 1, 'structured')
+    xs_, xg_ = es.x16.view(2 * B, 2, es.ldp), eg.x16.view(2 * B, 2, eg.ldp)
+    assert torch.equal(xs_[:, :, :N * es.ldr], xg_[:, :, :N * eg.ldr])   # the expanded input slab, pitch padding included
+    assert xs_[:, :, N * es.ldr:].float().abs().sum().item() == 0        # (the tail of the channel stride: zero here, unwritten by fgnn_to_bf16)
+    _ulp_close(es.dense(es.mult[1]), keep[(1, 'mult')], 2e-2)
+    _ulp_close(es.dense(es.mult[1]), eg.dense(eg.mult[1]), 2e-2)
+    raw = es.mult[1].view(2 * B, 32, es.ldp)
+    assert raw[:, :, N * es.ldr:].float().abs().sum().item() == 0        # tail of the channel stride
+    assert raw[:, :, :N * es.ldr].view(2 * B, 32, N, es.ldr)[..., N:].float().abs().sum().item() == 0      # pitch padding
+    for j in (1, 2):                                                     # records {mean, a, q, r2}: fp32 statistics of the same z
+        ra, rb = eg.nrm[(1, j)].view(-1, 4).cpu(), es.nrm[(1, j)].view(-1, 4).cpu()
+        assert rel(rb[:, 0], ra[:, 0]) < 1e-5 and rel(rb[:, 1:], ra[:, 1:]) < 1e-4, j
+    assert rel(ss, s_ref) < 2e-2
+    assert abs(ls - l_ref.item()) < 2e-3 * abs(l_ref.item())
+    keys = [k for k in g_ref if not is_zero_grad(k)]
+    assert l2rel(flat_of(gs, keys), flat_of(g_ref, keys)) < 5e-2
+    # the un-rounded evaluation of the same scheme is the common target: the structured path is at least as close to it as
+    # the generic kernels are (it skips three per-pixel roundings on the way to the class sums)
+    _, _, g32 = OB.step_fwd_bwd(x1, x2, sd, rounding=False)
+    assert l2rel(flat_of(gs, keys), flat_of(g32, keys)) <= 1.25 * l2rel(flat_of(gg, keys), flat_of(g32, keys)) + 1e-4
+    # bit-reproducible run to run
+    _, _, ss2, ls2, gs2 = _run(sd, x1, x2, 1, 'structured')
+    assert torch.equal(ss, ss2) and ls == ls2 and all(torch.equal(gs[k], gs2[k]) for k in gs)
+
+
+def test_cfg4_full_size_structured_against_same_point_oracle():
+    """BASELINE config 3 at full size (N = 200 dense ER pairs, batch 8, 4 blocks, bf16) through the structured block 1: the gates
+    of test_cfg4_full_size_against_same_point_oracle, unchanged."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    x1, x2 = synthetic.make_batch(4000, 8, 200, 'ErdosRenyi', 0.5, 0.1)
+    s16, l16, g16 = OB.step_fwd_bwd(x1, x2, sd)
+    s32, l32, g32 = O.step_fwd_bwd(x1, x2, sd)
+    eng, lay, scores, loss, grads = _run(sd, x1, x2, 4, 'structured')
+    assert torch.isfinite(scores).all() and all(torch.isfinite(g).all() for g in grads.values())
+    keys = [k for k in g32 if not is_zero_grad(k)]
+    f = lambda g: flat_of(g, keys)
+    assert l2rel(scores, s16) <= SAME_POINT * l2rel(s16, s32), (l2rel(scores, s16), l2rel(s16, s32))
+    assert l2rel(f(grads), f(g16)) <= SAME_POINT * l2rel(f(g16), f(g32)), (l2rel(f(grads), f(g16)), l2rel(f(g16), f(g32)))
+    assert abs(loss - l16.item()) < 2e-3 * abs(l16.item())
+    assert l2rel(scores, s32) <= 1.5 * l2rel(s16, s32) and l2rel(f(grads), f(g32)) <= 1.5 * l2rel(f(g16), f(g32))
+
+
+def test_cfg4_structured_against_reference_bf16_yardstick():
+    """The reference-generated fixture (N = 200, one pair): distance to the fp64 truth vs the reference's own bf16 run."""
+    d = load_golden('cfg4_er_n200_b1_4blk.npz')
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    n = int(d['n'])
+    x1, x2 = unpack_pairs(d['bits1'], n), unpack_pairs(d['bits2'], n)
+    eng, lay, scores, loss, grads = _run(sd, x1, x2, 4, 'structured')
+    keys = [k for k in sub(d, 'grad/') if not is_zero_grad(k)]
+    g64 = flat_of(sub(d, 'grad64/'), keys)
+    s64 = d['scores64_as_f32']
+    assert l2rel(scores, s64) <= BF16_CLASS * l2rel(d['scores_refbf16'], s64)
+    assert l2rel(flat_of(grads, keys), g64) <= BF16_CLASS * l2rel(flat_of(sub(d, 'grad_refbf16/'), keys), g64)
+    assert abs(loss - d['loss64'].item()) <= BF16_CLASS * abs(d['loss_refbf16'].item() - d['loss64'].item()) + 1e-3
+
+
+def test_ragged_structured_16_bit_against_per_pair_oracle():
+    """Ragged batch (Nmax = 120) in 16 bit through the structured block 1: the gates of test_ragged_bf16_against_per_pair_oracle."""
+    d = load_golden('cfg2_reg_n50_b2_4blk.npz')
+    sd = {k: v for k, v in sub(d, 'sd/').items() if k.startswith('ne_bm_block1') or k.startswith('ne_bm_block2')}
+    ns = [120, 75, 97]
+    xs, ys = [], []
+    for i, n in enumerate(ns):
+        a, b = synthetic.make_batch(9000 + i, 1, n, 'ErdosRenyi', 0.3, 0.05)
+        xs.append(a[0]); ys.append(b[0])
+    total = float(sum(ns))
+    s16, g16, g32 = [], None, None
+    for a, b in zip(xs, ys):
+        s, _, g = OB.step_fwd_bwd(a[None], b[None], sd, total_nodes=total)
+        _, _, gf = OB.step_fwd_bwd(a[None], b[None], sd, rounding=False, total_nodes=total)
+        s16.append(s[0])
+        g16 = g if g16 is None else {k: g16[k] + g[k] for k in g}
+        g32 = gf if g32 is None else {k: g32[k] + gf[k] for k in gf}
+    x1, nv = O.pad_graph_list(xs)
+    x2, _ = O.pad_graph_list(ys)
+    eng, lay, scores, loss, got = _run(sd, x1, x2, 2, 'structured', nvalid=nv)
+    for i, n in enumerate(ns):
+        assert scores[i, n:, :].abs().sum() == 0 and scores[i, :, n:].abs().sum() == 0
+        assert l2rel(scores[i, :n, :n], s16[i]) < 2e-2
+    keys = [k for k in g16 if not is_zero_grad(k)]
+    f = lambda g: flat_of(g, keys)
+    assert l2rel(f(got), f(g16)) <= SAME_POINT * l2rel(f(g16), f(g32)), (l2rel(f(got), f(g16)), l2rel(f(g16), f(g32)))
+
+
+def test_dense_and_bits_steps_alternate_on_one_engine():
+    """An engine built with block1='structured' runs dense inputs through the generic kernels; a following bit-packed step must not
+    see their partial rows (one row per graph, the rest re-zeroed)."""
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x1, x2 = synthetic.make_batch(77, 2, 40, 'ErdosRenyi', 0.3, 0.1)
+    x = torch.cat([x1, x2]).contiguous()
+    eng = FgnnEngineBF16(lay, 4, 40, DEV, block1='structured')
+    g0, g1, g2 = (torch.zeros_like(params) for _ in range(3))
+    eng.step(params, g0, None, bits=_bits(x))
+    eng.step(params, g1, x.to(DEV))
+    eng.step(params, g2, None, bits=_bits(x))
+    torch.cuda.synchronize()
+    assert torch.equal(g0, g2)
+    assert l2rel(g1.cpu(), g0.cpu()) < 5e-2
+    with pytest.raises(RuntimeError):
+        FgnnEngineBF16(lay, 4, 40, DEV).step(params, g1, None, bits=_bits(x))          # generic engine: bits refused loudly
+
+
+@pytest.mark.parametrize('B,N,family,p', [(2, 129, 'ErdosRenyi', 0.3), (1, 200, 'ErdosRenyi', 0.5), (1, 256, 'ErdosRenyi', 0.2), (2, 193, 'Regular', 0.1)])
+def test_fp32_structured_block1_with_four_word_rows(B, N, family, p):
+    """128 < N <= 256 in the fp32 engine (bit rows of four 64-bit words, class algebra in two or three chunks): against the generic
+    kernels / the fp64 oracle as in tests/test_gpu_struct.py."""
+    sd = sub(load_golden('cfg1_er_n20_b4_1blk.npz'), 'sd/')
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    x1, x2 = synthetic.make_batch(4200 + N, B, N, family, p, 0.1)
+    bits = _bits(torch.cat([x1, x2]))
+    out = []
+    for mode in ('generic', 'structured'):
+        eng = FgnnEngine(lay, 2 * B, N, DEV, block1=mode)
+        assert eng.struct1 == (mode == 'structured')
+        g = torch.zeros_like(params)
+        sc, loss = eng.step(params, g, None, bits=bits)
+        torch.cuda.synchronize()
+        out.append((eng.unpadded(eng.mult[1]).cpu(), eng.nrm[(1, 1)].cpu().clone(), eng.nrm[(1, 2)].cpu().clone(), sc.cpu().clone(), loss.item(),
+                    lay.unflatten(g.cpu().clone())))
+    a, b = out
+    assert rel(b[0], a[0]) < 1e-5, rel(b[0], a[0])
+    for k in (1, 2):
+        ra, rb = a[k].view(-1, 4), b[k].view(-1, 4)
+        assert rel(rb[:, 0], ra[:, 0]) < 2e-6 and rel(rb[:, 1:], ra[:, 1:]) < 2e-5, k
+    assert rel(b[3], a[3]) < 1e-5, rel(b[3], a[3])
+    assert abs(a[4] - b[4]) <= 1e-6 * abs(a[4])
+    _, _, g64 = O.step_fwd_bwd(x1.double(), x2.double(), {k: v.double() for k, v in sd.items()})
+    _, _, g32 = O.step_fwd_bwd(x1, x2, sd)
+    keys = [k for k in g64 if not is_zero_grad(k)]
+    flat = lambda gg: torch.cat([gg[k].reshape(-1).double() for k in keys])
+    t = flat(g64)
+    ours, theirs = ((flat(b[5]) - t).norm() / t.norm()).item(), ((flat(g32) - t).norm() / t.norm()).item()
+    generic = ((flat(a[5]) - t).norm() / t.norm()).item()
+    # yard-stick: the fp32 oracle AND the generic kernels on the same batch (two fp32 evaluations; with 2 x 32 x N^2 pre-activations
+    # of mlp3 per graph one of them may take a ReLU branch the fp64 run does not -- tests/gradgate.py -- and neither is special)
+    yard = max(theirs, generic)
+    assert ours < 2.0 * yard + 1e-6, (ours, theirs, generic)
+    for name in g64:
+        if is_zero_grad(name):
+            assert b[5][name].abs().max() < 1e-4, name
+        else:
+            ty = max(rel(g32[name], g64[name]), rel(a[5][name], g64[name]))
+            assert rel(b[5][name], g64[name]) < 4.0 * ty + 1e-5, (name, rel(b[5][name], g64[name]), ty)
