@@ -146,9 +146,10 @@ _SIGNATURES = {
     'fgnn_conv1x1_dw_chunks': [_I, _I],
     'fgnn_conv1x1_dw': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _I, _I, _I, _VP, _VP],
     'fgnn_chan_matmul_fwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP],
-    'fgnn_chan_matmul_fwd_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP, _VP],
+    'fgnn_chan_matmul_fwd_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _I, _I, _VP, _LL, _LL, _VP, _I, _VP],
     'fgnn_chan_matmul_fwd_fin_supported': [_I],
     'fgnn_chan_matmul_fwd_fin': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP],
+    'fgnn_chan_matmul_fwd_fin_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP, _I, _VP],
     'fgnn_colmax_fwd': [C.POINTER(Slab), _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_colmax_fwd_fin_supported': [_I],
     'fgnn_colmax_fwd_fin': [C.POINTER(Slab), _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _VP, _VP],
@@ -183,7 +184,7 @@ _SIGNATURES = {
     'fgnn_mlp_param_count': [_I, _I],
     'fgnn_reduce_partials': [_VP, _I, _I, _VP, _VP],
     'fgnn_chan_matmul_bwd': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
-    'fgnn_chan_matmul_bwd_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP],
+    'fgnn_chan_matmul_bwd_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _LL, _LL, _VP, _I, _I, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _I, _VP],
     'fgnn_sum_scale': [_VP, _I, _I, _F, _VP, _VP],
     'fgnn_adam_step': [_VP, _VP, _VP, _VP, _I, C.c_double, C.c_double, C.c_double, C.c_double, _I, C.c_double, _VP],
     'fgnn_adam_step_dev': [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP],

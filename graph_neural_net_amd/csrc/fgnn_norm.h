@@ -65,3 +65,50 @@ DEVI float4 finalize_wave(const float *part, const float *cnt, int g, int c, int
                           int lane, bool tr = false) {
     return finalize_reduce(finalize_load(part, cnt, g, c, C, tpg, lane, tr), nv, w, eps);
 }
+// any number of tiles: more than 256 (N > 90) are walked in passes of eight loads per lane (a plain loop pays one memory round
+// trip per 64 tiles); the same arithmetic as gn_finalize_kernel
+DEVI float4 finalize_wave_any(const float *part, const float *cnt, int g, int c, int C, int tpg, float nv, float w, float eps, int lane,
+                              bool tr = false) {
+    if (tpg <= 4 * WAVE) return finalize_wave(part, cnt, g, c, C, tpg, nv, w, eps, lane, tr);
+    constexpr int U = 8;
+    float sn = 0.f, sm = 0.f;
+    const float *cg = cnt + (long long)g * tpg;
+    const int ts = tr ? 1 : C;              // tile stride of the partials (float2 units)
+    const float2 *pg = reinterpret_cast<const float2 *>(part) + (long long)g * tpg * C + (long long)c * (tr ? tpg : 1);
+    for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
+        float n[U], x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
+            n[k] = t < tpg ? cg[tc] : 0.f;
+            x[k] = pg[(long long)tc * ts].x;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            sn += n[k];
+            sm += n[k] * x[k];
+        }
+    }
+    sn = wave_sum(sn);
+    sm = wave_sum(sm);
+    const float mean = sn > 0.f ? sm / sn : 0.f;
+    float m2 = 0.f;
+    for (int t0 = lane; t0 < tpg; t0 += U * WAVE) {
+        float n[U];
+        float2 pm[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int t = t0 + k * WAVE, tc = t < tpg ? t : 0;
+            n[k] = t < tpg ? cg[tc] : 0.f;
+            pm[k] = pg[(long long)tc * ts];
+            if (t >= tpg) pm[k].y = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const float d = pm[k].x - mean;
+            m2 += pm[k].y + n[k] * d * d;
+        }
+    }
+    m2 = wave_sum(m2);
+    return nrm_record(mean, m2, sn, nv, w, eps);
+}

@@ -885,13 +885,25 @@ DEVI void big_store(const f32x16 (&acc)[BigCfg<NT>::MAXT], const View &ov, int o
     }
 }
 
-// zero the part of an N x N output outside the first X = 32*ntv rows / columns
-DEVI void big_zero_fill(const View &ov, int o_off4, int N, int X, int tid) {
+// zero the part of an N x N output outside the first X = 32*ntv rows / columns.  tiles_only: the consumers step over the tiles
+// (32 consecutive pixels of the plane) that hold no pixel of the valid nv x nv corner and read only the corner otherwise, so what
+// can be read outside the X x X block is the tail [X, N) of the rows i < nv and -- when nv is a multiple of 32 -- the first 32
+// pixels of row nv, which share a tile with the last valid pixel: 2-3 x fewer bytes than the whole frame, and no N x N index loop
+DEVI void big_zero_fill(const View &ov, int o_off4, int N, int nv, int X, int tid, bool tiles_only) {
     if (X >= N) return;
-    for (int e = tid; e < N * N; e += BIG_THREADS) {
-        const int r = e / N, c = e - r * N;
-        if (r >= X || c >= X) buf_store(0.f, ov, e * 4, o_off4);
+    if (!tiles_only) {
+        for (int e = tid; e < N * N; e += BIG_THREADS) {
+            const int r = e / N, c = e - r * N;
+            if (r >= X || c >= X) buf_store(0.f, ov, e * 4, o_off4);
+        }
+        return;
     }
+    const int w = N - X;
+    for (int e = tid; e < nv * w; e += BIG_THREADS) {
+        const int r = e / w, c = X + (e - r * w);
+        buf_store(0.f, ov, (r * N + c) * 4, o_off4);
+    }
+    if (nv == X && tid < 32 && tid < N) buf_store(0.f, ov, (nv * N + tid) * 4, o_off4);
 }
 
 DEVI BigSrc big_src(const fgnn_slab &s, int G, int g, int c) {
@@ -912,19 +924,38 @@ DEVI BigSrc big_src_plain(const float *p, long long gs, long long ld, int G, int
     return b;
 }
 
-template <int NT>
+// FIN: as chan_matmul_fwd1_kernel<true> -- waves 0 / 1 finalize the GraphNorm records of the two operands from the tile statistics
+// of the mlp1 + mlp2 forward launch and publish them (the work of fgnn_gn_finalize2, without its launch)
+template <int NT, bool FIN>
 __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_fwd_big_kernel(const fgnn_slab ya, const fgnn_slab yb,
                                                                            const int *nvalid, int N, int G, float *out,
                                                                            long long ogstride, long long ldo,
-                                                                           const int *order) {
+                                                                           const int *order, const FinArgs F, const int fill) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];
+    __shared__ float4 fin_rec[2];
     const int C = ya.C, gi = blockIdx.x / C, c = blockIdx.x - gi * C, tid = threadIdx.x;
     const int g = order ? order[gi] : gi;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
-    const BigSrc A = big_src(ya, G, g, c), B = big_src(yb, G, g, c);
+    BigSrc A = FIN ? big_src_plain(ya.ptr, ya.gstride, ya.ldp, G, g, c) : big_src(ya, G, g, c);
+    BigSrc B = FIN ? big_src_plain(yb.ptr, yb.gstride, yb.ldp, G, g, c) : big_src(yb, G, g, c);
+    if (FIN) {
+        const int wv = tid >> 6, lane = tid & 63;
+        if (wv < 2) {
+            const float *gw = wv ? F.gw_b : F.gw_a;
+            const float4 r = finalize_wave_any(wv ? F.part_b : F.part_a, F.cnt, g, c, C, F.tpg, (float)nv, gw ? gw[c] : 1.f, F.eps, lane);
+            if (lane == 0) {
+                fin_rec[wv] = r;
+                reinterpret_cast<float4 *>(wv ? F.nrm_b : F.nrm_a)[g * C + c] = r;
+            }
+        }
+        __syncthreads();
+        const float4 ra = fin_rec[0], rb = fin_rec[1];
+        A.nr.on = true; A.nr.mean = ra.x; A.nr.a = ra.y; A.nr.beta = ya.beta ? ya.beta[c] : 0.f;
+        B.nr.on = true; B.nr.mean = rb.x; B.nr.a = rb.y; B.nr.beta = yb.beta ? yb.beta[c] : 0.f;
+    }
     const View vO = make_view(out, ogstride, ldo, G);
     const int o_off = g * vO.gs4 + c * vO.ld4;
-    big_zero_fill(vO, o_off, N, 32 * ntv, tid);
+    big_zero_fill(vO, o_off, N, nv, 32 * ntv, tid, fill != 0);
     if (ntv == 0) return;
     f32x16 acc[BigCfg<NT>::MAXT];
     big_gemm<NT, true, false>(acc, A, B, big_lds, N, nv, ntv, tid);
@@ -938,7 +969,7 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
                                                                            const int *nvalid, int N, int G, float *da,
                                                                            float *db, long long ogstride, long long ldo,
                                                                            float *s12a, float *s12b, const int *order,
-                                                                           int split) {
+                                                                           int split, const int fill) {
     extern __shared__ __attribute__((aligned(16))) float big_lds[];
     __shared__ float red[BIG_NW][4];
     // split: two workgroups per matrix, one per product (the longest-job-first schedule of ragged batches wants the finer
@@ -953,8 +984,8 @@ __global__ __launch_bounds__(BIG_THREADS) void chan_matmul_bwd_big_kernel(const 
     const BigSrc D = big_src_plain(dm, dmg, ldm, G, g, c);
     const View vOA = make_view(da, ogstride, ldo, G), vOB = make_view(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs4 + c * vOA.ld4;
-    if (do_a) big_zero_fill(vOA, o_off, N, 32 * ntv, tid);
-    if (do_b) big_zero_fill(vOB, o_off, N, 32 * ntv, tid);
+    if (do_a) big_zero_fill(vOA, o_off, N, nv, 32 * ntv, tid, fill != 0);
+    if (do_b) big_zero_fill(vOB, o_off, N, nv, 32 * ntv, tid, fill != 0);
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
     if (ntv > 0) {
         f32x16 acc[BigCfg<NT>::MAXT];
@@ -1003,13 +1034,22 @@ inline bool mm_no_order() { return (g_mm_wave_variant & 4) != 0; }
 
 }  // namespace
 
+template <int MT, bool FIN>
+static void launch_fwd_big(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int N, int G, float *out, long long ogstride,
+                           long long ldo, const int *order, const FinArgs &F, int fill, hipStream_t st) {
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_fwd_big_kernel<MT, FIN>, BigCfg<MT>::LDS_BYTES);
+    hipLaunchKernelGGL((chan_matmul_fwd_big_kernel<MT, FIN>), dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, st, *ya, *yb, nvalid, N, G, out,
+                       ogstride, ldo, order, F, fill);
+}
+
 extern "C" int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
                                     float *out, long long ogstride, long long ldo, void *stream) {
-    return fgnn_chan_matmul_fwd_ord(ya, yb, nvalid, G, N, out, ogstride, ldo, nullptr, stream);
+    return fgnn_chan_matmul_fwd_ord(ya, yb, nvalid, G, N, out, ogstride, ldo, nullptr, 0, stream);
 }
 
 extern "C" int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
-                                        float *out, long long ogstride, long long ldo, const int *order, void *stream) {
+                                        float *out, long long ogstride, long long ldo, const int *order, int fill, void *stream) {
     FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_fwd_ord: an order needs the nvalid it was derived from");
     if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr, "fgnn_chan_matmul_fwd: null argument");
@@ -1035,16 +1075,8 @@ extern "C" int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb
         FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
                    (long long)G * ogstride < 0x7fffffffll / 4,
                    "fgnn_chan_matmul_fwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
-#define FGNN_BIG_FWD(MT)                                                                                              \
-    {                                                                                                                 \
-        static LdsAttrCache attr_cache;                                                                           \
-        (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_fwd_big_kernel<MT>, BigCfg<MT>::LDS_BYTES);                   \
-        hipLaunchKernelGGL(chan_matmul_fwd_big_kernel<MT>, dim3(G * ya->C), dim3(BIG_THREADS), BigCfg<MT>::LDS_BYTES, \
-                           (hipStream_t)stream, *ya, *yb, nvalid, N, G, out, ogstride, ldo, order);                   \
-    }
-        if (N <= 128) FGNN_BIG_FWD(4)
-        else FGNN_BIG_FWD(8)
-#undef FGNN_BIG_FWD
+        if (N <= 128) launch_fwd_big<4, false>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, FinArgs{}, fill, (hipStream_t)stream);
+        else launch_fwd_big<8, false>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, FinArgs{}, fill, (hipStream_t)stream);
         FGNN_LAUNCH_CHECK();
         return 0;
     }
@@ -1054,7 +1086,7 @@ extern "C" int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb
     return 0;
 }
 
-extern "C" int fgnn_chan_matmul_fwd_fin_supported(int N) { return N <= TM ? 1 : 0; }
+extern "C" int fgnn_chan_matmul_fwd_fin_supported(int N) { return (N <= TM || big_path(N)) ? 1 : 0; }
 
 extern "C" int fgnn_debug_matmul_variant(int wave_per_matrix) {
     g_mm_wave_variant = wave_per_matrix;
@@ -1065,16 +1097,31 @@ extern "C" int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb
                                         const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
                                         const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
                                         void *stream) {
+    return fgnn_chan_matmul_fwd_fin_ord(ya, yb, part_a, part_b, cnt, gn_weight_a, gn_weight_b, eps, nvalid, G, N, out, ogstride, ldo, nullptr, 0, stream);
+}
+
+extern "C" int fgnn_chan_matmul_fwd_fin_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                                            const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                            const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
+                                            const int *order, int fill, void *stream) {
+    FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_fwd_fin_ord: an order needs the nvalid it was derived from");
+    if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr && part_a && part_b && cnt, "fgnn_chan_matmul_fwd_fin: null argument");
     FGNN_CHECK(ya->nrm && yb->nrm, "fgnn_chan_matmul_fwd_fin: the slabs must carry the record buffers to fill");
     FGNN_CHECK(ya->C == yb->C && ya->C > 0 && G > 0 && N > 0, "fgnn_chan_matmul_fwd_fin: bad shapes");
-    FGNN_CHECK(N <= TM, "fgnn_chan_matmul_fwd_fin: N=%d > %d (use fgnn_gn_finalize2 + fgnn_chan_matmul_fwd)", N, TM);
+    FGNN_CHECK(N <= TM || big_path(N), "fgnn_chan_matmul_fwd_fin: N=%d > 256 (use fgnn_gn_finalize2 + fgnn_chan_matmul_fwd)", N);
     FGNN_CHECK((long long)G * ya->gstride < 0x7fffffffll / 4 && (long long)G * yb->gstride < 0x7fffffffll / 4 &&
                (long long)G * ogstride < 0x7fffffffll / 4,
                "fgnn_chan_matmul_fwd_fin: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     const int M = G * ya->C;
     FinArgs F = {part_a, part_b, cnt, gn_weight_a, gn_weight_b, const_cast<float *>(ya->nrm), const_cast<float *>(yb->nrm), eps,
                  fgnn_tiles_per_graph(N)};
+    if (big_path(N)) {
+        if (N <= 128) launch_fwd_big<4, true>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, F, fill, (hipStream_t)stream);
+        else launch_fwd_big<8, true>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, F, fill, (hipStream_t)stream);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
     if (mm_wave_variant()) {
         launch_fwd_w<true>(ya, yb, nvalid, N, M, out, ogstride, ldo, F, (hipStream_t)stream);
         FGNN_LAUNCH_CHECK();
@@ -1090,13 +1137,13 @@ extern "C" int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, co
                                     long long ldm, const int *nvalid, int G, int N, float *da, float *db,
                                     long long ogstride, long long ldo, float *s12a, float *s12b, void *stream) {
     return fgnn_chan_matmul_bwd_ord(ya, yb, dm, dmgstride, ldm, nvalid, G, N, da, db, ogstride, ldo, s12a, s12b, nullptr,
-                                    stream);
+                                    0, stream);
 }
 
 extern "C" int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride,
                                         long long ldm, const int *nvalid, int G, int N, float *da, float *db,
                                         long long ogstride, long long ldo, float *s12a, float *s12b, const int *order,
-                                        void *stream) {
+                                        int fill, void *stream) {
     FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_bwd_ord: an order needs the nvalid it was derived from");
     if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && dm && da && db && ya->ptr && yb->ptr, "fgnn_chan_matmul_bwd: null argument");
@@ -1126,7 +1173,7 @@ extern "C" int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb
         (void)fgnn_raise_lds(attr_cache, (const void *)chan_matmul_bwd_big_kernel<MT>, BigCfg<MT>::LDS_BYTES);                   \
         hipLaunchKernelGGL(chan_matmul_bwd_big_kernel<MT>, dim3(G * ya->C * (split ? 2 : 1)), dim3(BIG_THREADS),      \
                            BigCfg<MT>::LDS_BYTES, (hipStream_t)stream, *ya, *yb, dm, dmgstride, ldm, nvalid, N, G, da, \
-                           db, ogstride, ldo, s12a, s12b, order, split);                                              \
+                           db, ogstride, ldo, s12a, s12b, order, split, fill);                                            \
     }
         // fewer than four rounds of workgroups (two per CU): schedule the products separately
         const int split = (order && !mm_no_split() && (long long)G * ya->C <= BIG_SPLIT_MAX_MATRICES) ? 1 : 0;

@@ -386,14 +386,14 @@ class FgnnEngine:
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             if fin:     # the matmul finalizes the GraphNorm records of mlp1 / mlp2 itself (one launch less)
                 r1, r2 = L.mlp[(k, 1)], L.mlp[(k, 2)]
-                _lib.call('fgnn_chan_matmul_fwd_fin', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
+                _lib.call('fgnn_chan_matmul_fwd_fin_ord', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
                           _lib.ptr(self.cnt), C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r2['gn_w'])),
-                          EPS, self._nv(), self.G, self.N, _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp, st,
-                          tag='fgnn_chan_matmul_fwd')
+                          EPS, self._nv(), self.G, self.N, _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp,
+                          _lib.ptr(self.mm_order) if self.mm_order is not None else None, self._fill(), st, tag='fgnn_chan_matmul_fwd')
             else:
                 _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
                           _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp,
-                          _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_fwd')
+                          _lib.ptr(self.mm_order) if self.mm_order is not None else None, self._fill(), st, tag='fgnn_chan_matmul_fwd')
             # the last block's statistics are finalized by the pooling kernel that consumes them
             pool_fin = k == L.num_blocks and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
             self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin, finalize=not pool_fin)
@@ -406,6 +406,11 @@ class FgnnEngine:
         else:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
         return self.E
+
+    def _fill(self):
+        """Padding of the per-channel products' outputs: with tile ranges every consumer steps over padding-only tiles, so only what
+        shares a tile with a valid pixel is zeroed (include/fgnn_hip.h, fgnn_chan_matmul_fwd_ord)."""
+        return 1 if self.ranges is not None else 0
 
     # ------------------------------------------------------------------ block 1 on its structured input (csrc/block1_struct.hip)
     def _struct_ws(self):
@@ -635,7 +640,7 @@ class FgnnEngine:
             _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
-                      _lib.ptr(self.mm_order) if self.mm_order is not None else None, st, tag='fgnn_chan_matmul_bwd')
+                      _lib.ptr(self.mm_order) if self.mm_order is not None else None, self._fill(), st, tag='fgnn_chan_matmul_bwd')
             if first and self.struct1:
                 W['struct_rows_clean'] = False
             if self.PAIR_BWD and dxs is None and L.depth == 3 and sin.C in (2, 32):

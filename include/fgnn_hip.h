@@ -224,9 +224,12 @@ int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nv
  * `order` (G graph indices from fgnn_ragged_tile_ranges_order: largest graph first), so that the hardware's in-order
  * dispatch is a longest-job-first schedule -- the matrices of a batch differ by up to (Nmax / nmin)^3 in work.  Results
  * do not depend on the order (every matrix is computed by one workgroup on its own).  order == NULL: as above.          */
+/* fill: what the kernel zeroes of the output outside the valid corner (64 < N <= 256).  0: all of it.  1: only what a consumer
+ * that steps over padding-only tiles (fgnn_ragged_tile_ranges) can read -- the row tails of the valid rows up to the next multiple
+ * of 32 columns and the head of the row after the last one; the rest of the frame is left as it was.                              */
 int fgnn_chan_matmul_fwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,
-                             float *out, long long ogstride, long long ldo, const int *order, void *stream);
-/* The same product with the work of fgnn_gn_finalize2 folded into its prologue (single-tile matrices, N <= 64):
+                             float *out, long long ogstride, long long ldo, const int *order, int fill, void *stream);
+/* The same product with the work of fgnn_gn_finalize2 folded into its prologue (one workgroup or wave per matrix: N <= 256):
  * each (g,c) workgroup finalizes the two GraphNorm records it needs from the tile statistics (part_a / part_b /
  * cnt of the preceding two-MLP fgnn_mlp_fwd call) while its tile loads are in flight, normalises with them and
  * writes them to ya->nrm / yb->nrm for the later consumers -- one launch less per block.                     */
@@ -234,6 +237,10 @@ int fgnn_chan_matmul_fwd_fin_supported(int N);
 int fgnn_chan_matmul_fwd_fin(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
                              const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
                              const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo, void *stream);
+int fgnn_chan_matmul_fwd_fin_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                                 const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                 const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
+                                 const int *order /* as fgnn_chan_matmul_fwd_ord; used for 64 < N <= 256 */, int fill, void *stream);
 
 /* ---- ColumnMaxPooling.forward (models/layers.py:202-203; masked: maskedtensor.py:213-228)
  * e[g,c,i] = max_j y[g,c,i,j] (first index on ties), idx int32; rows i >= nvalid -> 0.   */
@@ -378,7 +385,7 @@ int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *
  * items (dm is then read by both) */
 int fgnn_chan_matmul_bwd_ord(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride, long long ldm,
                              const int *nvalid, int G, int N, float *da, float *db, long long ogstride, long long ldo,
-                             float *s12a, float *s12b, const int *order, void *stream);
+                             float *s12a, float *s12b, const int *order, int fill /* as fgnn_chan_matmul_fwd_ord */, void *stream);
 
 /* ---- next to the hot path -------------------------------------------
  * Fused Adam over a flat fp32 buffer: torch.optim.Adam(amsgrad=False, weight_decay=0) single-tensor

@@ -118,9 +118,9 @@ def test_chan_matmul_longest_first_order_is_bit_identical(N, G, Cc):
         da, db = torch.full_like(out, 3.0), torch.full_like(out, 3.0)
         s12a, s12b = torch.full((G * Cc * 2,), 3.0, device=DEV), torch.full((G * Cc * 2,), 3.0, device=DEV)
         _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(nvd), G, N, _lib.ptr(out), Cc * P, P,
-                  _lib.ptr(o), _lib.stream_ptr())
+                  _lib.ptr(o), 0, _lib.stream_ptr())
         _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * P, P, _lib.ptr(nvd), G, N,
-                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(o), _lib.stream_ptr())
+                  _lib.ptr(da), _lib.ptr(db), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(o), 0, _lib.stream_ptr())
         res.append((out, da, db, s12a, s12b))
     for x, y in zip(*res):
         assert torch.equal(x, y)
@@ -149,6 +149,45 @@ def test_chan_matmul_ragged_padding_is_zero():
         ref = a[g, :, :n, :n].double() @ b[g, :, :n, :n].double()
         assert rel(out[g, :, :n, :n], ref) < 2e-6
         assert out[g, :, n:, :].abs().sum() == 0 and out[g, :, :, n:].abs().sum() == 0
+
+
+@pytest.mark.parametrize('N,nvs', [(120, [120, 75, 96, 64, 31, 1, 0]), (200, [200, 129, 160, 97]), (70, [70, 33, 64])])
+def test_chan_matmul_ragged_minimal_fill_covers_every_live_tile(N, nvs):
+    """fill = 1 (the tile-skipping engines): outputs poisoned with NaN beforehand; every pixel of every LIVE tile (a tile = 32
+    consecutive pixels of the plane, live = holds a pixel of the valid corner) must come out as the product (inside the corner) or
+    exactly zero (outside) -- for the forward product and both backward products; results equal fill = 0 bit for bit there."""
+    G, Cc = len(nvs), 2
+    rng = torch.Generator().manual_seed(N)
+    nv = torch.tensor(nvs, dtype=torch.int32)
+    nvd = nv.to(DEV)
+    P = N * N
+    a, b, dm = (torch.randn(G, Cc, N, N, generator=rng).to(DEV) for _ in range(3))
+    na = (torch.rand(G, Cc, 4, generator=rng) + 0.5).to(DEV).contiguous()
+    nb = (torch.rand(G, Cc, 4, generator=rng) + 0.5).to(DEV).contiguous()
+    sa, sb = _slab(a, nrm=na), _slab(b, nrm=nb)
+    order = torch.argsort(-nv, stable=True).to(torch.int32).to(DEV)
+    res = []
+    for fill in (0, 1):
+        out, da, db = (torch.full((G, Cc, N, N), float('nan'), device=DEV) for _ in range(3))
+        s12a, s12b = torch.empty(G * Cc * 2, device=DEV), torch.empty(G * Cc * 2, device=DEV)
+        _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(nvd), G, N, _lib.ptr(out), Cc * P, P, _lib.ptr(order), fill,
+                  _lib.stream_ptr())
+        _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(sa), C.byref(sb), _lib.ptr(dm), Cc * P, P, _lib.ptr(nvd), G, N, _lib.ptr(da), _lib.ptr(db),
+                  Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(order), fill, _lib.stream_ptr())
+        torch.cuda.synchronize()
+        res.append([t.cpu() for t in (out, da, db, s12a, s12b)])
+    assert not any(torch.isnan(t).any() for t in res[0])                 # fill = 0 writes the whole frame
+    for g, n in enumerate(nvs):
+        live = torch.zeros(P, dtype=torch.bool)
+        if n > 0:
+            pix = (torch.arange(n)[:, None] * N + torch.arange(n)[None, :]).reshape(-1)        # the valid corner
+            tiles = torch.unique(pix // 32)
+            idx = (tiles[:, None] * 32 + torch.arange(32)[None, :]).reshape(-1)
+            live[idx[idx < P]] = True
+        for k in range(3):
+            x0, x1 = res[0][k][g].reshape(Cc, P), res[1][k][g].reshape(Cc, P)
+            assert torch.equal(x1[:, live], x0[:, live]), (g, n, k)
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])
 
 
 def test_colmax_first_index_on_ties_bit_exact():

@@ -53,12 +53,12 @@ for name, variant, o in (('plain order', 1, None), ('largest first, one workgrou
 
     def fwd():
         s = sets[it[0] % K]; it[0] += 1
-        _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(s[0]), C.byref(s[1]), _lib.ptr(nv), G, N, _lib.ptr(s[3]), Cc * P, P, _lib.ptr(o), st)
+        _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(s[0]), C.byref(s[1]), _lib.ptr(nv), G, N, _lib.ptr(s[3]), Cc * P, P, _lib.ptr(o), 0, st)
 
     def bwd():
         s = sets[it[0] % K]; it[0] += 1
         _lib.call('fgnn_chan_matmul_bwd_ord', C.byref(s[0]), C.byref(s[1]), _lib.ptr(s[2]), Cc * P, P, _lib.ptr(nv), G, N,
-                  _lib.ptr(s[4]), _lib.ptr(s[5]), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(o), st)
+                  _lib.ptr(s[4]), _lib.ptr(s[5]), Cc * P, P, _lib.ptr(s12a), _lib.ptr(s12b), _lib.ptr(o), 0, st)
 
     tf, tb = timeit(fwd), timeit(bwd)
     print('%-52s fwd %6.1f us (%5.1f TFLOP/s)   bwd %6.1f us (%5.1f TFLOP/s)' % (name, tf, flops / tf / 1e6, tb, 2 * flops / tb / 1e6))
