@@ -176,9 +176,9 @@ _SIGNATURES = {
     'fgnn_block1_struct_ws_floats': [_I, _I],
     'fgnn_block1_struct_rows': [_I, _I],
     'fgnn_block1_struct_tables': [_VP, _VP, _VP, _VP, _I, _I, _VP, _VP],
-    'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
+    'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_block1_struct_bwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
-    'fgnn_block1_struct_fwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP],
+    'fgnn_block1_struct_fwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_block1_struct_bwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],
     'fgnn_mlp_param_count': [_I, _I],

@@ -46,9 +46,9 @@ struct TabArgs {
 };
 // bf: the 16-bit scheme of engine16 (oracle/fgnn_oracle_bf16.py): matrix-core operands R(W), R(relu(.)) and the stored R(z)
 DEVI float sb_r(float v, int bf) { return bf ? bf_lo(cvt_pk(v, 0.f)) : v; }
-__global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const int N, float *tab, const int bf) {
-    __shared__ float hbuf[2][FGNN_H];
-    const int cls = blockIdx.x, m = blockIdx.y, o = threadIdx.x;
+// one wave computes one table row (lanes 0..31 = the 32 channels; the hidden vectors travel by cross-lane reads: no LDS, no barrier)
+DEVI void sb_table_row(const TabArgs &A, const int N, float *tab, const int bf, const int cls, const int m, const int lane) {
+    const int o = lane & 31;
     float x0, x1;
     if (cls < 2) {
         x0 = (float)cls;
@@ -58,34 +58,30 @@ __global__ __launch_bounds__(64) void sb_tables_kernel(const TabArgs A, const in
         x1 = (float)((cls - 2) >> 1);
     }
     float *out = tab + ((long long)m * sb_classes(N) + cls) * SB_TAB;
-    if (o < FGNN_H) {
-        const float *W0 = A.W[m][0];
-        float a = A.b[m][0][o];
-        a = fmaf(sb_r(W0[o * 2 + 0], bf), x0, a);
-        a = fmaf(sb_r(W0[o * 2 + 1], bf), x1, a);
-        a = sb_r(fmaxf(a, 0.f), bf);
-        hbuf[0][o] = a;
-        out[o] = a;
-    }
-    __syncthreads();
-    if (o < FGNN_H) {
-        const float *W1 = A.W[m][1] + o * FGNN_H;
-        float a = A.b[m][1][o];
+    const float *W0 = A.W[m][0];
+    float a = A.b[m][0][o];
+    a = fmaf(sb_r(W0[o * 2 + 0], bf), x0, a);
+    a = fmaf(sb_r(W0[o * 2 + 1], bf), x1, a);
+    const float h1 = sb_r(fmaxf(a, 0.f), bf);
+    const float *W1 = A.W[m][1] + o * FGNN_H;
+    a = A.b[m][1][o];
 #pragma unroll
-        for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W1[c], bf), hbuf[0][c], a);
-        a = sb_r(fmaxf(a, 0.f), bf);
-        hbuf[1][o] = a;
-        out[FGNN_H + o] = a;
-    }
-    __syncthreads();
-    if (o < FGNN_H) {
-        const float *W2 = A.W[m][2] + o * FGNN_H;
-        float a = A.b[m][2][o];
+    for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W1[c], bf), __shfl(h1, c), a);
+    const float h2 = sb_r(fmaxf(a, 0.f), bf);
+    const float *W2 = A.W[m][2] + o * FGNN_H;
+    a = A.b[m][2][o];
 #pragma unroll
-        for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W2[c], bf), hbuf[1][c], a);
+    for (int c = 0; c < FGNN_H; ++c) a = fmaf(sb_r(W2[c], bf), __shfl(h2, c), a);
+    if (lane < FGNN_H) {
+        out[o] = h1;
+        out[FGNN_H + o] = h2;
         out[2 * FGNN_H + o] = a;
         out[3 * FGNN_H + o] = sb_r(a, bf);
     }
+}
+__global__ __launch_bounds__(256) void sb_tables_kernel(const TabArgs A, const int N, float *tab, const int bf) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), NC = sb_classes(N);
+    if (row < 2 * NC) sb_table_row(A, N, tab, bf, row % NC, row / NC, threadIdx.x & 63);
 }
 
 // per-graph bit structure in LDS (NWD 64-bit words per row: N <= 64 NWD), filled by the first 64 NWD threads of a group
@@ -231,14 +227,22 @@ DEVI void sb_store16(unsigned short *p, const unsigned (&o)[NWD]) {
 }
 
 // ---- KG: code plane + vertex records (+ the input slabs the other kernels of block 1 read) -------------------------------------
-// grid (G, ny): every workgroup builds the bit rows / columns of its graph and codes a band of rows
+// grid ntab + G ny: the first ntab workgroups build the class tables of the step (four rows each: the graph-independent launch of
+// fgnn_block1_struct_tables folded in), workgroup ntab + g ny + y builds the bit rows / columns of graph g and codes band y of its rows
 template <int NWD>
 __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, const int *nvalid, const int N, const int cp, unsigned *code,
                                                        float4 *vinfo, float *gones, float *xdeg, void *x16, const long long ldp16,
-                                                       const int pitch16) {
+                                                       const int pitch16, const int ny, const int ntab, const TabArgs TA, float *tab,
+                                                       const int bf) {
     __shared__ GraphBits<NWD> B;
     __shared__ float red[4];
-    const int g = blockIdx.x, y = blockIdx.y, ny = gridDim.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < ntab) {
+        const int row = blockIdx.x * 4 + (tid >> 6), NC = sb_classes(N);
+        if (row < 2 * NC) sb_table_row(TA, N, tab, bf, row % NC, row / NC, tid & 63);
+        return;
+    }
+    const int g = ((int)blockIdx.x - ntab) / ny, y = ((int)blockIdx.x - ntab) - g * ny;
     const int nv = nvalid_of(nvalid, g, N);
     sb_bits_rows(B, bits, g, tid, N, nv);
     __syncthreads();
@@ -878,7 +882,7 @@ extern "C" int fgnn_block1_struct_tables(const float *const *W1, const float *co
         A.b[1][l] = b2[l];
         FGNN_CHECK(W1[l] && b1[l] && W2[l] && b2[l], "fgnn_block1_struct_tables: layer %d missing", l);
     }
-    hipLaunchKernelGGL(sb_tables_kernel, dim3(2 + 2 * (N + 1), 2), dim3(64), 0, (hipStream_t)stream, A, N, tables, bf16_scheme ? 1 : 0);
+    hipLaunchKernelGGL(sb_tables_kernel, dim3((2 * (2 + 2 * (N + 1)) + 3) / 4), dim3(256), 0, (hipStream_t)stream, A, N, tables, bf16_scheme ? 1 : 0);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -897,6 +901,7 @@ struct FwdCall {
     float *xdeg;
     void *x16;
     float *ws;
+    const float *const *tW1, *const *tb1, *const *tW2, *const *tb2;      // optional: build the tables in the same launch
     hipStream_t st;
 };
 template <int NWD, bool BF>
@@ -906,8 +911,20 @@ int sb_fwd_launch(const FwdCall &c) {
     const int ny0 = (512 + c.G - 1) / c.G, ny = ny0 > (c.N + 3) / 4 ? (c.N + 3) / 4 : ny0;      // two workgroups per CU, at least one row per wave
     unsigned short *code = reinterpret_cast<unsigned short *>(c.ws + L.code);
     float4 *vinfo = reinterpret_cast<float4 *>(c.ws + L.vinfo);
-    hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(c.G, ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code), vinfo,
-                       c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch);
+    TabArgs TA = {};
+    int ntab = 0;
+    if (c.tW1) {
+        for (int l = 0; l < 3; ++l) {
+            FGNN_CHECK(c.tW1[l] && c.tb1[l] && c.tW2[l] && c.tb2[l], "fgnn_block1_struct_fwd: table weights of layer %d missing", l);
+            TA.W[0][l] = c.tW1[l];
+            TA.b[0][l] = c.tb1[l];
+            TA.W[1][l] = c.tW2[l];
+            TA.b[1][l] = c.tb2[l];
+        }
+        ntab = (2 * (2 + 2 * (c.N + 1)) + 3) / 4;
+    }
+    hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(ntab + c.G * ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code),
+                       vinfo, c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch, ny, ntab, TA, const_cast<float *>(c.tables), BF ? 1 : 0);
     FGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL((sb_fwd_kernel<NWD, BF>), dim3(c.G, SB_CG, parts), dim3(256), 0, c.st, code, vinfo, c.ws + L.gones, c.nvalid, c.N, L.cp, c.tables,
                        c.gnw1, c.gnb1, c.gnw2, c.gnb2, c.eps, c.nrm1, c.nrm2, c.mult, c.gstride, c.ldp, c.pitch);
@@ -918,6 +935,8 @@ template <bool BF>
 int sb_fwd_dispatch(const FwdCall &c) {
     FGNN_CHECK(c.bits && c.tables && c.gnw1 && c.gnb1 && c.gnw2 && c.gnb2 && c.nrm1 && c.nrm2 && c.mult && c.ws && c.G > 0,
                "fgnn_block1_struct_fwd: bad arguments");
+    FGNN_CHECK((c.tW1 != nullptr) == (c.tb1 != nullptr) && (c.tW1 != nullptr) == (c.tW2 != nullptr) && (c.tW1 != nullptr) == (c.tb2 != nullptr),
+               "fgnn_block1_struct_fwd: the four table weight arrays come together");
     FGNN_CHECK(c.N >= 1 && c.N <= SB_NMAX, "fgnn_block1_struct_fwd: N = %d (built for N <= %d)", c.N, SB_NMAX);
     FGNN_CHECK((reinterpret_cast<uintptr_t>(c.ws) & 15) == 0, "fgnn_block1_struct_fwd: workspace not 16-byte aligned");
     if (c.N <= 64) return sb_fwd_launch<1, BF>(c);
@@ -928,18 +947,22 @@ int sb_fwd_dispatch(const FwdCall &c) {
 
 extern "C" int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1,
                                       const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult,
-                                      long long gstride, long long ldp, float *xdeg, float *ws, void *stream) {
+                                      long long gstride, long long ldp, float *xdeg, float *ws, const float *const *tW1,
+                                      const float *const *tb1, const float *const *tW2, const float *const *tb2, void *stream) {
     FGNN_CHECK(ldp >= (long long)N * N && gstride >= FGNN_H * ldp, "fgnn_block1_struct_fwd: strides smaller than the planes");
-    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, N, xdeg, nullptr, ws, (hipStream_t)stream};
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, N, xdeg, nullptr, ws, tW1, tb1, tW2, tb2,
+                       (hipStream_t)stream};
     return sb_fwd_dispatch<false>(c);
 }
 
 extern "C" int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
                                         const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, void *mult,
-                                        long long gstride, long long ldp, void *x16, float *ws, void *stream) {
+                                        long long gstride, long long ldp, void *x16, float *ws, const float *const *tW1,
+                                        const float *const *tb1, const float *const *tW2, const float *const *tb2, void *stream) {
     FGNN_CHECK(ldr >= N && ldr % 8 == 0 && ldp >= (long long)N * ldr && ldp % 2 == 0 && gstride >= FGNN_H * ldp && gstride % 2 == 0,
                "fgnn_block1_struct_fwd16: pitches (ldr = %d, ldp = %lld, gstride = %lld)", ldr, ldp, gstride);
-    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, (hipStream_t)stream};
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, tW1, tb1, tW2, tb2,
+                       (hipStream_t)stream};
     return sb_fwd_dispatch<true>(c);
 }
 

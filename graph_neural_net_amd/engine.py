@@ -431,12 +431,11 @@ class FgnnEngine:
         st = _lib.stream_ptr()
         (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
-        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, 0, _lib.ptr(S['tab']), st)
         _lib.call('fgnn_block1_struct_fwd', _lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']),
                   C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
                   C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
                   _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
-                  _lib.ptr(self.xdeg), _lib.ptr(S['ws']), st)
+                  _lib.ptr(self.xdeg), _lib.ptr(S['ws']), w1, b1, w2, b2, st)      # (the class tables are built by the same launch)
 
     def _struct_bwd(self, params):
         """... and in the backward direction: class sums of d(mult), then the per-class GraphNorm / conv backward, instead of

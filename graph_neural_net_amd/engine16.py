@@ -222,12 +222,11 @@ class FgnnEngineBF16:
         st = _lib.stream_ptr()
         (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
-        _lib.call('fgnn_block1_struct_tables', w1, b1, w2, b2, self.N, 1, _lib.ptr(S['tab']), st)
         _lib.call('fgnn_block1_struct_fwd16', _lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']),
                   C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
                   C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
                   _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
-                  _lib.ptr(self.x16), _lib.ptr(S['ws']), st)
+                  _lib.ptr(self.x16), _lib.ptr(S['ws']), w1, b1, w2, b2, st)      # (the class tables are built by the same launch)
 
     def _struct_bwd(self, params):
         S, W = self._struct_ws(), self._bwd

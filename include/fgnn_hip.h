@@ -436,6 +436,9 @@ int fgnn_block1_struct_tables(const float *const *W1, const float *const *b1, co
 int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1, const float *gnb1,
                            const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult, long long gstride,
                            long long ldp, float *xdeg /* optional: (G, N) row sums, as fgnn_adjacency_degree writes them */, float *ws,
+                           const float *const *tW1, const float *const *tb1, const float *const *tW2, const float *const *tb2
+                           /* optional, all four or none: the arguments of fgnn_block1_struct_tables -- `tables` is then (re)built
+                              inside the first launch of this call instead of by a launch of its own */,
                            void *stream);
 int fgnn_block1_struct_bwd(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *const *W1,
                            const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
@@ -444,7 +447,8 @@ int fgnn_block1_struct_bwd(const unsigned *bits, const int *nvalid, int G, int N
 /* x16 (optional): the (G, 2, ldp) bf16 input slab (channel 0 = W, channel 1 = diag(row sums)) the later kernels of block 1 read */
 int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
                              const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2,
-                             void *mult /* bf16 */, long long gstride, long long ldp, void *x16 /* bf16, optional */, float *ws, void *stream);
+                             void *mult /* bf16 */, long long gstride, long long ldp, void *x16 /* bf16, optional */, float *ws,
+                             const float *const *tW1, const float *const *tb1, const float *const *tW2, const float *const *tb2, void *stream);
 int fgnn_block1_struct_bwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *const *W1,
                              const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
                              const void *dmult /* bf16 */, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2,
