@@ -39,6 +39,13 @@ DEVI int sb_classes(int N) { return 2 + 2 * (N + 1); }
 
 typedef unsigned long long u64;
 
+#ifdef SB_STAMPS
+__device__ unsigned long long *g_sb_stamps = nullptr;      // [kernel 0..3][workgroup < 2048][8] s_memtime ticks (tools/gpu_struct_stamps.py)
+#define SB_STAMP(kern, wg, i) if (threadIdx.x == 0 && g_sb_stamps && (wg) < 2048) g_sb_stamps[((kern) * 2048 + (wg)) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define SB_STAMP(kern, wg, i)
+#endif
+
 // ---- K0: the class tables of one model, graph independent: tab[m][class][h1 | h2 | z][32] -------------------------------
 struct TabArgs {
     const float *W[2][3];
@@ -244,10 +251,13 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
     }
     const int g = ((int)blockIdx.x - ntab) / ny, y = ((int)blockIdx.x - ntab) - g * ny;
     const int nv = nvalid_of(nvalid, g, N);
+    SB_STAMP(0, blockIdx.x - ntab, 0)
     sb_bits_rows(B, bits, g, tid, N, nv);
     __syncthreads();
+    SB_STAMP(0, blockIdx.x - ntab, 1)
     sb_bits_cols(B, tid, nv);
     __syncthreads();
+    SB_STAMP(0, blockIdx.x - ntab, 2)
     if (y == 0) {
         float on1 = 0.f;
         if (tid < N) {
@@ -272,6 +282,7 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
     for (int t = 0; t < NWD; ++t)
 #pragma unroll
         for (int w = 0; w < NWD; ++w) cw[t][w] = B.col[j0 + t][w];                 // j0 + t < 64 NWD
+    SB_STAMP(0, blockIdx.x - ntab, 3)
     unsigned short *code16 = reinterpret_cast<unsigned short *>(code) + (long long)g * N * cp;
     unsigned short *xa = reinterpret_cast<unsigned short *>(x16) + (long long)g * 2 * ldp16, *xb = xa + ldp16;
     for (int i = r0 + wv; i < r1; i += 4) {
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
             sb_store16<NWD>(xb + (long long)i * pitch16 + j0, dg16);
         }
     }
+    SB_STAMP(0, blockIdx.x - ntab, 4)
     if (x16 && y == ny - 1) {
         // tail of the channel stride of the 2-channel input slab of the 16-bit engine (mlp3 reads the slab as its skip connection)
         unsigned *x0 = reinterpret_cast<unsigned *>(xa), *x1 = reinterpret_cast<unsigned *>(xb);
@@ -363,6 +375,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     __shared__ float DR[MAXN], DC[MAXN];
     const int g = blockIdx.x, cg = blockIdx.y, part = blockIdx.z, nparts = gridDim.z, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N);
+    SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 0)
     const int NC = sb_classes(N);
     {   // wave wv owns channel cg * SB_CPG + wv of both models
         float4 vi[NWD];
@@ -392,6 +405,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
             }
         }
     }
+    SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 1)
     __syncthreads();
     const float fN = (float)nv;
     float k0[SB_CPG], k2[SB_CPG], k3[SB_CPG], v0[SB_CPG], rr[SB_CPG];
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     const unsigned short *cg16 = code + (long long)g * N * cp;
     float *out32 = reinterpret_cast<float *>(mult) + (BF ? 0 : (long long)g * gstride + (long long)cg * SB_CPG * ldp);
     unsigned *out16 = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(mult) + (BF ? (long long)g * gstride + (long long)cg * SB_CPG * ldp : 0));
+    SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 2)
     constexpr int RU = 2;                                        // rows in flight per wave
     for (int i0 = part * 4 + wv; i0 < N; i0 += 4 * nparts * RU) {
         unsigned cd[RU][NT];
@@ -479,6 +494,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
             }
         }
     }
+    SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 3)
     if constexpr (BF) {
         if (part == 0)                                           // tail of the channel stride
             for (int e = N * pitch / 2 + tid; e < (int)(ldp / 2); e += 256)
@@ -529,6 +545,7 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
     const float *src = reinterpret_cast<const float *>(dm) + (BF ? 0 : (long long)g * gstride + (long long)c * ldp);
     const unsigned short *src16 = reinterpret_cast<const unsigned short *>(dm) + (BF ? (long long)g * gstride + (long long)c * ldp : 0);
     const unsigned short *cg16 = code + (long long)g * N * cp;
+    SB_STAMP(2, blockIdx.x, 0)
     // lane <-> the NWD consecutive columns NWD lane + t: one load per row and operand
     const int j0 = NWD * lane;
     const bool lane_on = j0 < nv;
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
         colp[wv][1][j0 + k] = Qm[k];
         colp[wv][2][j0 + k] = U[k];
     }
+    SB_STAMP(2, blockIdx.x, 1)
     __syncthreads();
     // wave k < NWD: lane l owns vertex l + 64 k; the partial sums of the NWD waves meet in LDS (fixed order), wave 0 finishes
     __shared__ float fin[NWD][16];
@@ -654,6 +672,7 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
     } else if (wv != 0) {
         return;
     }
+    SB_STAMP(2, blockIdx.x, 2)
     if (lane == 0) {
         const float Tt = t[0], Ut = t[1], sCdc = t[2], sCs = t[3], sRdr = t[4], sQs = t[5], sqR = t[6], sqP = t[7];
         const float sd1 = t[8], swd1 = t[9], sd2 = t[10], swd2 = t[11], sz1 = t[12], sz2 = t[13];
@@ -677,6 +696,7 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
         coef[(long long)g * FGNN_H + c] = make_float4(ra.y, mm > 0.f ? -ra.y * s2a * ra.w / mm : 0.f, mm > 0.f ? -ra.y * s1a / mm : 0.f, ra.x);
         coef[((long long)G + g) * FGNN_H + c] = make_float4(rb.y, mm > 0.f ? -rb.y * s2b * rb.w / mm : 0.f, mm > 0.f ? -rb.y * s1b / mm : 0.f, rb.x);
     }
+    SB_STAMP(2, blockIdx.x, 3)
 }
 
 // ---- K3: the class algebra, KC instances per round, the rounds of a graph spread over wpg workgroups --------------
@@ -861,6 +881,10 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const float4 *vinfo,
 }
 
 }  // namespace
+
+#ifdef SB_STAMPS
+extern "C" int fgnn_debug_sb_stamps(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sb_stamps), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
+#endif
 
 extern "C" int fgnn_block1_struct_supported(int N, int depth, int c0) { return (N >= 1 && N <= SB_NMAX && depth == 3 && c0 == 2) ? 1 : 0; }
 extern "C" int fgnn_block1_struct_table_floats(int N) { return 2 * (2 + 2 * (N + 1)) * SB_TAB; }
