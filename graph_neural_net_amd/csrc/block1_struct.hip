@@ -513,6 +513,53 @@ template <int NWD>
 struct __attribute__((packed, aligned(4))) SbFloats {
     float v[NWD];
 };
+// Sums of NV (a power of two <= 16) per-lane values over the 64 lanes in ONE butterfly: at each of the first log2(NV) steps a lane
+// hands half of its values to its partner and keeps the other half (partner across lane bit 5, 4, 3, 2 in that order), so the
+// number of live values halves while the partner distance shrinks; the remaining steps reduce the single value left.  Lane L ends
+// with the total of value e(L) = bits (b5 b4 b3 b2)[first log2(NV)] of L read as a number: 2 + 1 + 1/2 + ... exchanges per value
+// instead of six (a per-row wave_sum pair was 28 of the 47 VALU instructions a row of the class-sum kernel cost at N = 50).
+// Fixed tree: bit-reproducible.
+template <int STEP>
+DEVI float ws_xchg(float x) {           // x of the partner lane of butterfly step STEP (partners differ in lane bit 5 - STEP)
+    if constexpr (STEP == 0) return __shfl_xor(x, 32);
+    else if constexpr (STEP == 1) return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+    else if constexpr (STEP == 2) return dpp_mov<0x140>(x);       // row_mirror: partner 15 - l inside a row of 16
+    else if constexpr (STEP == 3) return dpp_mov<0x141>(x);       // row_half_mirror: partner 7 - l inside 8
+    else if constexpr (STEP == 4) return dpp_mov<0x4E>(x);        // quad_perm [2,3,0,1]
+    else return dpp_mov<0xB1>(x);                                 // quad_perm [1,0,3,2]
+}
+template <int NV, int STEP>
+DEVI void ws_step(float (&v)[NV], int lane) {
+    constexpr int LIVE = (NV >> STEP) > 1 ? (NV >> STEP) : 1;     // values a lane holds before this step (compile-time: no dynamic indexing)
+    if constexpr (LIVE > 1) {
+        const bool up = (lane >> (5 - STEP)) & 1;                 // this lane keeps the upper half
+#pragma unroll
+        for (int k = 0; k < LIVE / 2; ++k) {
+            const float send = up ? v[k] : v[k + LIVE / 2], keep = up ? v[k + LIVE / 2] : v[k];
+            v[k] = keep + ws_xchg<STEP>(send);
+        }
+    } else {
+        v[0] += ws_xchg<STEP>(v[0]);
+    }
+}
+template <int NV>
+DEVI float wave_sum_multi(float (&v)[NV], int lane) {
+    static_assert(NV == 2 || NV == 4 || NV == 8 || NV == 16, "power of two");
+    ws_step<NV, 0>(v, lane);
+    ws_step<NV, 1>(v, lane);
+    ws_step<NV, 2>(v, lane);
+    ws_step<NV, 3>(v, lane);
+    ws_step<NV, 4>(v, lane);
+    ws_step<NV, 5>(v, lane);
+    return v[0];
+}
+// index of the value lane L holds after wave_sum_multi<NV> (valid in every lane; lanes that differ only in the low bits hold copies)
+template <int NV>
+DEVI int wave_sum_multi_index(int lane) {
+    constexpr int LG = NV == 2 ? 1 : (NV == 4 ? 2 : (NV == 8 ? 3 : 4));
+    return (lane >> (6 - LG)) & (NV - 1);
+}
+
 // (NWD + 1) / 2 dwords holding NWD consecutive 16-bit values
 template <int NWD>
 DEVI void sb_load16_packed(const unsigned short *p, unsigned (&o)[(NWD + 1) / 2]) {
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
     constexpr int MAXN = 64 * NWD, CS = 2 + MAXN, NW = sb_reduce_waves<NWD>();
     __shared__ float colp[NW][3][MAXN];                 // per wave: C, Qm, U per column
     __shared__ float Rs[MAXN], Ps[MAXN], Dg[MAXN];      // per row: sum, W-masked sum, diagonal entry
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // (wave-uniform: scalar row branches)
     const int pl = blockIdx.x, g = pl / FGNN_H, c = pl - g * FGNN_H;
     const int nv = nvalid_of(nvalid, g, N);
     const float4 ra = reinterpret_cast<const float4 *>(nrm1)[(long long)g * FGNN_H + c];
@@ -577,11 +624,12 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
                 }
             }
         }
+        float red[2 * RU];                                // {row sum, W-masked row sum} of the RU rows: one butterfly for all of them
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const int i = i0 + NW * u;
+            float rs = 0.f, rm = 0.f;
             if (i < nv) {
-                float rs = 0.f, rm = 0.f;
 #pragma unroll
                 for (int k = 0; k < NWD; ++k) {
                     const bool on = j0 + k < nv;
@@ -599,13 +647,23 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
                     U[k] = fmaf(x, (float)(cd & 0x7fffu), U[k]);
                     if (j0 + k == i) Dg[i] = x;
                 }
+            }
+            if constexpr (NWD == 1) {                     // (one column per lane: the per-row sums measured faster than the batched butterfly)
                 rs = wave_sum(rs);
                 rm = wave_sum(rm);
-                if (lane == 0) {
+                if (lane == 0 && i < nv) {
                     Rs[i] = rs;
                     Ps[i] = rm;
                 }
             }
+            red[2 * u] = rs;
+            red[2 * u + 1] = rm;
+        }
+        if constexpr (NWD > 1) {
+            const float tot = wave_sum_multi<2 * RU>(red, lane);
+            const int e = wave_sum_multi_index<2 * RU>(lane), i = i0 + NW * (e >> 1);
+            constexpr int LOW = 64 / (2 * RU) - 1;        // lanes with these bits clear are the writers
+            if ((lane & LOW) == 0 && i < nv) ((e & 1) ? Ps : Rs)[i] = tot;
         }
     }
 #pragma unroll
@@ -653,24 +711,17 @@ __global__ __launch_bounds__(64 * sb_reduce_waves<NWD>()) void sb_bwd_reduce_ker
         const float d2 = on ? u0 * Cj + p * Qj + q * dg : 0.f;            // dB_ii = u0 C_i + p (W^T dM)_ii + q_i dM_ii
         o1[2 + vx] = d1;
         o2[2 + vx] = d2;
-        const float part[14] = {Cj, Uj, Cj * degc, Cj * s, R * degr, Qj * s, q * R, q * Pm, d1, wii * d1, d2, wii * d2, d1 * za, d2 * zb};
-#pragma unroll
-        for (int e = 0; e < 14; ++e) {
-            t[e] = wave_sum(part[e]);
-            if (NWD > 1 && lane == 0) fin[wv][e] = t[e];
-        }
+        float part[16] = {Cj, Uj, Cj * degc, Cj * s, R * degr, Qj * s, q * R, q * Pm, d1, wii * d1, d2, wii * d2, d1 * za, d2 * zb, 0.f, 0.f};
+        const float tot = wave_sum_multi<16>(part, lane);
+        if ((lane & 3) == 0) fin[wv][wave_sum_multi_index<16>(lane)] = tot;
     }
-    if constexpr (NWD > 1) {
-        __syncthreads();
-        if (wv != 0) return;
+    __syncthreads();
+    if (wv != 0) return;
 #pragma unroll
-        for (int e = 0; e < 14; ++e) {
-            t[e] = fin[0][e];
+    for (int e = 0; e < 14; ++e) {
+        t[e] = fin[0][e];
 #pragma unroll
-            for (int w = 1; w < NWD; ++w) t[e] += fin[w][e];
-        }
-    } else if (wv != 0) {
-        return;
+        for (int w = 1; w < NWD; ++w) t[e] += fin[w][e];
     }
     SB_STAMP(2, blockIdx.x, 2)
     if (lane == 0) {

@@ -14,6 +14,7 @@ TAGS = {
     'mlp_bwd_pair_kernel<32>': 'mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_pair_kernel<2>': 'mlp_bwd_pair[cin=2,dx=0]',
     'mlp_bwd_pair_x3_kernel<32>': 'x3:mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_pair_x3_kernel<2>': 'x3:mlp_bwd_pair[cin=2,dx=0]',
     'sb_fwd_kernel': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel': 'fgnn_block1_struct_bwd',
+    'sb_fwd_kernel<1>': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel<1>': 'fgnn_block1_struct_bwd',
     'chan_matmul_bwd1_kernel': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd1_kernel': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_w_kernel<7, true>': 'fgnn_chan_matmul_fwd',
 }
 TAGS16 = {
@@ -23,10 +24,12 @@ TAGS16 = {
     'mlp_fwd16_kernel<32, 0, 2, 3>': 'mlp_fwd16[cin=32,nmlp=2]', 'mlp_fwd16_kernel<32, 32, 1, 3>': 'mlp_fwd16[cin=64,nmlp=1]',
     'mlp_fwd16_kernel<2, 0, 2, 3>': 'mlp_fwd16[cin=2,nmlp=2]', 'mlp_fwd16_kernel<32, 2, 1, 3>': 'mlp_fwd16[cin=34,nmlp=1]',
     'chan_matmul_bwd16_kernel<8, 7, 2>': 'fgnn_chan_matmul_bwd16', 'chan_matmul_fwd16_kernel<8, 7, true>': 'fgnn_chan_matmul_fwd16',
+    'sb_fwd_kernel<4, true>': 'fgnn_block1_struct_fwd16', 'sb_bwd_reduce_kernel<4, true>': 'fgnn_block1_struct_bwd16',
 }
 # ragged batches run the SKIP = true instantiations (the ', false' of the packed-input flag is stripped below)
 TAGS5 = {k.replace('>', ', true>') if k.startswith(('mlp_', )) else k: v for k, v in TAGS.items()}
-TAGS5.update({'chan_matmul_bwd_big_kernel<4>': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd_big_kernel<4>': 'fgnn_chan_matmul_fwd'})
+TAGS5.update({'chan_matmul_bwd_big_kernel<4>': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd_big_kernel<4>': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_big_kernel<4, true>': 'fgnn_chan_matmul_fwd',
+              'sb_fwd_kernel<2>': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel<2>': 'fgnn_block1_struct_bwd'})
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rel = lambda f: os.path.relpath(f, root)
 out = {'_note': 'HBM traffic per launch from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, '
