@@ -32,6 +32,7 @@ constexpr int SB_CG = 8;                 // channel groups of the forward kernel
 constexpr int SB_CPG = FGNN_H / SB_CG;   // channels per group
 constexpr int SB_TAB = 4 * FGNN_H;       // floats per table row: h1 | h2 | z (fp32, for the statistics) | z as stored (bf16 scheme: R(z))
 constexpr int SB_NMAX = 256;
+constexpr int SB_FW = 8;                 // waves per workgroup of the forward kernel
 constexpr int SB_KC = 32;                // class instances per round of the class-algebra kernel
 
 // class of a pixel's input value: 0 = off-diagonal, w = 0; 1 = off-diagonal, w = 1; 2 + 2 deg + w_ii = diagonal
@@ -358,12 +359,14 @@ DEVI ClassVals<NWD> sb_class_values(const float *tab_m, const float4 (&vi)[NWD],
 }
 
 // ---- K1: GraphNorm records of mlp1 / mlp2 + mult = Y1 Y2 in closed form, row by row ------------------------------
-// grid (G, SB_CG, parts), 256 threads: a workgroup writes SB_CPG channels; wave w takes the rows w + 4 part, + 4 parts, ...; a
+// grid (G, SB_CG, parts), SB_FW = 8 waves: a workgroup writes SB_CPG channels -- four waves form their class values (once per
+// workgroup: with 4-wave workgroups and twice the parts this prologue was 46 % of the kernel's VALU instructions at N = 200), then
+// wave w takes the rows w + 8 part, + 8 parts, ...; a
 // lane owns fixed columns and keeps their per-channel terms in registers, the row terms are wave-uniform:
 //     mult_c[i][j] = [k0 + k2 degr_i + v0 q_i] + [k1 degc_j + u0 s_j] + k3 (W^2)_ij + w_ij (p s_j + r q_i) + [i = j] q_i s_i
 // fp32 slabs: lane <-> columns lane + 64 t; bf16 slabs: lane <-> column pairs 2 lane + 128 t (one dword per store)
 template <int NWD, bool BF>
-__global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code, const float4 *vinfo, const float *gones, const int *nvalid,
+__global__ __launch_bounds__(64 * SB_FW) void sb_fwd_kernel(const unsigned short *code, const float4 *vinfo, const float *gones, const int *nvalid,
                                                       const int N, const int cp, const float *tab, const float *gnw1, const float *gnb1,
                                                       const float *gnw2, const float *gnb2, const float eps, float *nrm1, float *nrm2, void *mult,
                                                       const long long gstride, const long long ldp, const int pitch) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     const int nv = nvalid_of(nvalid, g, N);
     SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 0)
     const int NC = sb_classes(N);
-    {   // wave wv owns channel cg * SB_CPG + wv of both models
+    if (wv < SB_CPG) {   // wave wv < 4 owns channel cg * SB_CPG + wv of both models (the other waves join for the rows)
         float4 vi[NWD];
 #pragma unroll
         for (int k = 0; k < NWD; ++k) vi[k] = lane + 64 * k < nv ? vinfo[(long long)g * N + lane + 64 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 1)
     __syncthreads();
     const float fN = (float)nv;
-    float k0[SB_CPG], k2[SB_CPG], k3[SB_CPG], v0[SB_CPG], rr[SB_CPG];
-    float colc[SB_CPG][NT * CW], psv[SB_CPG][NT * CW], sv[SB_CPG][NT * CW];
+    float k0[SB_CPG], k2[SB_CPG], k3[SB_CPG], v0[SB_CPG], rr[SB_CPG], pk[SB_CPG];
+    float colc[SB_CPG][NT * CW], sv[SB_CPG][NT * CW];
     int col[NT * CW];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
 #pragma unroll
     for (int k = 0; k < SB_CPG; ++k) {
         const float u0 = sc[k][0], pp = sc[k][1];
+        pk[k] = pp;
         v0[k] = sc[k][2];
         rr[k] = sc[k][3];
         k0[k] = u0 * v0[k] * fN;
@@ -429,7 +433,6 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
             const int j = col[e] < MAXN ? col[e] : 0;
             sv[k][e] = S[k][j];
             colc[k][e] = k1 * DC[j] + u0 * sv[k][e];
-            psv[k][e] = pp * sv[k][e];
         }
     }
     const unsigned short *cg16 = code + (long long)g * N * cp;
@@ -437,11 +440,11 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     unsigned *out16 = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(mult) + (BF ? (long long)g * gstride + (long long)cg * SB_CPG * ldp : 0));
     SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 2)
     constexpr int RU = 2;                                        // rows in flight per wave
-    for (int i0 = part * 4 + wv; i0 < N; i0 += 4 * nparts * RU) {
+    for (int i0 = part * SB_FW + wv; i0 < N; i0 += SB_FW * nparts * RU) {
         unsigned cd[RU][NT];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            const int i = i0 + 4 * nparts * u;
+            const int i = i0 + SB_FW * nparts * u;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int j = col[t * CW];
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            const int i = i0 + 4 * nparts * u;
+            const int i = i0 + SB_FW * nparts * u;
             if (i >= N) break;
             const bool rowon = i < nv;
             const int ii = rowon ? i : 0;
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
                     for (int k = 0; k < SB_CPG; ++k) {
                         float v = rowc[k] + colc[k][e];
                         v = fmaf(k3[k], w2f, v);
-                        if (w) v += psv[k][e] + rq[k];
+                        if (w) v += fmaf(pk[k], sv[k][e], rq[k]);
                         if (j == i) v = fmaf(qk[k], sv[k][e], v);
                         val[k][h] = on ? v : 0.f;
                     }
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void sb_fwd_kernel(const unsigned short *code,
     SB_STAMP(1, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 3)
     if constexpr (BF) {
         if (part == 0)                                           // tail of the channel stride
-            for (int e = N * pitch / 2 + tid; e < (int)(ldp / 2); e += 256)
+            for (int e = N * pitch / 2 + tid; e < (int)(ldp / 2); e += 64 * SB_FW)
 #pragma unroll
                 for (int k = 0; k < SB_CPG; ++k) out16[((long long)k * ldp) / 2 + e] = 0u;
     }
@@ -981,7 +984,7 @@ struct FwdCall {
 };
 template <int NWD, bool BF>
 int sb_fwd_launch(const FwdCall &c) {
-    const int parts0 = (1024 + c.G * SB_CG - 1) / (c.G * SB_CG), parts = parts0 > 8 ? 8 : parts0;      // four workgroups per CU
+    const int parts0 = (512 + c.G * SB_CG - 1) / (c.G * SB_CG), parts = parts0 > 8 ? 8 : parts0;      // two 8-wave workgroups per CU
     const WsLayout L = sb_ws_layout(c.G, c.N);
     const int ny0 = (512 + c.G - 1) / c.G, ny = ny0 > (c.N + 3) / 4 ? (c.N + 3) / 4 : ny0;      // two workgroups per CU, at least one row per wave
     unsigned short *code = reinterpret_cast<unsigned short *>(c.ws + L.code);
@@ -1001,7 +1004,7 @@ int sb_fwd_launch(const FwdCall &c) {
     hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(ntab + c.G * ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code),
                        vinfo, c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch, ny, ntab, TA, const_cast<float *>(c.tables), BF ? 1 : 0);
     FGNN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((sb_fwd_kernel<NWD, BF>), dim3(c.G, SB_CG, parts), dim3(256), 0, c.st, code, vinfo, c.ws + L.gones, c.nvalid, c.N, L.cp, c.tables,
+    hipLaunchKernelGGL((sb_fwd_kernel<NWD, BF>), dim3(c.G, SB_CG, parts), dim3(64 * SB_FW), 0, c.st, code, vinfo, c.ws + L.gones, c.nvalid, c.N, L.cp, c.tables,
                        c.gnw1, c.gnb1, c.gnw2, c.gnb2, c.eps, c.nrm1, c.nrm2, c.mult, c.gstride, c.ldp, c.pitch);
     FGNN_LAUNCH_CHECK();
     return 0;
