@@ -56,6 +56,77 @@ __global__ __launch_bounds__(256) void colmax_fwd_kernel(const fgnn_slab y, cons
     }
 }
 
+// 64 < N <= 256: 16 lanes per row, four rows per wave, four waves per workgroup; lane l of a row group scans the KC consecutive
+// columns KC l .. KC l + KC - 1 (one or two 16-byte loads), the arg-max meets inside the row of 16 lanes by DPP row operations (no
+// LDS): a quarter of the waves of the row-per-wave kernel and a third of its instructions per row.  Same tie rule.
+template <int KC>
+struct __attribute__((packed, aligned(4))) ColFloats {
+    float v[KC];
+};
+template <int KC>
+__global__ __launch_bounds__(256) void colmax_fwd_rows16_kernel(const fgnn_slab y, const int *nvalid, int G, int N, float *e, int *idx) {
+    const int lane = threadIdx.x & 63, sub = lane & 15;
+    const long long t = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);      // row index over (g, c, i)
+    const int C = y.C;
+    const bool live = t < (long long)G * C * N;
+    const long long tc = live ? t : 0;
+    const int i = (int)(tc % N);
+    const int gc = (int)(tc / N);
+    const int g = gc / C, c = gc - g * C;
+    const int nv = nvalid_of(nvalid, g, N);
+    float best = 0.f;
+    int bi = 0;
+    if (live && i < nv) {                      // (uniform inside a row group of 16 lanes)
+        const float *row = y.ptr + (long long)g * y.gstride + (long long)c * y.ldp + (long long)i * N;
+        float mean = 0.f, a = 1.f, be = 0.f;
+        if (y.nrm) {
+            const float4 n = reinterpret_cast<const float4 *>(y.nrm)[gc];
+            mean = n.x;
+            a = n.y;
+            be = y.beta ? y.beta[c] : 0.f;
+        }
+        const int j0 = KC * sub;
+        float v[KC];
+        if (j0 + KC <= N) {
+            const ColFloats<KC> f = *reinterpret_cast<const ColFloats<KC> *>(row + j0);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) v[k] = f.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < KC; ++k) v[k] = j0 + k < N ? row[j0 + k] : 0.f;
+        }
+        best = -FLT_MAX;
+        bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const float x = y.nrm ? (v[k] - mean) * a + be : v[k];
+            if (j0 + k < nv && x > best) {
+                best = x;
+                bi = j0 + k;
+            }
+        }
+    }
+    // arg-max over the 16 lanes of the row group: larger value wins, equal values -> smaller column
+#define FGNN_COLMAX_STEP(CTRL)                                                                                         \
+    {                                                                                                                  \
+        const float ov = dpp_mov<CTRL>(best);                                                                          \
+        const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xf, 0xf, true);                                       \
+        if (ov > best || (ov == best && oi < bi)) {                                                                    \
+            best = ov;                                                                                                 \
+            bi = oi;                                                                                                   \
+        }                                                                                                              \
+    }
+    FGNN_COLMAX_STEP(0xB1)      // quad_perm [1,0,3,2]
+    FGNN_COLMAX_STEP(0x4E)      // quad_perm [2,3,0,1]
+    FGNN_COLMAX_STEP(0x141)     // row_half_mirror
+    FGNN_COLMAX_STEP(0x140)     // row_mirror
+#undef FGNN_COLMAX_STEP
+    if (live && sub == 0) {
+        e[t] = i < nv ? best : 0.f;
+        idx[t] = i < nv ? bi : 0;
+    }
+}
+
 // N <= 64: one wave per (g,c); the matrix is read with coalesced loads, normalised and staged in a
 // wave-private LDS tile (row stride N+1: conflict-free row scans), then lane i scans row i.
 // FIN: the record of the input does not exist yet; the wave finalizes it from the producer's tile statistics
@@ -542,6 +613,16 @@ extern "C" int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int
     if (N <= 64) {
         hipLaunchKernelGGL(colmax_fwd_lds_kernel<false>, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0,
                            (hipStream_t)stream, *y, nvalid, G, N, e, idx, ColmaxFin{});
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
+    if (N <= 128) {
+        hipLaunchKernelGGL(colmax_fwd_rows16_kernel<8>, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *y, nvalid, G, N, e, idx);
+        FGNN_LAUNCH_CHECK();
+        return 0;
+    }
+    if (N <= 256) {
+        hipLaunchKernelGGL(colmax_fwd_rows16_kernel<16>, dim3((unsigned)((tot + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *y, nvalid, G, N, e, idx);
         FGNN_LAUNCH_CHECK();
         return 0;
     }

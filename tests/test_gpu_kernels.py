@@ -190,6 +190,33 @@ def test_chan_matmul_ragged_minimal_fill_covers_every_live_tile(N, nvs):
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])
 
 
+@pytest.mark.parametrize('N,nvs', [(70, [70, 33]), (120, [120, 75, 1]), (128, [128, 127]), (129, [129, 64]), (200, [200, 131]), (256, [256, 255, 17])])
+def test_colmax_16_lanes_per_row_first_index_on_ties(N, nvs):
+    """64 < N <= 256 (colmax_fwd_rows16_kernel): values with many exact ties, ragged graphs, normalised input: value and FIRST arg-max
+    column per valid row bit-exact against torch, zeros in the padding rows."""
+    G, Cc = len(nvs), 3
+    rng = torch.Generator().manual_seed(N)
+    x = torch.randint(-3, 4, (G, Cc, N, N), generator=rng).float()
+    nrm = torch.zeros(G, Cc, 4)
+    nrm[..., 0] = torch.randint(-2, 3, (G, Cc), generator=rng).float()       # mean
+    nrm[..., 1] = 2.0 ** torch.randint(-1, 2, (G, Cc), generator=rng).float()  # a (power of two: exact arithmetic)
+    beta = torch.randint(-1, 2, (Cc,), generator=rng).float()
+    xd, nd, bd = x.to(DEV), nrm.to(DEV).contiguous(), beta.to(DEV)
+    nv = torch.tensor(nvs, dtype=torch.int32, device=DEV)
+    e = torch.full((G, Cc, N), 7.0, device=DEV)
+    idx = torch.full((G, Cc, N), 7, dtype=torch.int32, device=DEV)
+    s = _slab(xd, nrm=nd, beta=bd)
+    _lib.call('fgnn_colmax_fwd', C.byref(s), _lib.ptr(nv), G, N, _lib.ptr(e), _lib.ptr(idx), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    y = (x - nrm[..., 0, None, None]) * nrm[..., 1, None, None] + beta[None, :, None, None]
+    for g, n in enumerate(nvs):
+        val = y[g, :, :n, :n].max(-1)[0]
+        first = (y[g, :, :n, :n] == val.unsqueeze(-1)).float().argmax(-1)
+        assert torch.equal(e[g, :, :n].cpu(), val), (g, n)
+        assert torch.equal(idx[g, :, :n].cpu().long(), first), (g, n)
+        assert e[g, :, n:].abs().sum().item() == 0 and idx[g, :, n:].abs().sum().item() == 0
+
+
 def test_colmax_first_index_on_ties_bit_exact():
     G, Cc, N = 2, 3, 11
     x = torch.randint(-3, 4, (G, Cc, N, N)).float()      # many exact ties
