@@ -440,19 +440,29 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # with a collective in the capture the process group's watchdog thread is alive: its event queries must not be
+            # counted against this thread's capture ('thread_local'; the default 'global' mode would invalidate the capture)
+            with torch.cuda.graph(g, capture_error_mode='thread_local' if with_collective else 'global'):
                 model_work()
                 if with_collective:
                     dp.allreduce_sum_(comm)
             return g
         try:
             graph = capture(ar_in_graph)
-        except Exception as exc:                  # capture unsupported -> eager launches (still the HIP path)
+        except Exception as exc:                  # first fall back to a graph of the model work + an eager all-reduce ...
             graph = None
-            ar_in_graph = False
             if rank == 0:
-                print('bench.py: HIP graph capture failed (%s); running eager' % (exc,), file=sys.stderr)
+                print('bench.py: HIP graph capture%s failed (%s)' % (' with the all-reduce inside' if ar_in_graph else '', exc), file=sys.stderr)
             torch.cuda.synchronize()
+            if ar_in_graph:
+                ar_in_graph = False
+                try:
+                    graph = capture(False)
+                except Exception as exc2:         # ... then to eager launches (still the HIP path)
+                    graph = None
+                    if rank == 0:
+                        print('bench.py: HIP graph capture failed (%s); running eager' % (exc2,), file=sys.stderr)
+                    torch.cuda.synchronize()
 
     def step():
         if graph is not None:

@@ -190,7 +190,8 @@ class FgnnTrainer:
             t0 = self.opt.t
             g_model, g_opt = torch.cuda.CUDAGraph(), None
             exchange = world > 1 or self._force_collective
-            with torch.cuda.graph(g_model):
+            # (a collective inside the capture: 'thread_local', so that the process group's watchdog thread cannot invalidate it)
+            with torch.cuda.graph(g_model, capture_error_mode='thread_local' if (exchange and self.allreduce_in_graph) else 'global'):
                 scores, _ = eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
                 if not exchange or self.allreduce_in_graph:
                     # nothing to exchange, or the ONE collective rides in the graph: the whole step is one replay
