@@ -92,86 +92,21 @@ __global__ __launch_bounds__(256) void sb_tables_kernel(const TabArgs A, const i
     if (row < 2 * NC) sb_table_row(A, N, tab, bf, row % NC, row / NC, threadIdx.x & 63);
 }
 
-// per-graph bit structure in LDS (NWD 64-bit words per row: N <= 64 NWD), filled by the first 64 NWD threads of a group
+// row t of graph g restricted to the valid corner (bits >= nv cleared, rows >= nv empty) as 2 NWD dwords in LDS
 template <int NWD>
-struct GraphBits {
-    static constexpr int MAXN = 64 * NWD;
-    u64 row[MAXN][NWD], col[MAXN][NWD];
-    float degr[MAXN], degc[MAXN];
-    int wii[MAXN], cls[MAXN];
-};
-// row t of graph g restricted to the valid corner: bits >= nv cleared, rows >= nv empty
-template <int NWD>
-DEVI void sb_bits_rows(GraphBits<NWD> &B, const unsigned *bits, int g, int t, int N, int nv) {
+DEVI void sb_bits_rows(unsigned (*rows)[2 * NWD], const unsigned *bits, int g, int t, int N, int nv) {
     if (t < 64 * NWD) {
         const int words = (N + 31) / 32;
         const unsigned *r = bits + ((long long)g * N + (t < N ? t : 0)) * words;
 #pragma unroll
-        for (int w = 0; w < NWD; ++w) {
-            u64 v = 0ull;
-            if (t < nv) {
-                if (2 * w < words) v = r[2 * w];
-                if (2 * w + 1 < words) v |= (u64)r[2 * w + 1] << 32;
-                const int left = nv - 64 * w;                      // valid bits in this word
-                v = left >= 64 ? v : (left <= 0 ? 0ull : (v & ((1ull << left) - 1ull)));
-            }
-            B.row[t][w] = v;
+        for (int w = 0; w < 2 * NWD; ++w) {
+            unsigned v = (t < nv && w < words) ? r[w] : 0u;
+            const int left = nv - 32 * w;                          // valid bits in this word
+            v = left >= 32 ? v : (left <= 0 ? 0u : (v & ((1u << left) - 1u)));
+            rows[t][w] = v;
         }
     }
 }
-template <int NWD>
-DEVI void sb_bits_vertex(GraphBits<NWD> &B, int t) {           // what needs the vertex's own row only
-    int dr = 0;
-#pragma unroll
-    for (int w = 0; w < NWD; ++w) dr += __popcll(B.row[t][w]);
-    B.degr[t] = (float)dr;
-    const int wself = (int)((B.row[t][t >> 6] >> (t & 63)) & 1ull);
-    B.wii[t] = wself;
-    B.cls[t] = 2 + 2 * dr + wself;
-}
-// column t of the bit matrix from the rows in LDS: 32 rows per group, every shift a compile-time constant (one 32-bit LDS read,
-// one bit-field extract and one shift-or per bit; a wave instruction costs 4 cycles, so the 64-bit / dynamic-index form of this
-// loop was the longest phase of every kernel that called it)
-template <int NWD>
-DEVI void sb_bits_cols(GraphBits<NWD> &B, int t, int nv) {
-    if (t < 64 * NWD) {
-        const unsigned *rows32 = reinterpret_cast<const unsigned *>(&B.row[0][0]);      // [64 NWD][2 NWD] dwords
-        const int dw = t >> 5, sh = t & 31;
-        unsigned c32[2 * NWD];
-#pragma unroll
-        for (int h = 0; h < 2 * NWD; ++h) {              // rows 32 h .. 32 h + 31 (rows >= nv are empty)
-            unsigned acc = 0u;
-            if (32 * h < nv) {
-#pragma unroll
-                for (int k8 = 0; k8 < 32; k8 += 8) {
-                    unsigned r[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) r[k] = rows32[(32 * h + k8 + k) * 2 * NWD + dw];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc |= ((r[k] >> sh) & 1u) << (k8 + k);
-                }
-            }
-            c32[h] = acc;
-        }
-        int dc = 0;
-#pragma unroll
-        for (int w = 0; w < NWD; ++w) {
-            B.col[t][w] = (u64)c32[2 * w] | ((u64)c32[2 * w + 1] << 32);
-            dc += __popc(c32[2 * w]) + __popc(c32[2 * w + 1]);
-        }
-        B.degc[t] = (float)dc;
-        sb_bits_vertex(B, t);
-    }
-}
-template <int NWD>
-DEVI int sb_w2(const GraphBits<NWD> &B, int i, int j) {        // (W^2)_ij = |{k: w_ik = w_kj = 1}|
-    int s = 0;
-#pragma unroll
-    for (int w = 0; w < NWD; ++w) s += __popcll(B.row[i][w] & B.col[j][w]);
-    return s;
-}
-template <int NWD>
-DEVI bool sb_w(const GraphBits<NWD> &B, int i, int j) { return (B.row[i][j >> 6] >> (j & 63)) & 1ull; }
 
 // The normalised class values of channel c of one model in one graph: Y = u0 J + p W + diag(q)
 template <int NWD>
@@ -236,13 +171,18 @@ DEVI void sb_store16(unsigned short *p, const unsigned (&o)[NWD]) {
 
 // ---- KG: code plane + vertex records (+ the input slabs the other kernels of block 1 read) -------------------------------------
 // grid ntab + G ny: the first ntab workgroups build the class tables of the step (four rows each: the graph-independent launch of
-// fgnn_block1_struct_tables folded in), workgroup ntab + g ny + y builds the bit rows / columns of graph g and codes band y of its rows
+// fgnn_block1_struct_tables folded in); workgroup ntab + g ny + y loads the bit rows of graph g and owns the band of SB_CW columns
+// y SB_CW ..: it transposes ONLY those columns (a workgroup that transposed the whole matrix spent 4.6 of its 9.5 us there at
+// N = 200), writes the vertex records of the vertices in the band and, thread <-> row, the band's codes of every row.
+constexpr int SB_CW = 16;                // columns per workgroup of the per-graph kernel
 template <int NWD>
 __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, const int *nvalid, const int N, const int cp, unsigned *code,
                                                        float4 *vinfo, float *gones, float *xdeg, void *x16, const long long ldp16,
                                                        const int pitch16, const int ny, const int ntab, const TabArgs TA, float *tab,
                                                        const int bf) {
-    __shared__ GraphBits<NWD> B;
+    constexpr int MAXN = 64 * NWD, RW = 2 * NWD;                   // dwords per bit row
+    __shared__ unsigned rows[MAXN][RW];
+    __shared__ unsigned colw[SB_CW][RW];
     __shared__ float red[4];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < ntab) {
@@ -252,61 +192,90 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
     }
     const int g = ((int)blockIdx.x - ntab) / ny, y = ((int)blockIdx.x - ntab) - g * ny;
     const int nv = nvalid_of(nvalid, g, N);
+    const int c0 = y * SB_CW;                                      // first column of the band
     SB_STAMP(0, blockIdx.x - ntab, 0)
-    sb_bits_rows(B, bits, g, tid, N, nv);
+    sb_bits_rows<NWD>(rows, bits, g, tid, N, nv);
     __syncthreads();
     SB_STAMP(0, blockIdx.x - ntab, 1)
-    sb_bits_cols(B, tid, nv);
-    __syncthreads();
-    SB_STAMP(0, blockIdx.x - ntab, 2)
-    if (y == 0) {
-        float on1 = 0.f;
-        if (tid < N) {
-            const bool on = tid < nv;
-            const float dr = on ? B.degr[tid] : 0.f;
-            const int ws = on ? B.wii[tid] : 0;
-            vinfo[(long long)g * N + tid] = make_float4(dr, on ? B.degc[tid] : 0.f, __int_as_float(ws), __int_as_float(on ? B.cls[tid] : 0));
-            if (xdeg) xdeg[(long long)g * N + tid] = dr;                  // what fgnn_adjacency_degree would write
-            on1 = dr - (float)ws;
+    if (tid < SB_CW * RW) {
+        // dword h of column c0 + jl: bit r = w[32 h + r][c0 + jl]; every shift a compile-time constant
+        const int jl = tid % SB_CW, h = tid / SB_CW, j = c0 + jl;
+        unsigned acc = 0u;
+        if (j < nv && 32 * h < nv) {
+            const int dw = j >> 5, sh = j & 31;
+#pragma unroll
+            for (int k8 = 0; k8 < 32; k8 += 8) {
+                unsigned r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = rows[32 * h + k8 + k][dw];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc |= ((r[k] >> sh) & 1u) << (k8 + k);
+            }
         }
+        colw[jl][h] = acc;
+    }
+    // row sums and self loops (thread <-> vertex)
+    int dr = 0, ws = 0;
+    if (tid < MAXN) {
+#pragma unroll
+        for (int w = 0; w < RW; ++w) dr += __popc(rows[tid][w]);
+        ws = (rows[tid][tid >> 5] >> (tid & 31)) & 1u;
+    }
+    if (y == 0) {
+        float on1 = tid < nv ? (float)(dr - ws) : 0.f;
         on1 = wave_sum(on1);
         if ((tid & 63) == 0) red[tid >> 6] = on1;
-        __syncthreads();
-        if (tid == 0) gones[g] = (red[0] + red[1]) + (red[2] + red[3]);   // off-diagonal ones of the valid corner
     }
-    // band of rows of this workgroup: wave <-> row, lane <-> the NWD consecutive columns NWD lane + t, whose column words stay in
-    // registers (the row words are wave-uniform LDS broadcasts): no bank conflicts, one vector store per row and plane
-    const int rpc = (N + ny - 1) / ny, r0 = y * rpc, r1 = min(N, r0 + rpc);
-    const int lane = tid & 63, wv = tid >> 6, j0 = NWD * lane;
-    u64 cw[NWD][NWD];
+    __syncthreads();
+    SB_STAMP(0, blockIdx.x - ntab, 2)
+    if (y == 0 && tid == 0) gones[g] = (red[0] + red[1]) + (red[2] + red[3]);   // off-diagonal ones of the valid corner
+    if (tid >= c0 && tid < c0 + SB_CW && tid < N) {                // the records of the band's vertices
+        int dc = 0;
 #pragma unroll
-    for (int t = 0; t < NWD; ++t)
-#pragma unroll
-        for (int w = 0; w < NWD; ++w) cw[t][w] = B.col[j0 + t][w];                 // j0 + t < 64 NWD
+        for (int w = 0; w < RW; ++w) dc += __popc(colw[tid - c0][w]);
+        const bool on = tid < nv;
+        vinfo[(long long)g * N + tid] = make_float4(on ? (float)dr : 0.f, on ? (float)dc : 0.f, __int_as_float(on ? ws : 0),
+                                                    __int_as_float(on ? 2 + 2 * dr + ws : 0));
+        if (xdeg) xdeg[(long long)g * N + tid] = on ? (float)dr : 0.f;            // what fgnn_adjacency_degree would write
+    }
     SB_STAMP(0, blockIdx.x - ntab, 3)
+    // thread <-> row i: its SB_CW codes (W^2)_ij | w_ij << 15, j in the band (rows / bits outside the valid corner are empty)
     unsigned short *code16 = reinterpret_cast<unsigned short *>(code) + (long long)g * N * cp;
     unsigned short *xa = reinterpret_cast<unsigned short *>(x16) + (long long)g * 2 * ldp16, *xb = xa + ldp16;
-    for (int i = r0 + wv; i < r1; i += 4) {
-        u64 rw[NWD];
+    if (tid < N) {
+        const int i = tid;
+        unsigned rw[RW];
 #pragma unroll
-        for (int w = 0; w < NWD; ++w) rw[w] = B.row[i][w];                         // empty for i >= nv
-        const float dr = B.degr[i];
-        unsigned cdv[NWD], wv16[NWD], dg16[NWD];
+        for (int w = 0; w < RW; ++w) rw[w] = rows[i][w];
+        const unsigned dg = (i < nv) ? (cvt_pk((float)dr, 0.f) & 0xffffu) : 0u;
 #pragma unroll
-        for (int t = 0; t < NWD; ++t) {
-            int w2 = 0;
+        for (int q = 0; q < SB_CW / 8; ++q) {                      // eight columns = one 16-byte store per plane
+            const int jq = c0 + 8 * q;
+            const unsigned wbyte = jq < MAXN ? (rows[i][jq >> 5] >> (jq & 31)) & 0xffu : 0u;      // w_ij of the eight columns (jq is a multiple of 8)
+            unsigned cd[8], wb[8];
 #pragma unroll
-            for (int w = 0; w < NWD; ++w) w2 += __popcll(rw[w] & cw[t][w]);
-            const int j = j0 + t;
-            const bool wb = (rw[NWD == 1 ? 0 : (j >> 6)] >> (j & 63)) & 1ull;      // bits >= nv are cleared
-            cdv[t] = (i < nv && j < nv) ? ((unsigned)w2 | (wb ? 0x8000u : 0u)) : 0u;
-            wv16[t] = wb ? 0x3F80u : 0u;                                           // bf16 1.0
-            dg16[t] = (j == i && i < nv) ? (cvt_pk(dr, 0.f) & 0xffffu) : 0u;
-        }
-        if (j0 < cp) sb_store16<NWD>(code16 + (long long)i * cp + j0, cdv);
-        if (x16 && j0 < pitch16) {
-            sb_store16<NWD>(xa + (long long)i * pitch16 + j0, wv16);
-            sb_store16<NWD>(xb + (long long)i * pitch16 + j0, dg16);
+            for (int t = 0; t < 8; ++t) {
+                int w2 = 0;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) w2 += __popc(rw[w] & colw[8 * q + t][w]);
+                wb[t] = (wbyte >> t) & 1u;
+                cd[t] = (unsigned)w2 | (wb[t] << 15);              // 0 outside the valid corner: empty row or empty column
+            }
+            if (jq < cp)
+                *reinterpret_cast<uint4 *>(code16 + (long long)i * cp + jq) =
+                    make_uint4(cd[0] | (cd[1] << 16), cd[2] | (cd[3] << 16), cd[4] | (cd[5] << 16), cd[6] | (cd[7] << 16));
+            if (x16 && jq < pitch16) {
+                unsigned wv[8], dv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    wv[t] = wb[t] ? 0x3F80u : 0u;                  // bf16 1.0
+                    dv[t] = (jq + t == i) ? dg : 0u;
+                }
+                *reinterpret_cast<uint4 *>(xa + (long long)i * pitch16 + jq) =
+                    make_uint4(wv[0] | (wv[1] << 16), wv[2] | (wv[3] << 16), wv[4] | (wv[5] << 16), wv[6] | (wv[7] << 16));
+                *reinterpret_cast<uint4 *>(xb + (long long)i * pitch16 + jq) =
+                    make_uint4(dv[0] | (dv[1] << 16), dv[2] | (dv[3] << 16), dv[4] | (dv[5] << 16), dv[6] | (dv[7] << 16));
+            }
         }
     }
     SB_STAMP(0, blockIdx.x - ntab, 4)
@@ -986,7 +955,7 @@ template <int NWD, bool BF>
 int sb_fwd_launch(const FwdCall &c) {
     const int parts0 = (512 + c.G * SB_CG - 1) / (c.G * SB_CG), parts = parts0 > 8 ? 8 : parts0;      // two 8-wave workgroups per CU
     const WsLayout L = sb_ws_layout(c.G, c.N);
-    const int ny0 = (512 + c.G - 1) / c.G, ny = ny0 > (c.N + 3) / 4 ? (c.N + 3) / 4 : ny0;      // two workgroups per CU, at least one row per wave
+    const int ny = (L.cp + SB_CW - 1) / SB_CW;                 // column bands of the code plane (its pitch, a multiple of 8, included)
     unsigned short *code = reinterpret_cast<unsigned short *>(c.ws + L.code);
     float4 *vinfo = reinterpret_cast<float4 *>(c.ws + L.vinfo);
     TabArgs TA = {};
