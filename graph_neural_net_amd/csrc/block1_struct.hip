@@ -38,7 +38,6 @@ constexpr int SB_KC = 32;                // class instances per round of the cla
 // class of a pixel's input value: 0 = off-diagonal, w = 0; 1 = off-diagonal, w = 1; 2 + 2 deg + w_ii = diagonal
 DEVI int sb_classes(int N) { return 2 + 2 * (N + 1); }
 
-typedef unsigned long long u64;
 
 #ifdef SB_STAMPS
 __device__ unsigned long long *g_sb_stamps = nullptr;      // [kernel 0..3][workgroup < 2048][8] s_memtime ticks (tools/gpu_struct_stamps.py)
@@ -143,30 +142,6 @@ static WsLayout sb_ws_layout(int G, int N) {
     o += ((long long)G * N * L.cp / 2 + 3) & ~3LL;
     L.total = o;
     return L;
-}
-
-// NWD consecutive 16-bit values at p as one load / store (p is 2 NWD-byte aligned)
-template <int NWD>
-DEVI void sb_load16(const unsigned short *p, unsigned (&o)[NWD]) {
-    if constexpr (NWD == 4) {
-        const uint2 v = *reinterpret_cast<const uint2 *>(p);
-        o[0] = v.x & 0xffffu;
-        o[1] = v.x >> 16;
-        o[2] = v.y & 0xffffu;
-        o[3] = v.y >> 16;
-    } else if constexpr (NWD == 2) {
-        const unsigned v = *reinterpret_cast<const unsigned *>(p);
-        o[0] = v & 0xffffu;
-        o[1] = v >> 16;
-    } else {
-        o[0] = *p;
-    }
-}
-template <int NWD>
-DEVI void sb_store16(unsigned short *p, const unsigned (&o)[NWD]) {
-    if constexpr (NWD == 4) *reinterpret_cast<uint2 *>(p) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    else if constexpr (NWD == 2) *reinterpret_cast<unsigned *>(p) = o[0] | (o[1] << 16);
-    else *p = (unsigned short)o[0];
 }
 
 // ---- KG: code plane + vertex records (+ the input slabs the other kernels of block 1 read) -------------------------------------
