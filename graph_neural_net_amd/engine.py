@@ -446,10 +446,9 @@ class FgnnEngine:
         """... and in the backward direction: class sums of d(mult), then the per-class GraphNorm / conv backward, instead of
         fgnn_chan_matmul_bwd + fgnn_mlp_bwd_pair.  Leaves wpart / s12 of mlp1 and mlp2 for fgnn_grad_finalize."""
         S, W = self._struct_ws(), self._bwd
-        if not W.get('struct_rows_clean', True):        # a dense-input step on this engine has filled all rows in between
-            W['wpart'][(1, 1)].zero_()
-            W['wpart'][(1, 2)].zero_()
-        W['struct_rows_clean'] = True
+        # the structured backward writes the first fgnn_block1_struct_rows(G, N) partial rows of mlp1 / mlp2 of block 1; the reduction of
+        # this step reads exactly those (grad_finalize below), whatever the other rows hold from a dense-input step
+        W['struct_rows'] = int(_lib.load().fgnn_block1_struct_rows(self.G, self.N))
         (w1, _), (w2, _) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
         _lib.call('fgnn_block1_struct_bwd', _lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']), w1, w2,
@@ -501,7 +500,7 @@ class FgnnEngine:
             # fgnn_grad_finalize launch
             's12': {kj: torch.empty(self.G * 32 * 2, **f32) for kj in keys},
             # (the structured block 1 writes one row per graph: the other rows of its two buffers stay zero)
-            'wpart': {kj: (torch.zeros if (self.struct1 and kj in ((1, 1), (1, 2))) else torch.empty)(nwg * L.mlp[kj]['count'], **f32)
+            'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32)
                       for kj in keys},
             's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
             'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
@@ -645,8 +644,8 @@ class FgnnEngine:
                       self._nv(), self.G, self.N, _lib.ptr(W['dy1']), _lib.ptr(W['dy2']), gs, self.ldp,
                       _lib.ptr(W['s12'][(k, 1)]), _lib.ptr(W['s12'][(k, 2)]),
                       _lib.ptr(self.mm_order) if self.mm_order is not None else None, self._fill(), st, tag='fgnn_chan_matmul_bwd')
-            if first and self.struct1:
-                W['struct_rows_clean'] = False
+            if first:
+                W['struct_rows'] = 0                  # block 1 ran the generic kernels: all partial rows are live
             if self.PAIR_BWD and dxs is None and L.depth == 3 and sin.C in (2, 32):
                 self._mlp_bwd_pair(params, k, sin, din, emit=not first)
             else:
@@ -686,6 +685,8 @@ class FgnnEngine:
                 rec = L.mlp[kj]
                 jobs[i].wpart = W['wpart'][kj].data_ptr()
                 jobs[i].count = rec['count']
+                if kj in ((1, 1), (1, 2)) and W.get('struct_rows', 0):
+                    jobs[i].rows = W['struct_rows']         # block 1 on its structured input: the rows its backward wrote
                 jobs[i].out = grads.data_ptr() + 4 * rec['off']
                 jobs[i].s12 = W['s12'][kj].data_ptr()
                 jobs[i].nrm = self.nrm[kj].data_ptr()

@@ -235,10 +235,7 @@ class FgnnEngineBF16:
 
     def _struct_bwd(self, params):
         S, W = self._struct_ws(), self._bwd
-        if not W.get('struct_rows_clean', False):       # one partial row per graph: the other rows stay zero
-            W['wpart'][(1, 1)].zero_()
-            W['wpart'][(1, 2)].zero_()
-        W['struct_rows_clean'] = True
+        W['struct_rows'] = int(_lib.load().fgnn_block1_struct_rows(self.G, self.N))     # the partial rows this backward writes (read by grad_finalize)
         (w1, _), (w2, _) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
         _lib.call('fgnn_block1_struct_bwd16', _lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']), w1, w2,
@@ -376,7 +373,7 @@ class FgnnEngineBF16:
                 self._struct_bwd(params)
                 break
             if first:
-                W['struct_rows_clean'] = False          # the generic kernels fill every partial row of block 1
+                W['struct_rows'] = 0                    # the generic kernels fill every partial row of block 1
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             _lib.call('fgnn_chan_matmul_bwd16_tc', C.byref(ya), C.byref(yb), _lib.ptr(W['dmult']), gs, self.ldp,
                       _lib.ptr(W['s12part']), self.tpg, self._nv(), self.G, self.N, self.ldr, _lib.ptr(W['dy1']),
@@ -414,6 +411,8 @@ class FgnnEngineBF16:
                 rec = L.mlp[kj]
                 jobs[i].wpart = W['wpart'][kj].data_ptr()
                 jobs[i].count = rec['count']
+                if kj in ((1, 1), (1, 2)) and W.get('struct_rows', 0):
+                    jobs[i].rows = W['struct_rows']
                 jobs[i].out = grads.data_ptr() + 4 * rec['off']
                 jobs[i].s12 = W['s12'][kj].data_ptr()
                 jobs[i].nrm = self.nrm[kj].data_ptr()

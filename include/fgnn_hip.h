@@ -419,15 +419,16 @@ int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, const int *
  *   tables : (2 models, 2 + 2 (N + 1) classes, {h1, h2, z, z as stored}, 32) floats, graph independent: once per step.
  *            bf16_scheme != 0: the arithmetic of the 16-bit engine (matrix-core operands R(W), R(relu(.)), stored R(z))
  *   fwd    : GraphNorm records nrm1 / nrm2 (G, 32, 4) of mlp1 / mlp2 and the raw slab mult (G, 32, ldp)
- *   bwd    : from d(mult): row g of wpart1 / wpart2 (the partial layout of fgnn_mlp_bwd, one row per graph -- the caller keeps
- *            the other rows zero) and s12_1 / s12_2 (G, 32, 2), ready for fgnn_grad_finalize; csum is workspace
+ *   bwd    : from d(mult): the first fgnn_block1_struct_rows(G, N) rows of wpart1 / wpart2 (the partial layout of fgnn_mlp_bwd; the
+ *            other rows are not written: reduce exactly these, fgnn_grad_job.rows) and s12_1 / s12_2 (G, 32, 2), ready for
+ *            fgnn_grad_finalize
  * The ...16 forms take the bf16 slabs of the 16-bit engine (row pitch ldr elements, channel stride ldp, tables built with
  * bf16_scheme = 1): mult is rounded to nearest even on store, the statistics stay fp32 and the class sums of the backward pass
  * are formed in fp32 from the bf16 d(mult) (the generic 16-bit kernels round every pixel of dY1 / dY2 / dz instead).          */
 int fgnn_block1_struct_supported(int N, int depth, int original_features_num);      /* N <= 256, depth 3, 2 input channels */
 int fgnn_block1_struct_table_floats(int N);
 long long fgnn_block1_struct_ws_floats(int G, int N);       /* workspace shared by fwd and bwd of one step (16-byte aligned) */
-int fgnn_block1_struct_rows(int G, int N);                  /* bwd writes rows 0 .. rows-1 of wpart1 / wpart2 (<= fgnn_mlp_bwd_num_workgroups()) */
+int fgnn_block1_struct_rows(int G, int N);                  /* bwd writes rows 0 .. rows-1 of wpart1 / wpart2 (<= fgnn_mlp_bwd_num_workgroups()) and no others */
 int fgnn_block1_struct_tables(const float *const *W1, const float *const *b1, const float *const *W2, const float *const *b2, int N,
                               int bf16_scheme, float *tables, void *stream);
 /* nvalid: optional per-graph vertex counts (ragged batches: the N x N planes are padded; mult is written as 0 outside the valid
