@@ -230,3 +230,48 @@ def test_structured_block1_in_a_captured_training_step():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(grads, eager)
+
+@pytest.mark.parametrize('N,sizes', [(37, (37, 20, 1, 0)), (70, (70, 0, 33)), (130, (130, 64, 0))])
+def test_structured_block1_on_directed_graphs_with_self_loops_and_filler_graphs(N, sizes):
+    """Nothing in the structured kernels assumes the reference's generator: random DIRECTED adjacency with self loops (w_ii = 1,
+    row sums != column sums), filler graphs of size 0 (what FgnnTrainer pads a ragged bucket with) and of size 1, both engines on
+    the same bit-packed batch: block-1 tensors on the valid corners, scores, loss and every gradient against the generic kernels
+    (both are fp32 evaluations of the same function: fp32-rounding agreement; no flip-prone second block here)."""
+    sd = sub(load_golden('cfg1_er_n20_b4_1blk.npz'), 'sd/')
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    rng = np.random.default_rng(N)
+    B = len(sizes)
+    ws = (rng.random((2 * B, N, N)) < 0.5).astype(np.float32)         # valid corners AND padding: random bits
+    for g in range(2 * B):
+        n = sizes[g % B]
+        ws[g, :n, :n] = (rng.random((n, n)) < 0.3).astype(np.float32)
+        if n > 2:
+            ws[g, 1, 1] = 1.0                                        # a self loop
+            ws[g, 0, 2], ws[g, 2, 0] = 1.0, 0.0                      # an asymmetric edge
+    bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
+    nv = torch.tensor(list(sizes) * 2, dtype=torch.int32, device=DEV)
+    out = []
+    for mode in ('generic', 'structured'):
+        eng = FgnnEngine(lay, 2 * B, N, DEV, ragged=True, block1=mode)
+        g = torch.zeros_like(params)
+        sc, loss = eng.step(params, g, None, nvalid=nv, bits=bits, total_nodes=float(sum(sizes)))
+        torch.cuda.synchronize()
+        assert torch.isfinite(sc).all() and torch.isfinite(g).all() and np.isfinite(loss.item())
+        out.append((eng.unpadded(eng.mult[1]).cpu(), eng.nrm[(1, 1)].cpu().clone(), eng.nrm[(1, 2)].cpu().clone(), sc.cpu().clone(), loss.item(),
+                    lay.unflatten(g.cpu().clone())))
+    a, b = out
+    for i, n in enumerate(list(sizes) * 2):
+        if n > 1:
+            assert rel(b[0][i, :, :n, :n], a[0][i, :, :n, :n]) < 1e-5, (i, n)
+            for k in (1, 2):
+                ra, rb = a[k].view(2 * B, 32, 4)[i], b[k].view(2 * B, 32, 4)[i]
+                assert rel(rb[:, 0], ra[:, 0]) < 5e-6 and rel(rb[:, 1:], ra[:, 1:]) < 5e-5, (i, n, k)
+        assert b[0][i, :, n:, :].abs().sum() == 0 and b[0][i, :, :, n:].abs().sum() == 0
+    assert rel(b[3], a[3]) < 2e-5
+    assert abs(a[4] - b[4]) <= 2e-6 * abs(a[4])
+    for name in a[5]:
+        if is_zero_grad(name):
+            assert b[5][name].abs().max() < 1e-4, name
+        else:
+            assert rel(b[5][name], a[5][name]) < 2e-4, (name, rel(b[5][name], a[5][name]))
