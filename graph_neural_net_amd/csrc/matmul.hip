@@ -615,7 +615,13 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(cons
             for (int rb = 0; rb < NB; ++rb) {
                 const float a = t == 0 ? af[rb].x : (t == 1 ? af[rb].y : (t == 2 ? af[rb].z : af[rb].w));
 #pragma unroll
-                for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = mfma32(a, bv[cb], acc[rb][cb]);
+                for (int cb = 0; cb < NB; ++cb) {
+#ifdef FGNN_MM_NOMFMA       // measurement builds only (tools/gpu_mm_ablate.py): a VALU fma in place of every MFMA
+                    acc[rb][cb][(4 * q + t) & 15] += a * bv[cb];
+#else
+                    acc[rb][cb] = mfma32(a, bv[cb], acc[rb][cb]);
+#endif
+                }
             }
         }
     }
@@ -627,8 +633,12 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(cons
 #pragma unroll
         for (int rb = 0; rb < NB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
+#ifdef FGNN_MM_NOSTORE      // measurement builds only: the stores stay in the code but never execute
+                if (acc[rb][cb][r] == 12345.678f)
+#endif
                 rsrc_store(acc[rb][cb][r], rO, voffO + (32 * rb + (r & 3) + 8 * (r >> 2)) * N * 4, 0);
+            }
     }
 }
 
