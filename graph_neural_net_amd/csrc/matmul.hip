@@ -608,6 +608,8 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(cons
             af[rb] = *reinterpret_cast<const float4 *>(As + (32 * rb + j) * WLD + h * 32 + 4 * q);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            // k-steps past the matrix (k = 2 (4 q + t) >= N: up to three of the last quartet) would add 0 * 0: skipped (uniform)
+            if (q == KQ - 1 && 2 * (4 * q + t) >= N) break;
             float bv[NB];
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) bv[cb] = (xb[cb][4 * q + t] - meanB) * aeB[cb] + beB[cb];
