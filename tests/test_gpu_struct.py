@@ -21,7 +21,7 @@ def _bits(x1, x2):
 
 @pytest.mark.parametrize('B,N,family,p', [(3, 50, 'Regular', 0.2), (2, 33, 'ErdosRenyi', 0.4), (4, 64, 'ErdosRenyi', 0.1), (2, 7, 'ErdosRenyi', 0.5),
                                          (1, 1, 'ErdosRenyi', 0.5), (32, 50, 'Regular', 0.2), (2, 65, 'ErdosRenyi', 0.3), (2, 128, 'ErdosRenyi', 0.2),
-                                         (3, 97, 'Regular', 0.2)])
+                                         (3, 97, 'Regular', 0.2), (40, 100, 'ErdosRenyi', 0.2)])      # (last: 80 graphs x 4 rounds of class instances on 3 workgroups per graph)
 def test_structured_block1_equals_the_generic_kernels(B, N, family, p):
     """One block: mult, the GraphNorm records of mlp1 / mlp2, scores, loss and every gradient of the structured path against
     the generic path on the same bit-packed batch."""
