@@ -699,8 +699,7 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
 extern "C" int fgnn_score_row_blocks(int B, int N) {
     // few large pairs: more row blocks than FGNN_SCORE_SPLIT so that the launch fills the chip (8 rows per workgroup)
     if (B * FGNN_SCORE_SPLIT >= 512) return FGNN_SCORE_SPLIT;
-    if (N <= 64) return (N + 3) / 4;       // small batch of small pairs: one row per wave, B * N / 4 workgroups
-    return (N + 7) / 8;
+    return (N + 3) / 4;                    // small batch: one row per wave, B * N / 4 workgroups
 }
 
 extern "C" int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const int *nvalid, int B, int C, int N,
