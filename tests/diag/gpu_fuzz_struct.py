@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Random shapes through the structured block 1 against the generic kernels (both engines): python tests/diag/gpu_fuzz_struct.py [cases=40] [seed=0]
+Per case: random B in 1..6, N in 1..256, edge density, directed / undirected, self loops, ragged or not (sizes down to 0), 1 or 2
+blocks.  fp32 engine: mult / scores / loss / gradients to fp32-rounding agreement; 16-bit engine: finite, scores within 3e-2, gradients
+within 8e-2 (L2) of the generic 16-bit kernels.  Prints one line per case and a summary; exits 1 on a failure."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+from graph_neural_net_amd import synthetic                       # noqa: E402
+from graph_neural_net_amd.engine import FgnnEngine, ParamLayout  # noqa: E402
+from graph_neural_net_amd.engine16 import FgnnEngineBF16         # noqa: E402
+
+DEV = 'cuda:0'
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+bad = 0
+for case in range(cases):
+    B = int(rng.integers(1, 7))
+    N = int(rng.choice([1, 2, 7, 31, 32, 33, 50, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256])) if rng.random() < 0.6 else int(rng.integers(1, 257))
+    if N > 128:
+        B = min(B, 2)
+    nblk = int(rng.integers(1, 3))
+    ragged = bool(rng.random() < 0.5)
+    bf16 = bool(rng.random() < 0.35)
+    dens = float(rng.choice([0.05, 0.3, 0.6, 0.95]))
+    directed = bool(rng.random() < 0.4)
+    sizes = [int(rng.integers(0, N + 1)) for _ in range(B)] if ragged else [N] * B
+    if ragged:
+        sizes[int(rng.integers(0, B))] = N
+    ws = (rng.random((2 * B, N, N)) < 0.5).astype(np.float32)
+    x = torch.zeros(2 * B, 2, N, N)
+    for g in range(2 * B):
+        n = sizes[g % B]
+        a = (rng.random((n, n)) < dens).astype(np.float32)
+        if not directed:
+            a = np.triu(a, 1)
+            a = a + a.T
+        if rng.random() < 0.3 and n > 0:
+            a[np.arange(n), np.arange(n)] = (rng.random(n) < 0.2).astype(np.float32)
+        ws[g, :n, :n] = a
+        if not ragged:
+            ws[g] = 0
+            ws[g, :n, :n] = a
+        x[g, 0, :n, :n] = torch.from_numpy(a)
+        x[g, 1, :n, :n] = torch.diag(x[g, 0, :n, :n].sum(-1))
+    bits = torch.from_numpy(synthetic.pack_adjacency(ws).view(np.int32)).to(DEV)
+    nv = torch.tensor(sizes * 2, dtype=torch.int32, device=DEV) if ragged else None
+    lay = ParamLayout(2, nblk, 32, 32, 3)
+    params = lay.init_flat(int(rng.integers(0, 1000)), DEV)
+    # non-zero biases / affine parameters: with the reference's zero-initialised biases many pre-activations are EXACTLY zero in exact
+    # arithmetic (empty pixels), and which side of zero an fp32 evaluation lands on -- i.e. the ReLU mask of the backward pass -- is
+    # then arbitrary for ANY implementation (observed: forward identical, gradients 5 % apart on a 7-vertex graph)
+    gen = torch.Generator().manual_seed(int(rng.integers(0, 1000)))
+    pert = torch.zeros(lay.total)
+    for name, off, shape in lay.entries:
+        n = int(np.prod(shape))
+        if name.endswith('.bias') and '.convs.' in name:
+            pert[off:off + n] = 0.1 * torch.randn(n, generator=gen)
+        elif name.endswith('gn.weight'):
+            pert[off:off + n] = 0.2 * torch.randn(n, generator=gen)
+        elif name.endswith('gn.bias'):
+            pert[off:off + n] = 0.05 * torch.randn(n, generator=gen)
+    params = (params.cpu() + pert).to(DEV)
+    tot = float(max(1, sum(sizes)))
+    out = []
+    for mode in ('generic', 'structured'):
+        eng = (FgnnEngineBF16 if bf16 else FgnnEngine)(lay, 2 * B, N, DEV, ragged=ragged, block1=mode)
+        g = torch.zeros_like(params)
+        if mode == 'structured':
+            s, l = eng.step(params, g, None, nvalid=nv, bits=bits, total_nodes=tot)
+        elif bf16:
+            s, l = eng.step(params, g, x.contiguous().to(DEV), nvalid=nv, total_nodes=tot)
+        else:
+            s, l = eng.step(params, g, None, nvalid=nv, bits=bits, total_nodes=tot)
+        torch.cuda.synchronize()
+        out.append((s.cpu().clone(), l.item(), g.cpu().clone()))
+    (sa, la, ga), (sb, lb, gb) = out
+    ok = bool(torch.isfinite(sb).all() and torch.isfinite(gb).all() and np.isfinite(lb))
+    es, eg = rel(sb, sa) if sa.abs().max() > 0 else (sb - sa).abs().max().item(), l2(gb, ga) if ga.norm() > 0 else gb.norm().item()
+    # (two blocks of fp32: a ReLU of block 2 within rounding of zero may flip between the two evaluations: 3e-3 gradient class)
+    lim_s, lim_g = (3e-2, 8e-2) if bf16 else (5e-5, 2e-4 if nblk == 1 else 5e-3)
+    degenerate = ga.norm().item() < 1e-4           # symmetric / empty graphs: the exact gradient is 0, what is left is rounding
+    ok = ok and es < lim_s and (eg < lim_g or (degenerate and (ga - gb).abs().max().item() < 1e-4)) and abs(la - lb) <= (3e-3 if bf16 else 1e-5) * abs(la) + 1e-6
+    if not ok:
+        # Arbitration.  Two evaluations may legitimately differ far beyond rounding: exact ties (symmetric / nearly empty graphs: which
+        # of several equal maxima the pooling picks, which side of zero a pre-activation lands on) and, in 16 bit, rounding noise that
+        # GraphNorm amplifies by 1 / sqrt(var + eps) on graphs of a few vertices.  What must hold: against the fp64 oracle (fp32
+        # engine) resp. the un-rounded evaluation of the 16-bit scheme, pair by pair on the valid corners, the structured path is not
+        # further away than the generic kernels (x 2 + a floor).
+        from oracle import fgnn_oracle as O, fgnn_oracle_bf16 as OB
+        sd = {k: v.clone() for k, v in lay.unflatten(params.cpu()).items()}
+        gref = None
+        live = [b_ for b_ in range(B) if sizes[b_] > 0]
+        if live and not bf16:
+            xs1 = [x[b_, :, :sizes[b_], :sizes[b_]].double() for b_ in live]
+            xs2 = [x[B + b_, :, :sizes[b_], :sizes[b_]].double() for b_ in live]
+            _, _, gref = O.step_fwd_bwd_ragged(xs1, xs2, {k: v.double() for k, v in sd.items()})
+        elif live:
+            for b_ in live:
+                n = sizes[b_]
+                _, _, gg = OB.step_fwd_bwd(x[b_:b_ + 1, :, :n, :n], x[B + b_:B + b_ + 1, :, :n, :n], sd, rounding=False, total_nodes=tot)
+                gref = gg if gref is None else {k: gref[k] + gg[k] for k in gg}
+        if gref is None:
+            ok = bool(torch.isfinite(gb).all()) and gb.abs().max().item() < 1e-4
+        else:
+            keys = [k for k in gref if not k.endswith('convs.2.bias')]        # (analytically zero)
+            fr = torch.cat([gref[k].reshape(-1).double() for k in keys])
+            fa = torch.cat([lay.unflatten(ga)[k].reshape(-1).double() for k in keys])
+            fb = torch.cat([lay.unflatten(gb)[k].reshape(-1).double() for k in keys])
+            scale = fr.norm().item()
+            ea, eb = (fa - fr).norm().item(), (fb - fr).norm().item()
+            print('     |g ref| %.3e: generic off by %.3e, structured off by %.3e' % (scale, ea, eb))
+            if os.environ.get('FUZZ_TENSORS'):
+                ua, ub = lay.unflatten(ga), lay.unflatten(gb)
+                for k in keys:
+                    r = gref[k].double()
+                    print('       %-36s generic %.2e  structured %.2e' % (k, ((ua[k].double() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item(),
+                                                                             ((ub[k].double() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()))
+            # ... or within the class one flipped ReLU of mlp3 produces (tests/gradgate.py: 5e-5 ... 3e-3 of the gradient norm): `mult`
+            # differs by rounding between the two evaluations, so either may take a branch the fp64 run does not
+            flip = (not bf16) and eb <= 5e-3 * scale
+            if flip and eb > 2.0 * ea + 1e-5 * max(scale, 1.0):
+                print('     (flip class: counted, not a failure)')
+            ok = bool(torch.isfinite(gb).all()) and (eb <= 2.0 * ea + 1e-5 * max(scale, 1.0) or flip) and (bf16 or es < 1e-3 or scale < 1e-3)
+    bad += not ok
+    print('%s case %2d: %s B=%d N=%3d blocks=%d %s dens=%.2f %s sizes=%s  scores %.2e  grads %.2e  loss %.6g / %.6g'
+          % ('ok  ' if ok else 'FAIL', case, 'bf16' if bf16 else 'fp32', B, N, nblk, 'ragged' if ragged else 'const ', dens,
+             'directed' if directed else 'undirect', sizes if ragged else '-', es, eg, la, lb), flush=True)
+print('%d cases, %d failures' % (cases, bad))
+sys.exit(1 if bad else 0)
