@@ -296,3 +296,22 @@ def test_bench_self_launch_relays_the_worst_return_code():
     assert r.returncode != 0
     assert 'needs a GPU' in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+def test_structured_block1_host_geometry():
+    """The host-side geometry functions of csrc/block1_struct.hip (no GPU): what shapes it covers, the workspace size, and which
+    partial rows its backward writes -- the engine's reduction reads exactly those (fgnn_grad_job.rows)."""
+    lib = _lib.load()
+    assert lib.fgnn_block1_struct_supported(256, 3, 2) == 1 and lib.fgnn_block1_struct_supported(1, 3, 2) == 1
+    assert lib.fgnn_block1_struct_supported(257, 3, 2) == 0 and lib.fgnn_block1_struct_supported(50, 2, 2) == 0
+    assert lib.fgnn_block1_struct_supported(50, 3, 3) == 0
+    nwg = lib.fgnn_mlp_bwd_num_workgroups()
+    for G, N in ((64, 50), (16, 200), (16, 120), (256, 50), (80, 100), (2, 1), (4, 256)):
+        rows = lib.fgnn_block1_struct_rows(G, N)
+        chunks = (N + 2 + 31) // 32                      # rounds of 32 class instances (2 off-diagonal classes + one per vertex)
+        assert rows % G == 0 and G <= rows <= nwg and rows // G <= chunks, (G, N, rows)
+        assert rows // G == min(chunks, max(1, nwg // G)), (G, N, rows)
+        ws = lib.fgnn_block1_struct_ws_floats(G, N)
+        cs = 2 + (64 if N <= 64 else 128 if N <= 128 else 256)
+        cp = (N + 7) // 8 * 8
+        assert ws % 4 == 0 and ws >= 2 * G * 32 * cs + 2 * G * 32 * 4 + 4 * G * N + G + G * N * cp // 2, (G, N, ws)
+    assert lib.fgnn_block1_struct_table_floats(50) == 2 * (2 + 2 * 51) * 4 * 32
