@@ -15,7 +15,7 @@ from .optim import FlatAdam
 class FgnnTrainer:
     ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU); 288 GB HBM leave room to raise it
 
-    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32', collective='auto'):
+    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32', collective='auto', block1=None):
         """capture=True: constant-shape steps are captured in a HIP graph and replayed -- the launch overhead of ~40 kernels
         per step disappears.  With more than one rank the gradient all-reduce is recorded INSIDE that graph when the backend
         can be captured (RCCL: model work -> all-reduce -> fused Adam is one replay, no host launch on the critical path;
@@ -23,10 +23,13 @@ class FgnnTrainer:
         collective='always': issue the all-reduce with a single rank as well (exercises the RCCL path on a one-GPU box).
         precision='bf16': the model work runs on the bf16 kernel set (engine16; the reference's
         pl.Trainer(precision=16), commander_explore.py:120-122); parameters, gradients, Adam state and the collective
-        stay fp32."""
+        stay fp32.
+        block1='structured': batches handed over as bit-packed adjacency (train_step_bits) run block 1 on its structured form
+        (csrc/block1_struct.hip); None = the engines' default (FGNN_BLOCK1, 'generic').  Dense batches always run the generic kernels."""
         if precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be "fp32" or "bf16" (got %r)' % (precision,))
         self.precision = precision
+        self.block1 = block1
         self.layout = layout
         self.params = params_flat
         n = params_flat.numel()
@@ -71,8 +74,8 @@ class FgnnTrainer:
         def make():
             if self.precision == 'bf16':
                 from .engine16 import FgnnEngineBF16
-                return FgnnEngineBF16(self.layout, G, N, self.params.device, ragged=ragged)
-            return FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged)
+                return FgnnEngineBF16(self.layout, G, N, self.params.device, ragged=ragged, block1=self.block1)
+            return FgnnEngine(self.layout, G, N, self.params.device, ragged=ragged, block1=self.block1)
         self._engines.budget = self.ENGINE_CACHE_BYTES
         eng, evicted = self._engines.get((G, N, ragged), make, EngineCache.engine_bytes(G, N, self.layout.num_blocks))
         for g, n, r in evicted:
@@ -170,21 +173,24 @@ class FgnnTrainer:
         return self._reduce_and_update(), scores
 
     # ------------------------------------------------------------------ captured constant-shape step
-    def _captured_step(self, x1, x2):
-        B, _, N, _ = x1.shape
+    def _captured_step(self, x1, x2, bits=False):
+        """bits: x1, x2 are (B, N, ceil(N / 32)) int32 words of bit-packed adjacency instead of (B, c0, N, N) tensors."""
+        B, N = x1.shape[0], x1.shape[-2 if bits else -1]
         world = dp.world_size()
-        key = (B, N)
+        key = (B, N, 'bits') if bits else (B, N)
         st = self._graphs.get(key)
         if st is None:
             eng = self._engine(2 * B, N, False)
             xs = torch.cat([x1, x2]).contiguous().clone()
+            step = ((lambda: eng.step(self.params, self.grads, None, total_nodes=1.0, loss_out=self._loss_sum, bits=xs)) if bits else
+                    (lambda: eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)))
             self.opt.sync_hyper_parameters(grad_scale=None)
             # two eager steps on a side stream (allocations, kernel attributes); they do not touch the optimizer
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
+                    step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             t0 = self.opt.t
@@ -192,7 +198,7 @@ class FgnnTrainer:
             exchange = world > 1 or self._force_collective
             # (a collective inside the capture: 'thread_local', so that the process group's watchdog thread cannot invalidate it)
             with torch.cuda.graph(g_model, capture_error_mode='thread_local' if (exchange and self.allreduce_in_graph) else 'global'):
-                scores, _ = eng.step(self.params, self.grads, xs, total_nodes=1.0, loss_out=self._loss_sum)
+                scores, _ = step()
                 if not exchange or self.allreduce_in_graph:
                     # nothing to exchange, or the ONE collective rides in the graph: the whole step is one replay
                     if exchange:
@@ -216,6 +222,29 @@ class FgnnTrainer:
             return (self._loss_sum / self._nodes).reshape(()), scores
         g_model.replay()
         return self._reduce_and_update(opt_graph=g_opt), scores
+
+    def train_step_bits(self, bits1, bits2, nvalid=None):
+        """The same step with the local shard handed over as bit-packed adjacency: bits1, bits2
+        (B, N, ceil(N / 32)) int32 device tensors, bit j of row i = W[i][j] (synthetic.pack_adjacency / the loader's packing); the
+        tensor representation of loaders/data_generator.py:118-125 is built inside block 1's kernels, and with block1='structured'
+        block 1 runs on the class tables of csrc/block1_struct.hip.  nvalid: (B,) int32 for ragged batches (padded to N)."""
+        if bits1.dim() != 3 or bits1.shape != bits2.shape or bits1.dtype not in (torch.int32, torch.uint32) or not bits1.is_cuda:
+            raise RuntimeError('FgnnTrainer.train_step_bits: expected two (B, N, ceil(N/32)) int32 device tensors, got %s %s / %s %s'
+                               % (tuple(bits1.shape), bits1.dtype, tuple(bits2.shape), bits2.dtype))
+        B, N = bits1.shape[0], bits1.shape[1]
+        if bits1.shape[2] != (N + 31) // 32:
+            raise RuntimeError('FgnnTrainer.train_step_bits: %d words per row for N = %d (expected %d)' % (bits1.shape[2], N, (N + 31) // 32))
+        if self.capture and nvalid is None:
+            return self._captured_step(bits1, bits2, bits=True)
+        eng = self._engine(2 * B, N, nvalid is not None)
+        b = torch.cat([bits1, bits2]).contiguous()
+        nv = None if nvalid is None else torch.cat([nvalid, nvalid]).to(torch.int32)
+        if nvalid is None:
+            self._nodes.fill_(float(B * N))
+        else:
+            self._nodes.copy_(nvalid.sum().to(torch.float32).reshape(1))
+        scores, _ = eng.step(self.params, self.grads, None, nvalid=nv, total_nodes=1.0, loss_out=self._loss_sum, bits=b)
+        return self._reduce_and_update(), scores
 
     def train_step(self, x1, x2, nvalid=None):
         """x1, x2: (B, c0, N, N) local shard on the GPU.  Returns (loss of the global batch as a device

@@ -281,3 +281,54 @@ def test_structured_block1_on_directed_graphs_with_self_loops_and_filler_graphs(
             assert b[5][name].abs().max() < 1e-4, name
         else:
             assert rel(b[5][name], a[5][name]) < 2e-4, (name, rel(b[5][name], a[5][name]))
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_trainer_steps_on_bit_packed_batches(precision):
+    """FgnnTrainer.train_step_bits (model work on the structured block 1 + Adam, captured and eager): captured == eager bit for bit over
+    three steps with changing batches; against the dense-input trainer the parameters stay within the kernels' rounding class; a ragged
+    bit-packed step runs and agrees with the dense ragged step."""
+    from graph_neural_net_amd.trainer import FgnnTrainer
+    lay = ParamLayout(2, 2, 32, 32, 3)
+    p0 = lay.init_flat(5, DEV)
+    batches = [synthetic.make_batch(8100 + s, 4, 24, 'ErdosRenyi', 0.3, 0.05) for s in range(3)]
+    pk = lambda x: torch.from_numpy(synthetic.pack_adjacency(x[:, 0].numpy()).view(np.int32)).to(DEV)
+    res = {}
+    for mode in ('bits_capture', 'bits_eager', 'dense'):
+        tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, capture=(mode == 'bits_capture'), precision=precision, block1='structured')
+        losses = []
+        for x1, x2 in batches:
+            if mode == 'dense':
+                loss, _ = tr.train_step(x1.to(DEV), x2.to(DEV))
+            else:
+                loss, _ = tr.train_step_bits(pk(x1), pk(x2))
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        res[mode] = (tr.params.clone(), losses, tr.opt.t)
+    assert res['bits_capture'][2] == res['bits_eager'][2] == 3
+    assert torch.equal(res['bits_capture'][0], res['bits_eager'][0]) and res['bits_capture'][1] == res['bits_eager'][1]
+    tol = 2e-2 if precision == 'bf16' else 2e-4
+    # (Adam turns the rounding-level gradients of the analytically zero last-conv biases into full +-lr steps: left out)
+    keep = torch.ones(lay.total, dtype=torch.bool, device=DEV)
+    for name, off, shape in lay.entries:
+        if is_zero_grad(name):
+            keep[off:off + int(np.prod(shape))] = False
+    pdist = lambda a, b: ((a - b)[keep].norm() / (b - p0)[keep].norm()).item()
+    assert pdist(res['bits_eager'][0], res['dense'][0]) < (0.2 if precision == 'bf16' else 5e-2)
+    for a, b in zip(res['bits_eager'][1], res['dense'][1]):
+        assert abs(a - b) <= tol * abs(b)
+    # ragged: padded bit-packed batch with per-graph sizes
+    xs, ys = synthetic.make_ragged_batch(8200, 3, 9, 24)
+    n = [int(t.shape[-1]) for t in xs]
+    N = max(n)
+    pad = lambda lst: torch.stack([torch.nn.functional.pad(t, (0, N - t.shape[-1], 0, N - t.shape[-1])) for t in lst])
+    x1, x2 = pad(xs), pad(ys)
+    nv = torch.tensor(n, dtype=torch.int32, device=DEV)
+    out = []
+    for use_bits in (True, False):
+        tr = FgnnTrainer(lay, p0.clone(), lr=2e-3, precision=precision, block1='structured')
+        loss, _ = tr.train_step_bits(pk(x1), pk(x2), nvalid=nv) if use_bits else tr.train_step(x1.to(DEV), x2.to(DEV), nvalid=nv)
+        out.append((loss.item(), tr.params.clone()))
+    assert abs(out[0][0] - out[1][0]) <= tol * abs(out[1][0])
+    assert pdist(out[0][1], out[1][1]) < (0.2 if precision == 'bf16' else 5e-2)
+    with pytest.raises(RuntimeError):
+        FgnnTrainer(lay, p0.clone()).train_step_bits(x1.to(DEV), x2.to(DEV))          # dense tensors are refused loudly
