@@ -193,6 +193,49 @@ extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, in
     return 0;
 }
 
+// ---- the inverse of fgnn_expand_adjacency: (G, 2, N, N) tensor representation -> bit-packed adjacency, with a check that the
+// tensor IS a tensor representation (channel 0 in {0, 1}; channel 1 = diag(row sums of channel 0) on the valid corner).  One wave per
+// row: lane = column (64 per pass), the row's words are ballots; `bad` (optional, device int) is OR-ed with 1 where the check fails.
+namespace {
+__global__ __launch_bounds__(256) void pack_adjacency_kernel(const float *x, const int *nvalid, int G, int N, int words, unsigned *bits,
+                                                             int *bad) {
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // row over (g, i)
+    if (t >= (long long)G * N) return;
+    const int lane = threadIdx.x & 63, g = (int)(t / N), i = (int)(t - (long long)g * N);
+    const int nv = nvalid_of(nvalid, g, N);
+    const float *w = x + ((long long)g * 2) * N * N + (long long)i * N, *d = w + (long long)N * N;
+    int deg = 0;
+    bool wrong = false;
+    float dii = 0.f;
+    for (int j0 = 0; j0 < 32 * words; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = i < nv && j < nv;
+        const float v = in ? w[j] : 0.f, dv = in ? d[j] : 0.f;
+        wrong |= in && v != 0.f && v != 1.f;
+        wrong |= in && j != i && dv != 0.f;
+        if (in && j == i) dii = dv;
+        const unsigned long long m = __ballot(v != 0.f);
+        deg += __popcll(m);
+        if (lane == 0) {
+            bits[t * words + (j0 >> 5)] = (unsigned)m;
+            if ((j0 >> 5) + 1 < words) bits[t * words + (j0 >> 5) + 1] = (unsigned)(m >> 32);
+        }
+    }
+    dii = wave_sum(dii);                                       // (one lane holds it)
+    wrong |= i < nv && dii != (float)deg;
+    if (bad && __ballot(wrong) != 0ull && lane == 0) atomicOr(bad, 1);
+}
+}  // namespace
+
+extern "C" int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigned *bits, int *bad, void *stream) {
+    FGNN_CHECK(x && bits && G > 0 && N > 0, "fgnn_pack_adjacency: bad arguments");
+    const long long rows = (long long)G * N;
+    hipLaunchKernelGGL(pack_adjacency_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, nvalid, G, N,
+                       (N + 31) / 32, bits, bad);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- ragged batches: work-balanced tile ranges for the persistent MLP kernels (fgnn_mlp_fwd_args.ranges) -------------
 namespace {
 constexpr int RANGE_THREADS = 1024;

@@ -458,6 +458,10 @@ int fgnn_block1_struct_bwd16(const unsigned *bits, const int *nvalid, int G, int
 /* Input expansion (loaders/data_generator.py:118-125): bits (G, N, ceil(N/32)) uint32, bit j of row i =
  * W[i][j]  ->  x (G, 2, N, N) fp32 with x[g,0] = W, x[g,1] = diag(row sums); exact 0/1/integer values. */
 int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N, float *x, void *stream);
+/* ... and back: the (G, 2, N, N) tensor representation a dense loader produced -> bit-packed adjacency (rows / columns >= nvalid[g]
+ * read as empty).  bad (optional device int, zeroed by the caller): set to 1 if x is NOT a tensor representation on the valid corners
+ * (an entry of channel 0 outside {0, 1}, channel 1 != diag(row sums of channel 0)) -- the structured block 1 must not see such bits. */
+int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigned *bits, int *bad, void *stream);
 /* deg[g][i] = number of set bits j < nvalid[g] in row i (0 for rows >= nvalid[g]): the diagonal of channel 1, for the
  * kernels that expand the adjacency themselves (fgnn_mlp_fwd_args.xbits / xdeg) */
 int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream);

@@ -1,6 +1,7 @@
 """GPU: individual entry points of the C ABI against plain PyTorch fp32/fp64 references."""
 import ctypes as C
 
+import numpy as np
 import pytest
 import torch
 
@@ -380,3 +381,37 @@ def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel
     for gi, n in enumerate(nv.tolist()):
         assert float(res[0][gi, :, n:, :].abs().max()) == 0.0 if n < N else True
         assert float(res[0][gi, :, :, n:].abs().max()) == 0.0 if n < N else True
+
+@pytest.mark.parametrize('N', [1, 31, 32, 33, 50, 64, 65, 97, 200])
+def test_pack_tensor_representation_round_trip_and_check(N):
+    """inputs.pack_tensor_representation (dense loader batch -> bit-packed adjacency): the inverse of expand_adjacency bit for bit,
+    ragged sizes included; a tensor that is not a tensor representation (a 0.5 in channel 0, a wrong degree, an off-diagonal entry
+    in channel 1) is refused."""
+    from graph_neural_net_amd import inputs, synthetic
+    rng = np.random.default_rng(N)
+    G = 4
+    w = (rng.random((G, N, N)) < 0.4).astype(np.float32)            # directed, with self loops
+    bits = torch.from_numpy(synthetic.pack_adjacency(w).view(np.int32)).to(DEV)
+    x = inputs.expand_adjacency(bits, N)
+    back = inputs.pack_tensor_representation(x)
+    assert torch.equal(back, bits)
+    nv = torch.tensor([N, max(N // 2, 1), 1, 0], dtype=torch.int32, device=DEV)
+    xr = inputs.expand_adjacency(bits, N, nvalid=nv)
+    br = inputs.pack_tensor_representation(xr, nvalid=nv)
+    ref = synthetic.pack_adjacency(np.stack([np.pad(w[g, :n, :n], ((0, N - n), (0, N - n))) for g, n in enumerate(nv.tolist())]))
+    assert torch.equal(br.cpu(), torch.from_numpy(ref.view(np.int32)))
+    if N >= 2:
+        for bad in ('half', 'degree', 'offdiag'):
+            y = x.clone()
+            if bad == 'half':
+                y[1, 0, 0, N - 1] = 0.5
+            elif bad == 'degree':
+                y[2, 1, N - 1, N - 1] += 1.0
+            else:
+                y[0, 1, 0, 1] = 1.0
+            with pytest.raises(RuntimeError):
+                inputs.pack_tensor_representation(y)
+            b2, flag = inputs.pack_tensor_representation(y, check='device')
+            assert int(flag.item()) == 1
+        _, flag = inputs.pack_tensor_representation(x, check='device')
+        assert int(flag.item()) == 0
