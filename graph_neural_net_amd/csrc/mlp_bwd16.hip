@@ -62,12 +62,19 @@ DEVI void park_put(float *slot, int lane, const f32x16 &v) {
         reinterpret_cast<float4 *>(slot)[q * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
+// (the base pointers pass through an empty asm: the per-lane 64-bit addresses of these once-per-graph loads are then formed here, in
+// the rarely taken branch, instead of being hoisted out of the tile loop -- where they were the kernel's only spilled registers)
+template <typename T>
+DEVI const T *opaque_ptr(const T *p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
 DEVI void fetch_rec2(float *rec, const fgnn_slab16 &s, int g, int lane) {
     if (lane < 32) {
         float2 o = make_float2(1.f, 0.f);
         if (s.nrm && lane < s.C) {
-            const float4 n = reinterpret_cast<const float4 *>(s.nrm)[(long long)g * s.C + lane];
-            const float be = s.beta ? s.beta[lane] : 0.f;
+            const float4 n = reinterpret_cast<const float4 *>(opaque_ptr(s.nrm))[(long long)g * s.C + lane];
+            const float be = s.beta ? opaque_ptr(s.beta)[lane] : 0.f;
             o.x = n.y;
             o.y = be - n.x * n.y;
         }
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     auto graph_change = [&](int g) {
         fetch_rec2(recA, A.a, g, lane);
         if constexpr (CB > 0) fetch_rec2(recB, A.b, g, lane);
-        if (lane < 32) reinterpret_cast<float4 *>(recK)[lane] = reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + lane];
+        if (lane < 32) reinterpret_cast<float4 *>(recK)[lane] = reinterpret_cast<const float4 *>(opaque_ptr(A.coef))[(long long)g * FGNN_H + lane];
         cached_g = g;
         cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, g, A.N));
         const float2 ra = reinterpret_cast<const float2 *>(recA)[j];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
             lb_a = rb.x;
             lb_b = rb.y;
         }
-        if (normA) la_mean = A.a.nrm[((long long)g * A.a.C + j) * 4];
+        if (normA) la_mean = opaque_ptr(A.a.nrm)[((long long)g * A.a.C + j) * 4];
     };
     int first = T0 + wv;
     if constexpr (SKIP) first = __builtin_amdgcn_readfirstlane(next_live_tile_p(first, T1, NWB, tpg, 64, A.ldr, A.nvalid));
