@@ -681,6 +681,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
                                                                        float *coefa, float *coefb) {
     extern __shared__ __attribute__((aligned(16))) char mm_lds[];
     __shared__ float red[MM_NW][4];
+    __shared__ float t_keep;
     constexpr bool STRIP = MMCfg<NT, NCOL>::STRIP;
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -690,7 +691,6 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     const View16 vOA = make_view16(da, ogstride, ldo, G), vOB = make_view16(db, ogstride, ldo, G);
     const int o_off = g * vOA.gs2 + c * vOA.ld2;
     float sa1 = 0.f, sa2 = 0.f, sb1 = 0.f, sb2 = 0.f;
-    float T = 0.f;
     u32x4 pre_a[4], pre_b[4];
     constexpr bool PRE = STATS == 2 && STRIP;
     if constexpr (STATS == 2) {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
             }
         }
         wg_sum<1>(tp, red, tid);
-        T = tp[0];
+        if (tid == 0) t_keep = tp[0];    // parked in LDS: nothing below may hold a register across the two products
         __syncthreads();                 // `red` is used again at the end
     }
     {
@@ -725,17 +725,21 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
         };
         mm_gemm<NT, NCOL, true, true, true, false, PRE>(acc, D, B, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b, next);     // dA = dM Yb^T
         mm_store<NT, NCOL, STATS>(acc, mm_lds, vOA, o_off, A, N, ldr, nv, ntv, sa1, sa2, tid);
+        if constexpr (STATS != 0) {       // the sums of dA leave the registers before the second product starts
+            sa1 = wave_sum(sa1);
+            sa2 = wave_sum(sa2);
+            if (lane == 0) {
+                red[wv][0] = sa1;
+                red[wv][1] = sa2;
+            }
+        }
         mm_gemm<NT, NCOL, false, false, false, true, true>(acc, A, D, mm_lds, ldr, nv, ntv, tid, pre_a, pre_b);         // dB = Ya^T dM
         mm_store<NT, NCOL, STATS>(acc, mm_lds, vOB, o_off, B, N, ldr, nv, ntv, sb1, sb2, tid);
     }
     if constexpr (STATS != 0) {
-        sa1 = wave_sum(sa1);
-        sa2 = wave_sum(sa2);
         sb1 = wave_sum(sb1);
         sb2 = wave_sum(sb2);
         if (lane == 0) {
-            red[wv][0] = sa1;
-            red[wv][1] = sa2;
             red[wv][2] = sb1;
             red[wv][3] = sb2;
         }
@@ -746,6 +750,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
             for (int w = 0; w < MM_NW; ++w) v += red[w][tid];                      // fixed order
             if constexpr (STATS == 2) {
                 // lanes 0 / 2 hold S1 of dA / dB; lanes 1 / 3 form S2 from T and the S1 of their neighbour
+                const float T = t_keep;
                 const float s1 = __shfl(v, tid & ~1);
                 const Src16 &O = tid < 2 ? A : B;
                 const float beta = O.b + O.mean * O.a;                              // b = beta - mean a
