@@ -415,7 +415,7 @@ def _ulp_close_grad(got, ref, max_frac, what, flips=1e-2):
     assert frac <= max_frac, (what, frac)
 
 
-@pytest.mark.parametrize('N,B', [(24, 2), (50, 2), (200, 1)])
+@pytest.mark.parametrize('N,B', [(24, 2), (50, 2), (200, 1), (240, 1)])      # 240: the eight-column strip form of the products
 def test_backward_kernels_element_wise_on_identical_inputs(N, B):
     """fgnn_colmax_bwd16, fgnn_mlp_bwd16 (mlp3: two input gradients; mlp1 / mlp2: read-modify-write of the block-input
     gradient) and fgnn_chan_matmul_bwd16 through the C ABI, each fed the ORACLE's bf16 values (forward slabs, arg-max indices,
