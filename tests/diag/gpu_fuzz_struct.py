@@ -17,6 +17,7 @@ from graph_neural_net_amd.engine16 import FgnnEngineBF16         # noqa: E402
 
 DEV = 'cuda:0'
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ONLY = int(os.environ.get('FUZZ_ONLY', '-1'))        # run this case only; with FUZZ_DUMP=1 compare the two engines' saved tensors
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 rel = lambda a, b: ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
 l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
@@ -69,9 +70,13 @@ for case in range(cases):
             pert[off:off + n] = 0.05 * torch.randn(n, generator=gen)
     params = (params.cpu() + pert).to(DEV)
     tot = float(max(1, sum(sizes)))
+    if ONLY >= 0 and case != ONLY:          # (every random draw of the case is behind us: the stream stays aligned)
+        continue
     out = []
+    engs = {}
     for mode in ('generic', 'structured'):
         eng = (FgnnEngineBF16 if bf16 else FgnnEngine)(lay, 2 * B, N, DEV, ragged=ragged, block1=mode)
+        engs[mode] = eng
         g = torch.zeros_like(params)
         if mode == 'structured':
             s, l = eng.step(params, g, None, nvalid=nv, bits=bits, total_nodes=tot)
@@ -82,6 +87,50 @@ for case in range(cases):
         torch.cuda.synchronize()
         out.append((s.cpu().clone(), l.item(), g.cpu().clone()))
     (sa, la, ga), (sb, lb, gb) = out
+    if os.environ.get('FUZZ_DUMP') and not bf16:
+        ea_, eb_ = engs['generic'], engs['structured']
+        def corner(e, buf):
+            t = buf.view(e.G, 32, e.ldp)[:, :, :e.P].reshape(e.G, 32, e.N, e.N).cpu()
+            for g_ in range(e.G):
+                n_ = sizes[g_ % B]
+                t[g_, :, n_:, :] = 0
+                t[g_, :, :, n_:] = 0
+            return t
+        def cmp(name, a_, b_):
+            d = (a_.double() - b_.double()).abs()
+            per = [(d[g_].max() / a_[g_].double().abs().max().clamp_min(1e-30)).item() for g_ in range(a_.shape[0])]
+            print('     %-14s max rel per graph: %s' % (name, ' '.join('%.1e' % v for v in per)))
+        print('     argmax indices equal:', bool(torch.equal(ea_.idx, eb_.idx)), ' differing:', int((ea_.idx != eb_.idx).sum()))
+        for k_ in range(1, nblk + 1):
+            cmp('mult[%d]' % k_, corner(ea_, ea_.mult[k_]), corner(eb_, eb_.mult[k_]))
+            for j_ in (1, 2, 3):
+                if k_ == 1 and j_ < 3:
+                    continue
+                cmp('z[%d,%d]' % (k_, j_), corner(ea_, ea_.z[(k_, j_)]), corner(eb_, eb_.z[(k_, j_)]))
+            for j_ in (1, 2, 3):
+                cmp('nrm[%d,%d]' % (k_, j_), ea_.nrm[(k_, j_)].view(ea_.G, -1).cpu(), eb_.nrm[(k_, j_)].view(eb_.G, -1).cpu())
+        Wa_, Wb_ = ea_._bwd, eb_._bwd
+        cmp('dmult (blk 1)', corner(ea_, Wa_['dmult']), corner(eb_, Wb_['dmult']))
+        for i_ in (0, 1):
+            cmp('dy[%d]' % i_, corner(ea_, Wa_['dy'][i_]), corner(eb_, Wb_['dy'][i_]))
+        for kj_ in sorted(Wa_['s12']):
+            cmp('s12%s' % (kj_,), Wa_['s12'][kj_].view(ea_.G, -1).cpu(), Wb_['s12'][kj_].view(eb_.G, -1).cpu())
+    def bwd_on_generic_state():
+        """The structured engine's backward on the GENERIC engine's saved forward (embeddings, arg-max indices, scores, every slab and
+        record): what is left is the backward of the structured block 1 itself.  L2 distance of the gradients to the generic engine's."""
+        ea_, eb_ = engs['generic'], engs['structured']
+        for name_ in ('E', 'idx', 'scores', 'lse'):
+            getattr(eb_, name_).copy_(getattr(ea_, name_))
+        for k_ in range(1, nblk + 1):
+            eb_.mult[k_].copy_(ea_.mult[k_])
+            for j_ in (1, 2, 3):
+                eb_.nrm[(k_, j_)].copy_(ea_.nrm[(k_, j_)])
+                if not (k_ == 1 and j_ < 3):
+                    eb_.z[(k_, j_)].copy_(ea_.z[(k_, j_)])
+        g2_ = torch.zeros_like(params)
+        eb_.backward(params, g2_)
+        torch.cuda.synchronize()
+        return l2(g2_.cpu(), ga)
     ok = bool(torch.isfinite(sb).all() and torch.isfinite(gb).all() and np.isfinite(lb))
     es, eg = rel(sb, sa) if sa.abs().max() > 0 else (sb - sa).abs().max().item(), l2(gb, ga) if ga.norm() > 0 else gb.norm().item()
     # (two blocks of fp32: a ReLU of block 2 within rounding of zero may flip between the two evaluations: 3e-3 gradient class)
@@ -129,6 +178,13 @@ for case in range(cases):
             if flip and eb > 2.0 * ea + 1e-5 * max(scale, 1.0):
                 print('     (flip class: counted, not a failure)')
             ok = bool(torch.isfinite(gb).all()) and (eb <= 2.0 * ea + 1e-5 * max(scale, 1.0) or flip) and (bf16 or es < 1e-3 or scale < 1e-3)
+            if not ok and not bf16 and es < lim_s and bool(torch.isfinite(gb).all()):
+                # ... or several such decisions at once (large graphs: a few ReLUs / one arg-max of the pooling within rounding of a tie,
+                # each at a pixel that carries pooled gradient).  Then the forward states agree to rounding and the structured backward,
+                # run on the generic engine's forward state, must reproduce the generic gradients
+                same = bwd_on_generic_state()
+                print('     (tie class: forward within %.1e; structured backward on the generic forward state: %.2e from the generic gradients)' % (es, same))
+                ok = same < 1e-5
     bad += not ok
     print('%s case %2d: %s B=%d N=%3d blocks=%d %s dens=%.2f %s sizes=%s  scores %.2e  grads %.2e  loss %.6g / %.6g'
           % ('ok  ' if ok else 'FAIL', case, 'bf16' if bf16 else 'fp32', B, N, nblk, 'ragged' if ragged else 'const ', dens,
