@@ -50,6 +50,8 @@ def _unwrap_input(x):
 
 
 class Siamese_Node_Exp(nn.Module):
+    MODULE_STEPS_MAX = 8        # captured module steps kept per model (fused_step through the module surface), LRU
+
     def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
                  metric=None, precision='fp32'):
         """Same positional signature as the reference (models/trainers.py:21).  Two keyword-only extras:
@@ -259,11 +261,14 @@ class Siamese_Node_Exp(nn.Module):
             return loss, scores
         steps = self.__dict__.setdefault('_module_steps', {})
         key = (tuple(x1.shape), tuple(x2.shape), x1.dtype, x1.device, tuple(id(p) for p in params))
-        st = steps.get(key)
+        st = steps.pop(key, None)
         if st is None:
-            if len(steps) >= 4:                         # a handful of batch shapes; each holds a graph's private memory pool
+            # a handful of batch shapes, least recently used first out (each holds a graph's private memory pool; a loader that
+            # cycles through more shapes than MODULE_STEPS_MAX re-captures -- ~400 launches x 4 -- on every miss: raise the bound)
+            while len(steps) >= max(1, int(self.MODULE_STEPS_MAX)):
                 steps.pop(next(iter(steps)))
-            st = steps[key] = {'x1': torch.empty_like(x1), 'x2': torch.empty_like(x2), 'graph': None}
+            st = {'x1': torch.empty_like(x1), 'x2': torch.empty_like(x2), 'graph': None}
+        steps[key] = st                                 # (re-)inserted last = most recently used
         st['x1'].copy_(x1)
         st['x2'].copy_(x2)
         if st['graph'] is None:

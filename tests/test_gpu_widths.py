@@ -435,6 +435,15 @@ def test_fused_step_on_a_non_standard_width_is_the_captured_module_path():
         assert torch.equal(s4, model(y1, y2))
     l5, _ = model.fused_step(x1, x2)
     assert torch.equal(l5, l3)
+    # the captured steps are kept least-recently-used first out (Siamese_Node_Exp.MODULE_STEPS_MAX): with room for two, a third
+    # shape drops the one that was not just replayed -- the 3-pair batch (used last above) stays, the 2-pair one goes
+    model.MODULE_STEPS_MAX = 2
+    z1, z2 = x1[:1].contiguous(), x2[:1].contiguous()
+    model.fused_step(z1, z2)
+    kept = sorted(k[0][0] for k in model._module_steps)
+    assert kept == [1, 3], kept
+    l6, _ = model.fused_step(x1, x2)
+    assert torch.equal(l6, l3)
 
 
 def test_fused_step_on_models_that_run_zero_padded_on_the_engine():
