@@ -285,14 +285,21 @@ __global__ __launch_bounds__(RANGE_THREADS) void ragged_ranges_kernel(const int 
             w.next(tpg, T, pitch, nvalid, G);
         }
     }
-    incl[tid] = c;
-    __syncthreads();
-    for (int o = 1; o < RANGE_THREADS; o <<= 1) {          // inclusive scan of the chunk costs
-        const long long add = tid >= o ? incl[tid - o] : 0;
-        __syncthreads();
-        incl[tid] += add;
-        __syncthreads();
+    // inclusive scan of the chunk costs: within the wave by shuffles, across the 16 waves through their totals (two barriers
+    // instead of the twenty of a shared-memory doubling scan; integer sums: the same bounds bit for bit)
+    __shared__ long long wave_tot[RANGE_THREADS / 64];
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long up = __shfl_up(c, o);
+        if (lane >= o) c += up;
     }
+    if (lane == 63) wave_tot[wv] = c;
+    __syncthreads();
+    long long before = 0;
+    for (int w = 0; w < wv; ++w) before += wave_tot[w];
+    incl[tid] = c + before;
+    __syncthreads();
     const long long all = incl[RANGE_THREADS - 1];
     for (int b = tid; b <= FGNN_RANGE_WG; b += RANGE_THREADS) {
         if (b == FGNN_RANGE_WG) {
