@@ -715,9 +715,11 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const float4 *vinfo,
     __shared__ __attribute__((aligned(16))) float HB[KC][2 * FGNN_H];           // h1 | h2
     __shared__ __attribute__((aligned(16))) float DZ[KC][FGNN_H + 4], D2[KC][FGNN_H + 4], D1[KC][FGNN_H + 4];
     __shared__ float XI[KC][2];                                                 // the instance's input value (w, degree)
-    const int g = blockIdx.x / wpg, widx = blockIdx.x - g * wpg, m = blockIdx.y, tid = threadIdx.x;
-    const int nv = nvalid_of(nvalid, g, N);
-    const int NC = sb_classes(N), K = nv + 2;
+    // G * wpg <= rows of wpart: workgroup (g, widx) owns every wpg-th instance round of graph g.  More graphs than rows (wpg == 1,
+    // gridDim.x rows): workgroup b sums the graphs b, b + gridDim.x, ... into its one row
+    const int g0 = blockIdx.x / wpg, widx = blockIdx.x - g0 * wpg, m = blockIdx.y, tid = threadIdx.x;
+    const int gstep = G * wpg <= (int)gridDim.x ? G : (int)gridDim.x;
+    const int NC = sb_classes(N);
     const float *tm = tab + (long long)m * NC * SB_TAB;
     const int c = tid & 31, kq = tid >> 5;
     {
@@ -733,12 +735,15 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const float4 *vinfo,
             Wt[1][tid + 256 * q] = w[4 + q];
         }
     }
-    const float4 cf = coef[((long long)m * G + g) * FGNN_H + c];              // ca, cb, cc, mean of channel c
-    const float ones = gones[g], fN = (float)nv;
-    const float cnt0 = fN * fN - fN - ones, cnt1 = ones;
     const int wv = tid >> 6, lane = tid & 63, jj = lane & 31, hh = lane >> 5;
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float asum = 0.f, ab2 = 0.f;
+#pragma unroll 1
+    for (int g = g0; g < G; g += gstep) {
+    const int nv = nvalid_of(nvalid, g, N), K = nv + 2;
+    const float4 cf = coef[((long long)m * G + g) * FGNN_H + c];              // ca, cb, cc, mean of channel c
+    const float ones = gones[g], fN = (float)nv;
+    const float cnt0 = fN * fN - fN - ones, cnt1 = ones;
     const float *cs = csum + ((long long)m * G + g) * FGNN_H * CS;
 #pragma unroll 1
     for (int ch = widx; ch * KC < K; ch += wpg) {
@@ -863,8 +868,9 @@ __global__ __launch_bounds__(256) void sb_bwd_params_kernel(const float4 *vinfo,
         }
         __syncthreads();                                      // the next round overwrites the arrays
     }
+    }
     constexpr int PC = 32 * 2 + 32 + 2 * (32 * 32 + 32);
-    float *row = A.wpart[m] + ((long long)g * wpg + widx) * PC;
+    float *row = A.wpart[m] + (long long)blockIdx.x * PC;
     if (wv < 2) {
         float *dst = row + (wv == 0 ? 96 + 1024 + 32 : 96);
 #pragma unroll
@@ -887,8 +893,10 @@ extern "C" int fgnn_debug_sb_stamps(void *p) { return hipMemcpyToSymbol(HIP_SYMB
 extern "C" int fgnn_block1_struct_supported(int N, int depth, int c0) { return (N >= 1 && N <= SB_NMAX && depth == 3 && c0 == 2) ? 1 : 0; }
 extern "C" int fgnn_block1_struct_table_floats(int N) { return 2 * (2 + 2 * (N + 1)) * SB_TAB; }
 extern "C" long long fgnn_block1_struct_ws_floats(int G, int N) { return sb_ws_layout(G, N).total; }
-extern "C" int fgnn_block1_struct_rows(int G, int N) {          // rows of wpart the backward pass writes (the caller keeps the others zero)
-    const int chunks = (N + 2 + SB_KC - 1) / SB_KC, fit = fgnn_mlp_bwd_num_workgroups() / (G > 0 ? G : 1);
+extern "C" int fgnn_block1_struct_rows(int G, int N) {          // rows of wpart the backward pass writes (the reduction reads exactly these)
+    const int rows = fgnn_mlp_bwd_num_workgroups();
+    if (G >= rows) return rows;                                  // more graphs than rows: row b sums the graphs b, b + rows, ...
+    const int chunks = (N + 2 + SB_KC - 1) / SB_KC, fit = rows / (G > 0 ? G : 1);
     const int wpg = chunks < fit ? chunks : fit;
     return G * (wpg < 1 ? 1 : wpg);
 }
@@ -1020,8 +1028,8 @@ int sb_bwd_launch(const BwdCall &c) {
     A.wpart[0] = c.wpart1;
     A.wpart[1] = c.wpart2;
     A.bf = BF ? 1 : 0;
-    const int wpg = fgnn_block1_struct_rows(c.G, c.N) / c.G;
-    hipLaunchKernelGGL((sb_bwd_params_kernel<SB_KC>), dim3(c.G * wpg, 2), dim3(256), 0, c.st, vinfo, c.ws + L.gones, c.nvalid, c.G, c.N, L.CS, c.tables, csum,
+    const int rows = fgnn_block1_struct_rows(c.G, c.N), wpg = rows >= c.G ? rows / c.G : 1;
+    hipLaunchKernelGGL((sb_bwd_params_kernel<SB_KC>), dim3(rows, 2), dim3(256), 0, c.st, vinfo, c.ws + L.gones, c.nvalid, c.G, c.N, L.CS, c.tables, csum,
                        coef, A, wpg);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -1032,8 +1040,6 @@ int sb_bwd_dispatch(const BwdCall &c) {
                    c.s12_2 && c.G > 0,
                "fgnn_block1_struct_bwd: bad arguments");
     FGNN_CHECK(c.N >= 1 && c.N <= SB_NMAX, "fgnn_block1_struct_bwd: N = %d (built for N <= %d)", c.N, SB_NMAX);
-    FGNN_CHECK(c.G <= fgnn_mlp_bwd_num_workgroups(), "fgnn_block1_struct_bwd: one partial row per graph: G = %d exceeds the %d rows of wpart", c.G,
-               fgnn_mlp_bwd_num_workgroups());
     if (c.N <= 64) return sb_bwd_launch<1, BF>(c);
     if (c.N <= 128) return sb_bwd_launch<2, BF>(c);
     return sb_bwd_launch<4, BF>(c);

@@ -185,8 +185,7 @@ class FgnnEngine:
             raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
         # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged, N <= 256; anything else runs generic
         self.struct1 = (block1 == 'structured' and cu_share == 0
-                        and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0))
-                        and G <= _lib.load().fgnn_mlp_bwd_num_workgroups())
+                        and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0)))
         self._struct = None
         self.layout = layout
         self.G, self.N = G, N

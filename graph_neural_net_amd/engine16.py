@@ -31,8 +31,7 @@ class FgnnEngineBF16:
         if block1 not in ('generic', 'structured'):
             raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
         # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged; dense inputs run generic
-        self.struct1 = (block1 == 'structured' and bool(lib.fgnn_block1_struct_supported(N, layout.depth, layout.c0))
-                        and G <= lib.fgnn_mlp_bwd_num_workgroups())
+        self.struct1 = block1 == 'structured' and bool(lib.fgnn_block1_struct_supported(N, layout.depth, layout.c0))
         self._struct = None
         self.xbits = None
         if layout.depth != 3:

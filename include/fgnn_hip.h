@@ -428,7 +428,7 @@ int fgnn_lsap_accuracy(const float *cost, long long bstride, int ld, const int *
 int fgnn_block1_struct_supported(int N, int depth, int original_features_num);      /* N <= 256, depth 3, 2 input channels */
 int fgnn_block1_struct_table_floats(int N);
 long long fgnn_block1_struct_ws_floats(int G, int N);       /* workspace shared by fwd and bwd of one step (16-byte aligned) */
-int fgnn_block1_struct_rows(int G, int N);                  /* bwd writes rows 0 .. rows-1 of wpart1 / wpart2 (<= fgnn_mlp_bwd_num_workgroups()) and no others */
+int fgnn_block1_struct_rows(int G, int N);                  /* bwd writes rows 0 .. rows-1 of wpart1 / wpart2 (<= fgnn_mlp_bwd_num_workgroups()) and no others; G > that many rows: row b sums the graphs b, b + rows, ... */
 int fgnn_block1_struct_tables(const float *const *W1, const float *const *b1, const float *const *W2, const float *const *b2, int N,
                               int bf16_scheme, float *tables, void *stream);
 /* nvalid: optional per-graph vertex counts (ragged batches: the N x N planes are padded; mult is written as 0 outside the valid

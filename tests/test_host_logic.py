@@ -314,4 +314,6 @@ def test_structured_block1_host_geometry():
         cs = 2 + (64 if N <= 64 else 128 if N <= 128 else 256)
         cp = (N + 7) // 8 * 8
         assert ws % 4 == 0 and ws >= 2 * G * 32 * cs + 2 * G * 32 * 4 + 4 * G * N + G + G * N * cp // 2, (G, N, ws)
+    for G in (257, 300, 512, 1024):                      # more graphs than rows: row b sums the graphs b, b + nwg, ...
+        assert lib.fgnn_block1_struct_rows(G, 50) == nwg
     assert lib.fgnn_block1_struct_table_floats(50) == 2 * (2 + 2 * 51) * 4 * 32
