@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random shapes through the structured block 1 against the generic kernels (both engines): python tests/diag/gpu_fuzz_struct.py [cases=40] [seed=0]
-Per case: random B in 1..6, N in 1..256, edge density, directed / undirected, self loops, ragged or not (sizes down to 0), 1 or 2
+Per case: random B in 1..6 (8 % of the cases: 129..160 pairs of N <= 24, FUZZ_MANY), N in 1..256, edge density, directed / undirected, self loops, ragged or not (sizes down to 0), 1 or 2
 blocks.  fp32 engine: mult / scores / loss / gradients to fp32-rounding agreement; 16-bit engine: finite, scores within 3e-2, gradients
 within 8e-2 (L2) of the generic 16-bit kernels.  Prints one line per case and a summary; exits 1 on a failure."""
 import os
@@ -27,6 +27,9 @@ for case in range(cases):
     N = int(rng.choice([1, 2, 7, 31, 32, 33, 50, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256])) if rng.random() < 0.6 else int(rng.integers(1, 257))
     if N > 128:
         B = min(B, 2)
+    if rng.random() < float(os.environ.get('FUZZ_MANY', '0.08')):      # more graphs than partial rows of the structured backward (G > 256)
+        N = int(rng.integers(1, 25))
+        B = int(rng.integers(129, 161))
     nblk = int(rng.integers(1, 3))
     ragged = bool(rng.random() < 0.5)
     bf16 = bool(rng.random() < 0.35)
