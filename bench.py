@@ -254,6 +254,9 @@ def parse_args():
                          "the drop-in module surface -- Siamese_Node_Exp.forward, model.loss, loss.backward(), eager launches; "
                          "'fused_step': Siamese_Node_Exp.fused_step on the loader's batch (tensors or MaskedTensors): the module "
                          "surface with the step as ONE replayed graph")
+    ap.add_argument('--module-input-form', default='dense', choices=('dense', 'tensor_representation'),
+                    help="--path fused_step / module: the module's input_form ('tensor_representation': the dense loader batch is "
+                         'bit-packed + verified on the device and block 1 runs on its structured form)')
     ap.add_argument('--no-graph', action='store_true', help='do not capture the step in a HIP graph')
     ap.add_argument('--chains', type=int, default=None, choices=(1, 2),
                     help='2: the batch runs as two half-batch chains on two streams / disjoint halves of the CUs (FgnnEngineDual: '
@@ -266,7 +269,7 @@ def parse_args():
                          'bit-packed adjacency (block 1 expands it itself: SURVEY 8 row f3).  Default: bits with --block1 structured, else dense')
     ap.add_argument('--block1', default=None, choices=('generic', 'structured'),
                     help="block 1 on bit-packed inputs: 'structured' = csrc/block1_struct.hip (class tables + closed-form per-channel "
-                         "product; constant-size batches, N <= 64, fp32 engine), 'generic' = the kernels every block uses")
+                         "product; constant-size and ragged batches, N <= 256, fp32 and bf16 engines), 'generic' = the kernels every block uses")
     ap.add_argument('--settle', type=int, default=64, help='untimed replays before the warm-up steps (clock / TLB settling)')
     ap.add_argument('--windows', type=int, default=5,
                     help='the K-step timed window is repeated this many times; ms_per_step / value are the MEDIAN window, '
@@ -301,6 +304,9 @@ def main():
                               'input': sub['config']['input'], 'block1': sub['config']['block1'],
                               'roofline': {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')
                                            if sub['roofline'] and k in sub['roofline']}}
+    if rank == 0 and world == 1 and args.path == 'engine' and not args.no_extra_configs and out['config'].get('block1', 'generic') != 'generic':
+        # ... and through the module surface a user of the reference calls (dense loader batch in, fused_step)
+        out['module_surface'] = module_surface_leg(args, args.config, rank, world, dev, out['ms_per_step'])
     if rank == 0 and world == 1 and args.config == 'cfg2' and args.precision is None and args.path == 'engine' \
             and not args.no_extra_configs and args.batch is None and args.n is None:
         # BASELINE configs 4 and 5 (per-GPU shard) under the same K / W protocol, outside the headline's timed region
@@ -313,7 +319,10 @@ def main():
                           'dtype': sub['dtype'], 'workload': sub['config']['workload'],
                           'roofline': {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')
                                        if sub['roofline'] and k in sub['roofline']},
-                          'step_model': sub['step_model'], 'wall_s': round(time.time() - t0, 2)}
+                          'step_model': sub['step_model']}
+            if cfg == 'cfg5':
+                extra[cfg]['module_surface'] = module_surface_leg(args, cfg, rank, world, dev, sub['ms_per_step'])
+            extra[cfg]['wall_s'] = round(time.time() - t0, 2)
         out['extra_configs'] = extra
     if rank == 0:
         print(json.dumps(out))
@@ -322,10 +331,32 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=None, input_form=None):
+def module_surface_leg(args, config, rank, world, dev, engine_ms):
+    """The same workload through the drop-in module surface (models/trainers.py:60-76): `Siamese_Node_Exp.fused_step` on the DENSE
+    loader batch (tensors, or MaskedTensors for cfg5), same K / W protocol, with the module's input_form opt-in
+    ('tensor_representation': the batch is bit-packed + verified on the device inside the step and block 1 runs structured) and
+    without it ('dense': generic block 1)."""
+    leg = {}
+    for form in ('tensor_representation', 'dense'):
+        sub = run_config(args, config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), path='fused_step',
+                         module_input_form=form, profile=False)
+        leg[form] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'],
+                     'ms_per_step_min': sub['ms_per_step_min'], 'ms_per_step_max': sub['ms_per_step_max'],
+                     'block1': sub['config']['block1'], 'input': sub['config']['input']}
+    leg['ms_per_step'] = leg['tensor_representation']['ms_per_step']
+    leg['engine_ms_per_step'] = engine_ms
+    leg['vs_engine'] = leg['ms_per_step'] / engine_ms
+    leg['what'] = ("Siamese_Node_Exp(input_form='tensor_representation').fused_step({'input': x1}, {'input': x2}) on the dense loader "
+                   'batch: two pack launches (fgnn_pack_adjacency_ld, with the device verdict) + ONE replayed HIP graph per step')
+    return leg
+
+
+def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=None, input_form=None, path=None,
+               module_input_form=None, profile=True):
     """One measurement: build the workload of `config`, capture the step, settle, warm up, time `windows` windows of
     exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0).
-    block1 / input_form: override --block1 / --input (the dense-input line reported beside the headline)."""
+    block1 / input_form: override --block1 / --input (the dense-input line reported beside the headline); path /
+    module_input_form: override --path / --module-input-form (module_surface_leg)."""
     windows = args.windows if windows is None else windows
     precision = args.precision if config == args.config else None
     dense_er = config == 'cfg4'                   # the workload
@@ -334,7 +365,8 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     same = config == args.config
     B = args.batch if (same and args.batch is not None) else (8 if (dense_er or ragged) else 32)
     N = args.n if (same and args.n is not None) else (200 if dense_er else (120 if ragged else 50))
-    path = args.path if same else 'engine'
+    path = path if path is not None else (args.path if same else 'engine')
+    mform = module_input_form if module_input_form is not None else args.module_input_form
     no_graph = args.no_graph
     layout = ParamLayout(2, args.blocks, 32, 32, 3)
     params = layout.init_flat(0, dev)
@@ -400,7 +432,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                         in_features=32, out_features=32, depth_of_mlp=3)
         if ragged:
             node_emb['constant_n_vertices'] = False
-        model = Siamese_Node_Exp(2, node_emb, metric='max', precision='bf16' if bf16 else 'fp32').to(dev)
+        model = Siamese_Node_Exp(2, node_emb, metric='max', precision='bf16' if bf16 else 'fp32', input_form=mform).to(dev)
         with torch.no_grad():
             for (name, off, shape), (_, p) in zip(layout.entries, model.node_embedder.named_parameters()):
                 p.copy_(params[off:off + p.numel()].view(shape))
@@ -423,6 +455,9 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     graph = None
     model_work()                                  # allocates the backward workspace, sets kernel attributes
     torch.cuda.synchronize()
+    # did the module surface put this batch on the structured block 1?  (fused_step's engine of this shape says so)
+    surface_struct = bool(model is not None and path == 'fused_step' and any(
+        getattr(e, 'struct1', False) and getattr(e, '_step_state', None) is not None for e in model.node_embedder._engines.values()))
     comm = grads if path == 'engine' else model.node_embedder._flat_grad
     # the ONE collective of a step: recorded into the step's HIP graph when the backend can be captured (RCCL), so a step is one
     # replay with no host launch on its critical path; otherwise (gloo, --no-graph, module path) an eager call after the model work
@@ -511,7 +546,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     # ---- roofline leg: per-kernel durations from events on the launch stream (eager launches) ----
     roofline = None
     kernels = {}
-    if rank == 0 and args.profile_steps > 0 and not dual:
+    if rank == 0 and args.profile_steps > 0 and not dual and profile:
         model_work()                              # one eager step untimed: the replays before it ran from the graph's own launch path
         torch.cuda.synchronize()
         _lib.PROFILE = []
@@ -615,9 +650,11 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
                        'parallelism': 'dp%d' % world, 'hip_graph': graph is not None, 'allreduce_in_graph': bool(ar_in_graph), 'path': path, 'settle_steps': args.settle,
                        'chains': 2 if dual else 1,
-                       'input': 'bit-packed adjacency (N x ceil(N/32) words per graph)' if xbits is not None else 'dense (2, N, N) fp32 tensor representation',
+                       'input': ('bit-packed adjacency (N x ceil(N/32) words per graph)' if xbits is not None else
+                                 ('dense (2, N, N) fp32 loader batch, bit-packed + verified on the device inside the step (input_form='
+                                  "'tensor_representation')" if surface_struct else 'dense (2, N, N) fp32 tensor representation')),
                        'block1': ('structured: class tables + closed-form per-channel product (csrc/block1_struct.hip)'
-                                  if (struct1 and xbits is not None) else 'generic'),
+                                  if ((struct1 and xbits is not None) or surface_struct) else 'generic'),
                        'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
                                            ('mlp1 / mlp2 (forward, and the pair backward fgnn_mlp_bwd_pair_x3): 3 x bf16 split operands (8 / 6 partial '
                                             'products, fp32 accumulation) on v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)

@@ -197,15 +197,16 @@ extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, in
 // tensor IS a tensor representation (channel 0 in {0, 1}; channel 1 = diag(row sums of channel 0) on the valid corner).  One wave per
 // row: lane = column (64 per pass), the row's words are ballots; `bad` (optional, device int) is OR-ed with 1 where the check fails.
 namespace {
-__global__ __launch_bounds__(256) void pack_adjacency_kernel(const float *x, const int *nvalid, int G, int N, int words, unsigned *bits,
-                                                             int *bad) {
+__global__ __launch_bounds__(256) void pack_adjacency_kernel(const float *x, const int *nvalid, int G, int Nin, int N, int words,
+                                                             unsigned *bits, int *bad) {
+    // x: (G, 2, Nin, Nin); bits: (G, N, words) with N >= Nin -- rows / columns >= Nin are empty
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // row over (g, i)
     if (t >= (long long)G * N) return;
     const int lane = threadIdx.x & 63, g = (int)(t / N), i = (int)(t - (long long)g * N);
-    const int nv = nvalid_of(nvalid, g, N);
-    const float *w = x + ((long long)g * 2) * N * N + (long long)i * N, *d = w + (long long)N * N;
+    const int nv = min(nvalid_of(nvalid, g, N), Nin);
+    const float *w = x + ((long long)g * 2) * Nin * Nin + (long long)i * Nin, *d = w + (long long)Nin * Nin;
     int deg = 0;
-    bool wrong = false;
+    bool wrong = nvalid && (nvalid[g] > Nin || nvalid[g] < 0);
     float dii = 0.f;
     for (int j0 = 0; j0 < 32 * words; j0 += 64) {
         const int j = j0 + lane;
@@ -227,13 +228,16 @@ __global__ __launch_bounds__(256) void pack_adjacency_kernel(const float *x, con
 }
 }  // namespace
 
-extern "C" int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigned *bits, int *bad, void *stream) {
-    FGNN_CHECK(x && bits && G > 0 && N > 0, "fgnn_pack_adjacency: bad arguments");
+extern "C" int fgnn_pack_adjacency_ld(const float *x, const int *nvalid, int G, int Nin, int N, unsigned *bits, int *bad, void *stream) {
+    FGNN_CHECK(x && bits && G > 0 && Nin > 0 && N >= Nin, "fgnn_pack_adjacency_ld: bad arguments");
     const long long rows = (long long)G * N;
-    hipLaunchKernelGGL(pack_adjacency_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, nvalid, G, N,
+    hipLaunchKernelGGL(pack_adjacency_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, nvalid, G, Nin, N,
                        (N + 31) / 32, bits, bad);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigned *bits, int *bad, void *stream) {
+    return fgnn_pack_adjacency_ld(x, nvalid, G, N, N, bits, bad, stream);
 }
 
 // ---- ragged batches: work-balanced tile ranges for the persistent MLP kernels (fgnn_mlp_fwd_args.ranges) -------------

@@ -325,14 +325,20 @@ class FgnnEngineBF16:
             args.s12part = W['s12part'].data_ptr()
         return args
 
-    def backward(self, params, grads, grad_scale=1.0, hook=None):
+    def backward(self, params, grads, grad_scale=1.0, hook=None, gscale_dev=None):
+        """gscale_dev: a 1-element fp32 DEVICE tensor holding grad_scale / total_nodes (replaces both), as in FgnnEngine.backward:
+        the normaliser of a ragged batch never visits the host and a captured step survives another node count."""
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
-        gs = grad_scale / self.total_nodes
-        if W.get('gscale_value') != gs:
-            W['gscale'].fill_(gs)
-            W['gscale_value'] = gs
+        if gscale_dev is not None:
+            W['gscale'].copy_(gscale_dev.reshape(1))
+            W['gscale_value'] = None
+        else:
+            gs = grad_scale / self.total_nodes
+            if W.get('gscale_value') != gs:
+                W['gscale'].fill_(gs)
+                W['gscale_value'] = gs
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)

@@ -322,20 +322,21 @@ class Network(nn.Module):
     def _engine_for(self, x, nvalid, grad):
         return self._engine_for_shape(x.shape[0], x.shape[-1], nvalid is not None, x.device, grad)
 
-    def _engine_for_shape(self, G, N, ragged, device, grad):
+    def _engine_for_shape(self, G, N, ragged, device, grad, block1=None):
         # separate workspaces for grad / no-grad forwards: an evaluation forward between a training forward and its
         # backward must not overwrite the saved activations.  `grad` is passed in by the caller: inside an
         # autograd.Function's forward torch.is_grad_enabled() is always False.
         # The cache is bounded (LRU by bytes, ENGINE_CACHE_BYTES): a stream of ragged shapes re-uses a few workspaces; an
         # engine evicted between a forward and its backward stays alive through the autograd node that holds it.
         bf16 = getattr(self, 'precision', 'fp32') == 'bf16'
-        key = (G, N, ragged, device, grad if isinstance(grad, str) else bool(grad), bf16)       # 'step': Siamese_Node_Exp.fused_step
+        # 'step': Siamese_Node_Exp.fused_step; block1='structured': its tensor-representation form (bit-packed input, csrc/block1_struct.hip)
+        key = (G, N, ragged, device, grad if isinstance(grad, str) else bool(grad), bf16) + ((block1,) if block1 else ())
 
         def make():
             if bf16:
                 from .engine16 import FgnnEngineBF16
-                return FgnnEngineBF16(self._layout, G, N, device, ragged=ragged)
-            return FgnnEngine(self._layout, G, N, device, ragged=ragged, mfma='f32')
+                return FgnnEngineBF16(self._layout, G, N, device, ragged=ragged, block1=block1)
+            return FgnnEngine(self._layout, G, N, device, ragged=ragged, mfma='f32', block1=block1)
         self._engines.budget = self.ENGINE_CACHE_BYTES
         nbytes = EngineCache.engine_bytes(G, N, self._layout.num_blocks, 2 if bf16 else 4) // (1 if grad else 2)
         return self._engines.get(key, make, nbytes)[0]

@@ -52,9 +52,19 @@ def _unwrap_input(x):
 class Siamese_Node_Exp(nn.Module):
     MODULE_STEPS_MAX = 8        # captured module steps kept per model (fused_step through the module surface), LRU
 
+    INPUT_CHECK_EVERY = 128     # input_form='tensor_representation': the device verdict is read back on every k-th fused_step (0: never)
+
     def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
-                 metric=None, precision='fp32'):
-        """Same positional signature as the reference (models/trainers.py:21).  Two keyword-only extras:
+                 metric=None, precision='fp32', input_form='dense'):
+        """Same positional signature as the reference (models/trainers.py:21).  Three keyword-only extras:
+        input_form: 'dense' (default) -- block 1 makes no assumption about the input tensor; 'tensor_representation' -- the caller
+                states that every batch is what the reference's loaders yield (loaders/data_generator.py:118-125: channel 0 a 0/1
+                adjacency, channel 1 = diag(row sums)), and `fused_step` / `FgnnTrainer.from_module` then run block 1 on that structure
+                (csrc/block1_struct.hip: the batch is bit-packed on the device, mlp1 / mlp2 become class tables, the per-channel
+                product a closed form; same function, results equal to fp32 rounding).  The statement is VERIFIED on the device by
+                the packing kernel of every step; the verdict is read on the first step of each batch shape, on every
+                INPUT_CHECK_EVERY-th step and by `check_input_form()`, and a batch that is not a tensor representation raises.
+                Also settable later: `model.node_embedder.input_form = 'tensor_representation'`.
         metric: None -> the reference's default, the Hungarian matching accuracy (`accuracy_linear_assignment`: trainers.py:52,
                 metrics.py:92-116; SciPy's assignment computed on the device, csrc/lsap.hip); 'max' -> the arg-max accuracy
                 (`accuracy_max`, metrics.py:118-141); or any callable.  Neither copies the scores to the host.
@@ -89,6 +99,9 @@ class Siamese_Node_Exp(nn.Module):
             raise ValueError('precision must be "fp32" or "bf16" (got %r)' % (precision,))
         if precision == 'bf16':
             self.node_embedder.half()
+        if input_form not in ('dense', 'tensor_representation'):
+            raise ValueError('input_form must be "dense" or "tensor_representation" (got %r)' % (input_form,))
+        self.node_embedder.input_form = input_form
         self.lr, self.scheduler_decay, self.scheduler_step, self.lr_stop = lr, scheduler_decay, scheduler_step, lr_stop
 
     def forward(self, x1, x2):
@@ -157,27 +170,55 @@ class Siamese_Node_Exp(nn.Module):
         N = -(-nmax // 16) * 16 if ragged else nmax
         pad = net._pad
         c0e = pad['c0p'] if pad is not None else t1.shape[1]
-        eng = net._engine_for_shape(2 * B, N, ragged, dev, 'step')
+        if tuple(t1.shape) != tuple(t2.shape):
+            raise RuntimeError('fused_step: the two sides of the batch have different (padded) shapes %s / %s; use the module path '
+                               '`loss = model.loss(model(x1, x2)); loss.backward()`' % (tuple(t1.shape), tuple(t2.shape)))
+        # input_form='tensor_representation': the loader's dense batch is bit-packed (and verified) on the device and block 1 runs on
+        # its structured form -- where the kernels are built for the shape (2 input channels, depth 3, N <= 256); else the dense path
+        want_tr = getattr(net, 'input_form', 'dense') == 'tensor_representation' and t1.shape[1] == 2 and lay.c0 == 2 \
+            and t1.dtype == torch.float32
+        eng = net._engine_for_shape(2 * B, N, ragged, dev, 'step', block1='structured' if want_tr else None)
+        tr = want_tr and bool(getattr(eng, 'struct1', False))
         st = getattr(eng, '_step_state', None)
         if st is None:
-            st = eng._step_state = {'x': torch.zeros(2 * B, c0e, N, N, dtype=torch.float32, device=dev), 'graph': {},
+            st = eng._step_state = {'x': None if tr else torch.zeros(2 * B, c0e, N, N, dtype=torch.float32, device=dev), 'graph': {},
                                     'nv': torch.zeros(2 * B, dtype=torch.int32, device=dev) if ragged else None,
                                     'inv': torch.ones(1, dtype=torch.float32, device=dev),
-                                    'correct': torch.zeros(B, dtype=torch.int32, device=dev), 'nmax': N}
+                                    'correct': torch.zeros(B, dtype=torch.int32, device=dev), 'nmax': N, 'calls': 0}
+            if tr:      # (the verdict flag is the model's, shared by all batch shapes: check_input_form() reads one word)
+                st['bits'] = torch.zeros(2 * B, N, (N + 31) // 32, dtype=torch.int32, device=dev)
+                st['flag'] = self.__dict__.setdefault('_tr_flags', {}).setdefault(dev, torch.zeros(1, dtype=torch.int32, device=dev))
         c0 = t1.shape[1]
+        first_of_shape = st['calls'] == 0
+        st['calls'] += 1
         if ragged:
+            if first_of_shape or (self.INPUT_CHECK_EVERY and st['calls'] % self.INPUT_CHECK_EVERY == 0):
+                # both sides must share the per-pair vertex counts (the loss has target arange(n): toolbox/losses.py:27-34)
+                if not torch.equal(x1.nvalid, x2.nvalid):
+                    raise RuntimeError('fused_step: the two sides of a MaskedTensor batch must share the per-pair vertex counts; use '
+                                       'the module path `loss = model.loss(model(x1, x2)); loss.backward()`')
+            st['nv'][:B].copy_(x1.nvalid)
+            st['nv'][B:].copy_(x2.nvalid)
+        if tr:
+            # one launch per side straight from the loader's tensors: rows of ballots -> (B, N, ceil(N/32)) words of the engine's padded
+            # size, with the verdict (channel 0 in {0, 1}, channel 1 = diag(row sums), counts within the padded size) OR-ed into a flag
+            for half, t, xm in ((st['bits'][:B], t1, x1), (st['bits'][B:], t2, x2)):
+                _lib.call('fgnn_pack_adjacency_ld', _lib.ptr(t.contiguous()), _lib.ptr(xm.nvalid) if ragged else None, B, nmax, N,
+                          _lib.ptr(half), _lib.ptr(st['flag']), _lib.stream_ptr())
+            if first_of_shape or (self.INPUT_CHECK_EVERY and st['calls'] % self.INPUT_CHECK_EVERY == 0):
+                self._raise_if_not_representation(st)
+        elif ragged:
             if nmax < st['nmax']:                        # a smaller batch in the same workspace: the old values are padding now
                 st['x'].zero_()
-            st['nmax'] = nmax
             st['x'][:B, :c0, :nmax, :nmax].copy_(t1)
             st['x'][B:, :c0, :nmax, :nmax].copy_(t2)
-            st['nv'][:B].copy_(x1.nvalid)
-            st['nv'][B:].copy_(x1.nvalid)
         else:
             st['x'][:B, :c0].copy_(t1)
             st['x'][B:, :c0].copy_(t2)
+        st['nmax'] = nmax
         if st.get('flat') is not net._flat:             # (re)bound parameters: a captured graph holds the old addresses
             st['graph'], st['flat'] = {}, net._flat
+        xin, bits = (None, st['bits']) if tr else (st['x'], None)
 
         def work():
             params = net._engine_params()                # the bound flat buffer, or its zero-padded image (an index_copy_)
@@ -185,11 +226,11 @@ class Siamese_Node_Exp(nn.Module):
             if ragged:
                 # 1 / sum(n) on the device; the engine back-propagates sum-of-pair-losses * gscale and leaves the un-normalised loss
                 torch.reciprocal(st['nv'][:B].sum().to(torch.float32).reshape(1), out=st['inv'])
-                scores, loss = eng.forward(params, st['x'], nvalid=st['nv'], total_nodes=1.0, defer_loss=True)
+                scores, loss = eng.forward(params, xin, nvalid=st['nv'], total_nodes=1.0, defer_loss=True, bits=bits)
                 eng.backward(params, grads, gscale_dev=st['inv'])
                 loss.mul_(st['inv'])
             else:
-                scores, loss = eng.step(params, grads, st['x'])
+                scores, loss = eng.step(params, grads, xin, bits=bits)
             if pad is not None:
                 torch.index_select(pad['pgrad'], 0, pad['idx'], out=net._flat_grad)
             if metric and builtin_metric:
@@ -235,6 +276,23 @@ class Siamese_Node_Exp(nn.Module):
             return loss.reshape(()), scores, (st['correct'].sum(), total)
         acc, n = self.metric(scores)
         return loss.reshape(()), scores, (acc, n)
+
+    @staticmethod
+    def _raise_if_not_representation(st):
+        if int(st['flag'].item()) != 0:             # (one host synchronisation)
+            st['flag'].zero_()
+            raise RuntimeError("fused_step(input_form='tensor_representation'): a batch since the last check is NOT the tensor "
+                               'representation of a 0/1 adjacency (channel 0 in {0, 1}, channel 1 = diag(row sums), '
+                               'loaders/data_generator.py:118-125) -- the structured block 1 does not apply and the results of those '
+                               "steps are invalid; run it through the dense path (input_form='dense')")
+
+    def check_input_form(self):
+        """input_form='tensor_representation': read the device verdict of every fused_step since the last check now (one host
+        synchronisation); raises if one of those batches was not a tensor representation.  True if there was something to check."""
+        flags = self.__dict__.get('_tr_flags', {})
+        for flag in flags.values():
+            self._raise_if_not_representation({'flag': flag})
+        return bool(flags)
 
     def _captured_module_step(self, x1, x2, capture):
         """forward + loss + backward of the eager module path (models/trainers.py:60-76) as ONE replayed HIP graph per batch

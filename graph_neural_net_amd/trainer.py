@@ -15,7 +15,10 @@ from .optim import FlatAdam
 class FgnnTrainer:
     ENGINE_CACHE_BYTES = 8 << 30      # workspace budget of the per-shape engine cache (LRU); 288 GB HBM leave room to raise it
 
-    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32', collective='auto', block1=None):
+    INPUT_CHECK_EVERY = 128     # input_form='tensor_representation': the device verdict is read back on every k-th train_step (0: never)
+
+    def __init__(self, layout, params_flat, lr=1e-3, capture=False, precision='fp32', collective='auto', block1=None,
+                 input_form='dense'):
         """capture=True: constant-shape steps are captured in a HIP graph and replayed -- the launch overhead of ~40 kernels
         per step disappears.  With more than one rank the gradient all-reduce is recorded INSIDE that graph when the backend
         can be captured (RCCL: model work -> all-reduce -> fused Adam is one replay, no host launch on the critical path;
@@ -25,7 +28,20 @@ class FgnnTrainer:
         pl.Trainer(precision=16), commander_explore.py:120-122); parameters, gradients, Adam state and the collective
         stay fp32.
         block1='structured': batches handed over as bit-packed adjacency (train_step_bits) run block 1 on its structured form
-        (csrc/block1_struct.hip); None = the engines' default (FGNN_BLOCK1, 'generic').  Dense batches always run the generic kernels."""
+        (csrc/block1_struct.hip); None = the engines' default (FGNN_BLOCK1, 'generic').
+        input_form='tensor_representation': the caller states that the dense (B, 2, N, N) batches handed to train_step ARE what the
+        reference's loaders yield (loaders/data_generator.py:118-125); train_step then bit-packs them on the device
+        (fgnn_pack_adjacency, which also verifies the statement: the verdict is read on the first step of a shape and on every
+        INPUT_CHECK_EVERY-th step, and a batch that is not a tensor representation raises) and runs train_step_bits with the structured
+        block 1.  'dense' (default): dense batches run the generic kernels, whatever block1 says."""
+        if input_form not in ('dense', 'tensor_representation'):
+            raise ValueError('input_form must be "dense" or "tensor_representation" (got %r)' % (input_form,))
+        self.input_form = input_form
+        if input_form == 'tensor_representation' and block1 is None:
+            block1 = 'structured'
+        self._tr = {}               # (B, N) -> staging words of the packed batch
+        self._tr_flag = None
+        self._tr_calls = 0
         if precision not in ('fp32', 'bf16'):
             raise ValueError('precision must be "fp32" or "bf16" (got %r)' % (precision,))
         self.precision = precision
@@ -63,7 +79,8 @@ class FgnnTrainer:
             raise RuntimeError('FgnnTrainer.from_module: the module is not the standard node_embedding graph '
                                '(original_features_num 2 or 32, in_features = out_features = 32)')
         net._bind_flat()
-        return cls(lay, net._flat, lr=model.lr if lr is None else lr, capture=capture, precision=getattr(net, 'precision', 'fp32'))
+        return cls(lay, net._flat, lr=model.lr if lr is None else lr, capture=capture, precision=getattr(net, 'precision', 'fp32'),
+                   input_form=getattr(net, 'input_form', 'dense'))
 
     # ------------------------------------------------------------------ engines: bounded cache keyed on padded shapes
     def _engine(self, G, N, ragged):
@@ -212,8 +229,9 @@ class FgnnTrainer:
             self.opt.t = t0                               # a capture does not execute an update
             st = self._graphs[key] = (xs, g_model, g_opt, scores, B)
         xs, g_model, g_opt, scores, B = st
-        xs[:B].copy_(x1)
-        xs[B:].copy_(x2)
+        if x1.data_ptr() != xs.data_ptr():              # (train_step(input_form='tensor_representation') packs straight into xs)
+            xs[:B].copy_(x1)
+            xs[B:].copy_(x2)
         self._nodes.fill_(float(B * N))
         if g_opt is None:
             self.opt.sync_hyper_parameters(grad_scale=None)
@@ -222,6 +240,16 @@ class FgnnTrainer:
             return (self._loss_sum / self._nodes).reshape(()), scores
         g_model.replay()
         return self._reduce_and_update(opt_graph=g_opt), scores
+
+    def check_input_form(self):
+        """input_form='tensor_representation': read the device verdict of every train_step since the last check (one host
+        synchronisation); raises if one of those batches was not a tensor representation."""
+        if self._tr_flag is not None and int(self._tr_flag.item()) != 0:
+            self._tr_flag.zero_()
+            raise RuntimeError("FgnnTrainer(input_form='tensor_representation'): a batch since the last check is NOT the tensor "
+                               'representation of a 0/1 adjacency (channel 0 in {0, 1}, channel 1 = diag(row sums), '
+                               'loaders/data_generator.py:118-125); the updates of those steps are invalid -- run it through the dense '
+                               "path (input_form='dense')")
 
     def train_step_bits(self, bits1, bits2, nvalid=None):
         """The same step with the local shard handed over as bit-packed adjacency: bits1, bits2
@@ -249,6 +277,28 @@ class FgnnTrainer:
     def train_step(self, x1, x2, nvalid=None):
         """x1, x2: (B, c0, N, N) local shard on the GPU.  Returns (loss of the global batch as a device
         scalar, scores of the local shard)."""
+        if self.input_form == 'tensor_representation' and x1.dim() == 4 and x1.shape[1] == 2 and self.layout.c0 == 2 \
+                and x1.dtype == torch.float32 and x1.shape == x2.shape:
+            from . import _lib
+            B, N = x1.shape[0], x1.shape[-1]
+            if bool(_lib.load().fgnn_block1_struct_supported(N, self.layout.depth, self.layout.c0)):
+                w = self._tr.get((B, N))
+                first = w is None
+                if first:
+                    w = self._tr[(B, N)] = torch.zeros(2 * B, N, (N + 31) // 32, dtype=torch.int32, device=x1.device)
+                if self._tr_flag is None:
+                    self._tr_flag = torch.zeros(1, dtype=torch.int32, device=x1.device)
+                nv = None if nvalid is None else nvalid.to(device=x1.device, dtype=torch.int32)
+                for half, t in ((w[:B], x1), (w[B:], x2)):
+                    _lib.call('fgnn_pack_adjacency_ld', _lib.ptr(t.contiguous()), _lib.ptr(nv) if nv is not None else None, B, N, N,
+                              _lib.ptr(half), _lib.ptr(self._tr_flag), _lib.stream_ptr())
+                self._tr_calls += 1
+                if first or (self.INPUT_CHECK_EVERY and self._tr_calls % self.INPUT_CHECK_EVERY == 0):
+                    self.check_input_form()
+                out = self.train_step_bits(w[:B], w[B:], nvalid=nv)
+                if first and (B, N, 'bits') in self._graphs:        # from now on pack straight into the captured step's input words
+                    self._tr[(B, N)] = self._graphs[(B, N, 'bits')][0]
+                return out
         if self.capture and nvalid is None:
             return self._captured_step(x1, x2)
         B, _, N, _ = x1.shape

@@ -462,6 +462,11 @@ int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, int G, int N,
  * read as empty).  bad (optional device int, zeroed by the caller): set to 1 if x is NOT a tensor representation on the valid corners
  * (an entry of channel 0 outside {0, 1}, channel 1 != diag(row sums of channel 0)) -- the structured block 1 must not see such bits. */
 int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigned *bits, int *bad, void *stream);
+/* The same with the loader's padded size Nin (x is (G, 2, Nin, Nin)) smaller than the engine's N (bits are (G, N, ceil(N/32)): rows
+ * and columns >= Nin are empty): what Siamese_Node_Exp.fused_step(input_form='tensor_representation') runs on each side of a dense or
+ * MaskedTensor loader batch (loaders/loaders.py:5-15) in front of the structured block 1.  `bad` is OR-ed (sticky until the caller
+ * zeroes it); an nvalid[g] outside [0, Nin] also sets it. */
+int fgnn_pack_adjacency_ld(const float *x, const int *nvalid, int G, int Nin, int N, unsigned *bits, int *bad, void *stream);
 /* deg[g][i] = number of set bits j < nvalid[g] in row i (0 for rows >= nvalid[g]): the diagonal of channel 1, for the
  * kernels that expand the adjacency themselves (fgnn_mlp_fwd_args.xbits / xdeg) */
 int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream);

@@ -19,7 +19,7 @@ E2E_FWD_TOL = 3e-5
 def run_cases(mode, groups=None, pair_bwd=None):
     """-> (err, terr, score_err) dicts per group for the engine variant `mode`: 'f32' / 'x3' = the contraction of the MLP kernels
     on dense inputs; a trailing 's' ('f32s', 'x3s') = bit-packed inputs with block 1 on its structured form
-    (csrc/block1_struct.hip; N <= 64, larger cases run the generic block 1)."""
+    (csrc/block1_struct.hip; N <= 256)."""
     struct = mode.endswith('s')
     mfma = mode[:-1] if struct else mode
     groups = GG.load_groups() if groups is None else groups
