@@ -178,6 +178,28 @@ def cpu_baseline_ragged(layout, params, xs, ys, min_seconds=10.0, max_steps=100)
                       'threads = best of the sweep %s on the first 2 pairs' % (n, len(xs), dt, torch.__version__, cores, sorted(sweep))}
 
 
+_COLLECTIVES = ('all_reduce', 'all_gather', 'all_gather_into_tensor', 'all_gather_object', 'broadcast', 'broadcast_object_list', 'reduce',
+                'reduce_scatter', 'reduce_scatter_tensor', 'all_to_all', 'all_to_all_single', 'gather', 'scatter', 'send', 'recv',
+                'isend', 'irecv', 'barrier')
+
+
+def _count_collectives():
+    """(--verify-dir) wrap every data-moving entry point of torch.distributed with a counter -> the list the names are appended to."""
+    import torch.distributed as dist
+    calls = []
+    for name in _COLLECTIVES:
+        fn = getattr(dist, name, None)
+        if fn is None or getattr(fn, '_fgnn_counted', False):
+            continue
+
+        def wrapped(*a, _fn=fn, _name=name, **k):
+            calls.append(_name)
+            return _fn(*a, **k)
+        wrapped._fgnn_counted = True
+        setattr(dist, name, wrapped)
+    return calls
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
@@ -278,12 +300,18 @@ def parse_args():
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='do not append the cfg4 / cfg5 measurements (extra_configs) to the headline line')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
+    ap.add_argument('--verify-dir', default=None,
+                    help='(tests) every rank counts the torch.distributed calls of each timed step and, after the timed windows, runs ONE '
+                         'eager step + the all-reduce and writes DIR/rank<r>.pt: {collectives_per_step, comm = the all-reduced flat '
+                         'gradient, loss_sum, nodes, sizes} -- compared with a single-process run on the concatenated batch')
     ap.add_argument('--backend', default=None, help="torch.distributed backend (default: nccl = RCCL); 'gloo' lets "
                                                     'several ranks share one GPU for functional tests')
     return ap.parse_args()
 
 
 def main():
+    if os.environ.get('FGNN_BENCH_CHILD') and os.environ.get('FGNN_BENCH_FAIL_RANK') == os.environ.get('RANK'):
+        raise SystemExit(3)         # (tests: a rank that dies at start-up; the launcher must stop the job, see self_launch)
     args = parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         self_launch(args.gpus)                    # does not return
@@ -416,7 +444,9 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     dual = hasattr(eng, 'stage_inputs')
     if dual:
         eng.stage_inputs(x, nvalid)        # loader work, like the cat above: the chains' input buffers are resident before the timed region
-    total_nodes = float((sum(sizes) if ragged else B * N) * world)      # loss normaliser of the concatenated global batch
+    # loss normaliser of the concatenated global batch (toolbox/losses.py:27-34): ranks of a ragged batch hold different node
+    # counts, so the global count is summed over the ranks once at set-up (not a collective of the step)
+    total_nodes = dp.global_node_count(sum(sizes), dev) if ragged else float(B * N * world)
 
     def model_work():
         if xbits is not None:
@@ -499,13 +529,20 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                         print('bench.py: HIP graph capture failed (%s); running eager' % (exc2,), file=sys.stderr)
                     torch.cuda.synchronize()
 
+    calls, per_step = None, []
+    if args.verify_dir and same:
+        calls = _count_collectives()
+
     def step():
+        n0 = len(calls) if calls is not None else 0
         if graph is not None:
             graph.replay()
         else:
             model_work()
         if world > 1 and not ar_in_graph:
             dp.allreduce_sum_(comm)
+        if calls is not None:
+            per_step.append(calls[n0:])
 
     # Settling (untimed, part of the set-up like the capture runs above): the first ~20 replays after the set-up phase run
     # ~4 % slower than steady state (clocks, TLBs; `--steps 20 --warmup 5` gave 0.945 ms against 0.905 ms for any longer
@@ -542,6 +579,21 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         e1.record()
         torch.cuda.synchronize()
         allreduce_ms = e0.elapsed_time(e1) / 20
+
+    if calls is not None:       # (tests) one eager step + the collective, dumped by every rank
+        torch.cuda.synchronize()
+        comm.zero_()
+        model_work()
+        loss_local = float(eng._loss_target.item()) if path == 'engine' and not dual else None
+        if world > 1:
+            dp.allreduce_sum_(comm)
+        torch.cuda.synchronize()
+        os.makedirs(args.verify_dir, exist_ok=True)
+        torch.save({'collectives_per_step': per_step[-args.steps * max(1, windows):], 'comm': comm.detach().cpu().clone(),
+                    'loss_local': loss_local, 'total_nodes': total_nodes, 'sizes': sizes, 'world': world, 'rank': rank,
+                    'allreduce_in_graph': bool(ar_in_graph), 'batch_per_gpu': B, 'n': N,
+                    'input': 'bits' if xbits is not None else 'dense', 'struct1': struct1},
+                   os.path.join(args.verify_dir, 'rank%d.pt' % rank))
 
     # ---- roofline leg: per-kernel durations from events on the launch stream (eager launches) ----
     roofline = None

@@ -128,6 +128,9 @@ _SIGNATURES = {
     'fgnn_pack_x3_floats': [_I, _I, _I, _I, _I],
     'fgnn_pack_x3_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd_x3': [C.POINTER(MlpFwdArgs), _VP],
+    'fgnn_debug_mlp_fwd_masks': [C.POINTER(MlpFwdArgs), _VP, _VP, _VP],
+    'fgnn_debug_mlp_fwd_x3_masks': [C.POINTER(MlpFwdArgs), _VP, _VP, _VP],
+    'fgnn_debug_matmul_variant': [_I],
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],

@@ -155,9 +155,10 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
 
 // SKIP (ragged batches with A.ranges): the workgroup's tile range comes from fgnn_ragged_tile_ranges (equal work), the
 // waves step over tiles without a single valid pixel; those tiles only get empty statistics records after the main loop.
-template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false>
-__global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_kernel(
-    const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles) {
+// DBG (fgnn_debug_mlp_fwd_masks, test-only): the same tile code also exports the ReLU decisions it takes -- one bit per hidden
+// pre-activation, dbg[m][((g * (DEPTH-1) + layer) * 32 + channel) * tpg + tile], bit j = pixel 32 * tile + j.
+template <int CA, int CB, int NMLP, int DEPTH, bool PK, bool SKIP, bool DBG>
+DEVI void mlp_fwd_body(const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles, unsigned *const dbg0, unsigned *const dbg1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
@@ -312,6 +313,17 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
                 float hid[16], bl[16], wh[16];
                 load_bias(bl, wm + L::BIAS_F, l, h);
                 load_ops<16>(wh, wm, L::OFF_WH + 16 * (l - 1), lane);
+                if constexpr (DBG) {      // the decision relu1 takes: bit pattern > 0 as a signed integer
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned long long mk = __ballot(__float_as_int(acc[r]) > 0);
+                        if (lane == 0) {
+                            unsigned *o = (m == 0 ? dbg0 : dbg1) + (((long long)c.g * (DEPTH - 1) + (l - 1)) * 32 + ch_of(r, 0)) * tpg + c.tt;
+                            o[0] = (unsigned)mk;
+                            o[4ll * tpg] = (unsigned)(mk >> 32);       // channel ch_of(r, 1) = ch_of(r, 0) + 4
+                        }
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     hid[r] = relu1(acc[r]);
@@ -392,35 +404,56 @@ __global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 
 }
 
 template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false>
-int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
+__global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_kernel(
+    const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles) {
+    mlp_fwd_body<CA, CB, NMLP, DEPTH, PK, SKIP, false>(A, tpg, total_tiles, nullptr, nullptr);
+}
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false>
+__global__ __launch_bounds__((64 * fwd_waves<CA, CB>()), (fwd_waves<CA, CB>() / 4)) void mlp_fwd_dbg_kernel(
+    const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles, unsigned *d0, unsigned *d1) {
+    mlp_fwd_body<CA, CB, NMLP, DEPTH, PK, SKIP, true>(A, tpg, total_tiles, d0, d1);
+}
+
+struct DbgOut {
+    unsigned *m[2];
+};
+
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = false, bool DBG = false>
+int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st, const DbgOut &d) {
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>, LDS);
     int grid = (total + NW - 1) / NW;
     const int cap = a->cu_share == 2 ? 128 : 256;      // 2: half of the CUs (two launches on two streams side by side)
     if (grid > cap) grid = cap;
     if (SKIP) grid = FGNN_RANGE_WG;
-    hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
+    if constexpr (DBG) {
+        (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_dbg_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>, LDS);
+        hipLaunchKernelGGL((mlp_fwd_dbg_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total, d.m[0],
+                           d.m[1]);
+    } else {
+        (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>, LDS);
+        hipLaunchKernelGGL((mlp_fwd_kernel<CA, CB, NMLP, DEPTH, PK, SKIP>), dim3(grid), dim3(64 * NW), LDS, st, *a, tpg, total);
+    }
     FGNN_LAUNCH_CHECK();
     return 0;
 }
-template <int CA, int CB, int NMLP, int DEPTH, bool PK = false>
-int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
-    if (a->ranges) return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, true>(a, tpg, total, st);
-    return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, false>(a, tpg, total, st);
+template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool DBG = false>
+int launch_fwd(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st, const DbgOut &d) {
+    if (a->ranges) return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, true, DBG>(a, tpg, total, st, d);
+    return launch_fwd_impl<CA, CB, NMLP, DEPTH, PK, false, DBG>(a, tpg, total, st, d);
 }
 
-template <int NMLP, int DEPTH>
-int dispatch_c(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
+template <int NMLP, int DEPTH, bool DBG = false>
+int dispatch_c(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st, const DbgOut &d = DbgOut{}) {
     const int ca = a->a.C, cb = a->b.C;
     if (a->xbits) {          // the 2-channel slab comes from the bit-packed adjacency (built for depth 3)
         if constexpr (DEPTH == 3) {
-            if (ca == 2 && cb == 0) return launch_fwd<2, 0, NMLP, DEPTH, true>(a, tpg, total, st);
+            if (ca == 2 && cb == 0) return launch_fwd<2, 0, NMLP, DEPTH, true, DBG>(a, tpg, total, st, d);
             if constexpr (NMLP == 1) {
-                if (ca == 32 && cb == 2) return launch_fwd<32, 2, NMLP, DEPTH, true>(a, tpg, total, st);
+                if (ca == 32 && cb == 2) return launch_fwd<32, 2, NMLP, DEPTH, true, DBG>(a, tpg, total, st, d);
             }
         }
         fgnn_set_error("fgnn_mlp_fwd: xbits needs depth 3 and a 2-channel slab (2 or 32+2 input channels), got depth %d, %d + %d",
@@ -428,9 +461,11 @@ int dispatch_c(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
         return 1;
     }
 #define FGNN_CASE(A_, B_) \
-    if (ca == A_ && cb == B_) return launch_fwd<A_, B_, NMLP, DEPTH>(a, tpg, total, st);
+    if (ca == A_ && cb == B_) return launch_fwd<A_, B_, NMLP, DEPTH, false, DBG>(a, tpg, total, st, d);
     FGNN_CASE(2, 0)
-    FGNN_CASE(16, 0)
+    if constexpr (!DBG) {
+        FGNN_CASE(16, 0)
+    }
     FGNN_CASE(32, 0)
     if constexpr (NMLP == 1) {      // two-slab inputs (mlp3 = [mult ; in]) only come with a single MLP
         FGNN_CASE(32, 2)
@@ -453,7 +488,7 @@ extern "C" int fgnn_debug_fwd_stamps(void *p, int ca, int cb, int nmlp) {
 
 extern "C" int fgnn_tiles_per_graph(int N) { return (N * N + FGNN_TILE - 1) / FGNN_TILE; }
 
-extern "C" int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *a, void *stream) {
+static int mlp_fwd_entry(const fgnn_mlp_fwd_args *a, void *stream, unsigned *const *dbg) {
     FGNN_CHECK(a != nullptr, "fgnn_mlp_fwd: null args");
     FGNN_CHECK(a->G > 0 && a->N > 0, "fgnn_mlp_fwd: bad G=%d N=%d", a->G, a->N);
     FGNN_CHECK(a->nmlp == 1 || a->nmlp == 2, "fgnn_mlp_fwd: nmlp must be 1 or 2 (got %d)", a->nmlp);
@@ -478,10 +513,26 @@ extern "C" int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *a, void *stream) {
     const long long total = (long long)a->G * tpg;
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_fwd: too many tiles");
     hipStream_t st = (hipStream_t)stream;
+    if (dbg) {          // the decision-exporting twins exist for the fused engine's shapes: depth 3
+        FGNN_CHECK(a->depth == 3 && dbg[0] && (a->nmlp == 1 || dbg[1]), "fgnn_debug_mlp_fwd_masks: depth 3 and one mask buffer per MLP");
+        const DbgOut d = {{dbg[0], a->nmlp == 2 ? dbg[1] : nullptr}};
+        if (a->nmlp == 1) return dispatch_c<1, 3, true>(a, tpg, (int)total, st, d);
+        return dispatch_c<2, 3, true>(a, tpg, (int)total, st, d);
+    }
 #define FGNN_ND(NM_, D_) \
     if (a->nmlp == NM_ && a->depth == D_) return dispatch_c<NM_, D_>(a, tpg, (int)total, st);
     FGNN_ND(1, 1) FGNN_ND(1, 2) FGNN_ND(1, 3) FGNN_ND(2, 1) FGNN_ND(2, 2) FGNN_ND(2, 3)
 #undef FGNN_ND
     fgnn_set_error("fgnn_mlp_fwd: unsupported nmlp/depth");
     return 1;
+}
+
+extern "C" int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *a, void *stream) { return mlp_fwd_entry(a, stream, nullptr); }
+
+// Test-only (tests/test_gpu_grad_pinned.py): fgnn_mlp_fwd once more -- same tile code, same outputs -- that also writes the ReLU
+// decisions of the two hidden layers, masks[m]: (G, 2, 32, tiles per graph) words, bit j of word (g, layer, channel, t) = hidden
+// pre-activation of pixel 32 t + j > 0.  Words of tiles a ragged launch steps over are not written.
+extern "C" int fgnn_debug_mlp_fwd_masks(const fgnn_mlp_fwd_args *a, unsigned *masks0, unsigned *masks1, void *stream) {
+    unsigned *const dbg[2] = {masks0, masks1};
+    return mlp_fwd_entry(a, stream, dbg);
 }

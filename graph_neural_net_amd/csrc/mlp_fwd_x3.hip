@@ -45,9 +45,9 @@ DEVI void split_slab(X3 &x, const float (&v)[S > 0 ? S : 1], int h, const F16 &n
     }
 }
 
-template <int CA, int CB, int NMLP, bool PK, int NWT>
-__global__ __launch_bounds__(64 * NWT, NWT / 4) void mlp_fwd_x3_kernel(const fgnn_mlp_fwd_args A, const int tpg,
-                                                                      const int total_tiles) {
+// DBG (fgnn_debug_mlp_fwd_x3_masks, test-only): also exports the ReLU decisions, in the layout of fgnn_debug_mlp_fwd_masks
+template <int CA, int CB, int NMLP, bool PK, int NWT, bool DBG>
+DEVI void mlp_fwd_x3_body(const fgnn_mlp_fwd_args A, const int tpg, const int total_tiles, unsigned *const dbg0, unsigned *const dbg1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdX3Layout<CA, CB, NMLP, NWT>;
     constexpr int NW = NWT, DEPTH = 3;
@@ -160,6 +160,17 @@ __global__ __launch_bounds__(64 * NWT, NWT / 4) void mlp_fwd_x3_kernel(const fgn
                     float hid[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hid[r] = relu1(acc[r]);
+                    if constexpr (DBG) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned long long mk = __ballot(__float_as_int(acc[r]) > 0);
+                            if (lane == 0) {
+                                unsigned *o = (m == 0 ? dbg0 : dbg1) + (((long long)c.g * (DEPTH - 1) + (l - 1)) * 32 + ch_of(r, 0)) * tpg + c.tt;
+                                o[0] = (unsigned)mk;
+                                o[4ll * tpg] = (unsigned)(mk >> 32);
+                            }
+                        }
+                    }
                     split16m(H, hid, negI);
                 }
                 load_bias16(acc, wm + L::BIAS_F, l, h);
@@ -209,16 +220,32 @@ __global__ __launch_bounds__(64 * NWT, NWT / 4) void mlp_fwd_x3_kernel(const fgn
 }
 
 template <int CA, int CB, int NMLP, bool PK, int NWT>
-int launch_fwd_x3(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st) {
+__global__ __launch_bounds__(64 * NWT, NWT / 4) void mlp_fwd_x3_kernel(const fgnn_mlp_fwd_args A, const int tpg,
+                                                                      const int total_tiles) {
+    mlp_fwd_x3_body<CA, CB, NMLP, PK, NWT, false>(A, tpg, total_tiles, nullptr, nullptr);
+}
+template <int CA, int CB, int NMLP, bool PK, int NWT>
+__global__ __launch_bounds__(64 * NWT, NWT / 4) void mlp_fwd_x3_dbg_kernel(const fgnn_mlp_fwd_args A, const int tpg,
+                                                                          const int total_tiles, unsigned *d0, unsigned *d1) {
+    mlp_fwd_x3_body<CA, CB, NMLP, PK, NWT, true>(A, tpg, total_tiles, d0, d1);
+}
+
+template <int CA, int CB, int NMLP, bool PK, int NWT, bool DBG = false>
+int launch_fwd_x3(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st, unsigned *d0 = nullptr, unsigned *d1 = nullptr) {
     using L = FwdX3Layout<CA, CB, NMLP, NWT>;
     constexpr int LDS = L::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>, LDS);
     int grid = (total + NWT - 1) / NWT;
     const int cap = a->cu_share == 2 ? 128 : 256;
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL((mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>), dim3(grid), dim3(64 * NWT), LDS, st, *a, tpg, total);
+    if constexpr (DBG) {
+        (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_x3_dbg_kernel<CA, CB, NMLP, PK, NWT>, LDS);
+        hipLaunchKernelGGL((mlp_fwd_x3_dbg_kernel<CA, CB, NMLP, PK, NWT>), dim3(grid), dim3(64 * NWT), LDS, st, *a, tpg, total, d0, d1);
+    } else {
+        (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>, LDS);
+        hipLaunchKernelGGL((mlp_fwd_x3_kernel<CA, CB, NMLP, PK, NWT>), dim3(grid), dim3(64 * NWT), LDS, st, *a, tpg, total);
+    }
     FGNN_LAUNCH_CHECK();
     return 0;
 }
@@ -233,7 +260,7 @@ extern "C" int fgnn_mlp_x3_supported(int ca, int cb, int depth, int nmlp) {
     return ((ca == 2 || ca == 32) && cb == 0) || (ca == 32 && (cb == 2 || cb == 32)) ? 1 : 0;
 }
 
-extern "C" int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *a, void *stream) {
+static int mlp_fwd_x3_entry(const fgnn_mlp_fwd_args *a, void *stream, unsigned *const *dbg) {
     FGNN_CHECK(a != nullptr, "fgnn_mlp_fwd_x3: null args");
     FGNN_CHECK(a->G > 0 && a->N > 0, "fgnn_mlp_fwd_x3: bad G=%d N=%d", a->G, a->N);
     FGNN_CHECK(a->nmlp == 1 || a->nmlp == 2, "fgnn_mlp_fwd_x3: nmlp must be 1 or 2 (got %d)", a->nmlp);
@@ -259,6 +286,12 @@ extern "C" int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *a, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int ca = a->a.C, cb = a->b.C;
     constexpr int W = FWD_X3_WAVES;
+    if (dbg) {          // decision-exporting twins of the launches the engine issues (mlp1 + mlp2 of a block)
+        FGNN_CHECK(a->nmlp == 2 && dbg[0] && dbg[1], "fgnn_debug_mlp_fwd_x3_masks: built for the two-MLP launches (mlp1 + mlp2)");
+        if (a->xbits) return launch_fwd_x3<2, 0, 2, true, W, true>(a, tpg, (int)total, st, dbg[0], dbg[1]);
+        if (ca == 2) return launch_fwd_x3<2, 0, 2, false, W, true>(a, tpg, (int)total, st, dbg[0], dbg[1]);
+        return launch_fwd_x3<32, 0, 2, false, W, true>(a, tpg, (int)total, st, dbg[0], dbg[1]);
+    }
     if (a->xbits) {
         if (a->nmlp == 2 && ca == 2) return launch_fwd_x3<2, 0, 2, true, W>(a, tpg, (int)total, st);
         if (a->nmlp == 1 && ca == 32 && cb == 2) return launch_fwd_x3<32, 2, 1, true, W>(a, tpg, (int)total, st);
@@ -276,6 +309,14 @@ extern "C" int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *a, void *stream) {
     }
     if (cb == 2) return launch_fwd_x3<32, 2, 1, false, W>(a, tpg, (int)total, st);
     return launch_fwd_x3<32, 32, 1, false, W>(a, tpg, (int)total, st);
+}
+
+extern "C" int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *a, void *stream) { return mlp_fwd_x3_entry(a, stream, nullptr); }
+
+// Test-only twin of fgnn_debug_mlp_fwd_masks for the x3 forward (same outputs + the ReLU decisions of the two hidden layers)
+extern "C" int fgnn_debug_mlp_fwd_x3_masks(const fgnn_mlp_fwd_args *a, unsigned *masks0, unsigned *masks1, void *stream) {
+    unsigned *const dbg[2] = {masks0, masks1};
+    return mlp_fwd_x3_entry(a, stream, dbg);
 }
 
 // ---- operand images of the x3 kernels (once per step, like fgnn_pack_operands) -----------------------------------------

@@ -187,6 +187,7 @@ class FgnnEngine:
         self.struct1 = (block1 == 'structured' and cu_share == 0
                         and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0)))
         self._struct = None
+        self.decisions = None       # test-only, see export_decisions()
         self.layout = layout
         self.G, self.N = G, N
         self.P = N * N
@@ -317,6 +318,14 @@ class FgnnEngine:
         args.cu_share = self.cu_share
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd_x3' if (self.x3 and len(js) == 2) else 'fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        if self.decisions is not None:
+            # test-only (export_decisions): the decision-exporting twin of the launch above -- same tile code, same outputs written
+            # once more -- leaves one bit per hidden pre-activation of these MLPs
+            bufs = [torch.zeros(self.G * (L.depth - 1) * 32 * self.tpg, dtype=torch.int32, device=self.device) for _ in js]
+            _lib.call('fgnn_debug_mlp_fwd_x3_masks' if (self.x3 and len(js) == 2) else 'fgnn_debug_mlp_fwd_masks', C.byref(args),
+                      _lib.ptr(bufs[0]), _lib.ptr(bufs[1]) if len(js) == 2 else None, st)
+            for j, buf in zip(js, bufs):
+                self.decisions[(k, j)] = buf
         if not finalize:
             return
         if len(js) == 2:
@@ -702,6 +711,45 @@ class FgnnEngine:
         return scores, loss
 
     # ------------------------------------------------------------------ inspection (tests / module API)
+    def export_decisions(self, on=True):
+        """Test-only (tests/test_gpu_grad_pinned.py): from the next forward on, every fgnn_mlp_fwd launch is followed by its
+        decision-exporting twin (fgnn_debug_mlp_fwd_masks) and `relu_decisions()` returns the ReLU masks the step took; together with
+        self.idx (the arg-max of the pooling) these are ALL the discrete decisions of a step."""
+        self.decisions = {} if on else None
+
+    def relu_decisions(self, params=None):
+        """{(block, mlp, hidden layer): bool (G, 32, N, N)}: [pre-activation > 0] as the kernels' ReLU saw it.  MLPs that ran on the
+        class tables of the structured block 1 take theirs from the table (a class's hidden value > 0), expanded over the pixels."""
+        L, G, N, P = self.layout, self.G, self.N, self.P
+        out = {}
+        bit = torch.arange(32, device=self.device, dtype=torch.int32)
+        for (k, j), buf in self.decisions.items():
+            w = buf.view(G, L.depth - 1, 32, self.tpg)
+            m = ((w.unsqueeze(-1) >> bit) & 1).reshape(G, L.depth - 1, 32, self.tpg * 32)[..., :P].reshape(G, L.depth - 1, 32, N, N)
+            for l in range(L.depth - 1):
+                out[(k, j, l)] = m[:, l].bool()
+        if self.struct1 and self.xbits is not None and (1, 1) not in self.decisions:
+            nc = 2 + 2 * (N + 1)
+            tab = self._struct['tab'].view(2, nc, 4, 32)
+            words = (N + 31) // 32
+            b = self.xbits.view(G, N, words).to(torch.int64) & 0xffffffff
+            col = torch.arange(N, device=self.device)
+            wmat = ((b[:, :, col // 32] >> (col % 32)) & 1)                       # (G, N, N) 0/1
+            if self.nvalid is not None:
+                nv = self.nvalid.to(torch.int64)
+                inside = (col[None, :] < nv[:, None])
+                wmat = wmat * (inside[:, :, None] & inside[:, None, :])
+            deg = wmat.sum(-1)
+            eye = torch.eye(N, device=self.device, dtype=torch.bool)
+            diag_cls = 2 + 2 * deg + torch.diagonal(wmat, dim1=1, dim2=2)
+            cls = torch.where(eye[None], diag_cls[:, :, None].expand(G, N, N), wmat)      # (G, N, N) class of every pixel
+            for j in (1, 2):
+                for l in range(2):
+                    hv = tab[j - 1, :, l, :] > 0                                   # (classes, 32)
+                    out[(1, j, l)] = hv[cls].permute(0, 3, 1, 2).contiguous()      # (G, 32, N, N)
+        return out
+
+
     def normalized(self, k, j, params):
         """Materialise the normalised output of MLP (k, j) as a (G, 32, N, N) tensor."""
         rec = self.layout.mlp[(k, j)]

@@ -611,6 +611,18 @@ int fgnn_mlp_bwd16(const fgnn_mlp_bwd16_args *args, void *stream);
  * R(R(old + dx1) + dx2), bit-identical to the two read-modify-write launches.  One slab of 2 or 32 channels, constant-size batches. */
 int fgnn_mlp_bwd16_pair(const fgnn_mlp_bwd16_args *m1, const fgnn_mlp_bwd16_args *m2, void *stream);
 
+/* ---- test-only entry points (never on the product path; tests/ and tools/ call them) ---------------------------------------
+ * fgnn_debug_mlp_fwd_masks / fgnn_debug_mlp_fwd_x3_masks: fgnn_mlp_fwd / fgnn_mlp_fwd_x3 once more -- the same tile code, the same
+ * outputs, bit for bit -- that ALSO exports the ReLU decisions of the conv chain (models/layers.py:129-130), the input of the
+ * decision-pinned gradient test (tests/test_gpu_grad_pinned.py): masks[m] is (G, depth - 1, 32, fgnn_tiles_per_graph(N)) words, bit j
+ * of word (g, layer, channel, t) = [hidden pre-activation of pixel 32 t + j > 0] as `relu` sees it (bit pattern > 0).  Depth 3;
+ * words of tiles a ragged launch steps over are not written.  The x3 twin exists for the two-MLP launches (masks1 required).
+ * fgnn_debug_matmul_variant: 0 selects the workgroup-per-matrix forward product (N <= 64) that fgnn_chan_matmul_fwd_w replaced, 1
+ * (default) the wave-per-matrix kernel; process-global; for the bit-identity test of the two (tests/test_gpu_kernels.py). */
+int fgnn_debug_mlp_fwd_masks(const fgnn_mlp_fwd_args *args, unsigned *masks0, unsigned *masks1 /* nmlp == 2 */, void *stream);
+int fgnn_debug_mlp_fwd_x3_masks(const fgnn_mlp_fwd_args *args, unsigned *masks0, unsigned *masks1, void *stream);
+int fgnn_debug_matmul_variant(int wave_per_matrix);
+
 #ifdef __cplusplus
 }
 #endif

@@ -719,8 +719,87 @@ def main_round4():
     print(json.dumps(summary, indent=1, sort_keys=True))
 
 
+def tap_decisions(tap, B):
+    """The taps of one siamese step (side 1, then side 2) as the decisions of the STACKED batch cat(x1, x2): ({(blk, mlp, layer): bool
+    (2B, C, N, N)}, idx (2B, C, N))."""
+    per_side = len(tap.relu_in) // 2
+    masks = {}
+    for (tag, a), (_, b) in zip(tap.relu_in[:per_side], tap.relu_in[per_side:]):
+        # tag = 'ne_bm_block<k>_mlp<j>.convs.<l>'
+        blk = int(tag.split('block')[1].split('_')[0])
+        j = int(tag.split('_mlp')[1].split('.')[0])
+        l = int(tag.rsplit('.', 1)[1])
+        masks[(blk, j, l)] = torch.cat([a, b]) > 0
+    idx = torch.cat([tap.pool_in[0], tap.pool_in[1]]).max(-1)[1]
+    return masks, idx
+
+
+def check_pinned_oracle(model, x1, x2, tag):
+    """oracle/fgnn_oracle_pinned.py fed the reference's OWN decisions is torch.equal to the reference: scores, loss, every gradient,
+    in the model's dtype.  Returns (decisions, (scores, loss, grads) of the reference)."""
+    sys.path.insert(0, ROOT)
+    from oracle import fgnn_oracle_pinned as OP
+    dt = next(model.parameters()).dtype
+    s, l, g, tap = _tapped_step(model, x1.to(dt), x2.to(dt))
+    masks, idx = tap_decisions(tap, x1.shape[0])
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    s2, l2, g2 = OP.step_fwd_bwd_pinned(x1, x2, sd, masks, idx, dtype=dt)
+    assert torch.equal(s, s2), tag + ': pinned scores differ'
+    assert torch.equal(l, l2), tag + ': pinned loss differs'
+    for k in g:
+        assert torch.equal(g[k], g2[k]), tag + ': pinned gradient %s differs' % k
+    # ... and the plain oracle's own decision collector sees what the hooks saw
+    m3, i3 = OP.collect_decisions(torch.cat([x1, x2]).to(dt), {k: v for k, v in sd.items()})
+    # (the stacked 2B batch goes through ATen's conv in one call: same values per sample)
+    assert torch.equal(i3, idx) and all(torch.equal(m3[k], masks[k]) for k in masks), tag + ': collect_decisions differs'
+    return (masks, idx), (s, l, g)
+
+
+def main_round5():
+    """tests/golden/pinned_decisions.npz: a small step (2 blocks, perturbed weights, 3 pairs, N = 14) with the reference's decisions
+    and results in fp32 AND in fp64, each checked torch.equal against oracle/fgnn_oracle_pinned.py fed those decisions; plus the
+    cross evaluation the GPU test relies on -- the fp64 arithmetic on the branch the fp32 run took."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from graph_neural_net_amd import synthetic
+    from oracle import fgnn_oracle_pinned as OP
+    model = build_reference_model(2, seed=21)
+    perturb_(model, 210)
+    x1, x2 = synthetic.make_batch(2100, 3, 14, 'ErdosRenyi', 0.35, 0.1)
+    out = {'x1': x1.numpy(), 'x2': x2.numpy()}
+    for k, v in model.state_dict().items():
+        out['sd/' + k[len('node_embedder.'):]] = v.numpy()
+    (m32, i32), (s32, l32, g32) = check_pinned_oracle(model, x1, x2, 'fp32')
+    m64_model = f64(model)
+    (m64, i64), (s64, l64, g64) = check_pinned_oracle(m64_model, x1, x2, 'fp64')
+    for tag, (m, i, s, l, g) in (('f32', (m32, i32, s32, l32, g32)), ('f64', (m64, i64, s64, l64, g64))):
+        for k, v in OP.pack_decisions(m, i).items():
+            out['%s/%s' % (tag, k)] = v
+        out[tag + '/scores'] = s.numpy()
+        out[tag + '/loss'] = np.array(l.item())
+        for k, v in g.items():
+            out['%s/grad/%s' % (tag, k)] = v.numpy()
+    # the fp64 arithmetic on the fp32 run's branch (what tests/test_gpu_grad_pinned.py computes from the ENGINE's decisions)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    sx, lx, gx = OP.step_fwd_bwd_pinned(x1, x2, sd, m32, i32, dtype=torch.float64)
+    out['x64on32/loss'] = np.array(lx.item())
+    for k, v in gx.items():
+        out['x64on32/grad/' + k] = v.numpy()
+    flips = sum(int((m32[k] != m64[k]).sum()) for k in m32) + int((i32 != i64).sum())
+    np.savez_compressed(os.path.join(OUT, 'pinned_decisions.npz'), **out)
+    with open(os.path.join(OUT, 'golden_meta.json')) as f:
+        meta = json.load(f)
+    meta['cases']['pinned_decisions'] = {'pairs': 3, 'n': 14, 'blocks': 2, 'decisions_fp32_vs_fp64_differ': flips,
+                                         'pinned_oracle_bit_equal': ['fp32', 'fp64']}
+    with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print('pinned_decisions.npz written; decisions that differ between the fp32 and the fp64 run:', flips)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'round4':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round5':
+        main_round5()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round4':
         main_round4()
     elif len(sys.argv) > 1 and sys.argv[1] == 'round3':
         main_round3()

@@ -126,6 +126,90 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert out['ms_per_step_min'] <= out['ms_per_step'] <= out['ms_per_step_max'] and out['timed_windows'] == 2
 
 
+@pytest.mark.parametrize('config', ['cfg2', 'cfg5'])
+def test_bench_eight_rank_dress_rehearsal(tmp_path, config):
+    """The exact commands of the 8-GPU scaling run (`bench.py --gpus 8`, `--config cfg5 --gpus 8`: BASELINE configs 3 and 5) in the
+    functional form a one-GPU box can host -- eight fresh rank processes sharing cuda:0 over gloo (one GPU per rank over RCCL when
+    the node has eight): all eight ranks are seen, the global batch is 256 / 64 pairs, every timed step of every rank issues exactly
+    ONE collective (an all_reduce), every rank ends with the same buffer, and that buffer -- the gradient of the global batch, with
+    the global node count as normaliser -- equals a single-process run on the concatenated batch."""
+    import json
+    if torch.cuda.is_initialized():
+        pytest.skip('the GPU is already initialised in this process; run this file first / on its own')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    multi = torch.cuda.device_count() >= 8
+    vdir = os.path.join(str(tmp_path), 'verify')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--windows', '1', '--settle', '2',
+           '--no-cpu-baseline', '--profile-steps', '0', '--verify-dir', vdir] + ([] if multi else ['--backend', 'gloo']) \
+        + (['--config', 'cfg5'] if config == 'cfg5' else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    pairs = 8 if config == 'cfg5' else 32
+    assert out['n_gpus'] == 8 and out['ranks_seen'] == 8 and out['backend'] == ('nccl' if multi else 'gloo')
+    assert out['config']['global_batch'] == 8 * pairs and out['config']['parallelism'] == 'dp8' and out['scaling'] == 'weak'
+    assert abs(out['value'] - 8 * pairs / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
+    ranks = [torch.load(os.path.join(vdir, 'rank%d.pt' % k)) for k in range(8)]
+    for k, d in enumerate(ranks):
+        assert d['rank'] == k and d['world'] == 8 and d['batch_per_gpu'] == pairs
+        per_step = d['collectives_per_step']
+        assert len(per_step) == 2
+        if d['allreduce_in_graph']:         # RCCL: recorded into the replayed graph -- no host call per step
+            assert per_step == [[], []], (k, per_step)
+        else:
+            assert per_step == [['all_reduce'], ['all_reduce']], (k, per_step)
+        assert torch.equal(d['comm'], ranks[0]['comm']), k                 # one reduced buffer on every rank
+        assert d['total_nodes'] == ranks[0]['total_nodes']
+    if config == 'cfg5':                    # the ranks hold different node counts; the normaliser is their sum
+        assert len({tuple(d['sizes']) for d in ranks}) == 8
+        assert ranks[0]['total_nodes'] == float(sum(sum(d['sizes']) for d in ranks))
+    # the single-process run on the concatenated batch (a fresh child: this process never touches the GPU)
+    ref_path = os.path.join(str(tmp_path), 'ref.pt')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_bench_reference.py'), config, '8', ref_path], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ref = torch.load(ref_path)
+    got = ranks[0]['comm'].double()
+    loss = sum(d['loss_local'] for d in ranks)
+    assert ref['total_nodes'] == ranks[0]['total_nodes']
+    l2 = lambda a, b: ((a - b.double()).norm() / b.double().norm()).item()
+    assert abs(loss - ref['concat_loss']) < 1e-5 * abs(ref['concat_loss'])
+    if config == 'cfg2':
+        # same kernels, same tile geometry per graph; the weight-gradient partials are summed in another grouping (8 ranks x
+        # workgroups, then the all-reduce): summation-order differences only (SURVEY.md 8c: <= 2.4e-6 relative)
+        assert l2(got, ref['concat']) < 1e-5, l2(got, ref['concat'])
+    else:
+        # the shards on their own padded geometry, summed on one device: what the ranks computed, up to the order of the 8-term sum
+        assert l2(got, ref['shards']) < 1e-6, l2(got, ref['shards'])
+        # the ONE concatenated batch pads every graph to the global largest one: other tile boundaries, so the GraphNorm statistics
+        # are summed in another order and the gradients agree within the rounding / near-tie class of a 4-block N <= 120 step
+        assert l2(got, ref['concat']) < 5e-3, l2(got, ref['concat'])
+
+
+def test_bench_stops_all_ranks_when_one_dies_at_start_up(tmp_path):
+    """A rank that dies at start-up (bad device index, RCCL init failure ...) must not leave the others waiting in the rendezvous
+    until the distributed timeout: bench.py's launcher polls all of its rank processes, stops the others and exits non-zero at
+    once.  FGNN_BENCH_FAIL_RANK=3 makes rank 3 exit with code 3 at the start of main()."""
+    import time
+    if torch.cuda.is_initialized():
+        pytest.skip('the GPU is already initialised in this process; run this file first / on its own')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', FGNN_BENCH_FAIL_RANK='3')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--backend', 'gloo',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    dt = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert 'rank 3 exited with code 3' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]            # no result line from a broken job
+    assert dt < 120, dt                      # seconds (process start-up of the image), not the 10-minute rendezvous timeout
+
+
 def test_rccl_all_reduce_on_the_gradient_buffer(tmp_path):
     """The backend the N-GPU run uses (nccl = RCCL) initialises on this box and sums the trainer's communication buffer
     [flat gradient | loss sum | node count] in place on the device -- with the one rank a one-GPU box can host (the two-rank
