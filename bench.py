@@ -86,6 +86,19 @@ def algorithmic_per_pair(N, num_blocks=4, C=32, c0=2, elt=4):
     return 3.0 * (2 * fg + 2 * N * N * C), 2.0 * elt * N * N * by
 
 
+def executed_per_pair(N, num_blocks=4, C=32, c0=2, elt=4):
+    """The same model for a step whose block 1 runs on its STRUCTURED input (csrc/block1_struct.hip): mlp1, mlp2 and the per-channel
+    product of block 1 are not executed as dense work in either direction (class tables / closed form instead: integer and
+    per-class work, counted as 0 flops) -- what remains of block 1 is the write of `mult`, mlp3, and in the backward direction
+    mlp3's backward and one read of d(mult)."""
+    fl, by = algorithmic_per_pair(N, num_blocks, C, c0, elt)
+    fl -= 3.0 * 2 * (2 * N * N * 2 * (c0 * C + 2 * C * C) + 2 * N ** 3 * C)
+    # bytes per pixel and graph, block 1: forward 2 (c0 + C) [mlp1, mlp2] + 3 C [product] -> C [mult written];
+    # backward 2 (2 c0 + C) + 5 C -> C [d(mult) read]
+    by -= 2.0 * elt * N * N * ((2 * (c0 + C) + 3 * C - C) + (2 * (2 * c0 + C) + 5 * C - C))
+    return fl, by
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -111,11 +124,14 @@ def cpu_baseline(layout, params, x1, x2, min_seconds=10.0, max_steps=400):
     best, cores = None, 1
     big = x1.shape[-1] > 64          # N = 200: seconds per pair -- one un-warmed 1-pair run per thread count
     sl = 1 if big else min(16, x1.shape[0])      # (a 2-pair slice under-rates the high thread counts: ATen parallelises over the batch)
-    # thread counts beyond the point where the rate falls are not tried (measured on the 256-core box: 16 threads are the
-    # best, 128 threads are 20x slower, 256 threads took 200 s for two pairs)
-    for c in sorted({min(avail, v) for v in ((1, 8, 32) if big else (1, 4, 8, 16, 32, 64))}):
-        if best is not None and c > cores and sweep[max(sweep)] < 0.75 * (2.0 / best):
+    # the sweep goes up to 128 threads whatever the trend (measured on the 256-core box: 8-16 threads are the best, 128 threads are
+    # ~20x slower -- oversubscribed ATen kernels on 50 x 50 planes); all `avail` cores are only tried while the rate has not
+    # collapsed (256 threads took 200 s for two pairs)
+    for c in sorted({min(avail, v) for v in ((1, 8, 32, 128) if big else (1, 4, 8, 16, 32, 64, 128, avail))}):
+        if best is not None and c > 128 and sweep[max(sweep)] < 0.25 * (2.0 / best):
             break
+        if big and best is not None and c > cores and sweep[max(sweep)] < 0.75 * (2.0 / best):
+            break               # (N = 200: seconds per pair and thread count)
         torch.set_num_threads(c)
         if not big:
             O.step_fwd_bwd(x1[:sl], x2[:sl], sd)
@@ -300,6 +316,9 @@ def parse_args():
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='do not append the cfg4 / cfg5 measurements (extra_configs) to the headline line')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented steps for the roofline leg')
+    ap.add_argument('--trace-steps', type=int, default=0,
+                    help='(diagnostic) after the timed windows: synchronize, then this many steps with an event between every two; the '
+                         'per-step GPU times go to step_trace_ms (how a window starts after an idle device)')
     ap.add_argument('--verify-dir', default=None,
                     help='(tests) every rank counts the torch.distributed calls of each timed step and, after the timed windows, runs ONE '
                          'eager step + the all-reduce and writes DIR/rank<r>.pt: {collectives_per_step, comm = the all-reduced flat '
@@ -359,6 +378,49 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def time_in_graph(tag, engines, work, min_launches=24, replays=20):
+    """Average duration of the launches tagged `tag` when issued back to back inside a replayed HIP graph.  Every engine runs one full
+    step first (so its workspaces hold a step's real tensors), recording its launches; the graph then cycles through the recorded
+    launches of `tag` -- every block's, every engine's: distinct operand sets -- until at least `min_launches` are in it."""
+    sets = []
+    for e in engines:
+        work(e)                                   # allocations, kernel attributes
+        torch.cuda.synchronize()
+        _lib.PROFILE = []
+        work(e)
+        torch.cuda.synchronize()
+        rec, _lib.PROFILE = _lib.PROFILE, None
+        sets += [(name, a) for t, _, _, name, a in rec if t == tag]
+    if not sets:
+        raise RuntimeError('no launch tagged %s' % tag)
+    rounds = -(-min_launches // len(sets))
+
+    def burst():
+        for _ in range(rounds):
+            for name, a in sets:
+                _lib.relaunch(name, a)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        burst()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        burst()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    n = rounds * len(sets)
+    return {'ms': e0.elapsed_time(e1) / (replays * n), 'launches': n, 'replays': replays, 'sets': len(sets), 'engines': len(engines)}
+
+
 def module_surface_leg(args, config, rank, world, dev, engine_ms):
     """The same workload through the drop-in module surface (models/trainers.py:60-76): `Siamese_Node_Exp.fused_step` on the DENSE
     loader batch (tensors, or MaskedTensors for cfg5), same K / W protocol, with the module's input_form opt-in
@@ -413,26 +475,26 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         x1, x2 = synthetic.make_batch(4000 + rank, B, N, 'ErdosRenyi', 0.5, 0.1)
     else:
         x1, x2 = synthetic.make_batch(2000 + rank, B, N, 'Regular', 0.2, 0.1)
-    if bf16:
-        from graph_neural_net_amd.engine16 import FgnnEngineBF16
-        # cfg4 (16-bit engine) takes the same default as the fp32 lines: bit-packed adjacency + structured block 1
-        b1 = block1 if block1 is not None else (args.block1 if same else None)
-        if b1 is None:
-            b1 = 'structured' if (not (same and args.input == 'dense') and path == 'engine') else 'generic'
-        eng = FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged, block1=b1)
-    else:
+    def make_engine():
+        if bf16:
+            from graph_neural_net_amd.engine16 import FgnnEngineBF16
+            # cfg4 (16-bit engine) takes the same default as the fp32 lines: bit-packed adjacency + structured block 1
+            b1 = block1 if block1 is not None else (args.block1 if same else None)
+            if b1 is None:
+                b1 = 'structured' if (not (same and args.input == 'dense') and path == 'engine') else 'generic'
+            return FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged, block1=b1)
         chains = args.chains if (same and args.chains is not None) else 1
         mfma = args.mfma if (same and args.mfma is not None) else None
         if chains == 2:
             from graph_neural_net_amd.engine_dual import FgnnEngineDual
-            eng = FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
-        else:
-            # The headline line (cfg2, fp32 engine) hands the batch over as bit-packed adjacency and runs block 1 on its structured
-            # form unless told otherwise; `dense_input` in the JSON is the same step on the dense tensor through the generic kernels
-            b1 = block1 if block1 is not None else (args.block1 if same else None)
-            if b1 is None:      # cfg2 and cfg5 (fp32 engine, N <= 128): structured unless the dense input was asked for
-                b1 = 'structured' if (config in ('cfg2', 'cfg5') and not (same and args.input == 'dense') and path == 'engine') else 'generic'
-            eng = FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma, block1=b1)
+            return FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
+        # The headline line (cfg2, fp32 engine) hands the batch over as bit-packed adjacency and runs block 1 on its structured
+        # form unless told otherwise; `dense_input` in the JSON is the same step on the dense tensor through the generic kernels
+        b1 = block1 if block1 is not None else (args.block1 if same else None)
+        if b1 is None:      # cfg2 and cfg5 (fp32 engine, N <= 128): structured unless the dense input was asked for
+            b1 = 'structured' if (config in ('cfg2', 'cfg5') and not (same and args.input == 'dense') and path == 'engine') else 'generic'
+        return FgnnEngine(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma, block1=b1)
+    eng = make_engine()
     x = torch.cat([x1, x2]).contiguous().to(dev)
     struct1 = bool(getattr(eng, 'struct1', False))
     want = input_form if input_form is not None else (args.input if same else None)
@@ -448,11 +510,12 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     # counts, so the global count is summed over the ranks once at set-up (not a collective of the step)
     total_nodes = dp.global_node_count(sum(sizes), dev) if ragged else float(B * N * world)
 
-    def model_work():
+    def model_work(eng=eng):
         if xbits is not None:
             eng.step(params, grads, None, nvalid=nvalid, total_nodes=total_nodes, bits=xbits)
         else:
             eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)
+    engine_work = model_work
 
     model = None
     if path in ('module', 'fused_step'):
@@ -580,6 +643,17 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         torch.cuda.synchronize()
         allreduce_ms = e0.elapsed_time(e1) / 20
 
+    step_trace = None
+    if args.trace_steps > 0 and same:
+        torch.cuda.synchronize()
+        time.sleep(0.002)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.trace_steps + 1)]
+        evs[0].record()
+        for i in range(args.trace_steps):
+            step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        step_trace = [round(evs[i].elapsed_time(evs[i + 1]), 4) for i in range(args.trace_steps)]
     if calls is not None:       # (tests) one eager step + the collective, dumped by every rank
         torch.cuda.synchronize()
         comm.zero_()
@@ -607,7 +681,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         torch.cuda.synchronize()
         rec, _lib.PROFILE = _lib.PROFILE, None
         samples = {}
-        for tag, e0, e1 in rec:
+        for tag, e0, e1, _, _ in rec:
             samples.setdefault(tag, []).append(e0.elapsed_time(e1))
         # Average launch duration per kernel, robust against a stall of the box: a sample beyond 3 x the kernel's median is not
         # that kernel's duration (observed once: ONE 39 ms sample of a 10 us pooling launch made it the "dominant kernel" of the
@@ -623,7 +697,19 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                        'share': v[1] / tot} for t, v in kernels.items()}
         dom = max(kernels, key=lambda t: kernels[t][1])
         by, fl = kernel_model(dom, 2 * B, N, pix, cube)
-        dur = summary[dom]['avg_ms'] * 1e-3
+        eager_ms = summary[dom]['avg_ms']
+        # What that kernel costs INSIDE the replayed step (eager launches with events around them run 5-10 % longer: launch gaps, another
+        # clock state): >= 20 back-to-back launches of the dominant kernel in a replayed HIP graph, cycling through every launch of that
+        # kernel in a step (blocks 4, 3, 2 ...) of THREE engines' workspaces, so that no operand is served from the caches of the
+        # launch before -- the protocol of tools/gpu_mm_ablate.py.  Falls back to the eager figure if the capture fails.
+        ingraph = None
+        if path == 'engine':
+            try:
+                ingraph = time_in_graph(dom, [eng] + [make_engine() for _ in range(2)], engine_work)
+            except Exception as exc:          # noqa: BLE001 -- the eager figure stands
+                print('bench.py: in-graph timing of %s failed (%s); roofline from eager events' % (dom, exc), file=sys.stderr)
+                torch.cuda.synchronize()
+        dur = (ingraph['ms'] if ingraph else eager_ms) * 1e-3
         mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
         if fl / (mfma_peak * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
             ach = fl / dur / 1e12
@@ -648,7 +734,11 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                 roofline['traffic_source'] = tr.get('_source')
         except (OSError, ValueError):
             pass
-        roofline.update({'kernel': dom, 'avg_launch_ms': summary[dom]['avg_ms'], 'outliers_dropped': dropped,
+        roofline.update({'kernel': dom, 'avg_launch_ms': dur * 1e3, 'eager_launch_ms': eager_ms,
+                         'timing': ('%d back-to-back launches per replay of a HIP graph (x %d replays), cycling %d operand sets of %d engines'
+                                    % (ingraph['launches'], ingraph['replays'], ingraph['sets'], ingraph['engines'])) if ingraph else
+                                   'eager launches, events around each',
+                         'outliers_dropped': dropped,
                          'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
                          'alt_hbm_gbs': by / dur / 1e9, 'alt_mfma_tflops': fl / dur / 1e12})
         kernels = summary
@@ -676,9 +766,13 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         fl_pair, by_pair = algorithmic_per_pair(N, args.blocks, elt=2 if bf16 else 4)
+        struct_ran = bool((struct1 and xbits is not None) or surface_struct)
+        fl_exec, by_exec = executed_per_pair(N, args.blocks, elt=2 if bf16 else 4) if struct_ran else (fl_pair, by_pair)
         if ragged:      # mean over the pairs of this batch, each at its own size
             per = [algorithmic_per_pair(n, args.blocks) for n in sizes]
             fl_pair, by_pair = sum(p[0] for p in per) / B, sum(p[1] for p in per) / B
+            per = [executed_per_pair(n, args.blocks) if struct_ran else algorithmic_per_pair(n, args.blocks) for n in sizes]
+            fl_exec, by_exec = sum(p[0] for p in per) / B, sum(p[1] for p in per) / B
             workload = ('cfg5: variable-N Erdos-Renyi pairs (edge density 0.2, ER edge noise 0.1), n ~ U{30..%d} (this batch: %s), '
                         '%d pairs per GPU in ONE batch padded to its largest graph, %d FGNN blocks x 32 features, depth 3, '
                         'siamese fwd + triplet loss + bwd' % (args.n or 120, sizes, B, args.blocks))
@@ -696,7 +790,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                       'graph-pairs/sec FGNN fwd+bwd, N=%d %s pairs%s' % (N, 'dense ER' if dense_er else 'regular', ', bf16' if bf16 else ''),
             'value': value, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'ms_per_step_min': min(window_s) / args.steps * 1e3, 'ms_per_step_max': max(window_s) / args.steps * 1e3,
-            'timed_windows': len(window_s), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'timed_windows': len(window_s), 'window_ms_per_step': [round(w / args.steps * 1e3, 5) for w in window_s], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': workload,
                        'batch_per_gpu': B, 'global_batch': B * world, 'n_vertices': N, 'num_blocks': args.blocks,
@@ -713,10 +807,15 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                                             else 'v_mfma_f32_32x32x2_f32')),
                        'grad_allreduce': ('%s sum of %d fp32 per step' % (torch.distributed.get_backend(), layout.total)) if world > 1 else 'none'},
             'ranks_seen': dp.world_size(), 'backend': torch.distributed.get_backend() if world > 1 else None, 'allreduce_ms': allreduce_ms,
-            'roofline': roofline,
+            'roofline': roofline, 'step_trace_ms': step_trace,
             'step_model': {'algorithmic_gflop_per_pair': fl_pair / 1e9, 'algorithmic_mb_per_pair': by_pair / 1e6,
                            'hbm_frac_of_8TBs': value / world * by_pair / (HBM_PEAK_GBS * 1e9),
-                           'mfma_frac_of_peak': value / world * fl_pair / ((MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12)},
+                           'mfma_frac_of_peak': value / world * fl_pair / ((MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12),
+                           # the fractions above price the DENSE algorithm at this step time; with block 1 on its structured
+                           # input part of that work is not executed -- these price what the step really runs
+                           'executed_gflop_per_pair': fl_exec / 1e9, 'executed_mb_per_pair': by_exec / 1e6,
+                           'hbm_frac_executed': value / world * by_exec / (HBM_PEAK_GBS * 1e9),
+                           'mfma_frac_executed': value / world * fl_exec / ((MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF) * 1e12)},
             'kernels': kernels,
         }
         if cpu_leg:

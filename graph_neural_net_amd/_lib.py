@@ -264,9 +264,16 @@ def call(name, *args, tag=None):
         e0.record()
         rc = getattr(load(), name)(*args)
         e1.record()
-        PROFILE.append((tag or name, e0, e1))
+        PROFILE.append((tag or name, e0, e1, name, args))        # (name, args): enough to issue the same launch again, see relaunch()
     else:
         rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, last_error()))
+
+
+def relaunch(name, args):
+    """Issue a launch recorded in PROFILE once more, on the CURRENT stream (the stream is the last argument of every entry point)."""
+    rc = getattr(load(), name)(*args[:-1], stream_ptr())
     if rc != 0:
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, last_error()))
 

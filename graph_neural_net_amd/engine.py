@@ -180,6 +180,8 @@ class FgnnEngine:
         if mfma not in ('f32', 'x3'):
             raise ValueError("mfma must be 'f32' or 'x3' (got %r)" % (mfma,))
         self.x3 = (mfma == 'x3' and not ragged and layout.depth == 3 and layout.c0 in (2, 32))
+        parts = os.environ.get('FGNN_X3_PARTS', 'fwd,pair').split(',')
+        self.x3_fwd, self.x3_pair = self.x3 and 'fwd' in parts, self.x3 and 'pair' in parts
         block1 = self.BLOCK1 if block1 is None else block1
         if block1 not in ('generic', 'structured'):
             raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
@@ -236,10 +238,13 @@ class FgnnEngine:
             fl = _lib.load().fgnn_pack_x3_floats if self.x3 else _lib.load().fgnn_pack_floats
             f3 = 2 if self.x3 else 0
             b3 = 3 if self.x3 else 1
-            self._packs[('f', k, 12)] = (0, cin, 0, 2, torch.empty(fl(0, cin, 0, layout.depth, 2), **f32))
+            # (measurement switch FGNN_X3_PARTS = 'fwd' / 'pair': only that half of the x3 kernel pair, the other on fp32 MFMAs)
+            f12 = 2 if (self.x3 and not self.x3_fwd) else 0
+            b12 = 3 if (self.x3 and not self.x3_pair) else 1
+            self._packs[('f', k, 12)] = (f12, cin, 0, 2, torch.empty(fl(f12, cin, 0, layout.depth, 2), **f32))
             self._packs[('f', k, 3)] = (f3, 32, cin, 1, torch.empty(fl(f3, 32, cin, layout.depth, 1), **f32))
             for j in (1, 2):
-                self._packs[('b', k, j)] = (1, cin, 0, 1, torch.empty(fl(1, cin, 0, layout.depth, 1), **f32))
+                self._packs[('b', k, j)] = (b12, cin, 0, 1, torch.empty(fl(b12, cin, 0, layout.depth, 1), **f32))
             self._packs[('b', k, 3)] = (b3, 32, cin, 1, torch.empty(fl(b3, 32, cin, layout.depth, 1), **f32))
 
     # ------------------------------------------------------------------ helpers
@@ -317,12 +322,12 @@ class FgnnEngine:
             args.ranges = self.ranges.data_ptr()
         args.cu_share = self.cu_share
         st = _lib.stream_ptr()
-        _lib.call('fgnn_mlp_fwd_x3' if (self.x3 and len(js) == 2) else 'fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        _lib.call('fgnn_mlp_fwd_x3' if (self.x3_fwd and len(js) == 2) else 'fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         if self.decisions is not None:
             # test-only (export_decisions): the decision-exporting twin of the launch above -- same tile code, same outputs written
             # once more -- leaves one bit per hidden pre-activation of these MLPs
             bufs = [torch.zeros(self.G * (L.depth - 1) * 32 * self.tpg, dtype=torch.int32, device=self.device) for _ in js]
-            _lib.call('fgnn_debug_mlp_fwd_x3_masks' if (self.x3 and len(js) == 2) else 'fgnn_debug_mlp_fwd_masks', C.byref(args),
+            _lib.call('fgnn_debug_mlp_fwd_x3_masks' if (self.x3_fwd and len(js) == 2) else 'fgnn_debug_mlp_fwd_masks', C.byref(args),
                       _lib.ptr(bufs[0]), _lib.ptr(bufs[1]) if len(js) == 2 else None, st)
             for j, buf in zip(js, bufs):
                 self.decisions[(k, j)] = buf
@@ -350,7 +355,11 @@ class FgnnEngine:
         """x: (G, c0, N, N) contiguous device tensor -- or bits: (G, N, ceil(N/32)) int32 words of the bit-packed
         adjacency (bit j of row i = W[i][j], the format of inputs.expand_adjacency / synthetic.pack_adjacency): the
         (2, N, N) representation of loaders/data_generator.py:118-125 is then built inside block 1's kernels and never
-        exists in HBM.  Fills self.E / self.idx."""
+        exists in HBM.  Fills self.E / self.idx.
+        LIFETIME: x / bits, and an nvalid handed over as a contiguous int32 device tensor of G entries, are read IN PLACE -- by this
+        forward AND by the backward that follows it (block 1's backward re-reads the input; every backward kernel reads nvalid): the
+        caller must leave them untouched until backward() has been issued (stream order is enough).  Any other nvalid (host list,
+        int64, another device) is copied into the engine's own buffer.  A HIP graph captured around step() keeps those addresses."""
         L = self.layout
         if (nvalid is None) != (self.nvalid is None):
             raise RuntimeError('FgnnEngine: ragged flag and nvalid argument disagree')
@@ -540,7 +549,7 @@ class FgnnEngine:
         W = self._bwd
         a1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], None, None, None, False, False, False, None)
         a2 = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit, None)
-        _lib.call('fgnn_mlp_bwd_pair_x3' if self.x3 else 'fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
+        _lib.call('fgnn_mlp_bwd_pair_x3' if self.x3_pair else 'fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
                   tag='mlp_bwd_pair[cin=%d,dx=%d]' % (sin.C, sin.C if din is not None else 0))
 
     def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides):
@@ -705,7 +714,8 @@ class FgnnEngine:
         return grads
 
     def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):
-        """One training step's model work: forward + loss + backward."""
+        """One training step's model work: forward + loss + backward.  (x / bits / an int32 device nvalid are read in place by both
+        passes: see embed().)"""
         scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits)
         self.backward(params, grads)
         return scores, loss

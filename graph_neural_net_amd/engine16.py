@@ -156,7 +156,9 @@ class FgnnEngineBF16:
     def embed(self, params, x, nvalid=None, bits=None):
         """x: (G, 2, N, N) contiguous fp32 device tensor (0/1 adjacency + degrees: exact in bf16 for N <= 256) -- or bits:
         (G, N, ceil(N/32)) int32 words of the bit-packed adjacency (the input form of FgnnEngine.embed(bits=...)); with
-        block1='structured' block 1 then runs on the class tables (csrc/block1_struct.hip)."""
+        block1='structured' block 1 then runs on the class tables (csrc/block1_struct.hip).
+        LIFETIME: as FgnnEngine.embed -- bits and an int32 device nvalid of G entries are read in place by this forward and by the
+        backward after it; leave them untouched until backward() has been issued."""
         L = self.layout
         if (nvalid is None) != (self.nvalid is None):
             raise RuntimeError('FgnnEngineBF16: ragged flag and nvalid argument disagree')

@@ -63,7 +63,10 @@ class FgnnTrainer:
         self._force_collective = collective == 'always'
         self.allreduce_in_graph = False
         if dp.world_size() > 1 or self._force_collective:
-            # communicator set-up (RCCL: rings over xGMI) happens at the first collective: here, not inside a step or a capture
+            # communicator set-up (RCCL: rings over xGMI) happens at the first collective: here, not inside a step or a capture.
+            # NOTE: this IS a collective -- with more than one rank every rank must construct its trainers in the same order (a
+            # trainer built on rank 0 only, e.g. for evaluation, would wait here for the others: build it before init_process_group
+            # or on every rank)
             dp.warm_up_collective(params_flat.device, force=self._force_collective)
             self.allreduce_in_graph = bool(capture) and dp.collective_captures()
 
@@ -211,17 +214,41 @@ class FgnnTrainer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             t0 = self.opt.t
-            g_model, g_opt = torch.cuda.CUDAGraph(), None
+            g_opt = None
             exchange = world > 1 or self._force_collective
-            # (a collective inside the capture: 'thread_local', so that the process group's watchdog thread cannot invalidate it)
-            with torch.cuda.graph(g_model, capture_error_mode='thread_local' if (exchange and self.allreduce_in_graph) else 'global'):
-                scores, _ = step()
-                if not exchange or self.allreduce_in_graph:
-                    # nothing to exchange, or the ONE collective rides in the graph: the whole step is one replay
-                    if exchange:
-                        dp.allreduce_sum_(self.comm, force=self._force_collective)
-                    self.opt.set_grad_scale_reciprocal(self._nodes)
-                    self.opt.step_dev(self.grads)
+
+            def capture_model():
+                g = torch.cuda.CUDAGraph()
+                # (a collective inside the capture: 'thread_local', so that the process group's watchdog thread cannot invalidate it)
+                with torch.cuda.graph(g, capture_error_mode='thread_local' if (exchange and self.allreduce_in_graph) else 'global'):
+                    sc, _ = step()
+                    if not exchange or self.allreduce_in_graph:
+                        # nothing to exchange, or the ONE collective rides in the graph: the whole step is one replay
+                        if exchange:
+                            dp.allreduce_sum_(self.comm, force=self._force_collective)
+                        self.opt.set_grad_scale_reciprocal(self._nodes)
+                        self.opt.step_dev(self.grads)
+                return g, sc
+            if exchange and self.allreduce_in_graph:
+                # The collective may fail to capture on ONE rank only (a torch / RCCL build that cannot record it, a watchdog event
+                # query at the wrong moment); a rank that fell back alone would then wait in an eager all-reduce that the others never
+                # issue.  So the ranks AGREE: one eager flag all-reduce per captured shape (set-up, not a step collective); if any
+                # rank failed, all of them use the two-graph form (model work | eager all-reduce | optimizer).
+                try:
+                    g_model, scores = capture_model()
+                    failed = 0.0
+                except Exception:            # noqa: BLE001 -- any capture failure takes the fallback
+                    torch.cuda.synchronize()
+                    g_model, failed = None, 1.0
+                flag = torch.tensor([failed], dtype=torch.float32, device=self.params.device)
+                dp.allreduce_sum_(flag, force=self._force_collective)
+                if flag.item() > 0:
+                    self.allreduce_in_graph = False
+                    g_model = None
+            else:
+                g_model = None
+            if g_model is None:
+                g_model, scores = capture_model()
             if exchange and not self.allreduce_in_graph:
                 g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_opt):

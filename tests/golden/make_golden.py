@@ -796,8 +796,86 @@ def main_round5():
     print('pinned_decisions.npz written; decisions that differ between the fp32 and the fp64 run:', flips)
 
 
+def main_round5b():
+    """tests/golden/pinned_reference_errors.npz: the yard-stick of tests/test_gpu_grad_pinned.py.  For the three benchmarked shapes
+    (cfg2: the full 32-pair batch; cfg4 shape: 8 dense ER pairs of N = 200; cfg5: 8 ragged pairs, n in [30, 120]; weights of
+    cfg2_reg_n50_b2_4blk.npz) the per-tensor max-norm relative error of the REFERENCE's own fp32 gradients (8 threads and 1 thread)
+    against the fp64 evaluation of the branch that fp32 run took (oracle/fgnn_oracle_pinned.py with the fp32 run's decisions) -- i.e.
+    what pure fp32 rounding costs the reference once the decisions are out of the comparison.  The oracle stands in for the
+    reference (torch.equal to it: check_oracle_bit_equal / check_pinned_oracle, re-checked here on a slice of every case)."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from graph_neural_net_amd import synthetic
+    from oracle import fgnn_oracle as O, fgnn_oracle_pinned as OP
+    d = np.load(os.path.join(OUT, 'cfg2_reg_n50_b2_4blk.npz'))
+    sd = {k[3:]: torch.from_numpy(d[k]) for k in d.files if k.startswith('sd/')}
+    names = list(sd.keys())
+    model = build_reference_model(4, seed=0)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sd.items()})
+    out = {'names': np.array(names)}
+    trel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item() if b.abs().max() > 0 else (a.double() - b).abs().max().item()
+
+    def case(tag, x1, x2, sizes=None):
+        if sizes is None:
+            check_pinned_oracle(model, x1[:2], x2[:2], tag)                       # the pinned oracle == the reference, on a slice
+            run32 = lambda: O.step_fwd_bwd(x1, x2, sd)
+
+            def decide():           # side by side, like the step itself (ATen's blocking -- and with it the rounding -- depends on the batch)
+                (ma, ia), (mb, ib) = OP.collect_decisions(x1, sd), OP.collect_decisions(x2, sd)
+                return {k: torch.cat([ma[k], mb[k]]) for k in ma}, torch.cat([ia, ib])
+        else:
+            xs = [x1[b, :, :n, :n] for b, n in enumerate(sizes)]
+            ys = [x2[b, :, :n, :n] for b, n in enumerate(sizes)]
+            run32 = lambda: O.step_fwd_bwd_ragged(xs, ys, sd)
+
+            def decide():
+                B, nmax = len(sizes), x1.shape[-1]
+                masks, idx = {}, torch.zeros(2 * B, 32, nmax, dtype=torch.int64)
+                for b, n in enumerate(sizes):
+                    for gi, t in ((b, xs[b]), (B + b, ys[b])):
+                        m, i = OP.collect_decisions(t.unsqueeze(0), sd)
+                        for k, v in m.items():
+                            masks.setdefault(k, torch.zeros(2 * B, 32, nmax, nmax, dtype=torch.bool))[gi, :, :n, :n] = v[0]
+                        idx[gi, :, :n] = i[0]
+                return masks, idx
+        errs, lerr = {}, []
+        for threads in (8, 1):
+            # each fp32 run against the fp64 evaluation of ITS OWN branch (another GEMM blocking = another rounding of a
+            # pre-activation near zero: the two runs do not take the same decisions at N > 64)
+            torch.set_num_threads(threads)
+            _, l32, g32 = run32()
+            masks, idx = decide()
+            torch.set_num_threads(8)
+            if sizes is None:
+                _, l64, g64 = OP.step_fwd_bwd_pinned(x1, x2, sd, masks, idx, dtype=torch.float64)
+            else:
+                _, l64, g64 = OP.step_fwd_bwd_pinned_ragged(x1, x2, sizes, sd, masks, idx, dtype=torch.float64)
+            errs[threads] = np.array([trel(g32[k], g64[k]) for k in names])
+            lerr.append(abs(l32.item() - l64.item()) / abs(l64.item()))
+            del masks, idx, g64
+        e8, e1 = errs[8], errs[1]
+        out[tag + '/err8'], out[tag + '/err1'] = e8, e1
+        out[tag + '/loss_err'] = np.array(lerr)
+        live = np.array([not k.endswith(ZERO_GRAD_SUFFIX) for k in names])
+        print(tag, 'reference fp32 vs fp64 on its own branch: worst tensor 8 threads %.2e (%s), 1 thread %.2e; median %.2e / %.2e'
+              % (e8[live].max(), names[int(np.argmax(np.where(live, e8, 0)))], e1[live].max(), np.median(e8[live]), np.median(e1[live])), flush=True)
+
+    x1, x2 = synthetic.make_batch(2000, 32, 50, 'Regular', 0.2, 0.1)
+    case('cfg2', x1, x2)
+    xs, ys = synthetic.make_ragged_batch(5000, 8, 30, 120, 'ErdosRenyi', 0.2, 0.1)
+    sizes = [int(t.shape[-1]) for t in xs]
+    N = max(sizes)
+    pad = lambda lst: torch.stack([torch.nn.functional.pad(t, (0, N - t.shape[-1], 0, N - t.shape[-1])) for t in lst])
+    case('cfg5', pad(xs), pad(ys), sizes)
+    x1, x2 = synthetic.make_batch(4000, 8, 200, 'ErdosRenyi', 0.5, 0.1)
+    case('cfg4', x1, x2)
+    np.savez_compressed(os.path.join(OUT, 'pinned_reference_errors.npz'), **out)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'round5':
+    if len(sys.argv) > 1 and sys.argv[1] == 'round5b':
+        main_round5b()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'round5':
         main_round5()
     elif len(sys.argv) > 1 and sys.argv[1] == 'round4':
         main_round4()

@@ -95,7 +95,8 @@ def test_one_collective_per_step(tmp_path):
         assert len(per_step) == 3
         if mode == 'capture' and two['capture_in_graph']:
             # RCCL: the collective was recorded into the step's graph -- ONE call while capturing, none from the host after
-            assert per_step == [['all_reduce'], [], []], per_step
+            # (+ one flag all-reduce while capturing: the ranks agree that the capture worked on all of them, trainer.py)
+            assert per_step == [['all_reduce', 'all_reduce'], [], []], per_step
             continue
         for calls in per_step:
             assert calls == ['all_reduce'], (mode, per_step)
@@ -239,7 +240,8 @@ def test_rccl_all_reduce_inside_the_captured_step(tmp_path):
     """The RCCL all-reduce recorded INTO the trainer's HIP graph (model work -> all-reduce -> fused Adam = one replay), with the
     one rank a one-GPU box can host (collective='always' issues the collective although there is nothing to sum): three
     replayed steps must leave bit-identical parameters to the trainer without a collective, the host must have issued the
-    collective exactly once (while capturing), and replays must not call into torch.distributed at all."""
+    collective only while capturing (the recorded all-reduce + one flag all-reduce by which the ranks agree that the capture worked
+    everywhere), and replays must not call into torch.distributed at all."""
     code = (
         "import os, sys, torch, torch.distributed as dist\n"
         "sys.path.insert(0, %r)\n"
@@ -267,7 +269,7 @@ def test_rccl_all_reduce_inside_the_captured_step(tmp_path):
         "    out.append((tr.params.clone(), losses, per, tr.allreduce_in_graph))\n"
         "(pa, la, ca, ga), (pb, lb, cb, gb) = out\n"
         "assert not ga and ca == [0, 0, 0], (ga, ca)\n"
-        "assert gb and cb == [1, 0, 0], (gb, cb)\n"
+        "assert gb and cb == [2, 0, 0], (gb, cb)      # the captured all-reduce + the ranks' agreement flag, once per shape\n"
         "assert torch.equal(pa, pb) and la == lb, (la, lb)\n"
         "print('RCCL_IN_GRAPH_OK')\n"
         "dist.destroy_process_group()\n") % (ROOT,)

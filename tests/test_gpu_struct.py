@@ -9,10 +9,12 @@ import torch
 from graph_neural_net_amd import synthetic
 from graph_neural_net_amd.engine import FgnnEngine, ParamLayout
 from oracle import fgnn_oracle as O
+from oracle import fgnn_oracle_pinned as OP
 from util import is_zero_grad, load_golden, rel, sub
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+PINNED_TOL_1BLK = 2e-5       # one block, decisions pinned: max-norm relative per tensor against fp64 (fp32 rounding only)
 
 
 def _bits(x1, x2):
@@ -63,17 +65,30 @@ def test_structured_block1_equals_the_generic_kernels(B, N, family, p):
         t = flat(g64)
         ours, theirs = ((flat(b[5]) - t).norm() / t.norm()).item(), ((flat(g32) - t).norm() / t.norm()).item()
         # 2 x 32 x B N^2 pre-activations of mlp3: on the large case one of them within rounding of zero is likely, and whether THIS
-        # evaluation takes the fp64 branch there is a coin (tests/gradgate.py; profiles/r04_fuzz_struct.txt shows the signature).  What a
-        # ReLU flip cannot touch in a one-block model -- mlp3's last conv and its GraphNorm, upstream of every ReLU in the backward
-        # direction -- keeps the sharp gate; the rest may sit in the flip class (< 5e-3) there
+        # evaluation takes the fp64 branch there is a coin (tests/gradgate.py; profiles/r04_fuzz_struct.txt shows the signature)
         big = B * N * N >= 200000 or 2 * B >= 256        # (256+ graphs: 1.2e-5 against 3.6e-7 measured on the (128, 20) case, one such event)
-        downstream = ('ne_bm_block1_mlp3.convs.2.weight', 'ne_bm_block1_mlp3.gn.weight', 'ne_bm_block1_mlp3.gn.bias')
-        assert ours < (5e-3 if big else 2.0 * theirs + 1e-6), (ours, theirs)
-        for name in g64:
-            if is_zero_grad(name):
-                assert b[5][name].abs().max() < 1e-4, name
-            elif not big or name in downstream:
-                assert rel(b[5][name], g64[name]) < 4.0 * rel(g32[name], g64[name]) + 1e-5, (name, rel(b[5][name], g64[name]), rel(g32[name], g64[name]))
+        if big:
+            # ... so there the comparison takes the decisions out (tests/test_gpu_grad_pinned.py): fp64 arithmetic on the branch THIS
+            # engine took -- its exported ReLU decisions (class tables for mlp1 / mlp2, the mask export of mlp3's forward) and its
+            # arg-max indices -- and every tensor within fp32 rounding of it.  (Round 4 let these cases pass a flat 5e-3.)
+            eng.export_decisions(True)
+            g3 = torch.zeros_like(params)
+            eng.step(params, g3, None, bits=bits)
+            torch.cuda.synchronize()
+            assert torch.equal(g3, g)
+            _, _, gp = OP.step_fwd_bwd_pinned(x1, x2, sd, eng.relu_decisions(), eng.idx.to(torch.int64), dtype=torch.float64, device=DEV)
+            for name in g64:
+                if is_zero_grad(name):
+                    assert b[5][name].abs().max() < 1e-4, name
+                else:
+                    assert rel(b[5][name], gp[name]) < PINNED_TOL_1BLK, (name, rel(b[5][name], gp[name]))
+        else:
+            assert ours < 2.0 * theirs + 1e-6, (ours, theirs)
+            for name in g64:
+                if is_zero_grad(name):
+                    assert b[5][name].abs().max() < 1e-4, name
+                else:
+                    assert rel(b[5][name], g64[name]) < 4.0 * rel(g32[name], g64[name]) + 1e-5, (name, rel(b[5][name], g64[name]), rel(g32[name], g64[name]))
     else:
         assert torch.isfinite(b[3]).all() and abs(a[4] - b[4]) <= 1e-6 * abs(a[4]) + 1e-7
 

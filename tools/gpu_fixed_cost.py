@@ -20,7 +20,7 @@ def run(B, N, reps=20):
     torch.cuda.synchronize()
     rec, _lib.PROFILE = _lib.PROFILE, None
     acc = {}
-    for tag, e0, e1 in rec:
+    for tag, e0, e1, *_ in rec:
         a = acc.setdefault(tag, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
     print('B=%d N=%d (tiles=%d)' % (B, N, 2 * B * ((N * N + 31) // 32)))
     print('   ' + '  '.join('%s=%.1f' % (k.replace('fgnn_','').replace('chan_',''), v[1] / v[0] * 1e3) for k, v in sorted(acc.items()) if 'mlp' in k or 'matmul' in k))

@@ -28,7 +28,7 @@ for pair in (False, True):
     torch.cuda.synchronize()
     rec, _lib.PROFILE = _lib.PROFILE, None
     acc = {}
-    for tag, e0, e1 in rec:
+    for tag, e0, e1, *_ in rec:
         a = acc.setdefault(tag, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
     print(pair, ' '.join('%s=%.1f' % (k, v[1] / v[0] * 1e3) for k, v in sorted(acc.items()) if 'mlp_bwd' in k))
     gr = torch.cuda.CUDAGraph()

@@ -36,7 +36,7 @@ for _ in range(5): eng.step(params, grads, x, nvalid=nv)
 torch.cuda.synchronize()
 rec, _lib.PROFILE = _lib.PROFILE, None
 acc = {}
-for tag, e0, e1 in rec:
+for tag, e0, e1, *_ in rec:
     a = acc.setdefault(tag, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in acc.values())
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):

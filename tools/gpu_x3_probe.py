@@ -46,7 +46,7 @@ def profile(eng, grads, reps=10):
     torch.cuda.synchronize()
     rec, _lib.PROFILE = _lib.PROFILE, None
     acc = {}
-    for tag, e0, e1 in rec:
+    for tag, e0, e1, *_ in rec:
         a = acc.setdefault(tag, [0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1)
     return {k: v[1] / v[0] * 1e3 for k, v in acc.items()}
 
