@@ -471,6 +471,93 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
     }
 }
 
+// Scoring forward + triplet loss + their backward in ONE launch (a training step issues them back to back; N <= 64, 4 | C): grid
+// (B, CSPLIT_SMALL).  Every workgroup of pair b stages e1, e2, forms the full score matrix S in LDS (N^2 C fma: cheaper than a second
+// launch), the row log-sum-exps and dS = (exp(S - lse) - I) gscale, then produces de1 / de2 of ITS channels; workgroup y = 0 also
+// writes scores, lse and the pair-loss partials.  Arithmetic and summation orders are those of score_ce_fwd_kernel +
+// score_bwd_kernel<true, true>: results are bit-identical to the two launches (tests/test_gpu_kernels.py).
+__global__ __launch_bounds__(256) void score_ce_step_kernel(const float *e1, const float *e2, const int *nvalid, const float *gscale,
+                                                            int C, int N, int row_blocks, float *scores, float *lse, float *pair_loss,
+                                                            float *de1, float *de2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *s1 = sm, *s2 = sm + (size_t)C * N;
+    float *dS = s2 + (size_t)C * N;            // S, then dS: [i][j], row stride N + 1
+    const int ld = N + 1;
+    float *term = dS + (size_t)N * ld;         // per row: lse_i - S_ii (0 beyond nv)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = nvalid_of(nvalid, b, N);
+    const bool writer = blockIdx.y == 0;
+    copy_to_lds256(s1, e1 + (long long)b * C * N, C * N, tid);
+    copy_to_lds256(s2, e2 + (long long)b * C * N, C * N, tid);
+    const float gs = *gscale;
+    __syncthreads();
+    float *S = scores + (long long)b * N * N;
+    const float invN = 1.f / (float)N;
+    for (int e = tid; e < N * N; e += 256) {
+        const int i = (int)(((float)e + 0.5f) * invN), j = e - i * N;
+        float acc = 0.f;
+        if (i < nv && j < nv)
+            for (int c = 0; c < C; ++c) acc = fmaf(s1[c * N + i], s2[c * N + j], acc);
+        if (writer) S[e] = acc;
+        dS[i * ld + j] = acc;
+    }
+    __syncthreads();
+    for (int i = wave; i < N; i += 4) {        // one wave per row, as in score_ce_fwd_kernel
+        float l = 0.f, t = 0.f;
+        float *Sr = dS + (size_t)i * ld;
+        if (i < nv) {
+            float mx = -FLT_MAX;
+            for (int j = lane; j < nv; j += WAVE) mx = fmaxf(mx, Sr[j]);
+            mx = wave_max(mx);
+            float se = 0.f;
+            for (int j = lane; j < nv; j += WAVE) se += expf(Sr[j] - mx);
+            se = wave_sum(se);
+            l = mx + logf(se);
+            t = l - Sr[i];
+        }
+        // the row becomes dS in place (every lane has finished reading it: wave_sum is a full-wave exchange)
+        for (int j = lane; j < N; j += WAVE) {
+            float d = 0.f;
+            if (i < nv && j < nv) d = (expf(Sr[j] - l) - (i == j ? 1.f : 0.f)) * gs;
+            Sr[j] = d;
+        }
+        if (lane == 0) {
+            term[i] = t;
+            if (writer && lse) lse[(long long)b * N + i] = l;
+        }
+    }
+    __syncthreads();
+    if (writer && pair_loss && tid < row_blocks) {
+        // the partial sums of score_ce_fwd_kernel's workgroup (b, tid): wave w of it summed the rows i0 + w, i0 + w + 4, ...
+        const int rows = (N + row_blocks - 1) / row_blocks;
+        const int i0 = tid * rows, i1 = (i0 + rows < N) ? i0 + rows : N;
+        float wl[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            wl[w] = 0.f;
+            for (int i = i0 + w; i < i1; i += 4) wl[w] += term[i];
+        }
+        pair_loss[b * row_blocks + tid] = (wl[0] + wl[1]) + (wl[2] + wl[3]);
+    }
+    // ---- de1, de2 of this workgroup's channels (score_bwd_kernel) ----
+    const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int c0 = blockIdx.y * cper;
+    const int cn = (c0 + cper <= C ? cper : (C > c0 ? C - c0 : 0));
+    for (int e = tid; e < cn * N; e += 256) {
+        const int c = e / N, i = e - c * N;
+        float a1 = 0.f, a2 = 0.f;
+        if (i < nv) {
+            const float *r2 = s2 + (c0 + c) * N, *r1 = s1 + (c0 + c) * N;
+            for (int jj = 0; jj < nv; ++jj) {
+                a1 = fmaf(r2[jj], dS[i * ld + jj], a1);
+                a2 = fmaf(r1[jj], dS[jj * ld + i], a2);
+            }
+        }
+        de1[((long long)b * C + c0) * N + e] = a1;
+        de2[((long long)b * C + c0) * N + e] = a2;
+    }
+}
+
 // Large N (dS does not fit LDS): grid (B, CSPLIT, ceil(N / SB_BLK)).  Workgroup (b, cs, rb) stages the row block
 // dS[i0:i1, :] and produces de1 for those rows, then stages the column block dS[:, i0:i1] and produces de2 for
 // those columns -- no cross-workgroup reduction, nothing recomputed inside the inner loops.
@@ -726,6 +813,24 @@ extern "C" int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *
                                  void *stream) {
     FGNN_CHECK(e1 && e2 && scores && lse && gscale && de1 && de2 && B > 0, "fgnn_score_ce_bwd: bad arguments");
     return launch_score_bwd<true>(e1, e2, scores, lse, nullptr, nvalid, gscale, B, C, N, de1, de2, (hipStream_t)stream);
+}
+
+extern "C" int fgnn_score_ce_step_supported(int B, int C, int N) {
+    // the shapes where score_bwd_kernel stages the whole dS with CSPLIT_SMALL channel splits (small batches of small graphs)
+    return (N <= 64 && (long long)B * CSPLIT < 256 && C % CSPLIT_SMALL == 0) ? 1 : 0;
+}
+
+extern "C" int fgnn_score_ce_step(const float *e1, const float *e2, const int *nvalid, const float *gscale, int B, int C, int N,
+                                  int row_blocks, float *scores, float *lse, float *pair_loss, float *de1, float *de2, void *stream) {
+    FGNN_CHECK(e1 && e2 && gscale && scores && lse && pair_loss && de1 && de2 && B > 0 && row_blocks > 0 && row_blocks <= 256,
+               "fgnn_score_ce_step: bad arguments");
+    FGNN_CHECK(fgnn_score_ce_step_supported(B, C, N), "fgnn_score_ce_step: built for N <= 64, B < 64, C %% 8 == 0 (got B=%d C=%d N=%d); use "
+               "fgnn_score_ce_fwd_blocks + fgnn_score_ce_bwd", B, C, N);
+    const int lds = (2 * C * N + N * (N + 1) + N + 4) * (int)sizeof(float);
+    hipLaunchKernelGGL(score_ce_step_kernel, dim3(B, CSPLIT_SMALL), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, gscale, C, N,
+                       row_blocks, scores, lse, pair_loss, de1, de2);
+    FGNN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int fgnn_score_bwd(const float *e1, const float *e2, const float *dscores, const int *nvalid, int B, int C,

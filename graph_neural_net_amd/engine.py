@@ -159,6 +159,7 @@ class FgnnEngine:
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
     MM_ORDER = True               # ragged engines: longest-job-first order of the whole-matrix per-channel products
     PAIR_BWD = os.environ.get('FGNN_PAIR_BWD', '1') != '0'      # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd_pair)
+    SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '1') != '0'  # step(): scoring + loss + their backward as one launch (fgnn_score_ce_step)
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -210,6 +211,7 @@ class FgnnEngine:
         self.scores = torch.empty(self.B, N, N, **f32)
         self.lse = torch.empty(self.B, N, **f32)
         self.score_blocks = _lib.load().fgnn_score_row_blocks(self.B, N)      # row blocks per pair of the scoring kernel
+        self._score_step_ok = bool(_lib.load().fgnn_score_ce_step_supported(self.B, 32, N)) and self.score_blocks <= 256
         self.pair_loss = torch.empty(self.B * self.score_blocks, **f32)
         self.loss = torch.empty(1, **f32)
         self.nvalid = torch.empty(G, dtype=torch.int32, device=device) if ragged else None
@@ -475,20 +477,31 @@ class FgnnEngine:
                   _lib.ptr(W['wpart'][(1, 1)]), _lib.ptr(W['wpart'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
                   _lib.stream_ptr())
 
-    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None, pack=True):
+    def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None, pack=True,
+                with_score_bwd=False):
         """Siamese forward on the stacked batch x = cat(x1, x2) (or its bit-packed adjacency, see embed): returns
         (scores, loss).
         defer_loss: leave the final sum of the per-pair losses to the gradient-finalize launch of the
-        following backward() (one launch less per training step); `loss` is valid after that."""
+        following backward() (one launch less per training step); `loss` is valid after that.
+        with_score_bwd (step()): the backward of loss * 1 follows at once -- scoring, the loss and their backward run as ONE launch
+        where fgnn_score_ce_step is built for the shape (bit-identical to the two launches); backward() then starts at the pooling."""
         self.embed(params, x, nvalid, bits=bits, pack=pack)
         B, N = self.B, self.N
         st = _lib.stream_ptr()
         e1, e2 = self.E[:B], self.E[B:]
-        _lib.call('fgnn_score_ce_fwd_blocks', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N, self.score_blocks,
-                  _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), st)
         if total_nodes is None:
             total_nodes = B * N if nvalid is None else int(nvalid[:B].sum().item())
         self.total_nodes = float(total_nodes)
+        self._dE_done = False
+        if with_score_bwd and self.SCORE_STEP and self._score_step_ok:
+            W = self._alloc_bwd()
+            self._set_gscale(1.0 / self.total_nodes)
+            _lib.call('fgnn_score_ce_step', _lib.ptr(e1), _lib.ptr(e2), self._nv(), _lib.ptr(W['gscale']), B, 32, N, self.score_blocks,
+                      _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
+            self._dE_done = True
+        else:
+            _lib.call('fgnn_score_ce_fwd_blocks', _lib.ptr(e1), _lib.ptr(e2), self._nv(), B, 32, N, self.score_blocks,
+                      _lib.ptr(self.scores), _lib.ptr(self.lse), _lib.ptr(self.pair_loss), st)
         self._loss_pending = bool(defer_loss)
         self._loss_target = self.loss if loss_out is None else loss_out     # 1-element fp32 device tensor
         if not defer_loss:
@@ -602,18 +615,25 @@ class FgnnEngine:
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
+        if getattr(self, '_dE_done', False) and gscale_dev is None and grad_scale == 1.0:
+            self._dE_done = False              # forward(with_score_bwd=True) already left d loss / d E in W['dE']
+            return self.backward_from_dE(params, grads, W['dE'], finalize=finalize)
+        self._dE_done = False
         if gscale_dev is not None:
             W['gscale'].copy_(gscale_dev.reshape(1))
             W['gscale_value'] = None
         else:
-            gs = grad_scale / self.total_nodes
-            if W.get('gscale_value') != gs:        # a 1-element fill kernel per step otherwise
-                W['gscale'].fill_(gs)
-                W['gscale_value'] = gs
+            self._set_gscale(grad_scale / self.total_nodes)
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
         return self.backward_from_dE(params, grads, W['dE'], finalize=finalize)
+
+    def _set_gscale(self, gs):
+        W = self._bwd
+        if W.get('gscale_value') != gs:        # a 1-element fill kernel per step otherwise
+            W['gscale'].fill_(gs)
+            W['gscale_value'] = gs
 
     def backward_from_dE(self, params, grads, dE, finalize=True, dx=None):
         """Backward of the node embedder given d loss / d E  (G, 32, N).
@@ -716,7 +736,7 @@ class FgnnEngine:
     def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):
         """One training step's model work: forward + loss + backward.  (x / bits / an int32 device nvalid are read in place by both
         passes: see embed().)"""
-        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits)
+        scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits, with_score_bwd=True)
         self.backward(params, grads)
         return scores, loss
 

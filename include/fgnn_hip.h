@@ -268,6 +268,14 @@ int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const int *nvalid
 int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
                       const int *nvalid, const float *gscale, int B, int C, int N,
                       float *de1, float *de2, void *stream);
+/* Scoring forward + triplet loss + their backward in ONE launch -- what a training step issues back to back (models/trainers.py:60-76:
+ * `loss = self.loss(self(x1, x2))` followed at once by autograd's first two nodes): the outputs of fgnn_score_ce_fwd_blocks (scores,
+ * lse, pair_loss with `row_blocks` partial sums per pair) AND of fgnn_score_ce_bwd (de1, de2; gscale as there), bit-identical to
+ * the two launches.  Small batches of small graphs: fgnn_score_ce_step_supported(B, C, N) (N <= 64, B < 64, 8 | C). */
+int fgnn_score_ce_step_supported(int B, int C, int N);
+int fgnn_score_ce_step(const float *e1, const float *e2, const int *nvalid, const float *gscale, int B, int C, int N, int row_blocks,
+                       float *scores, float *lse, float *pair_loss, float *de1, float *de2, void *stream);
+
 /* triplet_loss on a given score tensor: lse (B,N), pair_loss (B) (toolbox/losses.py:27-34) */
 int fgnn_ce_fwd(const float *scores, const int *nvalid, int B, int N, float *lse, float *pair_loss, void *stream);
 /* dscores = (softmax_row(scores) - I) * (*gscale) on valid entries, 0 on padding */

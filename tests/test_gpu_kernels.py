@@ -239,6 +239,41 @@ def test_colmax_first_index_on_ties_bit_exact():
     assert torch.equal(dy.cpu(), ref)
 
 
+@pytest.mark.parametrize('B,Cc,N,ragged', [(32, 32, 50, False), (3, 32, 64, True), (5, 8, 9, True), (1, 32, 1, False), (8, 32, 33, True)])
+def test_score_ce_step_is_bit_identical_to_the_two_launches(B, Cc, N, ragged):
+    """fgnn_score_ce_step (scoring + triplet loss + their backward in one launch, what FgnnEngine.step issues) against
+    fgnn_score_ce_fwd_blocks + fgnn_score_ce_bwd: every output bit for bit, ragged batches with empty graphs included."""
+    lib = _lib.load()
+    assert lib.fgnn_score_ce_step_supported(B, Cc, N)
+    g = torch.Generator().manual_seed(B * 100 + N)
+    e1d, e2d = torch.randn(B, Cc, N, generator=g).to(DEV), torch.randn(B, Cc, N, generator=g).to(DEV)
+    nv = None
+    if ragged:
+        nv = torch.randint(0, N + 1, (B,), generator=g).to(torch.int32)
+        nv[0] = N
+        nv = nv.to(DEV)
+    blocks = lib.fgnn_score_row_blocks(B, N)
+    gscale = torch.tensor([1.0 / 1234.0], device=DEV)
+    outs = []
+    for fused in (False, True):
+        scores, lse = torch.full((B, N, N), 7.0, device=DEV), torch.full((B, N), 7.0, device=DEV)
+        pl = torch.full((B * blocks,), 7.0, device=DEV)
+        d1, d2 = torch.full_like(e1d, 7.0), torch.full_like(e2d, 7.0)
+        if fused:
+            _lib.call('fgnn_score_ce_step', _lib.ptr(e1d), _lib.ptr(e2d), _lib.ptr(nv), _lib.ptr(gscale), B, Cc, N, blocks, _lib.ptr(scores),
+                      _lib.ptr(lse), _lib.ptr(pl), _lib.ptr(d1), _lib.ptr(d2), _lib.stream_ptr())
+        else:
+            _lib.call('fgnn_score_ce_fwd_blocks', _lib.ptr(e1d), _lib.ptr(e2d), _lib.ptr(nv), B, Cc, N, blocks, _lib.ptr(scores),
+                      _lib.ptr(lse), _lib.ptr(pl), _lib.stream_ptr())
+            _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1d), _lib.ptr(e2d), _lib.ptr(scores), _lib.ptr(lse), _lib.ptr(nv), _lib.ptr(gscale),
+                      B, Cc, N, _lib.ptr(d1), _lib.ptr(d2), _lib.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append((scores, lse, pl, d1, d2))
+    for a, b, name in zip(outs[0], outs[1], ('scores', 'lse', 'pair_loss', 'de1', 'de2')):
+        assert torch.equal(a, b), name
+    assert not lib.fgnn_score_ce_step_supported(64, 32, 50) and not lib.fgnn_score_ce_step_supported(8, 32, 65)
+
+
 @pytest.mark.parametrize('B,Cc,N', [(3, 32, 50), (2, 8, 9)])
 def test_score_and_ce(B, Cc, N):
     e1 = torch.randn(B, Cc, N)
