@@ -102,7 +102,7 @@ class MlpBwd16Args(C.Structure):
 
 class GradJob(C.Structure):
     _fields_ = [('wpart', C.c_void_p), ('count', C.c_int), ('out', C.c_void_p), ('s12', C.c_void_p),
-                ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p), ('rows', C.c_int), ('scale', C.c_float)]
+                ('nrm', C.c_void_p), ('dgn_w', C.c_void_p), ('dgn_b', C.c_void_p), ('rows', C.c_int), ('scale', C.c_float), ('scale_dev', C.c_void_p)]
 
 
 class PackJob(C.Structure):
@@ -161,6 +161,7 @@ _SIGNATURES = {
     'fgnn_score_ce_fwd_blocks': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_score_ce_step_supported': [_I, _I, _I],
+    'fgnn_inv_node_count': [_VP, _I, _VP, _VP],
     'fgnn_score_ce_step': [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_score_bwd': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_ce_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP],

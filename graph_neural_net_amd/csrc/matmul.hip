@@ -490,6 +490,11 @@ __global__ __launch_bounds__(256, 4) void chan_matmul_bwd1_kernel(const fgnn_sla
 // load is out of range and returns 0), a padding ROW of B is out of range of the per-matrix buffer descriptor
 // (reads 0; its value only meets the zero columns of A), a padding row of A (ragged batches only) is selected to 0.
 // ---------------------------------------------------------------------------------------
+int g_mm_wave_variant = 1;
+inline bool mm_wave_variant() { return (g_mm_wave_variant & 1) != 0; }
+inline bool mm_no_split() { return (g_mm_wave_variant & 2) != 0; }
+inline bool mm_no_order() { return (g_mm_wave_variant & 4) != 0; }
+inline bool mm_narrow() { return (g_mm_wave_variant & 8) != 0; }      // the four-byte-access form of the wave-per-matrix kernel
 constexpr int WLD = 68;            // floats per row of the wave-private A tile
 constexpr int W_WAVES = 2;         // matrices (waves) per workgroup
 
@@ -644,10 +649,156 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w_kernel(cons
     }
 }
 
+// ---- the same kernel with 8-byte accesses (32 < N <= 64; round 5) ------------------------------------------------------------
+// A wave of the kernel above issues 56 + 56 four-byte loads and 64 four-byte stores per matrix; a wave can have 64 vector-memory
+// instructions outstanding, so its operands arrive in TWO dependent round trips.  Here every access moves 8 bytes per lane:
+//   A: lanes 0..31 read the column pair (2 l, 2 l + 1) of row i, lanes 32..63 of row i + 1 -> 28 loads for 56 rows; the pair lands in
+//      the de-interleaved LDS row (even columns at l, odd ones at 32 + l) with two conflict-free ds_write_b32;
+//   B: lane (j, h) reads the column pair (2 j, 2 j + 1) of row k = 2 s + h -> 28 loads; the MFMA column blocks are the EVEN and the ODD
+//      columns (block q, lane j <-> column 2 j + q) instead of the left and the right half;
+//   output: block (rb, 0) and (rb, 1) of a lane are the adjacent columns 2 j, 2 j + 1 of a row -> 32 eight-byte stores.
+// 56 loads in flight: one round trip.  Which lane computes which element changes, the arithmetic of an element does not (k order,
+// normalisation expression): bit-identical to the kernel above (tests/test_gpu_kernels.py).  An odd column that is padding is
+// selected to 0 after the load (its partner may be valid), an odd column beyond N is never stored.
+DEVI float2 rsrc_load2(rsrc_t r, int voff, int soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const unsigned a = v.x, b = v.y;            // (copy the elements to scalars first: see the note on vector elements in DESIGN.md)
+    return make_float2(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+DEVI void rsrc_store2(float x, float y, rsrc_t r, int voff, int soff) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 v;
+    v.x = __builtin_bit_cast(unsigned, x);
+    v.y = __builtin_bit_cast(unsigned, y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
+}
+
+template <int KQ, bool FIN>
+__global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w2_kernel(const fgnn_slab ya, const fgnn_slab yb,
+                                                                            const int *nvalid, int N, int M, float *out,
+                                                                            long long ogstride, long long ldo,
+                                                                            const FinArgs F) {
+    static_assert(KQ > 4, "two column blocks: 32 < N <= 64");
+    constexpr int KH = 4 * KQ;                         // k-steps; also: row PAIRS of A
+    __shared__ __attribute__((aligned(16))) float lds[W_WAVES * 64 * WLD];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gc = xcd_swizzle(blockIdx.x, gridDim.x) * W_WAVES + wv;
+    if (gc >= M) return;
+    const int C = ya.C;
+    const int g = gc / C, c = gc - g * C;
+    const int nv = __builtin_amdgcn_readfirstlane(nvalid_of(nvalid, g, N));
+    const int j = lane & 31, h = lane >> 5;
+    float *As = lds + wv * (64 * WLD);
+    const rsrc_t rA = mat_rsrc(ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp, nv * N * 4);
+    const rsrc_t rB = mat_rsrc(yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp, nv * N * 4);
+    const rsrc_t rO = mat_rsrc(out + (long long)g * ogstride + (long long)c * ldo, N * N * 4);
+
+    TilePartials ta, tb;
+    if (FIN) {
+        ta = finalize_load(F.part_a, F.cnt, g, c, C, F.tpg, lane);
+        tb = finalize_load(F.part_b, F.cnt, g, c, C, F.tpg, lane);
+    }
+    // ---- every load of the matrix pair goes out before anything waits: 28 + 28 eight-byte loads ----
+    const bool ok0 = 2 * j < nv, ok1 = 2 * j + 1 < nv;          // this lane's column pair (the same for A and B)
+    float2 xa[KH], xb[KH];
+    {
+        const int voffA = ok0 ? (h * N + 2 * j) * 4 : OOB_OFF;   // rows 2 p + h, p = 0 .. KH - 1 (rows >= nv are out of range: 0)
+#pragma unroll
+        for (int p = 0; p < KH; ++p) xa[p] = rsrc_load2(rA, voffA, 2 * p < N ? 2 * p * N * 4 : 0);
+        const int voffB = ok0 ? (h * N + 2 * j) * 4 : OOB_OFF;   // row k = 2 s + h
+#pragma unroll
+        for (int s = 0; s < KH; ++s) xb[s] = rsrc_load2(rB, voffB, 2 * s < N ? 2 * s * N * 4 : 0);
+    }
+    // ---- GraphNorm records ----
+    float meanA, aA, meanB, aB;
+    if (FIN) {
+        const float4 ra = finalize_reduce(ta, (float)nv, F.gw_a ? F.gw_a[c] : 1.f, F.eps);
+        const float4 rb = finalize_reduce(tb, (float)nv, F.gw_b ? F.gw_b[c] : 1.f, F.eps);
+        if (lane == 0) {
+            reinterpret_cast<float4 *>(F.nrm_a)[gc] = ra;
+            reinterpret_cast<float4 *>(F.nrm_b)[gc] = rb;
+        }
+        meanA = ra.x; aA = ra.y; meanB = rb.x; aB = rb.y;
+    } else {
+        const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+        meanA = na.mean; aA = na.a; meanB = nb.mean; aB = nb.a;
+    }
+    const bool onA = FIN || ya.nrm != nullptr, onB = FIN || yb.nrm != nullptr;
+    const float betaA = (onA && ya.beta) ? ya.beta[c] : 0.f, betaB = (onB && yb.beta) ? yb.beta[c] : 0.f;
+    // ---- A: normalise, stage rows 2 p + h: even column -> position j, odd column -> position 32 + j ----
+    {
+        const float a0 = ok0 ? aA : 0.f, b0 = ok0 ? betaA : 0.f, a1 = ok1 ? aA : 0.f, b1 = ok1 ? betaA : 0.f;
+#pragma unroll
+        for (int p = 0; p < KH; ++p) {
+            const int row = 2 * p + h;
+            const bool rok = row < nv;                            // (ragged: rows >= nv are zero; dense: nv == N, rows >= N never used)
+            const float v0 = (xa[p].x - meanA) * a0 + b0;
+            const float v1 = ((ok1 ? xa[p].y : 0.f) - meanA) * a1 + b1;
+            As[row * WLD + j] = rok ? v0 : 0.f;
+            As[row * WLD + 32 + j] = rok ? v1 : 0.f;
+        }
+    }
+    const float aeB[2] = {ok0 ? aB : 0.f, ok1 ? aB : 0.f}, beB[2] = {ok0 ? betaB : 0.f, ok1 ? betaB : 0.f};
+    // ---- products: 2 x 2 independent accumulator chains; column block q = columns 2 j + q ----
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        float4 af[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+            af[rb] = *reinterpret_cast<const float4 *>(As + (32 * rb + j) * WLD + h * 32 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (q == KQ - 1 && 2 * (4 * q + t) >= N) break;      // k-steps past the matrix: skipped (uniform), as above
+            float bv[2];
+            bv[0] = (xb[4 * q + t].x - meanB) * aeB[0] + beB[0];
+            bv[1] = ((ok1 ? xb[4 * q + t].y : 0.f) - meanB) * aeB[1] + beB[1];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const float a = t == 0 ? af[rb].x : (t == 1 ? af[rb].y : (t == 2 ? af[rb].z : af[rb].w));
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = mfma32(a, bv[cb], acc[rb][cb]);
+            }
+        }
+    }
+    // ---- output: row 32 rb + ch_of(r, h), columns (2 j, 2 j + 1); rows >= N are out of range of the descriptor ----
+    {
+        const bool two = 2 * j + 1 < N;
+        const int voffO = 2 * j < N ? (4 * h * N + 2 * j) * 4 : OOB_OFF;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int soff = (32 * rb + (r & 3) + 8 * (r >> 2)) * N * 4;
+                if (two) rsrc_store2(acc[rb][0][r], acc[rb][1][r], rO, voffO, soff);
+                else rsrc_store(acc[rb][0][r], rO, voffO, soff);
+            }
+    }
+}
+
 template <bool FIN>
 int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int N, int M, float *out, long long ogstride,
                  long long ldo, const FinArgs &F, hipStream_t st) {
     const int KQ = (N + 7) / 8, grid = (M + W_WAVES - 1) / W_WAVES;
+    if (KQ > 4 && !mm_narrow() && (N & 1) == 0) {      // (odd N: a column pair would straddle two rows -> the four-byte kernel)
+#define FGNN_W2(K_)                                                                                                       \
+    case K_:                                                                                                             \
+        hipLaunchKernelGGL((chan_matmul_fwd_w2_kernel<K_, FIN>), dim3(grid), dim3(64 * W_WAVES), 0, st, *ya, *yb, nvalid, N, \
+                           M, out, ogstride, ldo, F);                                                                    \
+        break;
+        switch (KQ) {
+            FGNN_W2(5) FGNN_W2(6) FGNN_W2(7) FGNN_W2(8)
+        }
+#undef FGNN_W2
+        return 0;
+    }
 #define FGNN_W(K_)                                                                                                       \
     case K_:                                                                                                             \
         hipLaunchKernelGGL((chan_matmul_fwd_w_kernel<K_, FIN>), dim3(grid), dim3(64 * W_WAVES), 0, st, *ya, *yb, nvalid, N, \
@@ -1039,10 +1190,6 @@ inline bool big_path(int N) { return N > TM && N <= 256; }
 // debug only (tests/diag/gpu_mm_variants_equal.py): 0 selects the workgroup-per-matrix forward kernel for N <= 64, whose
 // results the wave-per-matrix kernel reproduces bit for bit
 // bit 1: keep both products of a matrix in one workgroup even when an order is given; bit 2: ignore the order (tools/gpu_mm_big_probe.py)
-int g_mm_wave_variant = 1;
-inline bool mm_wave_variant() { return (g_mm_wave_variant & 1) != 0; }
-inline bool mm_no_split() { return (g_mm_wave_variant & 2) != 0; }
-inline bool mm_no_order() { return (g_mm_wave_variant & 4) != 0; }
 
 }  // namespace
 

@@ -379,7 +379,8 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J, in
     const fgnn_grad_job &jb = J.job[blockIdx.y];
     const int nblk = (jb.count + 63) / 64;
     if ((int)blockIdx.x < nblk) {
-        reduce_cols(jb.wpart, jb.rows > 0 ? jb.rows : num_wg, jb.count, jb.scale != 0.f ? jb.scale : 1.f, jb.out, blockIdx.x, sm);
+        reduce_cols(jb.wpart, jb.rows > 0 ? jb.rows : num_wg, jb.count, (jb.scale != 0.f ? jb.scale : 1.f) * (jb.scale_dev ? *jb.scale_dev : 1.f), jb.out,
+                    blockIdx.x, sm);
     } else if ((int)blockIdx.x == gridDim.x - 1 && jb.s12) {
         affine_reduce(jb.s12, jb.nrm, G, C, jb.dgn_w, jb.dgn_b, sm);
     }
@@ -418,6 +419,22 @@ __global__ __launch_bounds__(256) void pack_operands_kernel(const PackJobs J) {
 }
 
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(64) void inv_node_count_kernel(const int *nvalid, int B, float *out) {
+    int s = 0;
+    for (int b = threadIdx.x; b < B; b += 64) s += nvalid[b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[0] = s > 0 ? 1.f / (float)s : 0.f;
+}
+}  // namespace
+
+extern "C" int fgnn_inv_node_count(const int *nvalid, int B, float *out, void *stream) {
+    FGNN_CHECK(nvalid && out && B > 0, "fgnn_inv_node_count: bad arguments");
+    hipLaunchKernelGGL(inv_node_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nvalid, B, out);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp) {
     return kind == 0 ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;

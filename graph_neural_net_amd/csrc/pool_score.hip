@@ -476,24 +476,31 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
 // launch), the row log-sum-exps and dS = (exp(S - lse) - I) gscale, then produces de1 / de2 of ITS channels; workgroup y = 0 also
 // writes scores, lse and the pair-loss partials.  Arithmetic and summation orders are those of score_ce_fwd_kernel +
 // score_bwd_kernel<true, true>: results are bit-identical to the two launches (tests/test_gpu_kernels.py).
-__global__ __launch_bounds__(256) void score_ce_step_kernel(const float *e1, const float *e2, const int *nvalid, const float *gscale,
-                                                            int C, int N, int row_blocks, float *scores, float *lse, float *pair_loss,
-                                                            float *de1, float *de2) {
+constexpr int STEP_THREADS = 1024;       // 16 waves: the row pass (one wave per row, as in score_ce_fwd_kernel) is 4 rows deep at N = 50
+__global__ __launch_bounds__(STEP_THREADS) void score_ce_step_kernel(const float *e1, const float *e2, const int *nvalid,
+                                                                     const float *gscale, int C, int N, int row_blocks, float *scores,
+                                                                     float *lse, float *pair_loss, float *de1, float *de2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *s1 = sm, *s2 = sm + (size_t)C * N;
     float *dS = s2 + (size_t)C * N;            // S, then dS: [i][j], row stride N + 1
     const int ld = N + 1;
     float *term = dS + (size_t)N * ld;         // per row: lse_i - S_ii (0 beyond nv)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = STEP_THREADS, NWV = STEP_THREADS / 64;
     const int nv = nvalid_of(nvalid, b, N);
     const bool writer = blockIdx.y == 0;
-    copy_to_lds256(s1, e1 + (long long)b * C * N, C * N, tid);
-    copy_to_lds256(s2, e2 + (long long)b * C * N, C * N, tid);
+    {
+        const float *p1 = e1 + (long long)b * C * N, *p2 = e2 + (long long)b * C * N;
+        for (int e = tid; e < C * N; e += NT) {
+            s1[e] = p1[e];
+            s2[e] = p2[e];
+        }
+    }
     const float gs = *gscale;
     __syncthreads();
     float *S = scores + (long long)b * N * N;
     const float invN = 1.f / (float)N;
-    for (int e = tid; e < N * N; e += 256) {
+    for (int e = tid; e < N * N; e += NT) {
         const int i = (int)(((float)e + 0.5f) * invN), j = e - i * N;
         float acc = 0.f;
         if (i < nv && j < nv)
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(256) void score_ce_step_kernel(const float *e1, con
         dS[i * ld + j] = acc;
     }
     __syncthreads();
-    for (int i = wave; i < N; i += 4) {        // one wave per row, as in score_ce_fwd_kernel
+    for (int i = wave; i < N; i += NWV) {      // one wave per row, the arithmetic of score_ce_fwd_kernel
         float l = 0.f, t = 0.f;
         float *Sr = dS + (size_t)i * ld;
         if (i < nv) {
@@ -543,18 +550,16 @@ __global__ __launch_bounds__(256) void score_ce_step_kernel(const float *e1, con
     const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c0 = blockIdx.y * cper;
     const int cn = (c0 + cper <= C ? cper : (C > c0 ? C - c0 : 0));
-    for (int e = tid; e < cn * N; e += 256) {
-        const int c = e / N, i = e - c * N;
-        float a1 = 0.f, a2 = 0.f;
+    for (int e = tid; e < 2 * cn * N; e += NT) {       // (the two gradients of an element on two threads)
+        const int which = e >= cn * N, ee = which ? e - cn * N : e;
+        const int c = ee / N, i = ee - c * N;
+        float a = 0.f;
         if (i < nv) {
-            const float *r2 = s2 + (c0 + c) * N, *r1 = s1 + (c0 + c) * N;
-            for (int jj = 0; jj < nv; ++jj) {
-                a1 = fmaf(r2[jj], dS[i * ld + jj], a1);
-                a2 = fmaf(r1[jj], dS[jj * ld + i], a2);
-            }
+            const float *r = (which ? s1 : s2) + (c0 + c) * N;
+            if (which) for (int jj = 0; jj < nv; ++jj) a = fmaf(r[jj], dS[jj * ld + i], a);
+            else for (int jj = 0; jj < nv; ++jj) a = fmaf(r[jj], dS[i * ld + jj], a);
         }
-        de1[((long long)b * C + c0) * N + e] = a1;
-        de2[((long long)b * C + c0) * N + e] = a2;
+        (which ? de2 : de1)[((long long)b * C + c0) * N + ee] = a;
     }
 }
 
@@ -827,7 +832,7 @@ extern "C" int fgnn_score_ce_step(const float *e1, const float *e2, const int *n
     FGNN_CHECK(fgnn_score_ce_step_supported(B, C, N), "fgnn_score_ce_step: built for N <= 64, B < 64, C %% 8 == 0 (got B=%d C=%d N=%d); use "
                "fgnn_score_ce_fwd_blocks + fgnn_score_ce_bwd", B, C, N);
     const int lds = (2 * C * N + N * (N + 1) + N + 4) * (int)sizeof(float);
-    hipLaunchKernelGGL(score_ce_step_kernel, dim3(B, CSPLIT_SMALL), dim3(256), lds, (hipStream_t)stream, e1, e2, nvalid, gscale, C, N,
+    hipLaunchKernelGGL(score_ce_step_kernel, dim3(B, CSPLIT_SMALL), dim3(STEP_THREADS), lds, (hipStream_t)stream, e1, e2, nvalid, gscale, C, N,
                        row_blocks, scores, lse, pair_loss, de1, de2);
     FGNN_LAUNCH_CHECK();
     return 0;

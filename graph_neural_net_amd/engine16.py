@@ -333,9 +333,9 @@ class FgnnEngineBF16:
         W = self._alloc_bwd()
         B, N = self.B, self.N
         st = _lib.stream_ptr()
+        gs_t = W['gscale']
         if gscale_dev is not None:
-            W['gscale'].copy_(gscale_dev.reshape(1))
-            W['gscale_value'] = None
+            gs_t = gscale_dev                  # read in place (a 1-element fp32 device tensor; no copy launch)
         else:
             gs = grad_scale / self.total_nodes
             if W.get('gscale_value') != gs:
@@ -343,7 +343,7 @@ class FgnnEngineBF16:
                 W['gscale_value'] = gs
         e1, e2 = self.E[:B], self.E[B:]
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
-                  self._nv(), _lib.ptr(W['gscale']), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
+                  self._nv(), _lib.ptr(gs_t), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
         return self.backward_from_dE(params, grads, W['dE'], hook=hook)
 
     def backward_from_dE(self, params, grads, dE, hook=None):
@@ -414,6 +414,8 @@ class FgnnEngineBF16:
                     jobs[i].out = self._loss_target.data_ptr()
                     jobs[i].rows = self.B * self.score_blocks
                     jobs[i].scale = 1.0 / self.total_nodes
+                    if getattr(self, '_loss_scale_dev', None) is not None:       # 1 / sum(n) as a device scalar (forward(inv_nodes_dev=...))
+                        jobs[i].scale_dev = self._loss_scale_dev.data_ptr()
                     continue
                 rec = L.mlp[kj]
                 jobs[i].wpart = W['wpart'][kj].data_ptr()

@@ -52,6 +52,7 @@ def _unwrap_input(x):
 class Siamese_Node_Exp(nn.Module):
     MODULE_STEPS_MAX = 8        # captured module steps kept per model (fused_step through the module surface), LRU
 
+    RAGGED_GRANULE = int(__import__('os').environ.get('FGNN_RAGGED_GRANULE', '16'))    # MaskedTensor batches run padded to a multiple of this
     INPUT_CHECK_EVERY = 128     # input_form='tensor_representation': the device verdict is read back on every k-th fused_step (0: never)
 
     def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
@@ -167,7 +168,8 @@ class Siamese_Node_Exp(nn.Module):
         net._bind_flat()
         dev = t1.device
         B, nmax = t1.shape[0], t1.shape[-1]
-        N = -(-nmax // 16) * 16 if ragged else nmax
+        gran = max(1, int(self.RAGGED_GRANULE))
+        N = -(-nmax // gran) * gran if ragged else nmax
         pad = net._pad
         c0e = pad['c0p'] if pad is not None else t1.shape[1]
         if tuple(t1.shape) != tuple(t2.shape):
@@ -224,11 +226,12 @@ class Siamese_Node_Exp(nn.Module):
             params = net._engine_params()                # the bound flat buffer, or its zero-padded image (an index_copy_)
             grads = net._flat_grad if pad is None else pad['pgrad']
             if ragged:
-                # 1 / sum(n) on the device; the engine back-propagates sum-of-pair-losses * gscale and leaves the un-normalised loss
-                torch.reciprocal(st['nv'][:B].sum().to(torch.float32).reshape(1), out=st['inv'])
+                # 1 / sum(n) on the device (one tiny launch): the scoring backward reads it as its gradient scale and the loss job of
+                # the gradient-finalize launch multiplies it in -- no copy, no host round trip, nothing of the batch in the graph
+                _lib.call('fgnn_inv_node_count', _lib.ptr(st['nv']), B, _lib.ptr(st['inv']), _lib.stream_ptr())
+                eng._loss_scale_dev = st['inv']
                 scores, loss = eng.forward(params, xin, nvalid=st['nv'], total_nodes=1.0, defer_loss=True, bits=bits)
                 eng.backward(params, grads, gscale_dev=st['inv'])
-                loss.mul_(st['inv'])
             else:
                 scores, loss = eng.step(params, grads, xin, bits=bits)
             if pad is not None:

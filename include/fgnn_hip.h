@@ -380,8 +380,14 @@ typedef struct {
     const float *s12; const float *nrm; float *dgn_w; float *dgn_b;
     int rows;      /* rows of wpart to sum; 0 = num_wg (the MLP backward partials) */
     float scale;   /* factor applied to the sums; 0 = 1 (lets the loss = sum pair_loss / nodes ride along) */
+    const float *scale_dev;   /* optional device scalar multiplied in as well (1 / sum(n) of a ragged batch computed on the device:
+                                 fgnn_inv_node_count) */
 } fgnn_grad_job;
 int fgnn_grad_finalize(const fgnn_grad_job *jobs, int njobs, int num_wg, int G, int C, void *stream);
+/* out[0] = 1 / sum_{b < B} nvalid[b] (0 if the sum is 0): the normaliser of triplet_loss('mean') on a ragged batch
+ * (toolbox/losses.py:27-34) as a device scalar -- fgnn_score_ce_bwd's gscale and fgnn_grad_job.scale_dev read it, so a captured step
+ * serves batches of any node count without a host round trip. */
+int fgnn_inv_node_count(const int *nvalid, int B, float *out, void *stream);
 
 /* Matmul backward: da = dm @ Yb^T, db = Ya^T @ dm per (g,c) (autograd of layers.py:161-162) */
 int fgnn_chan_matmul_bwd(const fgnn_slab *ya, const fgnn_slab *yb, const float *dm, long long dmgstride, long long ldm,

@@ -386,10 +386,12 @@ def test_expand_adjacency_bit_exact():
     assert torch.equal(x.cpu(), torch.from_numpy(ref))
 
 
-@pytest.mark.parametrize('N', [1, 7, 32, 33, 50, 64])
+@pytest.mark.parametrize('N', [1, 7, 32, 33, 34, 40, 49, 50, 58, 64])
 def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel(N):
-    """The shipped N <= 64 forward (one wave per matrix) keeps the k-step order and the normalisation expression of the
-    workgroup-per-matrix kernel it replaced: outputs must be equal bit for bit (dense and ragged, normalised operands)."""
+    """The shipped N <= 64 forward (one wave per matrix; for even N > 32 with 8-byte accesses and the even / odd column blocks of
+    chan_matmul_fwd_w2_kernel) keeps the k-step order and the normalisation expression of the workgroup-per-matrix kernel it
+    replaced: outputs must be equal bit for bit (dense and ragged with odd and even vertex counts, normalised operands; the
+    untouched output is poisoned with NaN first).  Variants: 1 = shipped, 9 = the four-byte wave kernel, 0 = the workgroup kernel."""
     lib = _lib.load()
     G, Cc = 3, 5
     g = torch.Generator().manual_seed(N)
@@ -399,19 +401,27 @@ def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel
     nrm_b = (torch.rand(G, Cc, 4, generator=g) + 0.5).to(DEV)
     beta = torch.randn(Cc, generator=g).to(DEV)
     nv = torch.tensor([N, max(1, N // 2), max(0, N - 1)], dtype=torch.int32, device=DEV)
+    # ragged planes: what lies outside a graph's valid corner is garbage the wave kernels must not look at (the workgroup kernel
+    # they replaced gets the same operands with that garbage zeroed)
+    ap, bp = a.clone(), b.clone()
+    for gi, n in enumerate(nv.tolist()):
+        for t, fill in ((ap, float('nan')), (bp, float('nan')), (a, 0.0), (b, 0.0)):
+            t[gi, :, n:, :] = fill
+            t[gi, :, :, n:] = fill
     res = []
     try:
-        for variant in (1, 0):
+        for variant in (1, 0, 9):
             lib.fgnn_debug_matmul_variant(variant)
-            out = torch.full((G, Cc, N, N), 3.0, device=DEV)
-            sa, sb = _slab(a, nrm=nrm_a, beta=beta), _slab(b, nrm=nrm_b, beta=beta)
+            out = torch.full((G, Cc, N, N), float('nan'), device=DEV)
+            ua, ub = (a, b) if variant == 0 else (ap, bp)
+            sa, sb = _slab(ua, nrm=nrm_a, beta=beta), _slab(ub, nrm=nrm_b, beta=beta)
             _lib.call('fgnn_chan_matmul_fwd', C.byref(sa), C.byref(sb), _lib.ptr(nv), G, N, _lib.ptr(out), Cc * N * N, N * N,
                       _lib.stream_ptr())
             torch.cuda.synchronize()
             res.append(out.cpu())
     finally:
         lib.fgnn_debug_matmul_variant(1)
-    assert torch.equal(res[0], res[1])
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
     # padding rows / columns of the ragged graphs are exact zeros
     for gi, n in enumerate(nv.tolist()):
         assert float(res[0][gi, :, n:, :].abs().max()) == 0.0 if n < N else True
