@@ -787,14 +787,18 @@ template <bool FIN>
 int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int N, int M, float *out, long long ogstride,
                  long long ldo, const FinArgs &F, hipStream_t st) {
     const int KQ = (N + 7) / 8, grid = (M + W_WAVES - 1) / W_WAVES;
-    if (KQ > 4 && !mm_narrow() && (N & 1) == 0) {      // (odd N: a column pair would straddle two rows -> the four-byte kernel)
+    // Measured (tools/gpu_mm_wide_probe.py, profiles/r05_mm_wide_probe.txt: 30 back-to-back launches in a replayed graph, 64 x 32 matrices):
+    // N = 64: 21.8 - 22.4 us against 25.0 for the four-byte kernel; N = 50: 16.4 - 17.3 against 16.0 - 16.2; N = 40: 13.3 against 12.7 --
+    // the instruction count is not what limits the kernel below N ~ 58 (it moves its 61 MB at the ~4 TB/s this part reads at), so
+    // the eight-byte form runs where it wins: KQ = 8, even N (an odd N would let a column pair straddle two rows).
+    if (KQ == 8 && !mm_narrow() && (N & 1) == 0) {
 #define FGNN_W2(K_)                                                                                                       \
     case K_:                                                                                                             \
         hipLaunchKernelGGL((chan_matmul_fwd_w2_kernel<K_, FIN>), dim3(grid), dim3(64 * W_WAVES), 0, st, *ya, *yb, nvalid, N, \
                            M, out, ogstride, ldo, F);                                                                    \
         break;
         switch (KQ) {
-            FGNN_W2(5) FGNN_W2(6) FGNN_W2(7) FGNN_W2(8)
+            FGNN_W2(8)
         }
 #undef FGNN_W2
         return 0;

@@ -159,7 +159,10 @@ class FgnnEngine:
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges + tile skipping in fgnn_mlp_fwd / fgnn_mlp_bwd
     MM_ORDER = True               # ragged engines: longest-job-first order of the whole-matrix per-channel products
     PAIR_BWD = os.environ.get('FGNN_PAIR_BWD', '1') != '0'      # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd_pair)
-    SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '1') != '0'  # step(): scoring + loss + their backward as one launch (fgnn_score_ce_step)
+    # step(): scoring + loss + their backward as ONE launch (fgnn_score_ce_step, bit-identical to the two).  Off by default: measured in
+    # the replayed cfg2 step at 13.7 us against 5.8 + 7.0 us for the two launches it replaces (profiles/r05_c_graph_timeline.txt) --
+    # every workgroup of a pair repeats the score matrix and the row log-sum-exps, and inside a graph a launch boundary costs nothing
+    SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '0') != '0'
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')

@@ -52,7 +52,9 @@ def _unwrap_input(x):
 class Siamese_Node_Exp(nn.Module):
     MODULE_STEPS_MAX = 8        # captured module steps kept per model (fused_step through the module surface), LRU
 
-    RAGGED_GRANULE = int(__import__('os').environ.get('FGNN_RAGGED_GRANULE', '16'))    # MaskedTensor batches run padded to a multiple of this
+    # MaskedTensor batches run padded to a multiple of this (batches whose largest graphs fall in the same granule replay ONE graph; cfg5
+    # through fused_step: 0.861 ms at 8, 0.876 at 16, engine on the exact size 0.846 -- profiles/r05_cfg5_surface.txt)
+    RAGGED_GRANULE = int(__import__('os').environ.get('FGNN_RAGGED_GRANULE', '8'))
     INPUT_CHECK_EVERY = 128     # input_form='tensor_representation': the device verdict is read back on every k-th fused_step (0: never)
 
     def __init__(self, original_features_num, node_emb, lr=1e-3, scheduler_decay=0.5, scheduler_step=3, lr_stop=1e-5,
@@ -135,7 +137,7 @@ class Siamese_Node_Exp(nn.Module):
 
         Takes whatever the reference's loaders yield (loaders/loaders.py:5-15): tensors or {'input': T} dicts of constant-size
         batches, and MaskedTensor batches (both sides sharing the per-pair vertex counts).  A ragged batch runs zero-padded to its
-        largest graph rounded up to a multiple of 16 (so batches of nearby sizes replay the same graph); the vertex counts and
+        largest graph rounded up to a multiple of RAGGED_GRANULE = 8 (so batches of nearby sizes replay the same graph); the vertex counts and
         the loss normaliser 1 / sum(n) (toolbox/losses.py:27-34) live in device buffers that each call overwrites -- nothing
         about a batch is baked into the captured graph but its padded shape.  Models narrower than the engine (widths below 32,
         1 or 3..31 input channels) run on zero-padded parameters (Network._padded_layout): the scatter of the parameters and the
