@@ -351,6 +351,14 @@ def main():
                               'input': sub['config']['input'], 'block1': sub['config']['block1'],
                               'roofline': {k: sub['roofline'][k] for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')
                                            if sub['roofline'] and k in sub['roofline']}}
+    if rank == 0 and world == 1 and args.config == 'cfg2' and args.path == 'engine' and args.mfma is None and args.precision is None \
+            and not args.no_extra_configs:
+        # the same step with mlp1 / mlp2 on the bf16 matrix cores through the exact three-way operand split (--mfma x3; opt-in: it
+        # draws more power, the part runs at its package power limit and clocks ~4 % lower under it, so its gain -- 0 ... 45 us per
+        # step -- depends on the box: DESIGN.md section 7, round 5); measured here so that the record holds both on the same box
+        sub = run_config(args, args.config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), mfma='x3', profile=False)
+        out['mfma_x3'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'], 'ms_per_step_min': sub['ms_per_step_min'],
+                          'ms_per_step_max': sub['ms_per_step_max'], 'mlp_contraction': sub['config']['mlp_contraction']}
     if rank == 0 and world == 1 and args.path == 'engine' and not args.no_extra_configs and out['config'].get('block1', 'generic') != 'generic':
         # ... and through the module surface a user of the reference calls (dense loader batch in, fused_step)
         out['module_surface'] = module_surface_leg(args, args.config, rank, world, dev, out['ms_per_step'])
@@ -442,12 +450,13 @@ def module_surface_leg(args, config, rank, world, dev, engine_ms):
 
 
 def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=None, input_form=None, path=None,
-               module_input_form=None, profile=True):
+               module_input_form=None, profile=True, mfma=None):
     """One measurement: build the workload of `config`, capture the step, settle, warm up, time `windows` windows of
     exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0).
     block1 / input_form: override --block1 / --input (the dense-input line reported beside the headline); path /
     module_input_form: override --path / --module-input-form (module_surface_leg)."""
     windows = args.windows if windows is None else windows
+    mfma_arg = mfma
     precision = args.precision if config == args.config else None
     dense_er = config == 'cfg4'                   # the workload
     ragged = config == 'cfg5'                     # variable-N pairs, n in [30, N], one batch padded to its largest graph
@@ -484,7 +493,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                 b1 = 'structured' if (not (same and args.input == 'dense') and path == 'engine') else 'generic'
             return FgnnEngineBF16(layout, 2 * B, N, dev, ragged=ragged, block1=b1)
         chains = args.chains if (same and args.chains is not None) else 1
-        mfma = args.mfma if (same and args.mfma is not None) else None
+        mfma = mfma_arg if mfma_arg is not None else (args.mfma if (same and args.mfma is not None) else None)
         if chains == 2:
             from graph_neural_net_amd.engine_dual import FgnnEngineDual
             return FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
