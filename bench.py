@@ -708,13 +708,15 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         by, fl = kernel_model(dom, 2 * B, N, pix, cube)
         eager_ms = summary[dom]['avg_ms']
         # What that kernel costs INSIDE the replayed step (eager launches with events around them run 5-10 % longer: launch gaps, another
-        # clock state): >= 20 back-to-back launches of the dominant kernel in a replayed HIP graph, cycling through every launch of that
-        # kernel in a step (blocks 4, 3, 2 ...) of THREE engines' workspaces, so that no operand is served from the caches of the
-        # launch before -- the protocol of tools/gpu_mm_ablate.py.  Falls back to the eager figure if the capture fails.
+        # clock state): >= 24 back-to-back launches of the dominant kernel in a replayed HIP graph, cycling through every launch of that
+        # kernel in the step (blocks 4, 3, 2 ...: distinct operand sets of this engine's workspace, > 400 MB in rotation at cfg2) -- the
+        # protocol of tools/gpu_mm_ablate.py.  (Rotating THREE engines' workspaces -- nothing warm anywhere -- measures 70.5 us where the
+        # kernel trace of the replayed step shows 67.6: in the step dy1 / dy2 were written by the launch before.)  Falls back to the
+        # eager figure if the capture fails.
         ingraph = None
         if path == 'engine':
             try:
-                ingraph = time_in_graph(dom, [eng] + [make_engine() for _ in range(2)], engine_work)
+                ingraph = time_in_graph(dom, [eng], engine_work)
             except Exception as exc:          # noqa: BLE001 -- the eager figure stands
                 print('bench.py: in-graph timing of %s failed (%s); roofline from eager events' % (dom, exc), file=sys.stderr)
                 torch.cuda.synchronize()
