@@ -160,8 +160,6 @@ _SIGNATURES = {
     'fgnn_score_row_blocks': [_I, _I],
     'fgnn_score_ce_fwd_blocks': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_bwd': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
-    'fgnn_score_ce_bwd_s12_supported': [_I, _I, _I],
-    'fgnn_score_ce_bwd_s12': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_score_ce_step_supported': [_I, _I, _I],
     'fgnn_inv_node_count': [_VP, _I, _VP, _VP],
     'fgnn_score_ce_step': [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP],

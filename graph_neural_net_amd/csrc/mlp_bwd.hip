@@ -315,9 +315,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     // perturbs the register allocation of the tile loop (0 -> 40 spilled SGPRs in <32,0,3>)
     // POOL: the sums come from the pooled gradient itself, S1 = sum_i dE[c][i], S2 = sum_i dE[c][i] (z[c][i][idx[c][i]] - mean) -- what
     // fgnn_colmax_bwd computed while it wrote the dy slab this kernel no longer reads
-    // (measured at cfg2: the in-prologue sums cost the launch 10 us -- two dependent cold round trips in front of the first tile; with
-    // A.s12 given -- fgnn_score_ce_bwd_s12 forms the sums from the embeddings it holds anyway -- the prologue is the ordinary one)
-    const bool from_tiles = (CB > 0) && ((POOL && A.s12 == nullptr) || A.s12tiles != nullptr);
+    const bool from_tiles = (CB > 0) && (POOL || A.s12tiles != nullptr);
     float *wgK = tiles + L::TILE_F_ALL;
     const int g0 = T0 / tpg;
 
@@ -897,9 +895,9 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(a->dy && a->z && a->wpart, "fgnn_mlp_bwd: missing dy/z/wpart");
     FGNN_CHECK(a->coef || (a->s12 && a->znrm) || (a->s12tiles && a->znrm) || (a->pool_idx && a->znrm),
                "fgnn_mlp_bwd: need coef, or s12 + znrm, or s12tiles + znrm, or pool_idx + znrm");
-    FGNN_CHECK(!a->pool_idx || (!a->ranges && !a->coef && !a->s12tiles && (a->s12 || fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N))),
-               "fgnn_mlp_bwd: pool_idx is built for constant-size batches, with the dz coefficients derived in the kernel from s12 + znrm or, "
-               "without s12, from the pooled gradient itself (workgroup tile ranges spanning <= %d graphs); no coef / s12tiles", FGNN_BWD_COEF_GRAPHS);
+    FGNN_CHECK(!a->pool_idx || (!a->ranges && !a->coef && !a->s12 && !a->s12tiles && fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N)),
+               "fgnn_mlp_bwd: pool_idx is built for constant-size batches whose workgroup tile ranges span <= %d graphs, with the dz "
+               "coefficients derived in the kernel (no coef / s12 / s12tiles)", FGNN_BWD_COEF_GRAPHS);
     {
         const long long lim = 0x7fffffffll / 4, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&

@@ -402,20 +402,10 @@ __global__ __launch_bounds__(256) void score_ce_fwd_kernel(const float *e1, cons
 // grid (B, splits): every workgroup stages dS (N x N) once in LDS and handles C / gridDim.y channels.
 constexpr int CSPLIT = 4;          // channel splits of the blocked kernel and of large batches
 constexpr int CSPLIT_SMALL = 8;    // whole-dS staging at small batch (B * 4 < 256 workgroups)
-// S12: the embeddings came out of ColumnMaxPooling over a GraphNorm output (models/blocks_emb.py:38-43), y = a (z - mean) + beta; the
-// GraphNorm-backward sums of that MLP over the pooled gradient, S1 = sum_i dE[c][i] and S2 = sum_i dE[c][i] (z[c][i][idx] - mean), follow
-// from what this workgroup holds: (z - mean) at the arg-max is (E - beta) / a.  Written to s12 (G, C, 2) for graph b (from de1 / e1) and
-// graph B + b (de2 / e2); S2 = 0 where a = 0 (then dz = 0 whatever S2 is).
-struct PoolS12 {
-    const float *nrm;     // (G, C, 4) GraphNorm records {mean, a, q, r2} of the pooled MLP
-    const float *beta;    // (C) or nullptr = 0
-    float *s12;           // (G, C, 2) out, or nullptr: off
-    int B;
-};
 template <bool CE, bool STAGE>
 __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const float *e2, const float *scores,
                                                         const float *lse, const float *dscores, const int *nvalid,
-                                                        const float *gscale, int C, int N, float *de1, float *de2, const PoolS12 PS) {
+                                                        const float *gscale, int C, int N, float *de1, float *de2) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int cper = (C + (int)gridDim.y - 1) / (int)gridDim.y;
     const int c0 = blockIdx.y * cper;
@@ -478,29 +468,6 @@ __global__ __launch_bounds__(256) void score_bwd_kernel(const float *e1, const f
         }
         de1[((long long)b * C + c0) * N + e] = a1;
         de2[((long long)b * C + c0) * N + e] = a2;
-    }
-    if (STAGE && PS.s12) {
-        __syncthreads();                                   // every thread is done with dS: its space takes the two gradients
-        float *t1 = dS, *t2 = dS + (size_t)cn * N;
-        for (int e = tid; e < cn * N; e += 256) {          // (re-read what this thread just stored: L1 / L2 hits)
-            t1[e] = de1[((long long)b * C + c0) * N + e];
-            t2[e] = de2[((long long)b * C + c0) * N + e];
-        }
-        __syncthreads();
-        if (tid < 4 * cn) {
-            const int c = tid >> 2, side = (tid >> 1) & 1, k = tid & 1;      // side 0: graph b (e1), 1: graph B + b (e2)
-            const int g = side ? PS.B + b : b;
-            const float *t = (side ? t2 : t1) + c * N, *ev = (side ? s2 : s1) + c * N;
-            const float a = PS.nrm[((long long)g * C + c0 + c) * 4 + 1], beta = PS.beta ? PS.beta[c0 + c] : 0.f;
-            float acc = 0.f;
-            if (k == 0) {
-                for (int i = 0; i < nv; ++i) acc += t[i];
-            } else if (a != 0.f) {
-                const float ia = 1.f / a;
-                for (int i = 0; i < nv; ++i) acc = fmaf(t[i], (ev[i] - beta) * ia, acc);
-            }
-            PS.s12[((long long)g * C + c0 + c) * 2 + k] = acc;
-        }
     }
 }
 
@@ -789,13 +756,12 @@ extern "C" int fgnn_colmax_bwd(const float *de, const int *idx, const int *nvali
 static int score_lds_bytes(int C, int N) { return (2 * C * N + 4) * (int)sizeof(float); }
 static int score_bwd_lds_bytes(int C, int N, bool stage, int csplit = CSPLIT) {
     const int cper = (C + csplit - 1) / csplit;
-    const int ds = N * (N + 1) > 2 * cper * N ? N * (N + 1) : 2 * cper * N;      // (the pooled-gradient sums re-use dS for 2 cper N floats)
-    return (2 * cper * N + (stage ? ds : 0)) * (int)sizeof(float);
+    return (2 * cper * N + (stage ? N * (N + 1) : 0)) * (int)sizeof(float);
 }
 template <bool CE>
 static int launch_score_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
                             const float *dscores, const int *nvalid, const float *gscale, int B, int C, int N,
-                            float *de1, float *de2, hipStream_t st, const PoolS12 PS = PoolS12{}) {
+                            float *de1, float *de2, hipStream_t st) {
     // whole-dS staging gives only B x CSPLIT workgroups: with few large pairs (N > 64) the blocked kernel fills the chip better
     const bool stage = score_bwd_lds_bytes(C, N, true) <= 160 * 1024 && (N <= 64 || (long long)B * CSPLIT >= 256);
     const int csplit = (long long)B * CSPLIT < 256 ? CSPLIT_SMALL : CSPLIT;
@@ -805,9 +771,8 @@ static int launch_score_bwd(const float *e1, const float *e2, const float *score
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)score_bwd_kernel<CE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((score_bwd_kernel<CE, true>), dim3(B, csplit), dim3(256), lds, st, e1, e2, scores, lse, dscores,
-                           nvalid, gscale, C, N, de1, de2, PS);
+                           nvalid, gscale, C, N, de1, de2);
     } else {
-        FGNN_CHECK(!PS.s12, "score backward: the pooled-gradient sums (s12) are built into the whole-dS kernel (N <= 64)");
         const int cper = (C + CSPLIT - 1) / CSPLIT;
         // 16-wide blocks when the batch is small (N = 200, B = 8: 8 x 4 x 13 workgroups instead of 8 x 4 x 4)
         const int SB_BLK = (long long)B * CSPLIT * ((N + 63) / 64) >= 512 ? 64 : 16;
@@ -853,19 +818,6 @@ extern "C" int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *
                                  void *stream) {
     FGNN_CHECK(e1 && e2 && scores && lse && gscale && de1 && de2 && B > 0, "fgnn_score_ce_bwd: bad arguments");
     return launch_score_bwd<true>(e1, e2, scores, lse, nullptr, nvalid, gscale, B, C, N, de1, de2, (hipStream_t)stream);
-}
-
-extern "C" int fgnn_score_ce_bwd_s12_supported(int B, int C, int N) {
-    return (N <= 64 && score_bwd_lds_bytes(C, N, true) <= 160 * 1024) ? 1 : 0;
-}
-
-extern "C" int fgnn_score_ce_bwd_s12(const float *e1, const float *e2, const float *scores, const float *lse, const int *nvalid,
-                                     const float *gscale, int B, int C, int N, float *de1, float *de2, const float *nrm, const float *beta,
-                                     float *s12, void *stream) {
-    FGNN_CHECK(e1 && e2 && scores && lse && gscale && de1 && de2 && nrm && s12 && B > 0, "fgnn_score_ce_bwd_s12: bad arguments");
-    FGNN_CHECK(fgnn_score_ce_bwd_s12_supported(B, C, N), "fgnn_score_ce_bwd_s12: built for N <= 64 (got %d); use fgnn_score_ce_bwd + fgnn_colmax_bwd", N);
-    const PoolS12 PS = {nrm, beta, s12, B};
-    return launch_score_bwd<true>(e1, e2, scores, lse, nullptr, nvalid, gscale, B, C, N, de1, de2, (hipStream_t)stream, PS);
 }
 
 extern "C" int fgnn_score_ce_step_supported(int B, int C, int N) {

@@ -587,7 +587,7 @@ class FgnnEngine:
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
         if coef == 'pool':
             args.pool_idx = self.idx.data_ptr()
-            args.s12 = W['s12'][(k, j)].data_ptr()
+            args.s12_out = W['s12'][(k, j)].data_ptr()
             args.znrm = self.nrm[(k, j)].data_ptr()
         elif isinstance(coef, str):
             args.s12tiles = W['s12part'].data_ptr()
@@ -633,25 +633,9 @@ class FgnnEngine:
         else:
             self._set_gscale(grad_scale / self.total_nodes)
         e1, e2 = self.E[:B], self.E[B:]
-        if self._pool_in_mlp(None):
-            # ... with the GraphNorm-backward sums of the pooled MLP formed from the embeddings (no fgnn_colmax_bwd launch, no dy slab)
-            K = self.layout.num_blocks
-            rec = self.layout.mlp[(K, 3)]
-            _lib.call('fgnn_score_ce_bwd_s12', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse), self._nv(),
-                      _lib.ptr(gs_t), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), _lib.ptr(self.nrm[(K, 3)]),
-                      C.c_void_p(self._w(params, rec['gn_b'])), _lib.ptr(W['s12'][(K, 3)]), st, tag='fgnn_score_ce_bwd')
-            return self.backward_from_dE(params, grads, W['dE'], finalize=finalize, pool_s12=True)
         _lib.call('fgnn_score_ce_bwd', _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(self.scores), _lib.ptr(self.lse),
                   self._nv(), _lib.ptr(gs_t), B, 32, N, _lib.ptr(W['dE'][:B]), _lib.ptr(W['dE'][B:]), st)
         return self.backward_from_dE(params, grads, W['dE'], finalize=finalize)
-
-    def _pool_in_mlp(self, dx):
-        """The pooling's backward inside the last mlp3 backward (fgnn_mlp_bwd_args.pool_idx, S1 / S2 from fgnn_score_ce_bwd_s12): dy =
-        [j == idx] dE is built per tile -- no 20 MB dy slab written and read, no fgnn_colmax_bwd launch.  Constant-size batches of
-        N <= 64, more than one block (32 + 32 input channels), depth 3, no input gradient."""
-        L = self.layout
-        return (self.POOL_BWD and L.num_blocks > 1 and L.depth == 3 and self.ranges is None and self.nvalid is None and dx is None
-                and bool(_lib.load().fgnn_score_ce_bwd_s12_supported(self.B, 32, self.N)))
 
     def _set_gscale(self, gs):
         W = self._bwd
@@ -659,7 +643,7 @@ class FgnnEngine:
             W['gscale'].fill_(gs)
             W['gscale_value'] = gs
 
-    def backward_from_dE(self, params, grads, dE, finalize=True, dx=None, pool_s12=False):
+    def backward_from_dE(self, params, grads, dE, finalize=True, dx=None):
         """Backward of the node embedder given d loss / d E  (G, 32, N).
         dx: optional zero-initialised (G, c0, N, N) fp32 tensor that receives the gradient with respect to the input x (the
         reference's autograd gives it whenever the input requires grad; dense inputs and the fp32-MFMA kernels only).
@@ -679,9 +663,11 @@ class FgnnEngine:
         in_prologue = bool(_lib.load().fgnn_mlp_bwd_coef_tiles_supported(self.G, self.N)) and self.ranges is None
         dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
-        pool_in_mlp = pool_s12 and self._pool_in_mlp(dx) and dE.is_contiguous() and dE.dtype == torch.float32
-        # (pool_s12: W['s12'][(K, 3)] already holds the pooled-gradient sums, left by fgnn_score_ce_bwd_s12 in backward(); a dE that
-        # comes from somewhere else -- the module path's autograd -- takes fgnn_colmax_bwd)
+        # The pooling's backward inside the last mlp3 backward (fgnn_mlp_bwd_args.pool_idx): dy = [j == idx] dE is built per tile and
+        # S1 / S2 of that GraphNorm in the kernel's prologue -- no 20 MB dy slab written and read, one launch less.  Constant-size
+        # batches, 32 + 32 input channels (more than one block), depth 3, no input gradient.
+        pool_in_mlp = (self.POOL_BWD and K > 1 and L.depth == 3 and self.ranges is None and dx is None and in_prologue
+                       and dE.is_contiguous() and dE.dtype == torch.float32)
         if not pool_in_mlp:
             _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
                       _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)

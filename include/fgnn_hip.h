@@ -268,13 +268,6 @@ int fgnn_score_ce_fwd_blocks(const float *e1, const float *e2, const int *nvalid
 int fgnn_score_ce_bwd(const float *e1, const float *e2, const float *scores, const float *lse,
                       const int *nvalid, const float *gscale, int B, int C, int N,
                       float *de1, float *de2, void *stream);
-/* fgnn_score_ce_bwd that ALSO leaves the GraphNorm-backward sums of the MLP whose output was max-pooled into e1 / e2
- * (models/blocks_emb.py:38-43): s12 (G = 2 B, C, 2) = {sum_i dE[c][i], sum_i dE[c][i] (z[c][i][idx[c][i]] - mean)} with (z - mean) at the
- * arg-max recovered from the embedding, (E - beta) / a (nrm: that MLP's records (G, C, 4); beta (C) or NULL) -- what fgnn_colmax_bwd
- * computes while writing the dy slab; with fgnn_mlp_bwd_args.pool_idx neither that slab nor that launch is needed.  N <= 64. */
-int fgnn_score_ce_bwd_s12_supported(int B, int C, int N);
-int fgnn_score_ce_bwd_s12(const float *e1, const float *e2, const float *scores, const float *lse, const int *nvalid, const float *gscale,
-                          int B, int C, int N, float *de1, float *de2, const float *nrm, const float *beta, float *s12, void *stream);
 /* Scoring forward + triplet loss + their backward in ONE launch -- what a training step issues back to back (models/trainers.py:60-76:
  * `loss = self.loss(self(x1, x2))` followed at once by autograd's first two nodes): the outputs of fgnn_score_ce_fwd_blocks (scores,
  * lse, pair_loss with `row_blocks` partial sums per pair) AND of fgnn_score_ce_bwd (de1, de2; gscale as there), bit-identical to

@@ -665,43 +665,6 @@ def test_pair_backward_equals_the_two_launches_it_replaces(B, N, bits):
     assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
 
 
-@pytest.mark.parametrize('B,N,blocks,struct', [(4, 50, 4, False), (32, 50, 4, True), (3, 33, 2, False), (2, 64, 2, True), (5, 7, 3, False), (2, 1, 2, False)])
-def test_pooling_backward_inside_the_last_mlp3_backward(B, N, blocks, struct):
-    """POOL_BWD: fgnn_score_ce_bwd_s12 (the GraphNorm-backward sums of the pooled MLP from the embeddings, (z - mean) at the arg-max =
-    (E - beta) / a) + fgnn_mlp_bwd_args.pool_idx (dy = [j == idx] dE built per tile) against fgnn_score_ce_bwd + fgnn_colmax_bwd + the
-    slab-reading backward: same forward bit for bit; the sums agree to fp32 rounding (another evaluation of z - mean and another
-    summation order), every gradient to 1e-5."""
-    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
-    sd = {k: v for k, v in sd.items() if int(k.split('block')[1].split('_')[0]) <= blocks}
-    lay = ParamLayout(2, blocks, 32, 32, 3)
-    params = lay.flatten(sd, DEV)
-    x1, x2 = synthetic.make_batch(900 + N, B, N, 'ErdosRenyi', 0.3, 0.1)
-    x = torch.cat([x1, x2]).contiguous()
-    packed = torch.from_numpy(synthetic.pack_adjacency(x[:, 0].numpy()).view(np.int32)).to(DEV)
-    out = []
-    for pool in (False, True):
-        old = FgnnEngine.POOL_BWD
-        FgnnEngine.POOL_BWD = pool
-        try:
-            eng = FgnnEngine(lay, 2 * B, N, DEV, block1='structured' if struct else 'generic')
-            assert eng._pool_in_mlp(None) == pool
-            g = torch.zeros_like(params)
-            sc, loss = eng.step(params, g, None if struct else x.to(DEV), bits=packed if struct else None)
-            torch.cuda.synchronize()
-            out.append((sc.clone(), loss.clone(), g.clone(), eng._bwd['s12'][(blocks, 3)].clone()))
-        finally:
-            FgnnEngine.POOL_BWD = old
-    a, b = out
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    assert rel(b[3], a[3]) < 2e-5, rel(b[3], a[3])
-    ga, gb = lay.unflatten(a[2]), lay.unflatten(b[2])
-    for k in ga:
-        if is_zero_grad(k):
-            assert gb[k].abs().max() < 1e-4
-        else:
-            assert rel(gb[k], ga[k]) < 1e-5, (k, rel(gb[k], ga[k]))
-
-
 def test_pair_backward_on_ragged_batches():
     """The pair backward with per-graph vertex counts, with and without the padding-tile skipping: block-input gradients
     (valid corners) bit-identical to the two launches, parameter gradients up to the association of partial sums."""
