@@ -71,7 +71,7 @@ class MlpBwdArgs(C.Structure):
                 ('accumulate_a', C.c_int), ('accumulate_b', C.c_int),
                 ('wpart', C.c_void_p), ('s12part', C.c_void_p), ('packed', C.c_void_p),
                 ('s12tiles', C.c_void_p), ('s12_out', C.c_void_p), ('xbits', C.c_void_p), ('xdeg', C.c_void_p),
-                ('ranges', C.c_void_p), ('cu_share', C.c_int), ('pool_idx', C.c_void_p)]
+                ('ranges', C.c_void_p), ('cu_share', C.c_int)]
 
 
 class Slab16(C.Structure):

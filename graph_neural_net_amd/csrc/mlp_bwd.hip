@@ -232,21 +232,7 @@ DEVI void load_bias(float (&dst)[16], const float *tail, int layer, int h) {
 // SKIP (ragged batches with A.ranges): the workgroup's tile range comes from fgnn_ragged_tile_ranges (equal work), the
 // waves step over tiles without a single valid pixel (they contribute nothing to the parameter gradients); the only thing
 // such a tile still delivers is an empty S1/S2 record, stored after the main loop.
-// POOL: dy is not a slab -- the MLP's output went into the column max-pooling, dy[c][i][j] = [j == idx[c][i]] dE[c][i]; a lane builds
-// its 16 values from the two (G, 32, N) arrays (rows of 4 bytes per vertex: the lanes of a tile share at most two addresses per channel)
-DEVI void load_pool16(float (&x)[16], const View &vde, const View &vidx, const TileCtx &c, int h) {
-    const int voff = c.inb ? 4 * h * vde.ld4 + 4 * c.i : OOB_OFF;
-    const int s0 = c.g * vde.gs4;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int so = s0 + ((r & 3) + 8 * (r >> 2)) * vde.ld4;
-        const int bi = __builtin_bit_cast(int, buf_load(vidx, voff, so));
-        const float d = buf_load(vde, voff, so);
-        x[r] = bi == c.jj ? d : 0.f;
-    }
-}
-
-template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false, bool POOL = false>
+template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_args A, const int tpg,
                                                               const int total_tiles) {
     static_assert(DEPTH >= 1 && DEPTH <= 3, "tile-slot plan covers depth <= 3");
@@ -260,8 +246,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     const View vb = make_view(A.b.ptr, A.b.gstride, A.b.ldp, A.G);
     PackedSrc ps = {};
     if constexpr (PK) ps = make_packed_src(A.xbits, A.xdeg, A.G, A.N);
-    const View vdy = POOL ? make_view(A.dy, (long long)FGNN_H * A.N, A.N, A.G) : make_view(A.dy, A.dgstride, A.ldd, A.G);
-    const View vpi = make_view(reinterpret_cast<const float *>(A.pool_idx), (long long)FGNN_H * A.N, A.N, A.G);
+    const View vdy = make_view(A.dy, A.dgstride, A.ldd, A.G);
     const View vz = make_view(A.z, A.zgstride, A.ldz, A.G);
     const View vdxa = make_view(A.dxa, A.dxa_gstride, A.dxa_ld, A.G);
     const View vdxb = make_view(A.dxb, A.dxb_gstride, A.dxb_ld, A.G);
@@ -313,9 +298,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     // done per workgroup for the <= FGNN_BWD_COEF_GRAPHS graphs its tile range touches)
     // compiled into the two-slab kernels only (its user is mlp3): in the single-slab variants the extra prologue code
     // perturbs the register allocation of the tile loop (0 -> 40 spilled SGPRs in <32,0,3>)
-    // POOL: the sums come from the pooled gradient itself, S1 = sum_i dE[c][i], S2 = sum_i dE[c][i] (z[c][i][idx[c][i]] - mean) -- what
-    // fgnn_colmax_bwd computed while it wrote the dy slab this kernel no longer reads
-    const bool from_tiles = (CB > 0) && (POOL || A.s12tiles != nullptr);
+    const bool from_tiles = (CB > 0) && A.s12tiles != nullptr;
     float *wgK = tiles + L::TILE_F_ALL;
     const int g0 = T0 / tpg;
 
@@ -361,36 +344,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             // eight tile records in flight per thread and pass: rolled, this loop pays one (cold) memory round trip per
             // record -- five in a row for N = 50 -- at the very start of the kernel
             constexpr int TS = (64 * NW) / 32, U = 8;
-            if constexpr (POOL) {
-                // thread (channel cc, slice sl): vertices i = sl, sl + 16, ...; two dependent round trips (idx, then z at idx)
-                const int nvg = nvalid_of(A.nvalid, g, A.N);
-                const float *dep = A.dy + ((long long)g * FGNN_H + cc) * A.N;
-                const int *ixp = A.pool_idx + ((long long)g * FGNN_H + cc) * A.N;
-                const float *zp = A.z + (long long)g * A.zgstride + (long long)cc * A.ldz;
-                const float mean = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + cc].x;
-                for (int i0 = sl; i0 < nvg; i0 += TS * U) {
-                    float d[U], zv[U];
-                    int bi[U];
-#pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const int i = i0 + TS * k, ic = i < nvg ? i : 0;
-                        d[k] = dep[ic];
-                        bi[k] = ixp[ic];
-                    }
-#pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const int i = i0 + TS * k, ic = i < nvg ? i : 0;
-                        zv[k] = zp[(long long)ic * A.N + bi[k]];
-                    }
-#pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        if (i0 + TS * k < nvg) {
-                            p1 += d[k];
-                            p2 += d[k] * (zv[k] - mean);
-                        }
-                    }
-                }
-            } else
             for (int t0 = sl; t0 < tpg; t0 += TS * U) {
                 float2 v[U];
 #pragma unroll
@@ -506,8 +459,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
             }
             // this tile's dy / z (consumed after the recompute) and, when accumulating, the
             // current dx values (consumed at the very end) fly behind the recompute MFMAs
-            if constexpr (POOL) load_pool16(dyr, vdy, vpi, c, h);
-            else load_rows16(dyr, vdy, c, h);
+            load_rows16(dyr, vdy, c, h);
             load_rows16(zr, vz, c, h);
             if constexpr (EARLY_RMW) {
                 if (rmw) load_rows16(old, vdxa, c, h);
@@ -809,14 +761,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_kernel(const fgnn_mlp_bwd_
     PH_FLUSH
 }
 
-template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false, bool POOL = false>
+template <int CA, int CB, int DEPTH, bool PK = false, bool SKIP = false>
 int launch_bwd_impl(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     constexpr int LDS = BwdLayout<CA, CB, DEPTH>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP, POOL>, LDS);
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>, LDS);
     // BWD_WG workgroups = rows of the partials buffer (fgnn_grad_finalize); cu_share == 2: half of the CUs, half the rows
-    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP, POOL>), dim3(a->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st,
+    hipLaunchKernelGGL((mlp_bwd_kernel<CA, CB, DEPTH, PK, SKIP>), dim3(a->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st,
                        *a, tpg, total);
     FGNN_LAUNCH_CHECK();
     return 0;
@@ -824,16 +776,6 @@ int launch_bwd_impl(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t 
 template <int CA, int CB, int DEPTH, bool PK = false>
 int launch_bwd(const fgnn_mlp_bwd_args *a, int tpg, int total, hipStream_t st) {
     static_assert(BWD_WG == FGNN_RANGE_WG, "fgnn_ragged_tile_ranges splits for the backward grid");
-    if constexpr (CA == 32 && CB == 32 && DEPTH == 3 && !PK) {
-        if (a->pool_idx) {
-            if (a->ranges) return launch_bwd_impl<CA, CB, DEPTH, PK, true, true>(a, tpg, total, st);
-            return launch_bwd_impl<CA, CB, DEPTH, PK, false, true>(a, tpg, total, st);
-        }
-    }
-    if (a->pool_idx) {
-        fgnn_set_error("fgnn_mlp_bwd: pool_idx is built for 32 + 32 input channels, depth 3, a dense second slab (got %d + %d, depth %d)", CA, CB, DEPTH);
-        return 1;
-    }
     if (a->ranges) return launch_bwd_impl<CA, CB, DEPTH, PK, true>(a, tpg, total, st);
     return launch_bwd_impl<CA, CB, DEPTH, PK, false>(a, tpg, total, st);
 }
@@ -893,11 +835,7 @@ extern "C" int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *a, void *stream) {
     FGNN_CHECK(!a->xbits || a->xdeg, "fgnn_mlp_bwd: xbits without xdeg (fgnn_adjacency_degree)");
     FGNN_CHECK(!(pk_a && a->dxa) && !(pk_b && a->dxb), "fgnn_mlp_bwd: no gradient with respect to the packed adjacency");
     FGNN_CHECK(a->dy && a->z && a->wpart, "fgnn_mlp_bwd: missing dy/z/wpart");
-    FGNN_CHECK(a->coef || (a->s12 && a->znrm) || (a->s12tiles && a->znrm) || (a->pool_idx && a->znrm),
-               "fgnn_mlp_bwd: need coef, or s12 + znrm, or s12tiles + znrm, or pool_idx + znrm");
-    FGNN_CHECK(!a->pool_idx || (!a->ranges && !a->coef && !a->s12 && !a->s12tiles && fgnn_mlp_bwd_coef_tiles_supported(a->G, a->N)),
-               "fgnn_mlp_bwd: pool_idx is built for constant-size batches whose workgroup tile ranges span <= %d graphs, with the dz "
-               "coefficients derived in the kernel (no coef / s12 / s12tiles)", FGNN_BWD_COEF_GRAPHS);
+    FGNN_CHECK(a->coef || (a->s12 && a->znrm) || (a->s12tiles && a->znrm), "fgnn_mlp_bwd: need coef, or s12 + znrm, or s12tiles + znrm");
     {
         const long long lim = 0x7fffffffll / 4, G = a->G;
         FGNN_CHECK(G * a->a.gstride < lim && G * a->b.gstride < lim && G * a->dgstride < lim && G * a->zgstride < lim &&

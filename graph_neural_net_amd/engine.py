@@ -163,7 +163,6 @@ class FgnnEngine:
     # the replayed cfg2 step at 13.7 us against 5.8 + 7.0 us for the two launches it replaces (profiles/r05_c_graph_timeline.txt) --
     # every workgroup of a pair repeats the score matrix and the row log-sum-exps, and inside a graph a launch boundary costs nothing
     SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '0') != '0'
-    POOL_BWD = os.environ.get('FGNN_POOL_BWD', '1') != '0'      # the pooling's backward inside the last mlp3 backward (no fgnn_colmax_bwd launch)
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -585,11 +584,7 @@ class FgnnEngine:
             args.bias[l] = self._w(params, rec['b'][l])
         args.dy, args.dgstride, args.ldd = dy.data_ptr(), gs, self.ldp
         args.z, args.zgstride, args.ldz = self.z[(k, j)].data_ptr(), gs, self.ldp
-        if coef == 'pool':
-            args.pool_idx = self.idx.data_ptr()
-            args.s12_out = W['s12'][(k, j)].data_ptr()
-            args.znrm = self.nrm[(k, j)].data_ptr()
-        elif isinstance(coef, str):
+        if isinstance(coef, str):
             args.s12tiles = W['s12part'].data_ptr()
             args.s12_out = W['s12'][(k, j)].data_ptr()
             args.znrm = self.nrm[(k, j)].data_ptr()
@@ -663,14 +658,8 @@ class FgnnEngine:
         in_prologue = bool(_lib.load().fgnn_mlp_bwd_coef_tiles_supported(self.G, self.N)) and self.ranges is None
         dy = W['dy'][0]
         out = self._slab_z(K, 3, params)
-        # The pooling's backward inside the last mlp3 backward (fgnn_mlp_bwd_args.pool_idx): dy = [j == idx] dE is built per tile and
-        # S1 / S2 of that GraphNorm in the kernel's prologue -- no 20 MB dy slab written and read, one launch less.  Constant-size
-        # batches, 32 + 32 input channels (more than one block), depth 3, no input gradient.
-        pool_in_mlp = (self.POOL_BWD and K > 1 and L.depth == 3 and self.ranges is None and dx is None and in_prologue
-                       and dE.is_contiguous() and dE.dtype == torch.float32)
-        if not pool_in_mlp:
-            _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
-                      _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
+        _lib.call('fgnn_colmax_bwd', _lib.ptr(dE), _lib.ptr(self.idx), self._nv(), self.G, 32, self.N,
+                  _lib.ptr(dy), gs, self.ldp, C.byref(out), _lib.ptr(W['s12'][(K, 3)]), st)
         for k in range(K, 0, -1):
             sin = self._slab_in(k, params)
             first = (k == 1)
@@ -684,11 +673,8 @@ class FgnnEngine:
                 din, dxs = dx, (L.c0 * self.P, self.P)
             # mlp3: inputs [mult ; in].  Last block: dz coefficients derived in-kernel from the pooling's
             # S1/S2; other blocks: from the tile partials summed by fgnn_gn_bwd_coef_tiles below.
-            if k == K and pool_in_mlp:
-                self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dE, 'pool', W['dmult'], din, False, False, dx_strides=dxs)
-            else:
-                self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
-                              None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False, dx_strides=dxs)
+            self._mlp_bwd(params, k, 3, self._slab_raw(self.mult[k]), sin, dy,
+                          None if k == K else ('tiles' if in_prologue else W['coef'][2]), W['dmult'], din, False, False, dx_strides=dxs)
             if first and self.struct1 and self.xbits is not None and dxs is None:
                 self._struct_bwd(params)
                 dy = din

@@ -348,11 +348,6 @@ typedef struct {
     int cu_share;                            /* as in fgnn_mlp_fwd_args; 2 = fgnn_mlp_bwd_num_workgroups() / 2 workgroups and rows of
                                                 wpart.  IGNORED when `ranges` is given: a ragged launch always runs the full grid
                                                 and writes fgnn_mlp_bwd_num_workgroups() rows of wpart -- size wpart for that */
-    const int *pool_idx;                     /* optional, with dy = dE (G, 32, N): the MLP's output went into ColumnMaxPooling
-                                                (models/layers.py:202-203) and its gradient is dy[c][i][j] = [j == pool_idx[g][c][i]]
-                                                dE[g][c][i] -- built per tile from the two (G, 32, N) arrays instead of read from a
-                                                (G, 32, ldp) slab that fgnn_colmax_bwd would have to write first (dgstride, ldd are ignored;
-                                                s12 of this MLP comes from fgnn_score_ce_bwd_s12).  32 + 32 input channels, depth 3 */
 } fgnn_mlp_bwd_args;
 int fgnn_mlp_bwd(const fgnn_mlp_bwd_args *args, void *stream);
 int fgnn_mlp_bwd_x3(const fgnn_mlp_bwd_args *args, void *stream);   /* the x3 form (see fgnn_mlp_fwd_x3): image of kind 1 from
