@@ -6,6 +6,7 @@
 //
 //   forward : M  = Ya @ Yb
 //   backward: dA = dM @ Yb^T,   dB = Ya^T @ dM
+#include <cstdlib>
 #include "fgnn_common.h"
 #include "fgnn_norm.h"
 
@@ -490,11 +491,16 @@ __global__ __launch_bounds__(256, 4) void chan_matmul_bwd1_kernel(const fgnn_sla
 // load is out of range and returns 0), a padding ROW of B is out of range of the per-matrix buffer descriptor
 // (reads 0; its value only meets the zero columns of A), a padding row of A (ragged batches only) is selected to 0.
 // ---------------------------------------------------------------------------------------
-int g_mm_wave_variant = 1;
+int mm_variant_from_env() {         // FGNN_MM_VARIANT: the measurement switch of fgnn_debug_matmul_variant for whole-step runs
+    const char *e = getenv("FGNN_MM_VARIANT");
+    return e ? atoi(e) : 1;
+}
+int g_mm_wave_variant = mm_variant_from_env();
 inline bool mm_wave_variant() { return (g_mm_wave_variant & 1) != 0; }
 inline bool mm_no_split() { return (g_mm_wave_variant & 2) != 0; }
 inline bool mm_no_order() { return (g_mm_wave_variant & 4) != 0; }
 inline bool mm_narrow() { return (g_mm_wave_variant & 8) != 0; }      // the four-byte-access form of the wave-per-matrix kernel
+inline bool mm_pair_per_wave() { return (g_mm_wave_variant & 16) != 0; }      // two matrices per wave (chan_matmul_fwd_wp_kernel, N = 49 ... 56)
 constexpr int WLD = 68;            // floats per row of the wave-private A tile
 constexpr int W_WAVES = 2;         // matrices (waves) per workgroup
 
@@ -783,9 +789,133 @@ __global__ __launch_bounds__(64 * W_WAVES, 2) void chan_matmul_fwd_w2_kernel(con
     }
 }
 
+// ---- two matrices per wave (round 5 measurement; fgnn_debug_matmul_variant bit 4) ------------------------------------------------
+// Half as many waves (one per SIMD, up to 512 registers), each owning the matrix pairs gc and gc + 1: the operands of BOTH are requested
+// before the first product starts, so the 112 MFMAs of the first matrix (and its stores) run while the second matrix' rows are still
+// arriving -- the overlap that one matrix per resident wave cannot have.  Same element arithmetic as
+// chan_matmul_fwd_w_kernel: bit-identical results.
+template <int KQ, bool FIN>
+__global__ __launch_bounds__(64 * W_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void chan_matmul_fwd_wp_kernel(
+    const fgnn_slab ya, const fgnn_slab yb, const int *nvalid, int N, int M, float *out, long long ogstride, long long ldo, const FinArgs F) {
+    constexpr int KH = 4 * KQ;
+    constexpr bool TWO = KQ > 4;
+    constexpr int NB = TWO ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float lds[W_WAVES * 32 * NB * WLD];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gc0 = (xcd_swizzle(blockIdx.x, gridDim.x) * W_WAVES + wv) * 2;
+    if (gc0 >= M) return;
+    const int C = ya.C;
+    const int j = lane & 31, h = lane >> 5;
+    float *As = lds + wv * (32 * NB * WLD);
+    float xa[2][8 * KQ], xb[2][NB][KH];
+    TilePartials ta[2], tb[2];
+    int gq[2], cq[2], nvq[2];
+    rsrc_t rO[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gc = gc0 + m < M ? gc0 + m : gc0;               // (an odd matrix count: the last wave repeats its matrix, same values)
+        gq[m] = gc / C;
+        cq[m] = gc - gq[m] * C;
+        nvq[m] = __builtin_amdgcn_readfirstlane(nvalid_of(nvalid, gq[m], N));
+        const int g = gq[m], c = cq[m], nv = nvq[m];
+        const rsrc_t rA = mat_rsrc(ya.ptr + (long long)g * ya.gstride + (long long)c * ya.ldp, nv * N * 4);
+        const rsrc_t rB = mat_rsrc(yb.ptr + (long long)g * yb.gstride + (long long)c * yb.ldp, nv * N * 4);
+        rO[m] = mat_rsrc(out + (long long)g * ogstride + (long long)c * ldo, N * N * 4);
+        if (FIN) {
+            ta[m] = finalize_load(F.part_a, F.cnt, g, c, C, F.tpg, lane);
+            tb[m] = finalize_load(F.part_b, F.cnt, g, c, C, F.tpg, lane);
+        }
+        wave_rows_load<KQ>(xa[m], rA, N, lane < nv ? lane * 4 : OOB_OFF);
+        int voffB[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int col = 32 * cb + j;
+            voffB[cb] = col < nv ? (h * N + col) * 4 : OOB_OFF;
+        }
+#pragma unroll
+        for (int s = 0; s < KH; ++s)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) xb[m][cb][s] = rsrc_load(rB, voffB[cb] + s * 2 * N * 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);          // every load of both matrices is issued before the first product starts
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int g = gq[m], c = cq[m], nv = nvq[m], gc = g * C + c;
+        float meanA, aA, meanB, aB;
+        if (FIN) {
+            const float4 ra = finalize_reduce(ta[m], (float)nv, F.gw_a ? F.gw_a[c] : 1.f, F.eps);
+            const float4 rb = finalize_reduce(tb[m], (float)nv, F.gw_b ? F.gw_b[c] : 1.f, F.eps);
+            if (lane == 0) {
+                reinterpret_cast<float4 *>(F.nrm_a)[gc] = ra;
+                reinterpret_cast<float4 *>(F.nrm_b)[gc] = rb;
+            }
+            meanA = ra.x; aA = ra.y; meanB = rb.x; aB = rb.y;
+        } else {
+            const NormRec na = norm_of(ya, g, c), nb = norm_of(yb, g, c);
+            meanA = na.mean; aA = na.a; meanB = nb.mean; aB = nb.a;
+        }
+        const bool onA = FIN || ya.nrm != nullptr, onB = FIN || yb.nrm != nullptr;
+        const float betaA = (onA && ya.beta) ? ya.beta[c] : 0.f, betaB = (onB && yb.beta) ? yb.beta[c] : 0.f;
+        {
+            const bool okc = lane < nv;
+            wave_rows_stage<KQ>(As, xa[m], meanA, okc ? aA : 0.f, okc ? betaA : 0.f, nv, N, (lane & 1) * 32 + (lane >> 1));
+        }
+        float aeB[NB], beB[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const bool okc = 32 * cb + j < nv;
+            aeB[cb] = okc ? aB : 0.f;
+            beB[cb] = okc ? betaB : 0.f;
+        }
+        f32x16 acc[NB][NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            float4 af[NB];
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb)
+                af[rb] = *reinterpret_cast<const float4 *>(As + (32 * rb + j) * WLD + h * 32 + 4 * q);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (q == KQ - 1 && 2 * (4 * q + t) >= N) break;
+                float bv[NB];
+#pragma unroll
+                for (int cb = 0; cb < NB; ++cb) bv[cb] = (xb[m][cb][4 * q + t] - meanB) * aeB[cb] + beB[cb];
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb) {
+                    const float a = t == 0 ? af[rb].x : (t == 1 ? af[rb].y : (t == 2 ? af[rb].z : af[rb].w));
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) acc[rb][cb] = mfma32(a, bv[cb], acc[rb][cb]);
+                }
+            }
+        }
+        if (m == 1 && gc0 + 1 >= M) break;                       // the repeated matrix of an odd count is not stored twice
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int col = 32 * cb + j;
+            const int voffO = col < N ? (4 * h * N + col) * 4 : OOB_OFF;
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rsrc_store(acc[rb][cb][r], rO[m], voffO + (32 * rb + (r & 3) + 8 * (r >> 2)) * N * 4, 0);
+        }
+    }
+}
+
 template <bool FIN>
 int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int N, int M, float *out, long long ogstride,
                  long long ldo, const FinArgs &F, hipStream_t st) {
+    if (mm_pair_per_wave() && (N + 7) / 8 == 7) {             // (measurement build: the N = 49 ... 56 instantiation)
+        const int grid2 = ((M + 1) / 2 + W_WAVES - 1) / W_WAVES;
+        hipLaunchKernelGGL((chan_matmul_fwd_wp_kernel<7, FIN>), dim3(grid2), dim3(64 * W_WAVES), 0, st, *ya, *yb, nvalid, N, M, out, ogstride, ldo, F);
+        return 0;
+    }
     const int KQ = (N + 7) / 8, grid = (M + W_WAVES - 1) / W_WAVES;
     // Measured (tools/gpu_mm_wide_probe.py, profiles/r05_mm_wide_probe.txt: 30 back-to-back launches in a replayed graph, 64 x 32 matrices):
     // N = 64: 21.8 - 22.4 us against 25.0 for the four-byte kernel; N = 50: 16.4 - 17.3 against 16.0 - 16.2; N = 40: 13.3 against 12.7 --

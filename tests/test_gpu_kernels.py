@@ -391,7 +391,7 @@ def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel
     """The shipped N <= 64 forward (one wave per matrix; for even N > 32 with 8-byte accesses and the even / odd column blocks of
     chan_matmul_fwd_w2_kernel) keeps the k-step order and the normalisation expression of the workgroup-per-matrix kernel it
     replaced: outputs must be equal bit for bit (dense and ragged with odd and even vertex counts, normalised operands; the
-    untouched output is poisoned with NaN first).  Variants: 1 = shipped, 9 = the four-byte wave kernel, 0 = the workgroup kernel."""
+    untouched output is poisoned with NaN first).  Variants: 1 = shipped, 9 = the four-byte wave kernel, 0 = the workgroup kernel, 17 = two matrices per wave (a measurement build, N = 49 ... 56)."""
     lib = _lib.load()
     G, Cc = 3, 5
     g = torch.Generator().manual_seed(N)
@@ -410,7 +410,7 @@ def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel
             t[gi, :, :, n:] = fill
     res = []
     try:
-        for variant in (1, 0, 9):
+        for variant in (1, 0, 9, 17):
             lib.fgnn_debug_matmul_variant(variant)
             out = torch.full((G, Cc, N, N), float('nan'), device=DEV)
             ua, ub = (a, b) if variant == 0 else (ap, bp)
@@ -421,7 +421,7 @@ def test_wave_per_matrix_forward_matmul_is_bit_identical_to_the_workgroup_kernel
             res.append(out.cpu())
     finally:
         lib.fgnn_debug_matmul_variant(1)
-    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]) and torch.equal(res[0], res[3])      # (17: two matrices per wave, N = 49 ... 56)
     # padding rows / columns of the ragged graphs are exact zeros
     for gi, n in enumerate(nv.tolist()):
         assert float(res[0][gi, :, n:, :].abs().max()) == 0.0 if n < N else True

@@ -1,6 +1,6 @@
 """Isolated forward per-channel product at N = 50 (64 graphs x 32 channels): the 8-byte-access wave kernel (variant 1, shipped) against the
 four-byte one it replaces (variant 9) and the workgroup-per-matrix kernel (variant 0); 30 back-to-back launches in a replayed graph,
-three operand sets (the protocol of tools/gpu_mm_ablate.py).   usage (GPU box): python tools/gpu_mm_wide_probe.py [N ...]"""
+three operand sets (the protocol of tools/gpu_mm_ablate.py).  Variant 17 = two matrices per wave (chan_matmul_fwd_wp_kernel, N = 49 ... 56).   usage (GPU box): python tools/gpu_mm_wide_probe.py [N ...]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,7 @@ for N in [int(v) for v in sys.argv[1:]] or [50]:
         a, b = torch.randn(G, Cc, N, N, device=dev), torch.randn(G, Cc, N, N, device=dev)
         na, nb = torch.rand(G, Cc, 4, device=dev) + 0.5, torch.rand(G, Cc, 4, device=dev) + 0.5
         sets.append((_lib.make_slab(a, Cc * P, P, Cc, nrm=na), _lib.make_slab(b, Cc * P, P, Cc, nrm=nb), torch.empty_like(a), a, b, na, nb))
-    for variant in (1, 9, 0, 1, 9):
+    for variant in (1, 9, 17, 0, 1, 9, 17):
         lib.fgnn_debug_matmul_variant(variant)
         it = [0]
 
