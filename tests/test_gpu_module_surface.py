@@ -246,3 +246,29 @@ def test_bf16_fused_step_on_masked_tensor_batches_equals_the_eager_module_path()
         for name, p in model.named_parameters():
             if not is_zero_grad(name):
                 assert rel(p.grad, eager[name]) < 1e-4, (name, rel(p.grad, eager[name]))
+
+
+def test_tensor_representation_opt_in_on_a_zero_padded_model_and_on_shapes_it_is_not_built_for():
+    """A model narrower than the engine (16 / 24 features: run zero-padded, Network._padded_layout) takes the structured block 1 through
+    the opt-in as well -- same function as its dense form to rounding; one input channel or N > 256 fall back to the dense path of the
+    same module without complaint (nothing to verify there: no structure is assumed)."""
+    torch.manual_seed(13)
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=2, in_features=16, out_features=24, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, dict(ne), input_form='tensor_representation').to(DEV)
+    _perturb_biases(model, 5)
+    dense = Siamese_Node_Exp(2, dict(ne)).to(DEV)
+    dense.load_state_dict(model.state_dict())
+    x1, x2 = [t.to(DEV) for t in synthetic.make_batch(9400, 3, 22, 'ErdosRenyi', 0.3, 0.1)]
+    l1, s1 = model.fused_step(x1, x2)
+    l2, s2 = dense.fused_step(x1, x2)
+    eng = next(e for e in model.node_embedder._engines.values() if getattr(e, '_step_state', None) is not None)
+    assert eng.struct1 and 'bits' in eng._step_state
+    assert rel(s1, s2) < 2e-5 and abs(l1.item() - l2.item()) < 2e-5 * abs(l2.item())
+    for (name, p), q in zip(model.named_parameters(), dense.parameters()):
+        if not is_zero_grad(name):
+            assert rel(p.grad, q.grad) < 2e-4, (name, rel(p.grad, q.grad))
+    # one input channel: the dense path of the same module
+    one = Siamese_Node_Exp(1, dict(ne, in_features=32, out_features=32), input_form='tensor_representation').to(DEV)
+    a = torch.rand(2, 1, 12, 12, device=DEV)
+    one.fused_step(a, a.clone())
+    assert not one.check_input_form()                      # no flag was ever created: nothing was packed
