@@ -496,10 +496,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
         mfma = mfma_arg if mfma_arg is not None else (args.mfma if (same and args.mfma is not None) else None)
         if chains == 2:
             from graph_neural_net_amd.engine_dual import FgnnEngineDual
-            b1 = block1 if block1 is not None else (args.block1 if same else None)
-            if b1 is None:
-                b1 = 'structured' if (config in ('cfg2', 'cfg5') and not (same and args.input == 'dense') and path == 'engine') else 'generic'
-            return FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma, block1=b1)
+            return FgnnEngineDual(layout, 2 * B, N, dev, ragged=ragged, mfma=mfma)
         # The headline line (cfg2, fp32 engine) hands the batch over as bit-packed adjacency and runs block 1 on its structured
         # form unless told otherwise; `dense_input` in the JSON is the same step on the dense tensor through the generic kernels
         b1 = block1 if block1 is not None else (args.block1 if same else None)
@@ -510,22 +507,20 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
     x = torch.cat([x1, x2]).contiguous().to(dev)
     struct1 = bool(getattr(eng, 'struct1', False))
     want = input_form if input_form is not None else (args.input if same else None)
-    use_bits = (path == 'engine' and ((want == 'bits' and (struct1 or not bf16)) if want is not None else struct1))
+    use_bits = (path == 'engine' and not hasattr(eng, 'stage_inputs') and ((want == 'bits' and (struct1 or not bf16)) if want is not None else struct1))
     xbits = None
     if use_bits:     # the same batch as 32-bit words of adjacency rows (synthetic.pack_adjacency), resident in HBM like x
         import numpy as np
         xbits = torch.from_numpy(synthetic.pack_adjacency(torch.cat([x1, x2])[:, 0].numpy()).view(np.int32)).to(dev)
     dual = hasattr(eng, 'stage_inputs')
-    if dual:       # loader work, like the cat above: the chains' input buffers are resident before the timed region
-        eng.stage_inputs(None if xbits is not None else x, nvalid, bits=xbits)
+    if dual:
+        eng.stage_inputs(x, nvalid)        # loader work, like the cat above: the chains' input buffers are resident before the timed region
     # loss normaliser of the concatenated global batch (toolbox/losses.py:27-34): ranks of a ragged batch hold different node
     # counts, so the global count is summed over the ranks once at set-up (not a collective of the step)
     total_nodes = dp.global_node_count(sum(sizes), dev) if ragged else float(B * N * world)
 
     def model_work(eng=eng):
-        if dual:
-            eng.step(params, grads, None, total_nodes=total_nodes)
-        elif xbits is not None:
+        if xbits is not None:
             eng.step(params, grads, None, nvalid=nvalid, total_nodes=total_nodes, bits=xbits)
         else:
             eng.step(params, grads, None if dual else x, nvalid=None if dual else nvalid, total_nodes=total_nodes)

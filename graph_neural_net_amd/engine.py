@@ -190,7 +190,7 @@ class FgnnEngine:
         if block1 not in ('generic', 'structured'):
             raise ValueError("block1 must be 'generic' or 'structured' (got %r)" % (block1,))
         # the structured block 1 applies to bit-packed inputs (embed(bits=...)), constant-size or ragged, N <= 256; anything else runs generic
-        self.struct1 = (block1 == 'structured'
+        self.struct1 = (block1 == 'structured' and cu_share == 0
                         and bool(_lib.load().fgnn_block1_struct_supported(N, layout.depth, layout.c0)))
         self._struct = None
         self.decisions = None       # test-only, see export_decisions()
@@ -477,7 +477,7 @@ class FgnnEngine:
                   _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]),
                   C.c_void_p(self._w(params, r1['gn_b'])), C.c_void_p(self._w(params, r2['gn_b'])),
                   _lib.ptr(W['dmult']), 32 * self.ldp, self.ldp, _lib.ptr(S['ws']),
-                  _lib.ptr(W['wpart_s'][(1, 1)]), _lib.ptr(W['wpart_s'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
+                  _lib.ptr(W['wpart'][(1, 1)]), _lib.ptr(W['wpart'][(1, 2)]), _lib.ptr(W['s12'][(1, 1)]), _lib.ptr(W['s12'][(1, 2)]),
                   _lib.stream_ptr())
 
     def forward(self, params, x, nvalid=None, total_nodes=None, defer_loss=False, loss_out=None, bits=None, pack=True,
@@ -535,10 +535,6 @@ class FgnnEngine:
             # (the structured block 1 writes one row per graph: the other rows of its two buffers stay zero)
             'wpart': {kj: torch.empty(nwg * L.mlp[kj]['count'], **f32)
                       for kj in keys},
-            # the structured block 1 writes fgnn_block1_struct_rows(G, N) partial rows of mlp1 / mlp2 of block 1 into buffers of their own
-            # (FgnnEngineDual makes the two chains' rows neighbours: ONE reduction job over both)
-            'wpart_s': ({kj: torch.empty(int(_lib.load().fgnn_block1_struct_rows(self.G, self.N)) * L.mlp[kj]['count'], **f32)
-                         for kj in ((1, 1), (1, 2))} if self.struct1 else None),
             's12part': torch.empty(self.G * self.tpg * 32 * 2, **f32),
             'coef': [torch.empty(self.G * 32 * 4, **f32) for _ in range(3)],
             'nwg': nwg,
@@ -732,9 +728,7 @@ class FgnnEngine:
                 jobs[i].wpart = W['wpart'][kj].data_ptr()
                 jobs[i].count = rec['count']
                 if kj in ((1, 1), (1, 2)) and W.get('struct_rows', 0):
-                    # block 1 on its structured input: the rows its backward wrote (in a dual engine: of both chains, neighbours)
-                    jobs[i].wpart = W['wpart_s'][kj].data_ptr()
-                    jobs[i].rows = W['struct_rows'] if rows is None else W['struct_rows_joint']
+                    jobs[i].rows = W['struct_rows']         # block 1 on its structured input: the rows its backward wrote
                 jobs[i].out = grads.data_ptr() + 4 * rec['off']
                 jobs[i].s12 = W['s12'][kj].data_ptr()
                 jobs[i].nrm = self.nrm[kj].data_ptr()

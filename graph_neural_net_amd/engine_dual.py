@@ -28,16 +28,15 @@ from .engine import FgnnEngine
 class FgnnEngineDual:
     CU_SHARE = 2        # fgnn_mlp_fwd_args.cu_share of both chains: full-size workgroups on disjoint halves of the CUs
 
-    def __init__(self, layout, G, N, device, ragged=False, mfma=None, block1=None):
+    def __init__(self, layout, G, N, device, ragged=False, mfma=None):
         if G % 2 or G < 4:
             raise RuntimeError('FgnnEngineDual: G = 2 * pairs with at least two pairs (got G = %d)' % G)
         self.layout, self.G, self.N, self.device = layout, G, N, device
         self.B = G // 2
         self.h = [(self.B + 1) // 2, self.B // 2]                   # pairs per chain
         self.lo = [0, self.h[0]]
-        self.sub = [FgnnEngine(layout, 2 * h, N, device, ragged=ragged, cu_share=self.CU_SHARE, mfma=mfma, block1=block1) for h in self.h]
+        self.sub = [FgnnEngine(layout, 2 * h, N, device, ragged=ragged, cu_share=self.CU_SHARE, mfma=mfma) for h in self.h]
         self.x3 = self.sub[0].x3
-        self.struct1 = all(e.struct1 for e in self.sub)        # block 1 on bit-packed inputs runs structured in both chains (round 5)
         self.ragged = ragged
         self.side = torch.cuda.Stream(device=device)
         a, b = self.sub
@@ -122,14 +121,6 @@ class FgnnEngineDual:
             na = Wa['wpart'][kj].numel()
             joint = torch.empty(2 * na, **f32)
             Wa['wpart'][kj], Wb['wpart'][kj] = joint[:na], joint[na:]
-        if Wa.get('wpart_s') is not None and Wb.get('wpart_s') is not None:
-            lib = _lib.load()
-            ra, rb = int(lib.fgnn_block1_struct_rows(a.G, a.N)), int(lib.fgnn_block1_struct_rows(b.G, b.N))
-            for kj in list(Wa['wpart_s']):
-                na, nb = Wa['wpart_s'][kj].numel(), Wb['wpart_s'][kj].numel()
-                joint = torch.empty(na + nb, **f32)
-                Wa['wpart_s'][kj], Wb['wpart_s'][kj] = joint[:na], joint[na:]
-            Wa['struct_rows_joint'] = ra + rb
         self._bwd_joined = True
 
     def _total_nodes(self, total_nodes):
