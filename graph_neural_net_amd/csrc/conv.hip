@@ -591,8 +591,14 @@ extern "C" int fgnn_conv_chain(const fgnn_chain_args *a, void *stream) {
         hipLaunchKernelGGL((conv_chain_kernel<KH, MG, FL>), dim3(grid), dim3(64 * CONV_WAVES), lds, (hipStream_t)stream, a->x,  \
                            a->x_gstride, a->x_ld, a->depth, L, a->nvalid, a->G, a->N, tpg, ntiles);                        \
     }
-    bool full_all = true;           // every layer exactly `maxg` full groups, K_0 = 2 KH for the instantiated KH
-    for (int l = 0; l < a->depth; ++l) full_all = full_all && a->layer[l].M == 32 * maxg;
+    // FULL instantiation: every layer has exactly MG full output groups -- the MG the kernel is INSTANTIATED with (2 or 4), not the
+    // largest group count of this chain -- and K_0 = 2 KH for the instantiated KH.  (Until round 5 this compared against `maxg`: a
+    // chain of 32-wide layers with K_0 in {8, 32, 64, 128} -- the input-gradient chain of every MlpBlock_Real(> 64 -> 32), the forward
+    // of MlpBlock_Real(128 -> 32) -- ran the two-group kernel on one-group layers: wrong gradients, found by tests/diag/gpu_fuzz_models.py
+    // with another seed; tests/test_gpu_widths.py::test_mlp_block_width_sweep now covers these shapes.)
+    const int mg_inst = maxg <= 2 ? 2 : 4;
+    bool full_all = true;
+    for (int l = 0; l < a->depth; ++l) full_all = full_all && a->layer[l].M == 32 * mg_inst;
 #define FGNN_CHAIN(KH, MG)                                      \
     {                                                           \
         if (full_all && a->layer[0].K == 2 * KH) FGNN_CHAIN_(KH, MG, true) \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (not collected by pytest): random shapes through the fused engines against the oracle.
-Constant-size and ragged batches, 1-3 blocks, N up to 140; fp32 engine: scores 1e-4, flat gradient within 4x the fp32 oracle's own distance to the
+Constant-size and ragged batches, 1-3 blocks, N up to 140; fp32 engine: scores 1e-4 of fp64 (or 4x the fp32 oracle's own distance), flat gradient within 4x the fp32 oracle's own distance to the
 fp64 oracle (the tight per-tensor gates live in tests/test_gpu_parity.py); bf16 engine: finite, scores within 2e-1 L2 of the fp32
 oracle (depth-3 bf16 noise on un-trained weights; its real gates are the same-point tests of tests/test_gpu_bf16.py).  usage: python tests/diag/gpu_fuzz_shapes.py [cases=60] [seed=0]"""
 import os
@@ -40,7 +40,7 @@ def main():
             a, b = synthetic.make_pair(rng, n, 'ErdosRenyi', float(rng.uniform(0.1, 0.6)), 0.1)
             xs.append(torch.from_numpy(a)); ys.append(torch.from_numpy(b))
         s_ref, l_ref, g_ref = O.step_fwd_bwd_ragged(xs, ys, sd)
-        _, _, g64 = O.step_fwd_bwd_ragged([t.double() for t in xs], [t.double() for t in ys], {k: v.double() for k, v in sd.items()})
+        s64, l64, g64 = O.step_fwd_bwd_ragged([t.double() for t in xs], [t.double() for t in ys], {k: v.double() for k, v in sd.items()})
         x1, nv = O.pad_graph_list(xs)
         x2, _ = O.pad_graph_list(ys)
         N = x1.shape[-1]
@@ -62,14 +62,16 @@ def main():
                 msgs.append(name + ': non-finite')
         sc, loss, g = res['fp32']
         for i, n in enumerate(ns):
-            d = (sc[i, :n, :n] - s_ref[i]).abs().max().item()
-            # (n < 4: near-constant channels, GraphNorm divides rounding noise by sqrt(eps))
-            if d > (1e-4 if n >= 4 else 1e-2) * max(1.0, s_ref[i].abs().max().item()):
-                msgs.append('fp32 scores pair %d: %.2e' % (i, d))
+            # fp64 yard-stick: a channel that is nearly constant over a graph (tiny n, sparse graphs) has GraphNorm divide rounding
+            # noise by sqrt(eps), in the fp32 oracle exactly as here (seed 21 case 35: both 3e-4 / 1.4e-3 from fp64)
+            d = (sc[i, :n, :n].double() - s64[i]).abs().max().item()
+            d32 = (s_ref[i].double() - s64[i]).abs().max().item()
+            if d > max(1e-4 * max(1.0, s64[i].abs().max().item()), 4.0 * d32):
+                msgs.append('fp32 scores pair %d: %.2e from fp64 (fp32 oracle %.2e)' % (i, d, d32))
             if sc[i, n:, :].abs().sum() != 0 or sc[i, :, n:].abs().sum() != 0:
                 msgs.append('fp32 padding of pair %d not zero' % i)
-        if abs(loss - l_ref.item()) > 1e-5 * abs(l_ref.item()) + 1e-6:
-            msgs.append('fp32 loss %.7f vs %.7f' % (loss, l_ref.item()))
+        if abs(loss - l64.item()) > max(1e-5 * abs(l64.item()) + 1e-6, 4.0 * abs(l_ref.item() - l64.item())):
+            msgs.append('fp32 loss %.7f vs fp64 %.7f (fp32 oracle %.7f)' % (loss, l64.item(), l_ref.item()))
         keys = [k for k in g_ref if not is_zero_grad(k)]
         a = torch.cat([g[k].reshape(-1).double() for k in keys])
         b = torch.cat([g_ref[k].reshape(-1).double() for k in keys])

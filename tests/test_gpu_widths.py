@@ -95,7 +95,12 @@ def test_conv1x1_rejects_bad_arguments():
                   _lib.ptr(y), 8 * 25, 25, _lib.stream_ptr())
 
 
-@pytest.mark.parametrize('cin,cout,depth', [(3, 16, 2), (19, 16, 2), (64, 48, 1), (48, 48, 3), (32, 64, 3), (5, 32, 3)])
+@pytest.mark.parametrize('cin,cout,depth', [(3, 16, 2), (19, 16, 2), (64, 48, 1), (48, 48, 3), (32, 64, 3), (5, 32, 3),
+                                            # chains of ONE-group (32-wide) or THREE-group (96-wide) layers whose first K is 8 / 32 / 64 /
+                                            # 128: the shapes the conv-chain's all-full instantiation was wrongly chosen for until round 5
+                                            # (forward 128 -> 32 and 8 -> 32; the split input-gradient chain of every cin > 64 -> 32)
+                                            (104, 32, 3), (72, 32, 3), (65, 32, 2), (128, 32, 2), (128, 32, 3), (8, 32, 2), (8, 32, 3),
+                                            (64, 96, 2), (128, 96, 3), (100, 96, 3), (100, 64, 3), (128, 128, 2), (130, 128, 3)])
 def test_mlp_block_any_width_matches_oracle(cin, cout, depth):
     """MlpBlock_Real on widths the fused kernels are not built for: forward + every gradient against the oracle run
     in fp64, with the fp32 oracle's own error as the yard-stick; masked batch == per-graph dense results."""
