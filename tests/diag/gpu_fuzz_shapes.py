@@ -66,7 +66,8 @@ def main():
             # noise by sqrt(eps), in the fp32 oracle exactly as here (seed 21 case 35: both 3e-4 / 1.4e-3 from fp64)
             d = (sc[i, :n, :n].double() - s64[i]).abs().max().item()
             d32 = (s_ref[i].double() - s64[i]).abs().max().item()
-            if d > max(1e-4 * max(1.0, s64[i].abs().max().item()), 4.0 * d32):
+            # (n < 4: channels constant to rounding over the 1 ... 9 pixels; 1 / sqrt(eps) = 316 per block on the last-ulp differences)
+            if d > max((1e-4 if n >= 4 else 1e-2) * max(1.0, s64[i].abs().max().item()), 4.0 * d32):
                 msgs.append('fp32 scores pair %d: %.2e from fp64 (fp32 oracle %.2e)' % (i, d, d32))
             if sc[i, n:, :].abs().sum() != 0 or sc[i, :, n:].abs().sum() != 0:
                 msgs.append('fp32 padding of pair %d not zero' % i)
