@@ -3,7 +3,8 @@
 oracle -- original_features_num in {1, 2, 3, 7, 32}, widths 4..72, depth 1..3, 1..3 blocks, constant-size and ragged batches:
 exact engine, zero-padded engine and the per-layer conv.hip path.  Gates: scores within max(4x the fp32 oracle's distance to
 fp64, 3e-5); flat gradient within 4x the fp32 oracle's distance to fp64 + 2 % (a ReLU tie, see gpu_fuzz_shapes.py).
-usage: python tests/diag/gpu_fuzz_models.py [cases=60] [seed=0]"""
+`wide`: widths up to 128 and up to 64 input channels as well (the two- and four-group instantiations of the conv chain, split input-gradient chains).
+usage: python tests/diag/gpu_fuzz_models.py [cases=60] [seed=0] [wide]"""
 import os
 import sys
 
@@ -24,18 +25,19 @@ DEV = 'cuda:0'
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    wide = len(sys.argv) > 3 and sys.argv[3] == 'wide'
     rng = np.random.default_rng(seed)
     torch.set_num_threads(16)
     bad = 0
     for case in range(cases):
-        c0 = int(rng.choice([1, 2, 2, 3, 7, 32]))
-        win = int(rng.choice([4, 8, 16, 24, 32, 32, 40, 72]))
-        wout = int(rng.choice([4, 16, 32, 32, 48]))
+        c0 = int(rng.choice([1, 2, 2, 3, 7, 32] + ([40, 64] if wide else [])))
+        win = int(rng.choice([4, 8, 16, 24, 32, 32, 40, 72] + ([48, 64, 64, 96, 100, 128] if wide else [])))
+        wout = int(rng.choice([4, 16, 32, 32, 48] + ([64, 64, 96, 128] if wide else [])))
         depth = int(rng.integers(1, 4))
         nblk = int(rng.integers(1, 4))
         ragged = bool(rng.integers(0, 2))
         B = int(rng.integers(1, 4))
-        nmax = int(rng.choice([5, 12, 31, 33, 50, 70]))
+        nmax = int(rng.choice([5, 12, 31, 33] + ([] if wide else [50, 70])))
         ns = [int(rng.integers(2, nmax + 1)) for _ in range(B)] if ragged else [nmax] * B
         torch.manual_seed(case)
         sd = O.init_state_dict(original_features_num=c0, num_blocks=nblk, in_features=win, out_features=wout, depth_of_mlp=depth)
