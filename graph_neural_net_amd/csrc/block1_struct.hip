@@ -25,6 +25,7 @@
 #include "fgnn_common.h"
 #include "fgnn_norm.h"
 #include "fgnn_bf16.h"
+#include "fgnn_pack.h"
 
 namespace {
 
@@ -154,24 +155,31 @@ template <int NWD>
 __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, const int *nvalid, const int N, const int cp, unsigned *code,
                                                        float4 *vinfo, float *gones, float *xdeg, void *x16, const long long ldp16,
                                                        const int pitch16, const int ny, const int ntab, const TabArgs TA, float *tab,
-                                                       const int bf) {
+                                                       const int bf, const int npack, const PackJobs PJ) {
     constexpr int MAXN = 64 * NWD, RW = 2 * NWD;                   // dwords per bit row
     __shared__ unsigned rows[MAXN][RW];
     __shared__ unsigned colw[SB_CW][RW];
     __shared__ float red[4];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < ntab) {
-        const int row = blockIdx.x * 4 + (tid >> 6), NC = sb_classes(N);
+    if ((int)blockIdx.x < npack) {
+        // the step's operand packing (fgnn_pack_operands) as the leading workgroups of this launch: it reads the weights only, like the
+        // tables below, and every consumer of an image is a later launch
+        pack_job_body(PJ.job[blockIdx.x / PACK_BLOCKS_PER_JOB], blockIdx.x % PACK_BLOCKS_PER_JOB, PACK_BLOCKS_PER_JOB, tid);
+        return;
+    }
+    const int bid = (int)blockIdx.x - npack;
+    if (bid < ntab) {
+        const int row = bid * 4 + (tid >> 6), NC = sb_classes(N);
         if (row < 2 * NC) sb_table_row(TA, N, tab, bf, row % NC, row / NC, tid & 63);
         return;
     }
-    const int g = ((int)blockIdx.x - ntab) / ny, y = ((int)blockIdx.x - ntab) - g * ny;
+    const int g = (bid - ntab) / ny, y = (bid - ntab) - g * ny;
     const int nv = nvalid_of(nvalid, g, N);
     const int c0 = y * SB_CW;                                      // first column of the band
-    SB_STAMP(0, blockIdx.x - ntab, 0)
+    SB_STAMP(0, bid - ntab, 0)
     sb_bits_rows<NWD>(rows, bits, g, tid, N, nv);
     __syncthreads();
-    SB_STAMP(0, blockIdx.x - ntab, 1)
+    SB_STAMP(0, bid - ntab, 1)
     if (tid < SB_CW * RW) {
         // dword h of column c0 + jl: bit r = w[32 h + r][c0 + jl]; every shift a compile-time constant
         const int jl = tid % SB_CW, h = tid / SB_CW, j = c0 + jl;
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
         if ((tid & 63) == 0) red[tid >> 6] = on1;
     }
     __syncthreads();
-    SB_STAMP(0, blockIdx.x - ntab, 2)
+    SB_STAMP(0, bid - ntab, 2)
     if (y == 0 && tid == 0) gones[g] = (red[0] + red[1]) + (red[2] + red[3]);   // off-diagonal ones of the valid corner
     if (tid >= c0 && tid < c0 + SB_CW && tid < N) {                // the records of the band's vertices
         int dc = 0;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
                                                     __int_as_float(on ? 2 + 2 * dr + ws : 0));
         if (xdeg) xdeg[(long long)g * N + tid] = on ? (float)dr : 0.f;            // what fgnn_adjacency_degree would write
     }
-    SB_STAMP(0, blockIdx.x - ntab, 3)
+    SB_STAMP(0, bid - ntab, 3)
     // thread <-> row i: its SB_CW codes (W^2)_ij | w_ij << 15, j in the band (rows / bits outside the valid corner are empty)
     unsigned short *code16 = reinterpret_cast<unsigned short *>(code) + (long long)g * N * cp;
     unsigned short *xa = reinterpret_cast<unsigned short *>(x16) + (long long)g * 2 * ldp16, *xb = xa + ldp16;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
             }
         }
     }
-    SB_STAMP(0, blockIdx.x - ntab, 4)
+    SB_STAMP(0, bid - ntab, 4)
     if (x16 && y == ny - 1) {
         // tail of the channel stride of the 2-channel input slab of the 16-bit engine (mlp3 reads the slab as its skip connection)
         unsigned *x0 = reinterpret_cast<unsigned *>(xa), *x1 = reinterpret_cast<unsigned *>(xb);
@@ -933,6 +941,8 @@ struct FwdCall {
     float *ws;
     const float *const *tW1, *const *tb1, *const *tW2, *const *tb2;      // optional: build the tables in the same launch
     hipStream_t st;
+    const fgnn_pack_job *jobs;      // optional: the step's operand packing (fgnn_pack_operands) in the same launch
+    int njobs;
 };
 template <int NWD, bool BF>
 int sb_fwd_launch(const FwdCall &c) {
@@ -953,8 +963,16 @@ int sb_fwd_launch(const FwdCall &c) {
         }
         ntab = (2 * (2 + 2 * (c.N + 1)) + 3) / 4;
     }
-    hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(ntab + c.G * ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code),
-                       vinfo, c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch, ny, ntab, TA, const_cast<float *>(c.tables), BF ? 1 : 0);
+    PackJobs PJ = {};
+    FGNN_CHECK(c.njobs >= 0 && c.njobs <= FGNN_MAX_PACK_JOBS && (c.njobs == 0 || c.jobs), "fgnn_block1_struct_fwd_pack: 0 .. %d pack jobs", FGNN_MAX_PACK_JOBS);
+    for (int i = 0; i < c.njobs; ++i) {
+        FGNN_CHECK(c.jobs[i].out && c.jobs[i].depth >= 1 && c.jobs[i].depth <= FGNN_MAX_DEPTH && (c.jobs[i].nmlp == 1 || c.jobs[i].nmlp == 2),
+                   "fgnn_block1_struct_fwd_pack: job %d malformed", i);
+        PJ.job[i] = c.jobs[i];
+    }
+    const int npack = c.njobs * PACK_BLOCKS_PER_JOB;
+    hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(npack + ntab + c.G * ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code),
+                       vinfo, c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch, ny, ntab, TA, const_cast<float *>(c.tables), BF ? 1 : 0, npack, PJ);
     FGNN_LAUNCH_CHECK();
     hipLaunchKernelGGL((sb_fwd_kernel<NWD, BF>), dim3(c.G, SB_CG, parts), dim3(64 * SB_FW), 0, c.st, code, vinfo, c.ws + L.gones, c.nvalid, c.N, L.cp, c.tables,
                        c.gnw1, c.gnb1, c.gnw2, c.gnb2, c.eps, c.nrm1, c.nrm2, c.mult, c.gstride, c.ldp, c.pitch);
@@ -981,7 +999,18 @@ extern "C" int fgnn_block1_struct_fwd(const unsigned *bits, const int *nvalid, i
                                       const float *const *tb1, const float *const *tW2, const float *const *tb2, void *stream) {
     FGNN_CHECK(ldp >= (long long)N * N && gstride >= FGNN_H * ldp, "fgnn_block1_struct_fwd: strides smaller than the planes");
     const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, N, xdeg, nullptr, ws, tW1, tb1, tW2, tb2,
-                       (hipStream_t)stream};
+                       (hipStream_t)stream, nullptr, 0};
+    return sb_fwd_dispatch<false>(c);
+}
+
+extern "C" int fgnn_block1_struct_fwd_pack(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1,
+                                           const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult,
+                                           long long gstride, long long ldp, float *xdeg, float *ws, const float *const *tW1,
+                                           const float *const *tb1, const float *const *tW2, const float *const *tb2,
+                                           const fgnn_pack_job *jobs, int njobs, void *stream) {
+    FGNN_CHECK(ldp >= (long long)N * N && gstride >= FGNN_H * ldp, "fgnn_block1_struct_fwd_pack: strides smaller than the planes");
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, N, xdeg, nullptr, ws, tW1, tb1, tW2, tb2,
+                       (hipStream_t)stream, jobs, njobs};
     return sb_fwd_dispatch<false>(c);
 }
 
@@ -992,7 +1021,7 @@ extern "C" int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid,
     FGNN_CHECK(ldr >= N && ldr % 8 == 0 && ldp >= (long long)N * ldr && ldp % 2 == 0 && gstride >= FGNN_H * ldp && gstride % 2 == 0,
                "fgnn_block1_struct_fwd16: pitches (ldr = %d, ldp = %lld, gstride = %lld)", ldr, ldp, gstride);
     const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, tW1, tb1, tW2, tb2,
-                       (hipStream_t)stream};
+                       (hipStream_t)stream, nullptr, 0};
     return sb_fwd_dispatch<true>(c);
 }
 

@@ -118,3 +118,36 @@ DEVI void pk_store_regs(float *lds, const PkRegs<N4, NTHREADS> &r) {
         if (e < N4) dst[e] = r.v[k];
     }
 }
+
+// ---- one fgnn_pack_job (include/fgnn_hip.h): the LDS operand image(s) of one MLP kernel launch, written by `nbx` blocks of 256 threads.
+// Shared by fgnn_pack_operands (norm.hip) and by the first launch of the structured block 1, which carries the step's packing as
+// extra workgroups (block1_struct.hip: one launch less per step)
+struct PackJobs {
+    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
+};
+DEVI void pack_job_body(const fgnn_pack_job &jb, const int bx, const int nbx, const int tid) {
+    if (jb.kind == 0) {
+        const PkFwd p = pk_fwd(jb.ca, jb.cb, jb.depth);
+        const int per = p.floats;
+        for (int e = bx * 256 + tid; e < per * jb.nmlp; e += nbx * 256) {
+            const int m = e / per, r = e - m * per;
+            if (r < p.bias_f) {
+                const int t = r >> 6, l = r & 63;
+                jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l);
+            } else {
+                jb.out[m * per + r] = pk_bias_value(jb.bias[m], r - p.bias_f);
+            }
+        }
+    } else {
+        const PkBwd p = pk_bwd(jb.ca, jb.cb, jb.depth);
+        for (int e = bx * 256 + tid; e < p.floats; e += nbx * 256) {
+            if (e < p.bias_f) {
+                const int t = e >> 6, l = e & 63;
+                jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l);
+            } else {
+                jb.out[e] = pk_bias_value(jb.bias[0], e - p.bias_f);
+            }
+        }
+    }
+}
+constexpr int PACK_BLOCKS_PER_JOB = 48;

@@ -386,36 +386,9 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const GradJobs J, in
     }
 }
 
-struct PackJobs {
-    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
-};
-
 // grid (blocks per job, njobs): writes the LDS operand image(s) of one MLP kernel launch
 __global__ __launch_bounds__(256) void pack_operands_kernel(const PackJobs J) {
-    const fgnn_pack_job &jb = J.job[blockIdx.y];
-    if (jb.kind == 0) {
-        const PkFwd p = pk_fwd(jb.ca, jb.cb, jb.depth);
-        const int per = p.floats;
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < per * jb.nmlp; e += gridDim.x * 256) {
-            const int m = e / per, r = e - m * per;
-            if (r < p.bias_f) {
-                const int t = r >> 6, l = r & 63;
-                jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l);
-            } else {
-                jb.out[m * per + r] = pk_bias_value(jb.bias[m], r - p.bias_f);
-            }
-        }
-    } else {
-        const PkBwd p = pk_bwd(jb.ca, jb.cb, jb.depth);
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.floats; e += gridDim.x * 256) {
-            if (e < p.bias_f) {
-                const int t = e >> 6, l = e & 63;
-                jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l);
-            } else {
-                jb.out[e] = pk_bias_value(jb.bias[0], e - p.bias_f);
-            }
-        }
-    }
+    pack_job_body(J.job[blockIdx.y], blockIdx.x, gridDim.x, threadIdx.x);
 }
 
 }  // namespace
@@ -448,7 +421,7 @@ extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *st
                    "fgnn_pack_operands: job %d malformed", i);
         J.job[i] = jobs[i];
     }
-    hipLaunchKernelGGL(pack_operands_kernel, dim3(48, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(pack_operands_kernel, dim3(PACK_BLOCKS_PER_JOB, njobs), dim3(256), 0, (hipStream_t)stream, J);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

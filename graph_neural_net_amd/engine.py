@@ -163,6 +163,8 @@ class FgnnEngine:
     # the replayed cfg2 step at 13.7 us against 5.8 + 7.0 us for the two launches it replaces (profiles/r05_c_graph_timeline.txt) --
     # every workgroup of a pair repeats the score matrix and the row log-sum-exps, and inside a graph a launch boundary costs nothing
     SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '0') != '0'
+    # the step's operand packing as extra workgroups of the structured block 1's first launch (FGNN_PACK_IN_STRUCT=0: its own launch)
+    PACK_IN_STRUCT = os.environ.get('FGNN_PACK_IN_STRUCT', '1') != '0'
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -286,21 +288,24 @@ class FgnnEngine:
         L = self.layout
         self._pack_launch(params, list(self._packs.items()), 'fgnn_pack_x3_operands' if self.x3 else 'fgnn_pack_operands')
 
-    def _pack_launch(self, params, items, entry):
+    def _pack_jobs(self, params, chunk):
         L = self.layout
+        jobs = (_lib.PackJob * len(chunk))()
+        for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
+            jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
+            js = (1, 2) if which == 12 else (which,)
+            for m, j in enumerate(js):
+                rec = L.mlp[(k, j)]
+                for l in range(L.depth):
+                    jobs[i].W[m][l] = self._w(params, rec['w'][l])
+                    jobs[i].bias[m][l] = self._w(params, rec['b'][l])
+            jobs[i].out = buf.data_ptr()
+        return jobs
+
+    def _pack_launch(self, params, items, entry):
         for lo in range(0, len(items), _lib.MAX_PACK_JOBS):
             chunk = items[lo:lo + _lib.MAX_PACK_JOBS]
-            jobs = (_lib.PackJob * len(chunk))()
-            for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
-                jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
-                js = (1, 2) if which == 12 else (which,)
-                for m, j in enumerate(js):
-                    rec = L.mlp[(k, j)]
-                    for l in range(L.depth):
-                        jobs[i].W[m][l] = self._w(params, rec['w'][l])
-                        jobs[i].bias[m][l] = self._w(params, rec['b'][l])
-                jobs[i].out = buf.data_ptr()
-            _lib.call(entry, jobs, len(chunk), _lib.stream_ptr())
+            _lib.call(entry, self._pack_jobs(params, chunk), len(chunk), _lib.stream_ptr())
 
     def _mlp_fwd(self, params, k, js, a, b, finalize=True):
         """finalize=False: leave the tile statistics of the two MLPs un-finalized (the matmul that consumes them
@@ -397,12 +402,14 @@ class FgnnEngine:
                                    % ((self.G, L.c0, self.N, self.N), tuple(x.shape), x.dtype))
             self.x, self.xbits = x, None
         struct_now = self.struct1 and self.xbits is not None
-        if pack:                # (FgnnEngineDual packs once for both of its engines.  Running this launch on a second stream beside the
-            self.pack_operands(params)          # structured block 1, which reads no operand image, was measured: +20 us per step)
+        # the structured block 1's first launch carries the packing as extra workgroups (fgnn_block1_struct_fwd_pack: one launch less)
+        pack_in_struct = pack and struct_now and self.PACK_IN_STRUCT and not self.x3 and len(self._packs) <= _lib.MAX_PACK_JOBS
+        if pack and not pack_in_struct:     # (FgnnEngineDual packs once for both of its engines.  Running this launch on a second stream beside
+            self.pack_operands(params)      # the structured block 1, which reads no operand image, was measured: +20 us per step)
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
             if k == 1 and struct_now:
-                self._struct_fwd(params)
+                self._struct_fwd(params, with_pack=pack_in_struct)
                 pool_fin = L.num_blocks == 1 and bool(_lib.load().fgnn_colmax_fwd_fin_supported(self.N))
                 self._mlp_fwd(params, 1, (3,), self._slab_raw(self.mult[1]), sin, finalize=not pool_fin)
                 continue
@@ -452,17 +459,23 @@ class FgnnEngine:
         rec = self.layout.mlp[(1, j)]
         return ((C.c_void_p * 3)(*[self._w(params, o) for o in rec['w']]), (C.c_void_p * 3)(*[self._w(params, o) for o in rec['b']]))
 
-    def _struct_fwd(self, params):
-        """mlp1 + mlp2 + mult of block 1 from the class tables: two small launches instead of fgnn_mlp_fwd + fgnn_chan_matmul_fwd."""
+    def _struct_fwd(self, params, with_pack=False):
+        """mlp1 + mlp2 + mult of block 1 from the class tables: two small launches instead of fgnn_mlp_fwd + fgnn_chan_matmul_fwd.
+        with_pack: the first of them also packs the operand images of the step's MLP launches (pack_operands, without its launch)."""
         S = self._struct_ws()
         st = _lib.stream_ptr()
         (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
-        _lib.call('fgnn_block1_struct_fwd', _lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']),
-                  C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
-                  C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
-                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
-                  _lib.ptr(self.xdeg), _lib.ptr(S['ws']), w1, b1, w2, b2, st)      # (the class tables are built by the same launch)
+        args = [_lib.ptr(self.xbits), self._nv(), self.G, self.N, _lib.ptr(S['tab']),
+                C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
+                C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
+                _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
+                _lib.ptr(self.xdeg), _lib.ptr(S['ws']), w1, b1, w2, b2]      # (the class tables are built by the same launch)
+        if with_pack:
+            items = list(self._packs.items())
+            _lib.call('fgnn_block1_struct_fwd_pack', *args, self._pack_jobs(params, items), len(items), st)
+        else:
+            _lib.call('fgnn_block1_struct_fwd', *args, st)
 
     def _struct_bwd(self, params):
         """... and in the backward direction: class sums of d(mult), then the per-class GraphNorm / conv backward, instead of

@@ -459,6 +459,13 @@ int fgnn_block1_struct_bwd(const unsigned *bits, const int *nvalid, int G, int N
                            const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
                            const float *dmult, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2, float *s12_1,
                            float *s12_2, void *stream);
+/* fgnn_block1_struct_fwd with the step's operand packing folded in: `jobs` (njobs <= FGNN_MAX_PACK_JOBS) are what fgnn_pack_operands would be
+ * launched with; they run as extra workgroups of the first launch (which, like them, depends on the weights and the input only), one launch
+ * less per step.  Results identical to the two entry points called one after the other. */
+int fgnn_block1_struct_fwd_pack(const unsigned *bits, const int *nvalid, int G, int N, const float *tables, const float *gnw1, const float *gnb1,
+                                const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, float *mult, long long gstride,
+                                long long ldp, float *xdeg, float *ws, const float *const *tW1, const float *const *tb1,
+                                const float *const *tW2, const float *const *tb2, const fgnn_pack_job *jobs, int njobs, void *stream);
 /* x16 (optional): the (G, 2, ldp) bf16 input slab (channel 0 = W, channel 1 = diag(row sums)) the later kernels of block 1 read */
 int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
                              const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2,

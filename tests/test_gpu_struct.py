@@ -418,3 +418,38 @@ def test_trainer_steps_on_bit_packed_batches(precision):
     assert pdist(out[0][1], out[1][1]) < (0.2 if precision == 'bf16' else 5e-2)
     with pytest.raises(RuntimeError):
         FgnnTrainer(lay, p0.clone()).train_step_bits(x1.to(DEV), x2.to(DEV))          # dense tensors are refused loudly
+
+
+@pytest.mark.parametrize('nblk,B,N,ragged', [(4, 8, 50, False), (1, 2, 9, False), (3, 4, 70, True)])
+def test_operand_packing_inside_the_first_structured_launch_changes_nothing(nblk, B, N, ragged):
+    """fgnn_block1_struct_fwd_pack carries the step's fgnn_pack_operands jobs as extra workgroups of the structured block 1's first
+    launch (one launch less per step): scores, loss and every gradient bit for bit equal to the step with the packing launch."""
+    torch.manual_seed(N)
+    sd = O.init_state_dict(num_blocks=nblk)
+    x1, x2 = synthetic.make_batch(100 + N, B, N, 'ErdosRenyi', 0.3, 0.1)
+    nv = None
+    if ragged:
+        sizes = [N, 33, 64, 5][:B]
+        for b, n in enumerate(sizes):
+            for x in (x1, x2):
+                x[b, :, n:, :] = 0
+                x[b, :, :, n:] = 0
+                x[b, 1] = torch.diag(x[b, 0].sum(1))
+        nv = torch.tensor(sizes * 2, dtype=torch.int32, device=DEV)
+    lay = ParamLayout(2, nblk, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    bits = _bits(x1, x2)
+    res = []
+    for inside in (True, False):
+        eng = FgnnEngine(lay, 2 * B, N, DEV, ragged=ragged, block1='structured')
+        assert eng.struct1
+        eng.PACK_IN_STRUCT = inside
+        for buf in eng._packs.values():
+            buf[4].fill_(float('nan'))              # the images must come from THIS step's packing
+        grads = torch.zeros_like(params)
+        scores, loss = eng.step(params, grads, None, nvalid=nv, bits=bits)
+        torch.cuda.synchronize()
+        res.append((scores.clone(), loss.clone(), grads))
+    assert torch.isfinite(res[0][2]).all() and torch.isfinite(res[0][0]).all()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
