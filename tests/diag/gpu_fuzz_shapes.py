@@ -2,7 +2,7 @@
 """Diagnostic (not collected by pytest): random shapes through the fused engines against the oracle.
 Constant-size and ragged batches, 1-3 blocks, N up to 140; fp32 engine: scores 1e-4 of fp64 (or 4x the fp32 oracle's own distance), flat gradient within 4x the fp32 oracle's own distance to the
 fp64 oracle (the tight per-tensor gates live in tests/test_gpu_parity.py); bf16 engine: finite, scores within 2e-1 L2 of the fp32
-oracle (depth-3 bf16 noise on un-trained weights; its real gates are the same-point tests of tests/test_gpu_bf16.py).  usage: python tests/diag/gpu_fuzz_shapes.py [cases=60] [seed=0]"""
+oracle (depth-3 bf16 noise on un-trained weights; its real gates are the same-point tests of tests/test_gpu_bf16.py).  usage: python tests/diag/gpu_fuzz_shapes.py [cases=60] [seed=0] [big]"""
 import os
 import sys
 
@@ -27,11 +27,12 @@ def main():
     rng = np.random.default_rng(seed)
     torch.set_num_threads(16)
     bad = 0
+    big = len(sys.argv) > 3 and sys.argv[3] == 'big'          # N = 129 ... 256: the largest size class of every kernel
     for case in range(cases):
         nblk = int(rng.integers(1, 4))
         ragged = bool(rng.integers(0, 2))
-        B = int(rng.integers(1, 6))
-        nmax = int(rng.choice([3, 9, 20, 31, 32, 33, 50, 64, 65, 90, 128, 140]))
+        B = int(rng.integers(1, 3 if big else 6))
+        nmax = int(rng.choice([129, 160, 192, 200, 224, 225, 255, 256] if big else [3, 9, 20, 31, 32, 33, 50, 64, 65, 90, 128, 140]))
         ns = [int(rng.integers(1, nmax + 1)) for _ in range(B)] if ragged else [nmax] * B
         torch.manual_seed(case)
         sd = O.init_state_dict(num_blocks=nblk)
