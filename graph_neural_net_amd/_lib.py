@@ -185,6 +185,7 @@ _SIGNATURES = {
     'fgnn_block1_struct_fwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_block1_struct_bwd': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_block1_struct_fwd_pack': [_VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],
+    'fgnn_block1_struct_fwd16_pack': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP],
     'fgnn_block1_struct_fwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_block1_struct_bwd16': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _LL, _LL, _VP, _VP, _VP, _VP, _VP, _VP],
     'fgnn_mlp_bwd_coef_tiles_supported': [_I, _I],

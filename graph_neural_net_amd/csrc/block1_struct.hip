@@ -162,9 +162,10 @@ __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, con
     __shared__ float red[4];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < npack) {
-        // the step's operand packing (fgnn_pack_operands) as the leading workgroups of this launch: it reads the weights only, like the
+        // the step's operand packing (fgnn_pack_operands / fgnn_pack16_operands) as the leading workgroups of this launch: it reads the weights only, like the
         // tables below, and every consumer of an image is a later launch
-        pack_job_body(PJ.job[blockIdx.x / PACK_BLOCKS_PER_JOB], blockIdx.x % PACK_BLOCKS_PER_JOB, PACK_BLOCKS_PER_JOB, tid);
+        if (bf) pack16_job_body(PJ.job[blockIdx.x / PACK16_BLOCKS_PER_JOB], blockIdx.x % PACK16_BLOCKS_PER_JOB, PACK16_BLOCKS_PER_JOB, tid);
+        else pack_job_body(PJ.job[blockIdx.x / PACK_BLOCKS_PER_JOB], blockIdx.x % PACK_BLOCKS_PER_JOB, PACK_BLOCKS_PER_JOB, tid);
         return;
     }
     const int bid = (int)blockIdx.x - npack;
@@ -970,7 +971,12 @@ int sb_fwd_launch(const FwdCall &c) {
                    "fgnn_block1_struct_fwd_pack: job %d malformed", i);
         PJ.job[i] = c.jobs[i];
     }
-    const int npack = c.njobs * PACK_BLOCKS_PER_JOB;
+    if (BF) {
+        for (int i = 0; i < c.njobs; ++i)
+            FGNN_CHECK(c.jobs[i].depth >= 2 && (c.jobs[i].ca == 2 || c.jobs[i].ca == 32) && (c.jobs[i].cb == 0 || c.jobs[i].cb == 2 || c.jobs[i].cb == 32),
+                       "fgnn_block1_struct_fwd16_pack: job %d: depth >= 2 and slab widths 2 or 32 (as fgnn_pack16_operands)", i);
+    }
+    const int npack = c.njobs * (BF ? PACK16_BLOCKS_PER_JOB : PACK_BLOCKS_PER_JOB);
     hipLaunchKernelGGL((sb_graph_kernel<NWD>), dim3(npack + ntab + c.G * ny), dim3(256), 0, c.st, c.bits, c.nvalid, c.N, L.cp, reinterpret_cast<unsigned *>(code),
                        vinfo, c.ws + L.gones, c.xdeg, c.x16, c.ldp, c.pitch, ny, ntab, TA, const_cast<float *>(c.tables), BF ? 1 : 0, npack, PJ);
     FGNN_LAUNCH_CHECK();
@@ -1022,6 +1028,18 @@ extern "C" int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid,
                "fgnn_block1_struct_fwd16: pitches (ldr = %d, ldp = %lld, gstride = %lld)", ldr, ldp, gstride);
     const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, tW1, tb1, tW2, tb2,
                        (hipStream_t)stream, nullptr, 0};
+    return sb_fwd_dispatch<true>(c);
+}
+
+extern "C" int fgnn_block1_struct_fwd16_pack(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
+                                             const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, void *mult,
+                                             long long gstride, long long ldp, void *x16, float *ws, const float *const *tW1,
+                                             const float *const *tb1, const float *const *tW2, const float *const *tb2,
+                                             const fgnn_pack_job *jobs, int njobs, void *stream) {
+    FGNN_CHECK(ldr >= N && ldr % 8 == 0 && ldp >= (long long)N * ldr && ldp % 2 == 0 && gstride >= FGNN_H * ldp && gstride % 2 == 0,
+               "fgnn_block1_struct_fwd16_pack: pitches (ldr = %d, ldp = %lld, gstride = %lld)", ldr, ldp, gstride);
+    const FwdCall c = {bits, nvalid, G, N, tables, gnw1, gnb1, gnw2, gnb2, eps, nrm1, nrm2, mult, gstride, ldp, ldr, nullptr, x16, ws, tW1, tb1, tW2, tb2,
+                       (hipStream_t)stream, jobs, njobs};
     return sb_fwd_dispatch<true>(c);
 }
 

@@ -284,3 +284,41 @@ DEVI void load_slab16(unsigned (&x)[C >= 32 ? 16 : 2], const View16 &v, const Ti
         x[1] = buf_load_u32(v, voff, s0 + v.ld2);
     }
 }
+
+// ---- one fgnn_pack_job of the 16-bit kernel set (fgnn_pack16_operands): one thread per (step, lane) writes the lane's 4 dwords; the tail
+// is plain fp32.  Shared by misc16.hip's launch and by the structured block 1's first launch, which can carry the packing as extra
+// workgroups (block1_struct.hip)
+struct Pack16Jobs {
+    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
+};
+constexpr int PACK16_BLOCKS_PER_JOB = 32;
+__device__ __forceinline__ void pack16_job_body(const fgnn_pack_job &jb, const int bx, const int nbx, const int tid) {
+    const Pk16 p = pk16_layout(jb.kind, jb.ca, jb.cb, jb.depth);
+    const int nm = jb.kind == 0 ? jb.nmlp : 1;
+    unsigned *out = reinterpret_cast<unsigned *>(jb.out);
+    for (int m = 0; m < nm; ++m) {
+        unsigned *om = out + (long long)m * p.floats;
+        const float *const *W = jb.W[m];
+        const float *const *Bv = jb.bias[m];
+        for (int e = bx * 256 + tid; e < p.steps * 64; e += nbx * 256) {
+            const int step = e >> 6, l = e & 63;
+            uint4 v;
+            unsigned d[4];
+            float w8[8];
+            pk16_values8(jb.kind, p, jb.ca, jb.cb, jb.depth, W, step, l, w8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = cvt_pk(w8[2 * q], w8[2 * q + 1]);
+            v.x = d[0];
+            v.y = d[1];
+            v.z = d[2];
+            v.w = d[3];
+            reinterpret_cast<uint4 *>(om)[e] = v;
+        }
+        float *tail = reinterpret_cast<float *>(om + p.bias_f);
+        for (int e = bx * 256 + tid; e < 32 * p.nbias; e += nbx * 256) {
+            const int layer = e >> 5, r = e & 15, h = (e >> 4) & 1;
+            tail[e] = Bv[layer][pk16_ch(r, h)];                                   // compact [layer][h][16]
+            if (jb.kind == 0) tail[32 * p.nbias + e] = Bv[layer][e & 31];         // plain [layer][32]
+        }
+    }
+}

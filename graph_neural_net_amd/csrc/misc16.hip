@@ -5,41 +5,9 @@
 
 namespace {
 
-struct Pack16Jobs {
-    fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
-};
-
 // grid (blocks per job, njobs): one thread per (step, lane) writes the lane's 4 dwords; the tail is plain fp32
 __global__ __launch_bounds__(256) void pack16_kernel(const Pack16Jobs J) {
-    const fgnn_pack_job &jb = J.job[blockIdx.y];
-    const Pk16 p = pk16_layout(jb.kind, jb.ca, jb.cb, jb.depth);
-    const int nm = jb.kind == 0 ? jb.nmlp : 1;
-    unsigned *out = reinterpret_cast<unsigned *>(jb.out);
-    for (int m = 0; m < nm; ++m) {
-        unsigned *om = out + (long long)m * p.floats;
-        const float *const *W = jb.W[m];
-        const float *const *Bv = jb.bias[m];
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < p.steps * 64; e += gridDim.x * 256) {
-            const int step = e >> 6, l = e & 63;
-            uint4 v;
-            unsigned d[4];
-            float w8[8];
-            pk16_values8(jb.kind, p, jb.ca, jb.cb, jb.depth, W, step, l, w8);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d[q] = cvt_pk(w8[2 * q], w8[2 * q + 1]);
-            v.x = d[0];
-            v.y = d[1];
-            v.z = d[2];
-            v.w = d[3];
-            reinterpret_cast<uint4 *>(om)[e] = v;
-        }
-        float *tail = reinterpret_cast<float *>(om + p.bias_f);
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < 32 * p.nbias; e += gridDim.x * 256) {
-            const int layer = e >> 5, r = e & 15, h = (e >> 4) & 1;
-            tail[e] = Bv[layer][pk16_ch(r, h)];                                   // compact [layer][h][16]
-            if (jb.kind == 0) tail[32 * p.nbias + e] = Bv[layer][e & 31];         // plain [layer][32]
-        }
-    }
+    pack16_job_body(J.job[blockIdx.y], blockIdx.x, gridDim.x, threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void to_bf16_kernel(const float *x, const int *nvalid, int C, int N, int ldr,
@@ -226,7 +194,7 @@ extern "C" int fgnn_pack16_operands(const fgnn_pack_job *jobs, int njobs, void *
                    "fgnn_pack16_operands: job %d: slab widths must be 2 or 32", i);
         J.job[i] = jobs[i];
     }
-    hipLaunchKernelGGL(pack16_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, J);
+    hipLaunchKernelGGL(pack16_kernel, dim3(PACK16_BLOCKS_PER_JOB, njobs), dim3(256), 0, (hipStream_t)stream, J);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

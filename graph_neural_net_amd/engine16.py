@@ -24,6 +24,7 @@ class FgnnEngineBF16:
     SKIP_PADDING_TILES = True     # ragged engines: fgnn_ragged_tile_ranges16 + tile skipping in fgnn_mlp_fwd16 / fgnn_mlp_bwd16
     PAIR_BWD = True               # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd16_pair), constant-size batches
     BLOCK1 = os.environ.get('FGNN_BLOCK1', 'generic')      # 'structured': csrc/block1_struct.hip for bit-packed inputs
+    PACK_IN_STRUCT = os.environ.get('FGNN_PACK_IN_STRUCT', '1') != '0'      # as FgnnEngine.PACK_IN_STRUCT
 
     def __init__(self, layout, G, N, device, ragged=False, block1=None):
         lib = _lib.load()
@@ -101,22 +102,25 @@ class FgnnEngineBF16:
     def _slab_raw(self, t):
         return _lib.make_slab16(t, 32 * self.ldp, self.ldp, 32)
 
-    def pack_operands(self, params):
+    def _pack_jobs(self, params, chunk):
         L = self.layout
+        jobs = (_lib.PackJob * len(chunk))()
+        for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
+            jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
+            js = (1, 2) if which == 12 else (which,)
+            for m, j in enumerate(js):
+                rec = L.mlp[(k, j)]
+                for l in range(L.depth):
+                    jobs[i].W[m][l] = self._w(params, rec['w'][l])
+                    jobs[i].bias[m][l] = self._w(params, rec['b'][l])
+            jobs[i].out = buf.data_ptr()
+        return jobs
+
+    def pack_operands(self, params):
         items = list(self._packs.items())
         for lo in range(0, len(items), _lib.MAX_PACK_JOBS):
             chunk = items[lo:lo + _lib.MAX_PACK_JOBS]
-            jobs = (_lib.PackJob * len(chunk))()
-            for i, ((kind, k, which), (knd, ca, cb, nmlp, buf)) in enumerate(chunk):
-                jobs[i].kind, jobs[i].ca, jobs[i].cb, jobs[i].depth, jobs[i].nmlp = knd, ca, cb, L.depth, nmlp
-                js = (1, 2) if which == 12 else (which,)
-                for m, j in enumerate(js):
-                    rec = L.mlp[(k, j)]
-                    for l in range(L.depth):
-                        jobs[i].W[m][l] = self._w(params, rec['w'][l])
-                        jobs[i].bias[m][l] = self._w(params, rec['b'][l])
-                jobs[i].out = buf.data_ptr()
-            _lib.call('fgnn_pack16_operands', jobs, len(chunk), _lib.stream_ptr())
+            _lib.call('fgnn_pack16_operands', self._pack_jobs(params, chunk), len(chunk), _lib.stream_ptr())
 
     def _mlp_fwd(self, params, k, js, a, b, finalize=True):
         """finalize=False: leave the tile statistics un-finalized (the matmul that consumes the two outputs finalizes them in
@@ -188,12 +192,15 @@ class FgnnEngineBF16:
         if bits is None:
             _lib.call('fgnn_to_bf16', _lib.ptr(x), self._nv(), self.G, 2, self.N, self.ldr, _lib.ptr(self.x16),
                       2 * self.ldp, self.ldp, st)
-        self.pack_operands(params)
+        # the structured block 1's first launch carries the packing as extra workgroups (fgnn_block1_struct_fwd16_pack: one launch less)
+        pack_in_struct = bits is not None and self.PACK_IN_STRUCT and len(self._packs) <= _lib.MAX_PACK_JOBS
+        if not pack_in_struct:
+            self.pack_operands(params)
         gs = 32 * self.ldp
         for k in range(1, L.num_blocks + 1):
             sin = self._slab_in(k, params)
             if k == 1 and bits is not None:
-                self._struct_fwd(params)           # mlp1 + mlp2 + mult of block 1 from the class tables; also writes x16
+                self._struct_fwd(params, with_pack=pack_in_struct)      # mlp1 + mlp2 + mult of block 1 from the class tables; also writes x16
                 self._mlp_fwd(params, k, (3,), self._slab_raw(self.mult[k]), sin)
                 continue
             # mlp1 / mlp2's GraphNorm records are finalized by the matmul that consumes them (one launch less per block)
@@ -223,16 +230,21 @@ class FgnnEngineBF16:
         rec = self.layout.mlp[(1, j)]
         return ((C.c_void_p * 3)(*[self._w(params, o) for o in rec['w']]), (C.c_void_p * 3)(*[self._w(params, o) for o in rec['b']]))
 
-    def _struct_fwd(self, params):
+    def _struct_fwd(self, params, with_pack=False):
         S = self._struct_ws()
         st = _lib.stream_ptr()
         (w1, b1), (w2, b2) = self._w3(params, 1), self._w3(params, 2)
         r1, r2 = self.layout.mlp[(1, 1)], self.layout.mlp[(1, 2)]
-        _lib.call('fgnn_block1_struct_fwd16', _lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']),
-                  C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
-                  C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
-                  _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
-                  _lib.ptr(self.x16), _lib.ptr(S['ws']), w1, b1, w2, b2, st)      # (the class tables are built by the same launch)
+        args = [_lib.ptr(self.xbits), self._nv(), self.G, self.N, self.ldr, _lib.ptr(S['tab']),
+                C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r1['gn_b'])),
+                C.c_void_p(self._w(params, r2['gn_w'])), C.c_void_p(self._w(params, r2['gn_b'])), EPS,
+                _lib.ptr(self.nrm[(1, 1)]), _lib.ptr(self.nrm[(1, 2)]), _lib.ptr(self.mult[1]), 32 * self.ldp, self.ldp,
+                _lib.ptr(self.x16), _lib.ptr(S['ws']), w1, b1, w2, b2]      # (the class tables are built by the same launch)
+        if with_pack:       # ... and the operand images of the step's MLP launches (pack_operands, without its launch)
+            items = list(self._packs.items())
+            _lib.call('fgnn_block1_struct_fwd16_pack', *args, self._pack_jobs(params, items), len(items), st)
+        else:
+            _lib.call('fgnn_block1_struct_fwd16', *args, st)
 
     def _struct_bwd(self, params):
         S, W = self._struct_ws(), self._bwd

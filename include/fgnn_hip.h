@@ -471,6 +471,11 @@ int fgnn_block1_struct_fwd16(const unsigned *bits, const int *nvalid, int G, int
                              const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2,
                              void *mult /* bf16 */, long long gstride, long long ldp, void *x16 /* bf16, optional */, float *ws,
                              const float *const *tW1, const float *const *tb1, const float *const *tW2, const float *const *tb2, void *stream);
+/* ... and fgnn_block1_struct_fwd16 with the jobs of fgnn_pack16_operands riding in its first launch */
+int fgnn_block1_struct_fwd16_pack(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *gnw1,
+                                  const float *gnb1, const float *gnw2, const float *gnb2, float eps, float *nrm1, float *nrm2, void *mult,
+                                  long long gstride, long long ldp, void *x16, float *ws, const float *const *tW1, const float *const *tb1,
+                                  const float *const *tW2, const float *const *tb2, const fgnn_pack_job *jobs, int njobs, void *stream);
 int fgnn_block1_struct_bwd16(const unsigned *bits, const int *nvalid, int G, int N, int ldr, const float *tables, const float *const *W1,
                              const float *const *W2, const float *nrm1, const float *nrm2, const float *gnb1, const float *gnb2,
                              const void *dmult /* bf16 */, long long gstride, long long ldp, float *ws, float *wpart1, float *wpart2,

@@ -343,3 +343,28 @@ def test_structured_16_bit_backward_on_the_generic_forward_state(N, B, nblk):
     assert worst_same < 1e-6, worst_same
     assert worst_b1 < 2e-2, worst_b1
     print('same-state 16-bit backward: other tensors %.1e, block-1 mlp1 / mlp2 %.1e' % (worst_same, worst_b1))
+
+
+@pytest.mark.parametrize('N,B,nblk', [(50, 2, 4), (200, 1, 2)])
+def test_operand_packing_inside_the_first_structured_launch_changes_nothing_16(N, B, nblk):
+    """fgnn_block1_struct_fwd16_pack: the jobs of fgnn_pack16_operands as extra workgroups of the structured block 1's first launch --
+    scores, loss and every gradient of the 16-bit step bit for bit equal to the step with the packing launch (images poisoned first)."""
+    torch.manual_seed(N)
+    sd = O.init_state_dict(num_blocks=nblk)
+    x1, x2 = synthetic.make_batch(300 + N, B, N, 'ErdosRenyi', 0.3, 0.1)
+    lay = ParamLayout(2, nblk, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    bits = _bits(torch.cat([x1, x2]))
+    res = []
+    for inside in (True, False):
+        eng = FgnnEngineBF16(lay, 2 * B, N, DEV, block1='structured')
+        eng.PACK_IN_STRUCT = inside
+        for buf in eng._packs.values():
+            buf[4].fill_(float('nan'))
+        grads = torch.zeros_like(params)
+        scores, loss = eng.step(params, grads, None, bits=bits)
+        torch.cuda.synchronize()
+        res.append((scores.clone(), loss.clone(), grads))
+    assert torch.isfinite(res[0][2]).all() and torch.isfinite(res[0][0]).all()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
