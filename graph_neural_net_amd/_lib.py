@@ -199,6 +199,7 @@ _SIGNATURES = {
     'fgnn_expand_adjacency': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_pack_adjacency': [_VP, _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_pack_adjacency_ld': [_VP, _VP, _I, _I, _I, _VP, _VP, _VP],
+    'fgnn_pack_adjacency_pair': [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP],
     'fgnn_adjacency_degree': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_accuracy_max': [_VP, _VP, _I, _I, _VP, _VP],
     'fgnn_lsap_accuracy': [_VP, _LL, _I, _VP, _I, _I, _VP, _VP, _VP],

@@ -197,16 +197,36 @@ extern "C" int fgnn_expand_adjacency(const unsigned *bits, const int *nvalid, in
 // tensor IS a tensor representation (channel 0 in {0, 1}; channel 1 = diag(row sums of channel 0) on the valid corner).  One wave per
 // row: lane = column (64 per pass), the row's words are ballots; `bad` (optional, device int) is OR-ed with 1 where the check fails.
 namespace {
+// x2 != nullptr (fgnn_pack_adjacency_pair): the G graphs are the B = G / 2 graphs of x followed by the B graphs of x2, each side with its
+// own vertex counts (nvalid / nvalid2, B entries each); the counts are also copied to nv_out (G entries) and block 0 leaves 1 / sum(nvalid)
+// in inv_out -- what two launches per side, two copies and fgnn_inv_node_count did
 __global__ __launch_bounds__(256) void pack_adjacency_kernel(const float *x, const int *nvalid, int G, int Nin, int N, int words,
-                                                             unsigned *bits, int *bad) {
+                                                             unsigned *bits, int *bad, const float *x2, const int *nvalid2, int *nv_out,
+                                                             float *inv_out) {
     // x: (G, 2, Nin, Nin); bits: (G, N, words) with N >= Nin -- rows / columns >= Nin are empty
+    const int B = x2 ? G / 2 : G;
+    if (blockIdx.x == 0 && threadIdx.x < 64 && x2 && nvalid) {
+        if (inv_out) {
+            int sum = 0;
+            for (int b = threadIdx.x; b < B; b += 64) sum += nvalid[b];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            if (threadIdx.x == 0) inv_out[0] = sum > 0 ? 1.f / (float)sum : 0.f;
+        }
+        if (nv_out) {
+            for (int b = threadIdx.x; b < G; b += 64) nv_out[b] = b < B ? nvalid[b] : nvalid2[b - B];
+        }
+    }
     const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);      // row over (g, i)
     if (t >= (long long)G * N) return;
     const int lane = threadIdx.x & 63, g = (int)(t / N), i = (int)(t - (long long)g * N);
-    const int nv = min(nvalid_of(nvalid, g, N), Nin);
-    const float *w = x + ((long long)g * 2) * Nin * Nin + (long long)i * Nin, *d = w + (long long)Nin * Nin;
+    const bool second = g >= B;           // (only with x2)
+    const int gs = second ? g - B : g;
+    const float *xs = second ? x2 : x;
+    const int *nvs = second ? nvalid2 : nvalid;
+    const int nv = min(nvalid_of(nvs, gs, N), Nin);
+    const float *w = xs + ((long long)gs * 2) * Nin * Nin + (long long)i * Nin, *d = w + (long long)Nin * Nin;
     int deg = 0;
-    bool wrong = nvalid && (nvalid[g] > Nin || nvalid[g] < 0);
+    bool wrong = nvs && (nvs[gs] > Nin || nvs[gs] < 0);
     float dii = 0.f;
     for (int j0 = 0; j0 < 32 * words; j0 += 64) {
         const int j = j0 + lane;
@@ -232,7 +252,18 @@ extern "C" int fgnn_pack_adjacency_ld(const float *x, const int *nvalid, int G, 
     FGNN_CHECK(x && bits && G > 0 && Nin > 0 && N >= Nin, "fgnn_pack_adjacency_ld: bad arguments");
     const long long rows = (long long)G * N;
     hipLaunchKernelGGL(pack_adjacency_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, nvalid, G, Nin, N,
-                       (N + 31) / 32, bits, bad);
+                       (N + 31) / 32, bits, bad, (const float *)nullptr, (const int *)nullptr, (int *)nullptr, (float *)nullptr);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int fgnn_pack_adjacency_pair(const float *x1, const float *x2, const int *nvalid1, const int *nvalid2, int B, int Nin, int N,
+                                        unsigned *bits, int *nv_out, float *inv_out, int *bad, void *stream) {
+    FGNN_CHECK(x1 && x2 && bits && B > 0 && Nin > 0 && N >= Nin, "fgnn_pack_adjacency_pair: bad arguments");
+    FGNN_CHECK((nvalid1 == nullptr) == (nvalid2 == nullptr) && (nvalid1 || (!nv_out && !inv_out)),
+               "fgnn_pack_adjacency_pair: both sides ragged or none; nv_out / inv_out need the vertex counts");
+    const long long rows = 2ll * B * N;
+    hipLaunchKernelGGL(pack_adjacency_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x1, nvalid1, 2 * B, Nin, N,
+                       (N + 31) / 32, bits, bad, x2, nvalid2, nv_out, inv_out);
     FGNN_LAUNCH_CHECK();
     return 0;
 }

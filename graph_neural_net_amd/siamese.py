@@ -201,14 +201,23 @@ class Siamese_Node_Exp(nn.Module):
                 if not torch.equal(x1.nvalid, x2.nvalid):
                     raise RuntimeError('fused_step: the two sides of a MaskedTensor batch must share the per-pair vertex counts; use '
                                        'the module path `loss = model.loss(model(x1, x2)); loss.backward()`')
-            st['nv'][:B].copy_(x1.nvalid)
-            st['nv'][B:].copy_(x2.nvalid)
+            if not tr:
+                st['nv'][:B].copy_(x1.nvalid)
+                st['nv'][B:].copy_(x2.nvalid)
         if tr:
-            # one launch per side straight from the loader's tensors: rows of ballots -> (B, N, ceil(N/32)) words of the engine's padded
-            # size, with the verdict (channel 0 in {0, 1}, channel 1 = diag(row sums), counts within the padded size) OR-ed into a flag
-            for half, t, xm in ((st['bits'][:B], t1, x1), (st['bits'][B:], t2, x2)):
-                _lib.call('fgnn_pack_adjacency_ld', _lib.ptr(t.contiguous()), _lib.ptr(xm.nvalid) if ragged else None, B, nmax, N,
-                          _lib.ptr(half), _lib.ptr(st['flag']), _lib.stream_ptr())
+            # ONE launch straight from the loader's tensors, both sides: rows of ballots -> (2 B, N, ceil(N/32)) words of the engine's padded
+            # size, with the verdict (channel 0 in {0, 1}, channel 1 = diag(row sums), counts within the padded size) OR-ed into a flag;
+            # ragged batches: the same launch copies the vertex counts into the engine's buffer and leaves 1 / sum(n) in st['inv']
+            nv1 = nv2 = None
+            if ragged:
+                nv1, nv2 = x1.nvalid, x2.nvalid
+                if nv1.dtype != torch.int32 or not nv1.is_cuda or not nv1.is_contiguous() or nv2.dtype != torch.int32 \
+                        or not nv2.is_cuda or not nv2.is_contiguous():
+                    nv1, nv2 = nv1.to(device=dev, dtype=torch.int32).contiguous(), nv2.to(device=dev, dtype=torch.int32).contiguous()
+            _lib.call('fgnn_pack_adjacency_pair', _lib.ptr(t1.contiguous()), _lib.ptr(t2.contiguous()),
+                      _lib.ptr(nv1) if ragged else None, _lib.ptr(nv2) if ragged else None, B, nmax, N, _lib.ptr(st['bits']),
+                      _lib.ptr(st['nv']) if ragged else None, _lib.ptr(st['inv']) if ragged else None, _lib.ptr(st['flag']),
+                      _lib.stream_ptr())
             if first_of_shape or (self.INPUT_CHECK_EVERY and st['calls'] % self.INPUT_CHECK_EVERY == 0):
                 self._raise_if_not_representation(st)
         elif ragged:
@@ -230,7 +239,8 @@ class Siamese_Node_Exp(nn.Module):
             if ragged:
                 # 1 / sum(n) on the device (one tiny launch): the scoring backward reads it as its gradient scale and the loss job of
                 # the gradient-finalize launch multiplies it in -- no copy, no host round trip, nothing of the batch in the graph
-                _lib.call('fgnn_inv_node_count', _lib.ptr(st['nv']), B, _lib.ptr(st['inv']), _lib.stream_ptr())
+                if not tr:      # (input_form='tensor_representation': the packing launch in front of the graph has written st['inv'])
+                    _lib.call('fgnn_inv_node_count', _lib.ptr(st['nv']), B, _lib.ptr(st['inv']), _lib.stream_ptr())
                 eng._loss_scale_dev = st['inv']
                 scores, loss = eng.forward(params, xin, nvalid=st['nv'], total_nodes=1.0, defer_loss=True, bits=bits)
                 eng.backward(params, grads, gscale_dev=st['inv'])

@@ -316,9 +316,9 @@ class FgnnTrainer:
                 if self._tr_flag is None:
                     self._tr_flag = torch.zeros(1, dtype=torch.int32, device=x1.device)
                 nv = None if nvalid is None else nvalid.to(device=x1.device, dtype=torch.int32)
-                for half, t in ((w[:B], x1), (w[B:], x2)):
-                    _lib.call('fgnn_pack_adjacency_ld', _lib.ptr(t.contiguous()), _lib.ptr(nv) if nv is not None else None, B, N, N,
-                              _lib.ptr(half), _lib.ptr(self._tr_flag), _lib.stream_ptr())
+                nvp = _lib.ptr(nv) if nv is not None else None      # (both sides of a pair share their vertex counts)
+                _lib.call('fgnn_pack_adjacency_pair', _lib.ptr(x1.contiguous()), _lib.ptr(x2.contiguous()), nvp, nvp, B, N, N, _lib.ptr(w),
+                          None, None, _lib.ptr(self._tr_flag), _lib.stream_ptr())         # one launch for both sides
                 self._tr_calls += 1
                 if first or (self.INPUT_CHECK_EVERY and self._tr_calls % self.INPUT_CHECK_EVERY == 0):
                     self.check_input_form()

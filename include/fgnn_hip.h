@@ -493,6 +493,12 @@ int fgnn_pack_adjacency(const float *x, const int *nvalid, int G, int N, unsigne
  * MaskedTensor loader batch (loaders/loaders.py:5-15) in front of the structured block 1.  `bad` is OR-ed (sticky until the caller
  * zeroes it); an nvalid[g] outside [0, Nin] also sets it. */
 int fgnn_pack_adjacency_ld(const float *x, const int *nvalid, int G, int Nin, int N, unsigned *bits, int *bad, void *stream);
+/* Both sides of a siamese batch in ONE launch (loaders/loaders.py:12-15 yields the two sides as two tensors): bits (2 B, N, words) = the B graphs
+ * of x1 followed by the B graphs of x2, each side with its own vertex counts (both NULL: constant-size).  Optionally the counts are copied to
+ * nv_out (2 B entries: the engine's nvalid) and 1 / sum(nvalid1) -- the normaliser of triplet_loss 'mean', toolbox/losses.py:27-34 -- is left
+ * in inv_out (what fgnn_inv_node_count computes).  Same verdict flag as fgnn_pack_adjacency_ld. */
+int fgnn_pack_adjacency_pair(const float *x1, const float *x2, const int *nvalid1, const int *nvalid2, int B, int Nin, int N, unsigned *bits,
+                             int *nv_out, float *inv_out, int *bad, void *stream);
 /* deg[g][i] = number of set bits j < nvalid[g] in row i (0 for rows >= nvalid[g]): the diagonal of channel 1, for the
  * kernels that expand the adjacency themselves (fgnn_mlp_fwd_args.xbits / xdeg) */
 int fgnn_adjacency_degree(const unsigned *bits, const int *nvalid, int G, int N, float *deg, void *stream);

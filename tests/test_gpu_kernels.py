@@ -460,3 +460,55 @@ def test_pack_tensor_representation_round_trip_and_check(N):
             assert int(flag.item()) == 1
         _, flag = inputs.pack_tensor_representation(x, check='device')
         assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize('Nin,N,ragged', [(50, 50, False), (33, 40, True), (97, 104, True), (1, 8, True), (64, 64, True)])
+def test_pack_adjacency_pair_equals_the_two_launches_it_replaces(Nin, N, ragged):
+    """fgnn_pack_adjacency_pair (both sides of a siamese batch in one launch, loaders/loaders.py:12-15) against two fgnn_pack_adjacency_ld
+    launches + the copy of the vertex counts + fgnn_inv_node_count: words, counts, 1 / sum(n) and the verdict flag bit for bit; a bad entry
+    on EITHER side raises the flag."""
+    from graph_neural_net_amd import inputs, synthetic
+    rng = np.random.default_rng(7 * Nin + N)
+    B = 3
+    nv1 = torch.tensor([Nin, max(Nin // 2, 1), 1], dtype=torch.int32, device=DEV) if ragged else None
+    nv2 = torch.tensor([max(Nin - 1, 1), Nin, max(Nin // 3, 1)], dtype=torch.int32, device=DEV) if ragged else None
+    xs = []
+    for nv in (nv1, nv2):
+        w = (rng.random((B, Nin, Nin)) < 0.4).astype(np.float32)
+        bits = torch.from_numpy(synthetic.pack_adjacency(w).view(np.int32)).to(DEV)
+        xs.append(inputs.expand_adjacency(bits, Nin, nvalid=nv).contiguous())
+    words = (N + 31) // 32
+
+    def two(x1, x2):
+        bits = torch.full((2 * B, N, words), -1, dtype=torch.int32, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        for half, x, nv in ((bits[:B], x1, nv1), (bits[B:], x2, nv2)):
+            _lib.call('fgnn_pack_adjacency_ld', _lib.ptr(x), _lib.ptr(nv) if ragged else None, B, Nin, N, _lib.ptr(half), _lib.ptr(flag),
+                      _lib.stream_ptr())
+        return bits, flag
+
+    def one(x1, x2):
+        bits = torch.full((2 * B, N, words), -1, dtype=torch.int32, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        nvo = torch.full((2 * B,), -7, dtype=torch.int32, device=DEV)
+        inv = torch.full((1,), -7.0, device=DEV)
+        _lib.call('fgnn_pack_adjacency_pair', _lib.ptr(x1), _lib.ptr(x2), _lib.ptr(nv1) if ragged else None, _lib.ptr(nv2) if ragged else None,
+                  B, Nin, N, _lib.ptr(bits), _lib.ptr(nvo) if ragged else None, _lib.ptr(inv) if ragged else None, _lib.ptr(flag),
+                  _lib.stream_ptr())
+        return bits, flag, nvo, inv
+
+    b2, f2 = two(*xs)
+    b1, f1, nvo, inv = one(*xs)
+    torch.cuda.synchronize()
+    assert torch.equal(b1, b2) and int(f1.item()) == int(f2.item()) == 0
+    if ragged:
+        assert torch.equal(nvo, torch.cat([nv1, nv2]))
+        ref = torch.empty(1, device=DEV)
+        _lib.call('fgnn_inv_node_count', _lib.ptr(nv1), B, _lib.ptr(ref), _lib.stream_ptr())
+        assert torch.equal(inv, ref)
+    if Nin >= 2:
+        for side in (0, 1):
+            ys = [x.clone() for x in xs]
+            ys[side][0, 0, 0, 1] = 0.5
+            _, f, _, _ = one(*ys)
+            assert int(f.item()) == 1
