@@ -88,6 +88,54 @@ HD float pk_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, int
     return jj < cb ? W[0][pk_ch(u, hh) * cin + ca + jj] : 0.f;
 }
 
+// ---- the same images for the 16-pixel-tile kernels (fgnn_t16.h, v_mfma_f32_16x16x4_f32) --------------------------------------
+// Same containers (PkFwd / PkBwd offsets, [t / 4][lane][4]); a "step" t of a 32-channel set is now (k-step s = t >> 1, row
+// block b = t & 1): lane (m = l & 15, k = l >> 4) holds Mx[row pkt_row(b, m)][contracted channel pkt_chan(s, k)].  A
+// 2-channel slab is one k-step: t = b, lanes k = 0, 1 carry channels 0, 1, the rest zeros.
+HD constexpr int pkt_chan(int s, int q) { return 8 * (s >> 1) + 2 * (s & 1) + (q >> 1) + 4 * (q & 1); }
+HD constexpr int pkt_row(int b, int m) { return pkt_chan(4 * b + (m & 3), m >> 2); }
+// contracted channel of step t, lane quarter k, for a slab of c channels (-1: none)
+HD constexpr int pkt_in(int c, int t, int k) { return c == 32 ? pkt_chan(t >> 1, k) : ((t >> 1) == 0 && k < c ? k : -1); }
+HD float pkt_bias_value(const float *const *bias, int idx) { return bias[idx >> 5][pkt_chan(idx & 7, (idx >> 3) & 3)]; }
+HD float pkt_fwd_value(const PkFwd &p, int ca, int cb, const float *const *W, int t, int l) {
+    const int m = l & 15, k = l >> 4, cin = ca + cb;
+    if (t < p.off_w1b) {
+        const int u = t - p.off_w1a, c = u < (ca == 32 ? 16 : 2) ? pkt_in(ca, u, k) : -1;
+        return c >= 0 ? W[0][pkt_row(u & 1, m) * cin + c] : 0.f;
+    }
+    if (t < p.off_wh) {
+        const int u = t - p.off_w1b, c = u < (cb == 32 ? 16 : 2) ? pkt_in(cb, u, k) : -1;
+        return c >= 0 ? W[0][pkt_row(u & 1, m) * cin + ca + c] : 0.f;
+    }
+    const int u = t - p.off_wh, v = u & 15;
+    return W[1 + (u >> 4)][pkt_row(v & 1, m) * FGNN_H + pkt_chan(v >> 1, k)];
+}
+HD float pkt_bwd_value(const PkBwd &p, int ca, int cb, const float *const *W, int t, int l) {
+    const int m = l & 15, k = l >> 4, cin = ca + cb;
+    if (t < p.off_w1b) {
+        const int u = t - p.off_w1a, c = u < (ca == 32 ? 16 : 2) ? pkt_in(ca, u, k) : -1;
+        return c >= 0 ? W[0][pkt_row(u & 1, m) * cin + c] : 0.f;
+    }
+    if (t < p.off_wh) {
+        const int u = t - p.off_w1b, c = u < (cb == 32 ? 16 : 2) ? pkt_in(cb, u, k) : -1;
+        return c >= 0 ? W[0][pkt_row(u & 1, m) * cin + ca + c] : 0.f;
+    }
+    if (t < p.off_wt) {
+        const int u = t - p.off_wh, v = u & 15;
+        return W[1 + (u >> 4)][pkt_row(v & 1, m) * FGNN_H + pkt_chan(v >> 1, k)];
+    }
+    if (t < p.off_wt0a) {       // W_l^T: row = input channel of W_l, contracted = its output channel
+        const int u = t - p.off_wt, v = u & 15;
+        return W[1 + (u >> 4)][pkt_chan(v >> 1, k) * FGNN_H + pkt_row(v & 1, m)];
+    }
+    if (t < p.off_wt0b) {
+        const int v = t - p.off_wt0a, r = pkt_row(v & 1, m);
+        return r < ca ? W[0][pkt_chan(v >> 1, k) * cin + r] : 0.f;
+    }
+    const int v = t - p.off_wt0b, r = pkt_row(v & 1, m);
+    return r < cb ? W[0][pkt_chan(v >> 1, k) * cin + ca + r] : 0.f;
+}
+
 // The same copy split in two halves, so that a prologue can put the image loads in flight FIRST and do its other
 // (dependent) loads and arithmetic before the values are needed: one memory round trip instead of two.
 template <int N4, int NTHREADS>
@@ -126,16 +174,18 @@ struct PackJobs {
     fgnn_pack_job job[FGNN_MAX_PACK_JOBS];
 };
 DEVI void pack_job_body(const fgnn_pack_job &jb, const int bx, const int nbx, const int tid) {
-    if (jb.kind == 0) {
+    const bool t16 = jb.kind >= 4;          // kinds 4 / 5: the 16-pixel-tile images of kinds 0 / 1
+    if (jb.kind == 0 || jb.kind == 4) {
         const PkFwd p = pk_fwd(jb.ca, jb.cb, jb.depth);
         const int per = p.floats;
         for (int e = bx * 256 + tid; e < per * jb.nmlp; e += nbx * 256) {
             const int m = e / per, r = e - m * per;
             if (r < p.bias_f) {
                 const int t = r >> 6, l = r & 63;
-                jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] = pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l);
+                jb.out[m * per + (t >> 2) * 256 + l * 4 + (t & 3)] =
+                    t16 ? pkt_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l) : pk_fwd_value(p, jb.ca, jb.cb, jb.W[m], t, l);
             } else {
-                jb.out[m * per + r] = pk_bias_value(jb.bias[m], r - p.bias_f);
+                jb.out[m * per + r] = t16 ? pkt_bias_value(jb.bias[m], r - p.bias_f) : pk_bias_value(jb.bias[m], r - p.bias_f);
             }
         }
     } else {
@@ -143,9 +193,10 @@ DEVI void pack_job_body(const fgnn_pack_job &jb, const int bx, const int nbx, co
         for (int e = bx * 256 + tid; e < p.floats; e += nbx * 256) {
             if (e < p.bias_f) {
                 const int t = e >> 6, l = e & 63;
-                jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] = pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l);
+                jb.out[(t >> 2) * 256 + l * 4 + (t & 3)] =
+                    t16 ? pkt_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l) : pk_bwd_value(p, jb.ca, jb.cb, jb.W[0], t, l);
             } else {
-                jb.out[e] = pk_bias_value(jb.bias[0], e - p.bias_f);
+                jb.out[e] = t16 ? pkt_bias_value(jb.bias[0], e - p.bias_f) : pk_bias_value(jb.bias[0], e - p.bias_f);
             }
         }
     }

@@ -410,7 +410,7 @@ extern "C" int fgnn_inv_node_count(const int *nvalid, int B, float *out, void *s
 }
 
 extern "C" int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp) {
-    return kind == 0 ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;
+    return (kind == 0 || kind == 4) ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;     // 4 / 5: the *_t16 kernels' images
 }
 
 extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *stream) {

@@ -165,6 +165,9 @@ class FgnnEngine:
     SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '0') != '0'
     # the step's operand packing as extra workgroups of the structured block 1's first launch (FGNN_PACK_IN_STRUCT=0: its own launch)
     PACK_IN_STRUCT = os.environ.get('FGNN_PACK_IN_STRUCT', '1') != '0'
+    # round 6: the MLP kernels on 16-pixel tiles / v_mfma_f32_16x16x4_f32 (csrc/*_t16.hip) where they are built; FGNN_T16=0: the
+    # 32-pixel kernels everywhere.  A comma list selects single kernels for A/B runs: 'pair', 'bwd', 'fwd'
+    T16 = os.environ.get('FGNN_T16', 'pair,bwd,fwd')
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -181,6 +184,7 @@ class FgnnEngine:
         three-way operand split of csrc/fgnn_x3.h (fp32 tensors, fp32 accumulation, error of an fp32 rounding per product;
         built for depth 3 and constant-size batches -- other cases use 'f32')."""
         _lib.load()
+        self.T16 = type(self).T16           # (snapshot: the operand images below are packed for the kernel set chosen here)
         self.cu_share = int(cu_share)
         mfma = self.MFMA if mfma is None else mfma
         if mfma not in ('f32', 'x3'):
@@ -248,6 +252,8 @@ class FgnnEngine:
             # (measurement switch FGNN_X3_PARTS = 'fwd' / 'pair': only that half of the x3 kernel pair, the other on fp32 MFMAs)
             f12 = 2 if (self.x3 and not self.x3_fwd) else 0
             b12 = 3 if (self.x3 and not self.x3_pair) else 1
+            if self._t16_pair(cin):
+                b12 = 5
             self._packs[('f', k, 12)] = (f12, cin, 0, 2, torch.empty(fl(f12, cin, 0, layout.depth, 2), **f32))
             self._packs[('f', k, 3)] = (f3, 32, cin, 1, torch.empty(fl(f3, 32, cin, layout.depth, 1), **f32))
             for j in (1, 2):
@@ -255,6 +261,13 @@ class FgnnEngine:
             self._packs[('b', k, 3)] = (b3, 32, cin, 1, torch.empty(fl(b3, 32, cin, layout.depth, 1), **f32))
 
     # ------------------------------------------------------------------ helpers
+    def _t16(self, what):
+        return self.T16 not in ('0', '') and what in self.T16.split(',')
+
+    def _t16_pair(self, cin):
+        """mlp1 + mlp2 backward of a block on the 16-pixel-tile kernel (fgnn_mlp_bwd_pair_t16): dense 32-channel input slab, depth 3"""
+        return (self._t16('pair') and self.PAIR_BWD and not self.x3_pair and self.layout.depth == 3 and cin == 32 and self.N <= 256)
+
     def _nv(self):
         return _lib.ptr(self.nvalid) if self.nvalid is not None else None
 
@@ -578,7 +591,8 @@ class FgnnEngine:
         W = self._bwd
         a1 = self._mlp_bwd_args(params, k, 1, sin, None, W['dy1'], None, None, None, False, False, False, None)
         a2 = self._mlp_bwd_args(params, k, 2, sin, None, W['dy2'], None, din, None, True, False, emit, None)
-        _lib.call('fgnn_mlp_bwd_pair_x3' if self.x3_pair else 'fgnn_mlp_bwd_pair', C.byref(a1), C.byref(a2), _lib.stream_ptr(),
+        entry = 'fgnn_mlp_bwd_pair_x3' if self.x3_pair else ('fgnn_mlp_bwd_pair_t16' if self._t16_pair(sin.C) else 'fgnn_mlp_bwd_pair')
+        _lib.call(entry, C.byref(a1), C.byref(a2), _lib.stream_ptr(),
                   tag='mlp_bwd_pair[cin=%d,dx=%d]' % (sin.C, sin.C if din is not None else 0))
 
     def _mlp_bwd_args(self, params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides):

@@ -58,7 +58,8 @@ int fgnn_mlp_bwd_num_workgroups(void);
  * The MLP kernels keep their MFMA A-operands (weights, biases, transposed weights) in LDS.
  * Weights are constant within a step, so the images of all MLP launches can be packed ONCE
  * per step by one small launch and are then copied straight into LDS by every workgroup.
- * kind 0 = forward image (nmlp MLPs), kind 1 = backward image (one MLP; uses W[0], bias[0]). */
+ * kind 0 = forward image (nmlp MLPs), kind 1 = backward image (one MLP; uses W[0], bias[0]);
+ * kind 4 / 5 = the same two images in the layout of the 16-pixel-tile kernels (fgnn_*_t16; same sizes). */
 #define FGNN_MAX_PACK_JOBS 24
 typedef struct {
     int kind, ca, cb, depth, nmlp;
@@ -363,6 +364,15 @@ int fgnn_mlp_bwd_pair(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, 
  * fgnn_pack_x3_operands; the weight-gradient operands are transposed on the matrix pipe instead of through LDS tiles
  * (csrc/mlp_bwd_pair_x3.hip).  d_in is bit-identical to two accumulating fgnn_mlp_bwd_x3 launches.  No `ranges`. */
 int fgnn_mlp_bwd_pair_x3(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
+/* Round 6: the same launch on 16-pixel tiles / v_mfma_f32_16x16x4_f32 (csrc/mlp_bwd_pair_t16.hip, csrc/fgnn_t16.h) -- same arguments,
+ * work unit (a 32-pixel tile, processed as two halves), S1/S2 records and partial rows as fgnn_mlp_bwd_pair, so it is a drop-in; the
+ * operand images are of kind 5 (fgnn_pack_operands; kind 4 = the forward image for the *_t16 forward kernel).  The recomputed hidden
+ * activations follow the SAME fma sequence as the 32-pixel kernels (bit-identical ReLU masks); d_in is one fma chain over (the
+ * gradient mlp3 left, mlp1's terms, mlp2's terms) instead of three separately rounded sums, the weight-gradient sums run in another
+ * pixel order: equal to the 32-pixel kernel to fp32 rounding, not bit for bit.  Depth 3, one dense 32-channel slab, N <= 256,
+ * constant-size and ragged batches (nvalid, ranges). */
+int fgnn_mlp_bwd_pair_t16_supported(int ca, int depth);
+int fgnn_mlp_bwd_pair_t16(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
 int fgnn_mlp_bwd_coef_tiles_supported(int G, int N);   /* s12tiles usable: a workgroup spans <= FGNN_BWD_COEF_GRAPHS graphs */
 /* floats per workgroup in `wpart` for an MLP with Cin input channels and `depth` convs:
