@@ -27,7 +27,18 @@ DEVI constexpr int chan(int s, int q) { return 8 * (s >> 1) + 2 * (s & 1) + (q >
 DEVI constexpr int chan_s(int s) { return 8 * (s >> 1) + 2 * (s & 1); }        // register part
 DEVI int chan_q(int q) { return (q >> 1) + 4 * (q & 1); }                       // lane part
 
-DEVI f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#ifndef FGNN_ABL
+#define FGNN_ABL 0          // measurement switch (tools/build_variant.sh ... -DFGNN_ABL=mask): ablated builds, never shipped.  1 no partner waits, 2 operands
+                            // from registers instead of the LDS image, 4 no global traffic in the tile loop, 8 no staging writes, 16 no weight gradients, 32 no MFMAs
+#endif
+DEVI f32x4 mfma16(float a, float b, f32x4 c) {
+#if FGNN_ABL & 32           // no matrix instructions: everything but the MFMA pipe
+    c[0] += a * b;
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
 
 DEVI f32x4 zero4() {
     f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -43,7 +54,12 @@ DEVI void gemm32(f32x4 (&acc)[2], const float *wl, const float (&bop)[8], int la
     const float4 *p = reinterpret_cast<const float4 *>(wl) + (OFF / 4) * 64 + lane;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+#if FGNN_ABL & 2           // operands from registers instead of the LDS image
+        const float4 w = make_float4(bop[0], bop[1], bop[2], bop[3 + (u & 1)]);
+        (void)p;
+#else
         const float4 w = p[u * 64];
+#endif
         acc[0] = mfma16(w.x, bop[2 * u], acc[0]);
         acc[1] = mfma16(w.y, bop[2 * u], acc[1]);
         acc[0] = mfma16(w.z, bop[2 * u + 1], acc[0]);
@@ -70,6 +86,9 @@ DEVI void load_bias(f32x4 (&acc)[2], const float *tail, int layer, int q) {
 // ---- LDS tiles [channel][pixel] ------------------------------------------------------------------------------------------
 // lane_base = chan_q(q) * TLD + px (floats); register s goes to row chan(s, q): a compile-time offset on top
 DEVI void stage8(float *T, int lane_base, const float (&v)[8]) {
+#if FGNN_ABL & 8           // no staging writes
+    if (v[0] != 1.2345e-30f) return;
+#endif
 #pragma unroll
     for (int s = 0; s < 8; ++s) T[lane_base + chan_s(s) * TLD] = v[s];
 }
@@ -77,6 +96,9 @@ DEVI void stage8(float *T, int lane_base, const float (&v)[8]) {
 // dW[2 mb + nb] += Dt (rows = out channel 16 mb ..) x In (rows = in channel 16 nb ..), contraction over the 16 pixels;
 // db[mb] from the same reads (lane (i, q) holds pixels 4 q .. 4 q + 3 of channel 16 mb + i)
 DEVI void wgrad16(f32x4 (&dW)[4], float (&db)[2], const float *Dt, const float *In, int lane) {
+#if FGNN_ABL & 16           // no weight gradients
+    return;
+#endif
     const int i = lane & 15, q = lane >> 4;
     const float4 a0 = *reinterpret_cast<const float4 *>(Dt + i * TLD + 4 * q);
     const float4 a1 = *reinterpret_cast<const float4 *>(Dt + (16 + i) * TLD + 4 * q);
@@ -102,12 +124,23 @@ DEVI void wgrad16(f32x4 (&dW)[4], float (&db)[2], const float *Dt, const float *
 // pixel does not exist), s0 = graph offset in bytes
 DEVI int lane_voff(const View &v, int q, int p, bool inb) { return inb ? chan_q(q) * v.ld4 + 4 * p : OOB_OFF; }
 DEVI void load8(float (&x)[8], const View &v, int voff, int s0) {
+#if FGNN_ABL & 4           // no global traffic in the tile loop
+    for (int s = 0; s < 8; ++s) x[s] = __builtin_bit_cast(float, voff + s0 + s);
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 8; ++s) x[s] = buf_load(v, voff, s0 + chan_s(s) * v.ld4);
 }
+#ifndef FGNN_STORE_AUX
+#define FGNN_STORE_AUX 0    // cache policy of the slab stores (measurement switch): 2 = nt, 16 = sc1 (write-through), 17 = sc0 sc1
+#endif
 DEVI void store8(const float (&x)[8], const View &v, int voff, int s0) {
+#if FGNN_ABL & 4
+    if (x[0] != 1.2345e-30f) return;
+#endif
 #pragma unroll
-    for (int s = 0; s < 8; ++s) buf_store(x[s], v, voff, s0 + chan_s(s) * v.ld4);
+    for (int s = 0; s < 8; ++s)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[s]), v.r, voff, s0 + chan_s(s) * v.ld4, FGNN_STORE_AUX);
 }
 
 // row / column of pixel p in an N x N plane without an integer division: (p + 0.5) / N is at least 0.5 / N away from an

@@ -20,6 +20,18 @@
 #include "fgnn_t16.h"
 #include "fgnn_pack.h"
 
+#ifdef FGNN_PHASES
+// Debug build only (-DFGNN_PHASES): per-wave cycle stamps of the half-tile phases, summed over the wave's halves (tools/gpu_phases_t16.py)
+__device__ unsigned long long *g_phase16_buf = nullptr;
+#define PH_DECL unsigned long long ph_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ph_last_ = __builtin_amdgcn_s_memtime();
+#define PH(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[k] += t_ - ph_last_; ph_last_ = t_; }
+#define PH_FLUSH if (g_phase16_buf && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; ++k_) g_phase16_buf[((long long)blockIdx.x * NW + wv) * 16 + k_] = ph_[k_]; }
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_FLUSH
+#endif
+
 namespace {
 
 using namespace t16;
@@ -37,11 +49,18 @@ DEVI float4 coef_from_sums(const float4 n, const float2 sv, float nv) {
     k.w = m > 0.f ? -n.y * sv.x / m : 0.f;
     return k;
 }
-DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch) {
+DEVI float4 coef_record(const fgnn_mlp_bwd_args &A, int g, int ch, int nv) {
     if (A.coef) return reinterpret_cast<const float4 *>(A.coef)[(long long)g * FGNN_H + ch];
     const float4 n = reinterpret_cast<const float4 *>(A.znrm)[(long long)g * FGNN_H + ch];
     const float2 sv = reinterpret_cast<const float2 *>(A.s12)[(long long)g * FGNN_H + ch];
-    return coef_from_sums(n, sv, (float)nvalid_of(A.nvalid, g, A.N));
+    return coef_from_sums(n, sv, (float)nv);
+}
+// vertex count of graph g through a buffer descriptor (an empty one without nvalid: returns 0, no access).  `nvalid ? nvalid[g] : N`
+// compiles to ONE load through a select of the two addresses -- a FLAT load, which makes every later s_waitcnt of the tile loop
+// a full drain (flat operations complete out of order with respect to buffer loads)
+DEVI int graph_nv(const rsrc_t &rnv, bool ragged, int g, int N) {
+    const int v = __builtin_amdgcn_raw_buffer_load_b32(rnv, g * 4, 0, 0);
+    return __builtin_amdgcn_readfirstlane(ragged ? v : N);
 }
 
 struct PairLayout16 {
@@ -54,7 +73,7 @@ struct PairLayout16 {
     static constexpr int PCOUNT = 32 * 32 + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int TILE_OFF = 2 * WEIGHT_F;
     static constexpr int XCH_OFF = TILE_OFF + NW * NSLOT * TILE_F;        // per pair: the handed-over dx fragment [s][lane]
-    static constexpr int FLAG_OFF = XCH_OFF + NP * 512;                   // per pair: ready, consumed (+ padding)
+    static constexpr int FLAG_OFF = XCH_OFF + NP * 1024;                  // (two slots per pair); per pair: ready, consumed counters (+ padding)
     static constexpr int REC_OFF = FLAG_OFF + 4 * NP;                     // per wave: {coef[32], nrm[32]} float4 (graph changes only)
     static constexpr int MAIN_F = REC_OFF + NW * 256;
     static constexpr int RED_F = NW * PCOUNT;
@@ -67,7 +86,8 @@ struct PairArgs {
 
 // SKIP (ragged batches with ranges): work-balanced tile range from fgnn_ragged_tile_ranges, padding-only tiles are stepped over
 // (the two waves of a pair walk the same tile sequence, so the hand-over protocol is unchanged)
-template <bool SKIP>
+// HAS_DX: the input gradient exists (every block but one whose input is the model input)
+template <bool SKIP, bool HAS_DX>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const PairArgs P, const int tpg, const int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = PairLayout16;
@@ -81,11 +101,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     const View vz = make_view(A.z, A.zgstride, A.ldz, A.G);
     const View vdx = make_view(P.m[1].dxa, P.m[1].dxa_gstride, P.m[1].dxa_ld, P.m[1].G);
 
+    PH_DECL
     float *wl = smem + role * L::WEIGHT_F;              // this wave's MLP image
     float *my = smem + L::TILE_OFF + wv * (L::NSLOT * TILE_F);
     float *XA = my, *S0 = my + TILE_F, *S1 = my + 2 * TILE_F, *S2 = my + 3 * TILE_F;
-    float *XCH = smem + L::XCH_OFF + pair * 512;
-    int *flags = reinterpret_cast<int *>(smem + L::FLAG_OFF) + 4 * pair;     // [0] = half whose dx is ready, [1] = half consumed
+    float *XCH = smem + L::XCH_OFF + pair * 1024;
+    int *flags = reinterpret_cast<int *>(smem + L::FLAG_OFF) + 4 * pair;     // [0] = fragments handed over, [1] = fragments consumed
     const int lane_base = chan_q(q) * TLD + px;
 
     f32x4 dW0[4], dW1[4], dW2[4];
@@ -102,15 +123,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         T1 = A.ranges[blockIdx.x + 1];
     }
     const bool normA = A.a.nrm != nullptr;
-    const bool has_dx = P.m[1].dxa != nullptr;
+    constexpr bool has_dx = HAS_DX;
     const bool emit = role == 1 && normA && has_dx && P.m[1].s12part != nullptr;
     const bool rmw = has_dx && P.m[1].accumulate_a;
     const bool ragged = A.nvalid != nullptr;
+    const rsrc_t rnv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.nvalid), 0, ragged ? A.G * 4 : 0, 0x00020000);
     const float rcpN = 1.f / (float)A.N;
 
     // Prologue = ONE memory round trip: both operand images (into registers), the first half tile, the per-graph records.
     constexpr int N4 = L::WEIGHT_F / 4, N4PAD = (N4 + 63) & ~63, IMG_PER = (N4PAD + N4 + 64 * NW - 1) / (64 * NW);
     float4 img[IMG_PER];
+    PH(14)              // kernel arguments arrived (descriptors built)
     {
         const rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.m[0].packed), 0, N4 * 16, 0x00020000);
         const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.m[1].packed), 0, N4 * 16, 0x00020000);
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    PH(15)              // image loads issued
 
     // per-graph records of this lane's 8 channels, kept in registers for all tiles of a graph
     float mean[8], av[8], beta[8], kx[8], ky[8], kz[8], kw[8];
@@ -140,9 +164,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     // at a graph change: one channel per lane (lanes 0..31) fetches / derives the records, a wave-private LDS copy hands every lane
     // its 8 channels (the derivation -- two divisions per channel -- is then one instance per lane instead of eight)
     float4 *rec = reinterpret_cast<float4 *>(smem + L::REC_OFF) + wv * 64;
-    auto fetch_records = [&](int g) {
+    auto fetch_records = [&](int g, int nv) {
         if (lane < 32) {
-            rec[lane] = coef_record(A, g, lane);
+            rec[lane] = coef_record(A, g, lane, nv);
             if (normA) rec[32 + lane] = reinterpret_cast<const float4 *>(A.a.nrm)[(long long)g * A.a.C + lane];
         }
     };
@@ -162,7 +186,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         }
     };
 
-    float xa[8];
+    // loop-carried loads: every slab of a half is requested while the PREVIOUS half computes (x after its layer-1 stage, dy / z as
+    // soon as dz has consumed their registers, the old d_in after the hand-over), so no wave waits for HBM inside a half
+    float xa[8], dyr[8], zr[8], oldr[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) oldr[s] = 0.f;
     int cached_g = -1, cur_nv = A.N;
     int tile = T0 + pair;
     if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_live_tile(tile, T1, NP, tpg, A.N, A.nvalid));
@@ -171,25 +199,40 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         const bool act = tile < T1;
         const int g = __builtin_amdgcn_readfirstlane(act ? tile / tpg : 0);
         const int p = (act ? tile - g * tpg : 0) * 32 + px;
-        load8(xa, va, lane_voff(va, q, p, act && p < P2), g * va.gs4);
+        const bool inb0 = act && p < P2;
+        load8(xa, va, lane_voff(va, q, p, inb0), g * va.gs4);
+        load8(dyr, vdy, lane_voff(vdy, q, p, inb0), g * vdy.gs4);
+        load8(zr, vz, lane_voff(vz, q, p, inb0), g * vz.gs4);
+        if (has_dx) load8(oldr, vdx, lane_voff(vdx, q, p, inb0 && rmw && role == 0), g * vdx.gs4);
         if (act) {
-            fetch_records(g);
+            cur_nv = graph_nv(rnv, ragged, g, A.N);
+            fetch_records(g, cur_nv);
             cached_g = g;
-            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, g, A.N));
         }
     }
+    PH(12)              // prologue a: kernel arguments, descriptors, every load of the prologue issued
 #pragma unroll
     for (int k = 0; k < IMG_PER; ++k) {
         const int e = threadIdx.x + k * (64 * NW);
         if (e < N4) reinterpret_cast<float4 *>(smem)[e] = img[k];
         else if (e >= N4PAD && e < N4PAD + N4) reinterpret_cast<float4 *>(smem)[N4 + e - N4PAD] = img[k];
     }
-    if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = -1;
+    if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = 0;
+    PH(13)              // prologue b: images (and everything requested before them) arrived, written to LDS
     __syncthreads();
     if (cached_g >= 0) read_records();
+    PH(9)               // prologue
 
-    int prev_h = -1;                                 // role 0: the half index whose dx sits in the hand-over slot
-    float s1 = 0.f, s2 = 0.f;                        // role 1: S1 / S2 of the current 32-pixel tile (lane = channel)
+#ifdef FGNN_STAGGER         // measurement switch: the mlp2 waves start late by FGNN_STAGGER x 64 cycles
+    if (role == 1) __builtin_amdgcn_s_sleep(FGNN_STAGGER);
+#endif
+    int hk = 0;                                      // fragments this pair has handed over so far (two slots: the mlp1 wave may run a half ahead)
+    // role 1: S1 / S2 of the input slab's producer, accumulated PER LANE (pixel column, 8 channels) over the pair's consecutive tiles of
+    // a graph and reduced over the pixels once, at the pair's last tile of the graph -- the consumers (fgnn_gn_bwd_coef_tiles, the
+    // prologue of fgnn_mlp_bwd) only sum a graph's tile records, so the other tiles of the run carry zeros
+    float es1[8], es2[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) es1[s] = es2[s] = 0.f;
     while (tile < T1) {
         int tnext = tile + NP;
         if constexpr (SKIP) {
@@ -199,10 +242,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         const int p = tt * 32 + 16 * hf + px;
         const bool inb = p < P2;
         if (g != cached_g) {
-            fetch_records(g);
+            cur_nv = graph_nv(rnv, ragged, g, A.N);
+            fetch_records(g, cur_nv);
             read_records();
             cached_g = g;
-            cur_nv = __builtin_amdgcn_readfirstlane(nvalid_of(A.nvalid, g, A.N));
         }
         bool valid = inb;
         if (ragged) {
@@ -215,23 +258,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 
         // the next half's input slab: the other half of this tile, or the first half of the pair's next tile
         const int ntile = hf == 0 ? tile : tnext, nhf = hf ^ 1;
-        int nvoff, ns0;
+        int np, ng;
+        bool ninb;
         {
             const bool act = ntile < T1;
-            const int ng = __builtin_amdgcn_readfirstlane(act ? ntile / tpg : 0);
-            const int np = (act ? ntile - ng * tpg : 0) * 32 + 16 * nhf + px;
-            nvoff = lane_voff(va, q, np, act && np < P2);
-            ns0 = ng * va.gs4;
+            ng = __builtin_amdgcn_readfirstlane(act ? ntile / tpg : 0);
+            np = (act ? ntile - ng * tpg : 0) * 32 + 16 * nhf + px;
+            ninb = act && np < P2;
         }
         float nxa[8];
 
         {
-            float dyr[8], zr[8];
             f32x4 dx[2];
-            load8(dyr, vdy, lane_voff(vdy, q, p, inb), g * vdy.gs4);
-            load8(zr, vz, lane_voff(vz, q, p, inb), g * vz.gs4);
             const int dvoff = lane_voff(vdx, q, p, inb), ds0 = g * vdx.gs4;
-            dx[0] = dx[1] = zero4();
 
             // ---- forward recompute of the hidden activations (bit-identical to the forward's chain) ----
             float h1[8], h2[8];
@@ -252,6 +291,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
                 for (int s = 0; s < 8; ++s) h2[s] = relu1(acc[s >> 2][s & 3]);
                 stage8(S1, lane_base, h2);
             }
+            PH(1)       // x arrived, normalised, two layers recomputed and staged
             // ---- dz from (dy, z, coef); the ONLY place the padding mask is applied ----
             float dpre[8];
 #pragma unroll
@@ -261,6 +301,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
                 for (int s = 0; s < 8; ++s) dpre[s] = valid ? dpre[s] : 0.f;
             }
             stage8(S2, lane_base, dpre);
+            load8(dyr, vdy, lane_voff(vdy, q, np, ninb), ng * vdy.gs4);      // the next half's dy / z into the registers just consumed
+            load8(zr, vz, lane_voff(vz, q, np, ninb), ng * vz.gs4);
+            PH(2)       // dz (waits for dy, z)
             __builtin_amdgcn_sched_barrier(0);
             // ---- layer 2: dgrad, weight gradient (dz x h2), ReLU mask of h2 ----
             {
@@ -271,14 +314,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #pragma unroll
                 for (int s = 0; s < 8; ++s) dpre[s] = h2[s] > 0.f ? a2[s >> 2][s & 3] : 0.f;
             }
+            PH(3)       // layer 2 dgrad + wgrad + mask
             __builtin_amdgcn_sched_barrier(0);
             stage8(S1, lane_base, dpre);         // h2's tile is dead: its reads were issued above (LDS is in order within a wave)
-            if (role == 0 && rmw) {              // the gradient mlp3 left in d_in: the start of the dx chain (needed a layer from here)
-                float old[8];
-                load8(old, vdx, dvoff, ds0);
-#pragma unroll
-                for (int s = 0; s < 8; ++s) dx[s >> 2][s & 3] = old[s];
-            }
             // ---- layer 1 ----
             {
                 f32x4 a2[2];
@@ -288,71 +326,97 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #pragma unroll
                 for (int s = 0; s < 8; ++s) dpre[s] = h1[s] > 0.f ? a2[s >> 2][s & 3] : 0.f;
             }
+            PH(4)       // layer 1
             __builtin_amdgcn_sched_barrier(0);
             stage8(S2, lane_base, dpre);         // dz's tile is dead
             __builtin_amdgcn_sched_barrier(0);
-            load8(nxa, va, nvoff, ns0);
+            // the dx chain starts from the gradient mlp3 left in d_in (mlp1 wave; zeros otherwise)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dx[s >> 2][s & 3] = oldr[s];
+            // The next half's x and old d_in.  Both are issued HERE, in straight-line code and by both waves (the mlp2 wave's d_in loads are
+            // out of range: no traffic, zeros): memory operations issued behind the spin loops below, or on one side of a branch, make the
+            // compiler lose count of what is in flight, and the wait for x at the top of the loop becomes a full drain (stores included)
+            load8(nxa, va, lane_voff(va, q, np, ninb), ng * va.gs4);
+            if (has_dx) load8(oldr, vdx, lane_voff(vdx, q, np, ninb && rmw && role == 0), ng * vdx.gs4);
             // ---- layer 0: the dx chain runs through both waves of the pair ----
-            const int hidx = 2 * tile + hf;
             // (ONE call site per weight gradient: accumulators that are updated on both sides of a branch cost a second register set)
             if (role == 0 && has_dx) gemm32<L::OFF_WT0>(dx, wl, dpre, lane);
             wgrad16(dW0, db0, S2, XA, lane);
+            PH(5)       // layer 0 weight gradient (+ mlp1's dgrad)
             if (role == 0) {
                 if (has_dx) {
-                    // the slot still holds the fragment handed over one half ago: wait until the mlp2 wave has read it
-                    if (prev_h >= 0) {
-                        while (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != prev_h) __builtin_amdgcn_s_sleep(1);
+                    // slot hk & 1 still holds fragment hk - 2: wait until the mlp2 wave has read it
+                    if (hk >= 2) {
+#if !(FGNN_ABL & 1)
+                        while (__hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < hk - 1) __builtin_amdgcn_s_sleep(1);
+#endif
                     }
+                    PH(6)   // waiting for the partner wave
+                    float *slot = XCH + (hk & 1) * 512;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) XCH[s * 64 + lane] = dx[s >> 2][s & 3];
-                    __hip_atomic_store(&flags[0], hidx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    prev_h = hidx;
+                    for (int s = 0; s < 8; ++s) slot[s * 64 + lane] = dx[s >> 2][s & 3];
+                    __hip_atomic_store(&flags[0], hk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             } else {
                 if (has_dx) {
-                    while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != hidx) __builtin_amdgcn_s_sleep(1);
+#if !(FGNN_ABL & 1)
+                    while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < hk + 1) __builtin_amdgcn_s_sleep(1);
+#endif
+                    PH(6)   // waiting for the partner wave
+                    const float *slot = XCH + (hk & 1) * 512;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) dx[s >> 2][s & 3] = XCH[s * 64 + lane];
-                    __hip_atomic_store(&flags[1], hidx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    for (int s = 0; s < 8; ++s) dx[s >> 2][s & 3] = slot[s * 64 + lane];
+                    __hip_atomic_store(&flags[1], hk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     gemm32<L::OFF_WT0>(dx, wl, dpre, lane);
                     float v[8];
 #pragma unroll
                     for (int s = 0; s < 8; ++s) v[s] = dx[s >> 2][s & 3];
                     store8(v, vdx, dvoff, ds0);
                     if (emit) {
-                        // GraphNorm-backward sums of the producer of the input slab: S1 = sum v, S2 = sum v (z_in - mean_in) over
-                        // the valid pixels, transposed through the dead h1 / dpre_1 tiles so that lane (ch, hh) owns 8 pixels of a channel
-                        float u[8];
-#pragma unroll
-                        for (int s = 0; s < 8; ++s) u[s] = xa[s] - mean[s];
+                        // GraphNorm-backward sums of the producer of the input slab: S1 = sum v, S2 = sum v (z_in - mean_in) over the valid pixels
                         if (!full) {
 #pragma unroll
                             for (int s = 0; s < 8; ++s) v[s] = valid ? v[s] : 0.f;
                         }
-                        stage8(S0, lane_base, v);
-                        stage8(S1, lane_base, u);
-                        const int ch = lane & 31, hh = lane >> 5;
-                        const float4 *vp = reinterpret_cast<const float4 *>(S0 + ch * TLD + 8 * hh);
-                        const float4 *up = reinterpret_cast<const float4 *>(S1 + ch * TLD + 8 * hh);
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const float4 a = vp[k], b = up[k];
-                            s1 += (a.x + a.y) + (a.z + a.w);
-                            s2 += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+                        for (int s = 0; s < 8; ++s) {
+                            es1[s] += v[s];
+                            es2[s] = fmaf(v[s], xa[s] - mean[s], es2[s]);
                         }
                     }
                 }
             }
+            ++hk;
         }
+        PH(7)           // hand-over / mlp2's dgrad, store, emission
         if (emit && hf == 1) {
-            const float t1 = s1 + __shfl_xor(s1, 32), t2 = s2 + __shfl_xor(s2, 32);
+            // the pair's last tile of this graph: reduce the lane sums over the pixels (transposed through the dead h1 / dpre_1 tiles:
+            // lane (ch, hh) owns 8 pixel columns of a channel); any other tile: an empty record
+            float t1 = 0.f, t2 = 0.f;
+            if (ntile >= T1 || ng != g) {
+                stage8(S0, lane_base, es1);
+                stage8(S1, lane_base, es2);
+                const int ch = lane & 31, hh = lane >> 5;
+                const float4 *vp = reinterpret_cast<const float4 *>(S0 + ch * TLD + 8 * hh);
+                const float4 *up = reinterpret_cast<const float4 *>(S1 + ch * TLD + 8 * hh);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float4 a = vp[k], b = up[k];
+                    t1 += (a.x + a.y) + (a.z + a.w);
+                    t2 += (b.x + b.y) + (b.z + b.w);
+                }
+                t1 += __shfl_xor(t1, 32);
+                t2 += __shfl_xor(t2, 32);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) es1[s] = es2[s] = 0.f;
+            }
             if (lane < 32) reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)g * tpg + tt) * FGNN_H + lane] = make_float2(t1, t2);
-            s1 = s2 = 0.f;
         }
 #pragma unroll
         for (int s = 0; s < 8; ++s) xa[s] = nxa[s];
         tile = ntile;
         hf = nhf;
+        PH(8)           // record store, loop bookkeeping
     }
 
     if constexpr (SKIP) {
@@ -379,6 +443,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         db2[b] += __shfl_xor(db2[b], 32);
     }
     __syncthreads();                       // everyone done with the operand images and the tile buffers
+    PH(10)              // waiting for the slowest wave of the workgroup
     {
         float *red = smem + wv * PCOUNT;
         auto put = [&](int off, const f32x4 (&dW)[4], const float (&db)[2]) {
@@ -413,24 +478,30 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         }
         reinterpret_cast<float4 *>(P.m[m].wpart + (long long)blockIdx.x * PCOUNT)[ee] = a;
     }
+    PH(11)              // workgroup reduction + partial store
+    PH_FLUSH
 }
 
-template <bool SKIP>
+template <bool SKIP, bool HAS_DX>
 int launch_pair16(const fgnn_mlp_bwd_args *a1, const fgnn_mlp_bwd_args *a2, int tpg, int total, hipStream_t st) {
     constexpr int LDS = PairLayout16::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_pair_t16_kernel<SKIP>, LDS);
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_bwd_pair_t16_kernel<SKIP, HAS_DX>, LDS);
     PairArgs P;
     P.m[0] = *a1;
     P.m[1] = *a2;
-    hipLaunchKernelGGL((mlp_bwd_pair_t16_kernel<SKIP>), dim3(a1->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st, P, tpg,
+    hipLaunchKernelGGL((mlp_bwd_pair_t16_kernel<SKIP, HAS_DX>), dim3(a1->cu_share == 2 && !SKIP ? BWD_WG / 2 : BWD_WG), dim3(64 * NW), LDS, st, P, tpg,
                        total);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
+
+#ifdef FGNN_PHASES
+extern "C" int fgnn_debug_phase_buffer_t16(void *p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_phase16_buf), &p, sizeof(p)) == hipSuccess ? 0 : 1; }
+#endif
 
 extern "C" int fgnn_mlp_bwd_pair_t16_supported(int ca, int depth) { return (depth == 3 && ca == 32) ? 1 : 0; }
 
@@ -462,6 +533,6 @@ extern "C" int fgnn_mlp_bwd_pair_t16(const fgnn_mlp_bwd_args *a1, const fgnn_mlp
     const long long total = (long long)a1->G * tpg;
     FGNN_CHECK(total < (1ll << 29), "fgnn_mlp_bwd_pair_t16: too many tiles");
     hipStream_t st = (hipStream_t)stream;
-    if (a1->ranges) return launch_pair16<true>(a1, a2, tpg, (int)total, st);
-    return launch_pair16<false>(a1, a2, tpg, (int)total, st);
+    if (a2->dxa) return a1->ranges ? launch_pair16<true, true>(a1, a2, tpg, (int)total, st) : launch_pair16<false, true>(a1, a2, tpg, (int)total, st);
+    return a1->ranges ? launch_pair16<true, false>(a1, a2, tpg, (int)total, st) : launch_pair16<false, false>(a1, a2, tpg, (int)total, st);
 }
