@@ -359,6 +359,19 @@ def main():
         sub = run_config(args, args.config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), mfma='x3', profile=False)
         out['mfma_x3'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'], 'ms_per_step_min': sub['ms_per_step_min'],
                           'ms_per_step_max': sub['ms_per_step_max'], 'mlp_contraction': sub['config']['mlp_contraction']}
+    if rank == 0 and world == 1 and args.config == 'cfg2' and args.path == 'engine' and args.mfma is None and args.precision is None \
+            and args.batch is None and args.n is None and not args.no_extra_configs:
+        # how the reference is actually run (side entries; the headline stays cfg2, fp32, 32 pairs per GPU):
+        #   precision16 -- the cfg2 workload on the 16-bit engine (commander_explore.py:120-122 trains at precision=16; bf16 here)
+        #   batch256    -- cfg2 at the reference's default_config.yaml batch (256 pairs) on one GPU
+        sub = run_config(args, args.config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), profile=False, precision_override='bf16')
+        out['precision16'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'], 'ms_per_step_min': sub['ms_per_step_min'],
+                              'ms_per_step_max': sub['ms_per_step_max'], 'dtype': sub['dtype'], 'batch_per_gpu': sub['config']['batch_per_gpu'],
+                              'workload': sub['config']['workload'], 'block1': sub['config'].get('block1'), 'input': sub['config'].get('input')}
+        sub = run_config(args, args.config, rank, world, dev, cpu_leg=False, windows=min(args.windows, 3), profile=False, batch_override=256)
+        out['batch256'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'], 'ms_per_step_min': sub['ms_per_step_min'],
+                           'ms_per_step_max': sub['ms_per_step_max'], 'dtype': sub['dtype'], 'batch_per_gpu': sub['config']['batch_per_gpu'],
+                           'workload': sub['config']['workload'], 'block1': sub['config'].get('block1'), 'input': sub['config'].get('input')}
     if rank == 0 and world == 1 and args.path == 'engine' and not args.no_extra_configs and out['config'].get('block1', 'generic') != 'generic':
         # ... and through the module surface a user of the reference calls (dense loader batch in, fused_step)
         out['module_surface'] = module_surface_leg(args, args.config, rank, world, dev, out['ms_per_step'])
@@ -450,19 +463,19 @@ def module_surface_leg(args, config, rank, world, dev, engine_ms):
 
 
 def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=None, input_form=None, path=None,
-               module_input_form=None, profile=True, mfma=None):
+               module_input_form=None, profile=True, mfma=None, precision_override=None, batch_override=None):
     """One measurement: build the workload of `config`, capture the step, settle, warm up, time `windows` windows of
     exactly K steps (barrier + synchronize on both sides, max over ranks), roofline leg.  Returns the JSON dict (rank 0).
     block1 / input_form: override --block1 / --input (the dense-input line reported beside the headline); path /
     module_input_form: override --path / --module-input-form (module_surface_leg)."""
     windows = args.windows if windows is None else windows
     mfma_arg = mfma
-    precision = args.precision if config == args.config else None
+    precision = precision_override if precision_override is not None else (args.precision if config == args.config else None)
     dense_er = config == 'cfg4'                   # the workload
     ragged = config == 'cfg5'                     # variable-N pairs, n in [30, N], one batch padded to its largest graph
     bf16 = (precision == 'bf16') if precision else dense_er      # the kernel set
     same = config == args.config
-    B = args.batch if (same and args.batch is not None) else (8 if (dense_er or ragged) else 32)
+    B = batch_override if batch_override is not None else (args.batch if (same and args.batch is not None) else (8 if (dense_er or ragged) else 32))
     N = args.n if (same and args.n is not None) else (200 if dense_er else (120 if ragged else 50))
     path = path if path is not None else (args.path if same else 'engine')
     mform = module_input_form if module_input_form is not None else args.module_input_form

@@ -167,6 +167,20 @@ DEVI void pk_store_regs(float *lds, const PkRegs<N4, NTHREADS> &r) {
     }
 }
 
+// ---- the image's way into LDS without registers (round 6, the *_t16 kernels): global_load_lds_dwordx4, 1 KiB per wave instruction ----
+// The image region in LDS and the packed buffer are both padded to whole KiB (pk_pad_floats): a wave instruction moves 64 x 16 B, the
+// destination is wave-uniform base + lane x 16.  Nothing to store afterwards: the loads land in LDS; the prologue's barrier
+// (__syncthreads waits vmcnt(0)) orders them before the first read.
+HD constexpr int pk_pad_floats(int floats) { return (floats + 255) & ~255; }
+template <int NWAVES>
+DEVI void pk_glds(float *lds_dst, const float *packed, int padded_floats, int wv, int lane) {
+    const int chunks = padded_floats / 256;
+    for (int c = wv; c < chunks; c += NWAVES)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(packed + c * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void *)(unsigned long long)(unsigned)(unsigned long long)(lds_dst + c * 256),
+                                         16, 0, 0);
+}
+
 // ---- one fgnn_pack_job (include/fgnn_hip.h): the LDS operand image(s) of one MLP kernel launch, written by `nbx` blocks of 256 threads.
 // Shared by fgnn_pack_operands (norm.hip) and by the first launch of the structured block 1, which carries the step's packing as
 // extra workgroups (block1_struct.hip: one launch less per step)

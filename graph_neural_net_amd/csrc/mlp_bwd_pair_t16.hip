@@ -68,7 +68,7 @@ struct PairLayout16 {
     static constexpr PkBwd PK = pk_bwd(32, 0, DEPTH);                      // one image per MLP: fgnn_pack.h (kind 5)
     static constexpr int OFF_W0 = PK.off_w1a, OFF_W1 = PK.off_wh, OFF_WT1 = PK.off_wt, OFF_WT2 = PK.off_wt + 16, OFF_WT0 = PK.off_wt0a;
     static constexpr int BIAS_F = PK.bias_f;
-    static constexpr int WEIGHT_F = PK.floats;                            // floats per image
+    static constexpr int WEIGHT_F = pk_pad_floats(PK.floats);             // floats per image (whole KiB: global_load_lds)
     static constexpr int NSLOT = 4;                                       // per wave: x_a, h1, h2 / dpre_1, dz / dpre_0
     static constexpr int PCOUNT = 32 * 32 + 32 + (DEPTH - 1) * (32 * 32 + 32);
     static constexpr int TILE_OFF = 2 * WEIGHT_F;
@@ -92,7 +92,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = PairLayout16;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wv >> 2, pair = wv & 3;            // role 0: mlp1 (starts the dx chain), role 1: mlp2 (finishes it, stores, emits)
+#ifdef FGNN_SWAP_ROLES      // measurement switch: the older waves (0..3) run mlp2
+    const int role = 1 - (wv >> 2), pair = wv & 3;
+#else
+    const int role = wv >> 2, pair = wv & 3;
+#endif            // role 0: mlp1 (starts the dx chain), role 1: mlp2 (finishes it, stores, emits)
     const int px = lane & 15, q = lane >> 4;
     const fgnn_mlp_bwd_args &A = P.m[role];
     const int P2 = A.N * A.N;
@@ -130,26 +134,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     const rsrc_t rnv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.nvalid), 0, ragged ? A.G * 4 : 0, 0x00020000);
     const float rcpN = 1.f / (float)A.N;
 
-    // Prologue = ONE memory round trip: both operand images (into registers), the first half tile, the per-graph records.
-    constexpr int N4 = L::WEIGHT_F / 4, N4PAD = (N4 + 63) & ~63, IMG_PER = (N4PAD + N4 + 64 * NW - 1) / (64 * NW);
-    float4 img[IMG_PER];
+    // Prologue = ONE memory round trip: both operand images (straight into LDS), the first half tile, the per-graph records.
     PH(14)              // kernel arguments arrived (descriptors built)
-    {
-        const rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.m[0].packed), 0, N4 * 16, 0x00020000);
-        const rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.m[1].packed), 0, N4 * 16, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < IMG_PER; ++k) {
-            const int e = threadIdx.x + k * (64 * NW);
-            const bool second = __builtin_amdgcn_readfirstlane(e) >= N4PAD;
-            const rsrc_t rs = second ? r1 : r0;
-            const int off = (second ? e - N4PAD : e) * 16;                                    // past the end: returns 0
-            img[k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
-            img[k].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 4, 0));
-            img[k].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 8, 0));
-            img[k].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 12, 0));
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    pk_glds<NW>(smem, P.m[0].packed, L::WEIGHT_F, wv, lane);
+    pk_glds<NW>(smem + L::WEIGHT_F, P.m[1].packed, L::WEIGHT_F, wv, lane);
     PH(15)              // image loads issued
 
     // per-graph records of this lane's 8 channels, kept in registers for all tiles of a graph
@@ -201,9 +189,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         const int p = (act ? tile - g * tpg : 0) * 32 + px;
         const bool inb0 = act && p < P2;
         load8(xa, va, lane_voff(va, q, p, inb0), g * va.gs4);
-        load8(dyr, vdy, lane_voff(vdy, q, p, inb0), g * vdy.gs4);
-        load8(zr, vz, lane_voff(vz, q, p, inb0), g * vz.gs4);
-        if (has_dx) load8(oldr, vdx, lane_voff(vdx, q, p, inb0 && rmw && role == 0), g * vdx.gs4);
         if (act) {
             cur_nv = graph_nv(rnv, ragged, g, A.N);
             fetch_records(g, cur_nv);
@@ -211,21 +196,33 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
         }
     }
     PH(12)              // prologue a: kernel arguments, descriptors, every load of the prologue issued
-#pragma unroll
-    for (int k = 0; k < IMG_PER; ++k) {
-        const int e = threadIdx.x + k * (64 * NW);
-        if (e < N4) reinterpret_cast<float4 *>(smem)[e] = img[k];
-        else if (e >= N4PAD && e < N4PAD + N4) reinterpret_cast<float4 *>(smem)[N4 + e - N4PAD] = img[k];
-    }
     if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = 0;
     PH(13)              // prologue b: images (and everything requested before them) arrived, written to LDS
     __syncthreads();
+    // The first half's dy / z / old d_in are requested only now: the barrier above drains every outstanding load, and at a kernel's start
+    // all CUs fetch at once (~ 10 B per cycle and CU) -- the first MFMA should wait for the images and x (57 KB per CU), not for these 48 KB
+    {
+        const bool act = tile < T1;
+        const int g = __builtin_amdgcn_readfirstlane(act ? tile / tpg : 0);
+        const int p = (act ? tile - g * tpg : 0) * 32 + px;
+        const bool inb0 = act && p < P2;
+        load8(dyr, vdy, lane_voff(vdy, q, p, inb0), g * vdy.gs4);
+        load8(zr, vz, lane_voff(vz, q, p, inb0), g * vz.gs4);
+        if (has_dx) load8(oldr, vdx, lane_voff(vdx, q, p, inb0 && rmw && role == 0), g * vdx.gs4);
+    }
     if (cached_g >= 0) read_records();
     PH(9)               // prologue
 
 #ifdef FGNN_STAGGER         // measurement switch: the mlp2 waves start late by FGNN_STAGGER x 64 cycles
     if (role == 1) __builtin_amdgcn_s_sleep(FGNN_STAGGER);
 #endif
+#ifndef FGNN_PRIO
+#define FGNN_PRIO 1
+#endif
+    // Static priority for the mlp2 waves: they are the younger half of the workgroup (waves 4..7) -- the loser of every arbitration for the
+    // SIMD's matrix / vector issue -- AND carry the longer half (hand-over wait, dgrad at the very end, store, sums), so they set the
+    // kernel's duration while the mlp1 waves idle ~ 15 % at the hand-over slots.  One s_setprio before the loop: 62.7 -> 59.3 us.
+    if (FGNN_PRIO > 0 && role == 1) __builtin_amdgcn_s_setprio(FGNN_PRIO);
     int hk = 0;                                      // fragments this pair has handed over so far (two slots: the mlp1 wave may run a half ahead)
     // role 1: S1 / S2 of the input slab's producer, accumulated PER LANE (pixel column, 8 channels) over the pair's consecutive tiles of
     // a graph and reduced over the pixels once, at the pair's last tile of the graph -- the consumers (fgnn_gn_bwd_coef_tiles, the
@@ -266,18 +263,20 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
             np = (act ? ntile - ng * tpg : 0) * 32 + 16 * nhf + px;
             ninb = act && np < P2;
         }
-        float nxa[8];
 
         {
             f32x4 dx[2];
             const int dvoff = lane_voff(vdx, q, p, inb), ds0 = g * vdx.gs4;
 
             // ---- forward recompute of the hidden activations (bit-identical to the forward's chain) ----
-            float h1[8], h2[8];
+            float h1[8], h2[8], u[8];
             {
                 float ya[8];        // (without a record: mean = 0, a = 1, beta = 0, i.e. x itself)
 #pragma unroll
-                for (int s = 0; s < 8; ++s) ya[s] = (xa[s] - mean[s]) * av[s] + beta[s];
+                for (int s = 0; s < 8; ++s) {
+                    u[s] = xa[s] - mean[s];             // (kept for the S2 sums; xa itself is free for the next half's loads)
+                    ya[s] = u[s] * av[s] + beta[s];
+                }
                 stage8(XA, lane_base, ya);
                 f32x4 acc[2];
                 load_bias(acc, wl + L::BIAS_F, 0, q);
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
             // The next half's x and old d_in.  Both are issued HERE, in straight-line code and by both waves (the mlp2 wave's d_in loads are
             // out of range: no traffic, zeros): memory operations issued behind the spin loops below, or on one side of a branch, make the
             // compiler lose count of what is in flight, and the wait for x at the top of the loop becomes a full drain (stores included)
-            load8(nxa, va, lane_voff(va, q, np, ninb), ng * va.gs4);
+            load8(xa, va, lane_voff(va, q, np, ninb), ng * va.gs4);
             if (has_dx) load8(oldr, vdx, lane_voff(vdx, q, np, ninb && rmw && role == 0), ng * vdx.gs4);
             // ---- layer 0: the dx chain runs through both waves of the pair ----
             // (ONE call site per weight gradient: accumulators that are updated on both sides of a branch cost a second register set)
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #pragma unroll
                         for (int s = 0; s < 8; ++s) {
                             es1[s] += v[s];
-                            es2[s] = fmaf(v[s], xa[s] - mean[s], es2[s]);
+                            es2[s] = fmaf(v[s], u[s], es2[s]);
                         }
                     }
                 }
@@ -412,8 +411,6 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
             }
             if (lane < 32) reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)g * tpg + tt) * FGNN_H + lane] = make_float2(t1, t2);
         }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) xa[s] = nxa[s];
         tile = ntile;
         hf = nhf;
         PH(8)           // record store, loop bookkeeping

@@ -410,7 +410,9 @@ extern "C" int fgnn_inv_node_count(const int *nvalid, int B, float *out, void *s
 }
 
 extern "C" int fgnn_pack_floats(int kind, int ca, int cb, int depth, int nmlp) {
-    return (kind == 0 || kind == 4) ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;     // 4 / 5: the *_t16 kernels' images
+    if (kind >= 4)      // the *_t16 kernels' images: same layouts, each image padded to whole KiB (copied with global_load_lds, fgnn_pack.h)
+        return kind == 4 ? pk_pad_floats(pk_fwd(ca, cb, depth).floats * nmlp) : pk_pad_floats(pk_bwd(ca, cb, depth).floats);
+    return kind == 0 ? pk_fwd(ca, cb, depth).floats * nmlp : pk_bwd(ca, cb, depth).floats;
 }
 
 extern "C" int fgnn_pack_operands(const fgnn_pack_job *jobs, int njobs, void *stream) {
