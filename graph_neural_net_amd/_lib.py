@@ -176,6 +176,8 @@ _SIGNATURES = {
     'fgnn_mlp_bwd_x3': [C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_pair': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_pair_supported': [_I, _I],
+    'fgnn_mlp_bwd_t16': [C.POINTER(MlpBwdArgs), _VP],
+    'fgnn_mlp_bwd_t16_supported': [C.POINTER(MlpBwdArgs)],
     'fgnn_mlp_bwd_pair_t16': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],
     'fgnn_mlp_bwd_pair_t16_supported': [_I, _I],
     'fgnn_mlp_bwd_pair_x3': [C.POINTER(MlpBwdArgs), C.POINTER(MlpBwdArgs), _VP],

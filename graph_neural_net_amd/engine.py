@@ -258,6 +258,8 @@ class FgnnEngine:
             self._packs[('f', k, 3)] = (f3, 32, cin, 1, torch.empty(fl(f3, 32, cin, layout.depth, 1), **f32))
             for j in (1, 2):
                 self._packs[('b', k, j)] = (b12, cin, 0, 1, torch.empty(fl(b12, cin, 0, layout.depth, 1), **f32))
+            if self._t16_bwd3(cin):
+                b3 = 5
             self._packs[('b', k, 3)] = (b3, 32, cin, 1, torch.empty(fl(b3, 32, cin, layout.depth, 1), **f32))
 
     # ------------------------------------------------------------------ helpers
@@ -267,6 +269,10 @@ class FgnnEngine:
     def _t16_pair(self, cin):
         """mlp1 + mlp2 backward of a block on the 16-pixel-tile kernel (fgnn_mlp_bwd_pair_t16): dense 32-channel input slab, depth 3"""
         return (self._t16('pair') and self.PAIR_BWD and not self.x3_pair and self.layout.depth == 3 and cin == 32 and self.N <= 256)
+
+    def _t16_bwd3(self, cin):
+        """mlp3 backward of a block on the 16-pixel-tile kernel (fgnn_mlp_bwd_t16): depth 3, input [mult ; 32 or 2 channels]"""
+        return self._t16('bwd') and not self.x3 and self.layout.depth == 3 and cin in (2, 32) and self.N <= 256
 
     def _nv(self):
         return _lib.ptr(self.nvalid) if self.nvalid is not None else None
@@ -580,7 +586,13 @@ class FgnnEngine:
         dx_strides: (graph stride, channel stride) of the dx tensors when they are not workspace slabs (the gradient with
         respect to the model input, a (G, c0, N, N) tensor)."""
         args = self._mlp_bwd_args(params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides)
-        _lib.call('fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd', C.byref(args), _lib.stream_ptr(),
+        entry = 'fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd'
+        if j == 3 and b is not None and self._t16_bwd3(b.C):
+            if _lib.load().fgnn_mlp_bwd_t16_supported(C.byref(args)):
+                entry = 'fgnn_mlp_bwd_t16'
+            else:
+                args.packed = None          # (the image of this MLP was packed for the 16-pixel kernel: the 32-pixel one builds its own)
+        _lib.call(entry, C.byref(args), _lib.stream_ptr(),
                   tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
                                                 (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))
 

@@ -371,6 +371,13 @@ int fgnn_mlp_bwd_pair_x3(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m
  * gradient mlp3 left, mlp1's terms, mlp2's terms) instead of three separately rounded sums, the weight-gradient sums run in another
  * pixel order: equal to the 32-pixel kernel to fp32 rounding, not bit for bit.  Depth 3, one dense 32-channel slab, N <= 256,
  * constant-size and ragged batches (nvalid, ranges). */
+/* ... and fgnn_mlp_bwd for a two-slab MLP (mlp3 of a block: [mult ; in]) on 16-pixel tiles (csrc/mlp_bwd_t16.hip): work is assigned in
+ * 16-pixel halves (4.94 per wave instead of 2.47 32-pixel tiles at the benchmarked shape).  Same argument block, partial rows and
+ * results (to fp32 rounding) as fgnn_mlp_bwd; image of kind 5.  fgnn_mlp_bwd_t16_supported(args) says whether an argument block is one
+ * of the built shapes: depth 3, slab a = 32 raw channels with dxa stored, slab b = 32 normalised channels with dxb stored, or 2 raw
+ * channels (dense or bit-packed) without dxb; no accumulation; N <= 256. */
+int fgnn_mlp_bwd_t16_supported(const fgnn_mlp_bwd_args *args);
+int fgnn_mlp_bwd_t16(const fgnn_mlp_bwd_args *args, void *stream);
 int fgnn_mlp_bwd_pair_t16_supported(int ca, int depth);
 int fgnn_mlp_bwd_pair_t16(const fgnn_mlp_bwd_args *m1, const fgnn_mlp_bwd_args *m2, void *stream);
 #define FGNN_BWD_COEF_GRAPHS 4
