@@ -124,6 +124,9 @@ _SIGNATURES = {
     'fgnn_pack_floats': [_I, _I, _I, _I, _I],
     'fgnn_pack_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd': [C.POINTER(MlpFwdArgs), _VP],
+    'fgnn_mlp_fwd_t16': [C.POINTER(MlpFwdArgs), _VP],
+    'fgnn_mlp_fwd_t16_supported': [C.POINTER(MlpFwdArgs)],
+    'fgnn_mlp_fwd_t16_records': [_I],
     'fgnn_mlp_x3_supported': [_I, _I, _I, _I],
     'fgnn_pack_x3_floats': [_I, _I, _I, _I, _I],
     'fgnn_pack_x3_operands': [_VP, _I, _VP],
@@ -133,6 +136,8 @@ _SIGNATURES = {
     'fgnn_debug_matmul_variant': [_I],
     'fgnn_gn_finalize': [_VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP],
+    'fgnn_gn_finalize_r': [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP],
+    'fgnn_gn_finalize2_r': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef2': [_VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_gn_plane_supported': [_I],
     'fgnn_gn_plane_fwd': [_VP, _LL, _LL, _VP, _VP, _VP, _I, _I, _I, _F, _VP, _LL, _LL, _VP, _VP],
@@ -153,9 +158,11 @@ _SIGNATURES = {
     'fgnn_chan_matmul_fwd_fin_supported': [_I],
     'fgnn_chan_matmul_fwd_fin': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_chan_matmul_fwd_fin_ord': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _LL, _LL, _VP, _I, _VP],
+    'fgnn_chan_matmul_fwd_fin_ord_r': [C.POINTER(Slab), C.POINTER(Slab), _VP, _VP, _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP, _LL, _LL, _VP, _I, _VP],
     'fgnn_colmax_fwd': [C.POINTER(Slab), _VP, _I, _I, _VP, _VP, _VP],
     'fgnn_colmax_fwd_fin_supported': [_I],
     'fgnn_colmax_fwd_fin': [C.POINTER(Slab), _VP, _VP, _VP, _F, _VP, _I, _I, _VP, _VP, _VP],
+    'fgnn_colmax_fwd_fin_r': [C.POINTER(Slab), _VP, _VP, _VP, _F, _VP, _I, _I, _I, _VP, _VP, _VP],
     'fgnn_score_ce_fwd': [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP],
     'fgnn_score_row_blocks': [_I, _I],
     'fgnn_score_ce_fwd_blocks': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP],

@@ -118,7 +118,7 @@ struct ClassVals {
 // (W^2)_ij | w_ij << 15, plus per-vertex {row sum, column sum, w_ii, class} records; the forward kernel, the class-sum kernel
 // and the class algebra read those (L2-resident: N^2 x 2 bytes per graph against the 32 N^2 values of a slab).  (A first form
 // that re-derived the popcounts from LDS bit rows in every (graph, channel group) workgroup cost 105 / 100 / 51 us at N = 200,
-// 16 graphs, against 19.5 / 21.3 / 8.8 us now: profiles/r04_cfg4_struct_timelines.txt, r04_final_cfg4_graph_timeline.txt.)
+// 16 graphs, against 19.5 / 21.3 / 8.8 us now: profiles/archive/r04_cfg4_struct_timelines.txt, r04_final_cfg4_graph_timeline.txt.)
 // Workspace of one step (fwd fills, bwd reads):
 struct WsLayout {
     long long csum, coef, vinfo, gones, code, total;      // offsets in floats

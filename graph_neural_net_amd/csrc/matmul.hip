@@ -917,7 +917,7 @@ int launch_fwd_w(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, in
         return 0;
     }
     const int KQ = (N + 7) / 8, grid = (M + W_WAVES - 1) / W_WAVES;
-    // Measured (tools/gpu_mm_wide_probe.py, profiles/r05_mm_wide_probe.txt: 30 back-to-back launches in a replayed graph, 64 x 32 matrices):
+    // Measured (tools/gpu_mm_wide_probe.py, profiles/archive/r05_mm_wide_probe.txt: 30 back-to-back launches in a replayed graph, 64 x 32 matrices):
     // N = 64: 21.8 - 22.4 us against 25.0 for the four-byte kernel; N = 50: 16.4 - 17.3 against 16.0 - 16.2; N = 40: 13.3 against 12.7 --
     // the instruction count is not what limits the kernel below N ~ 58 (it moves its 61 MB at the ~4 TB/s this part reads at), so
     // the eight-byte form runs where it wins: KQ = 8, even N (an odd N would let a column pair straddle two rows).
@@ -1397,6 +1397,14 @@ extern "C" int fgnn_chan_matmul_fwd_fin_ord(const fgnn_slab *ya, const fgnn_slab
                                             const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
                                             const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
                                             const int *order, int fill, void *stream) {
+    return fgnn_chan_matmul_fwd_fin_ord_r(ya, yb, part_a, part_b, cnt, gn_weight_a, gn_weight_b, eps, nvalid, G, N, fgnn_tiles_per_graph(N), out,
+                                          ogstride, ldo, order, fill, stream);
+}
+// _r: `recs` statistics records per graph (fgnn_mlp_fwd_t16: one per 16-pixel half)
+extern "C" int fgnn_chan_matmul_fwd_fin_ord_r(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                                              const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                              const int *nvalid, int G, int N, int recs, float *out, long long ogstride, long long ldo,
+                                              const int *order, int fill, void *stream) {
     FGNN_CHECK(!order || nvalid, "fgnn_chan_matmul_fwd_fin_ord: an order needs the nvalid it was derived from");
     if (mm_no_order()) order = nullptr;
     FGNN_CHECK(ya && yb && out && ya->ptr && yb->ptr && part_a && part_b && cnt, "fgnn_chan_matmul_fwd_fin: null argument");
@@ -1407,8 +1415,8 @@ extern "C" int fgnn_chan_matmul_fwd_fin_ord(const fgnn_slab *ya, const fgnn_slab
                (long long)G * ogstride < 0x7fffffffll / 4,
                "fgnn_chan_matmul_fwd_fin: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     const int M = G * ya->C;
-    FinArgs F = {part_a, part_b, cnt, gn_weight_a, gn_weight_b, const_cast<float *>(ya->nrm), const_cast<float *>(yb->nrm), eps,
-                 fgnn_tiles_per_graph(N)};
+    FGNN_CHECK(recs > 0, "fgnn_chan_matmul_fwd_fin: recs");
+    FinArgs F = {part_a, part_b, cnt, gn_weight_a, gn_weight_b, const_cast<float *>(ya->nrm), const_cast<float *>(yb->nrm), eps, recs};
     if (big_path(N)) {
         if (N <= 128) launch_fwd_big<4, true>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, F, fill, (hipStream_t)stream);
         else launch_fwd_big<8, true>(ya, yb, nvalid, N, G, out, ogstride, ldo, order, F, fill, (hipStream_t)stream);

@@ -443,6 +443,11 @@ extern "C" int fgnn_gn_finalize_tpg(const float *part, const float *cnt, const f
                                     int G, int C, int N, int tpg, float eps, float *nrm, void *stream) {
     return gn_finalize_launch(part, cnt, gn_weight, nvalid, G, C, N, tpg, eps, nrm, 1, stream);
 }
+// _r: the tile statistics hold `recs` records per graph instead of fgnn_tiles_per_graph(N) (fgnn_mlp_fwd_t16: one per 16-pixel half)
+extern "C" int fgnn_gn_finalize_r(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
+                                  int G, int C, int N, int recs, float eps, float *nrm, void *stream) {
+    return gn_finalize_launch(part, cnt, gn_weight, nvalid, G, C, N, recs, eps, nrm, 0, stream);
+}
 extern "C" int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight, const int *nvalid,
                                 int G, int C, int N, float eps, float *nrm, void *stream) {
     return gn_finalize_launch(part, cnt, gn_weight, nvalid, G, C, N, fgnn_tiles_per_graph(N), eps, nrm, 0, stream);
@@ -463,6 +468,11 @@ extern "C" int fgnn_gn_finalize2_tpg(const float *part0, const float *part1, con
                                      const float *gn_weight1, const int *nvalid, int G, int C, int N, int tpg, float eps,
                                      float *nrm0, float *nrm1, void *stream) {
     return gn_finalize2_launch(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, tpg, eps, nrm0, nrm1, 1, stream);
+}
+extern "C" int fgnn_gn_finalize2_r(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
+                                   const float *gn_weight1, const int *nvalid, int G, int C, int N, int recs, float eps,
+                                   float *nrm0, float *nrm1, void *stream) {
+    return gn_finalize2_launch(part0, part1, cnt, gn_weight0, gn_weight1, nvalid, G, C, N, recs, eps, nrm0, nrm1, 0, stream);
 }
 extern "C" int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
                                  const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,

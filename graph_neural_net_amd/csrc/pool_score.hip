@@ -731,9 +731,15 @@ extern "C" int fgnn_colmax_fwd_fin_supported(int N) { return N <= 64 ? 1 : 0; }
 
 extern "C" int fgnn_colmax_fwd_fin(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
                                    const int *nvalid, int G, int N, float *e, int *idx, void *stream) {
+    return fgnn_colmax_fwd_fin_r(y, part, cnt, gn_weight, eps, nvalid, G, N, fgnn_tiles_per_graph(N), e, idx, stream);
+}
+// _r: `recs` statistics records per graph (fgnn_mlp_fwd_t16: one per 16-pixel half)
+extern "C" int fgnn_colmax_fwd_fin_r(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
+                                     const int *nvalid, int G, int N, int recs, float *e, int *idx, void *stream) {
     FGNN_CHECK(y && y->ptr && y->nrm && part && cnt && e && idx && G > 0 && N > 0 && y->C > 0, "fgnn_colmax_fwd_fin: bad arguments");
     FGNN_CHECK(N <= 64, "fgnn_colmax_fwd_fin: N=%d > 64 (use fgnn_gn_finalize + fgnn_colmax_fwd)", N);
-    const ColmaxFin F = {part, cnt, gn_weight, eps, fgnn_tiles_per_graph(N)};
+    FGNN_CHECK(recs > 0, "fgnn_colmax_fwd_fin: recs");
+    const ColmaxFin F = {part, cnt, gn_weight, eps, recs};
     hipLaunchKernelGGL(colmax_fwd_lds_kernel<true>, dim3((unsigned)((G * y->C + 3) / 4)), dim3(256), 0, (hipStream_t)stream, *y,
                        nvalid, G, N, e, idx, F);
     FGNN_LAUNCH_CHECK();

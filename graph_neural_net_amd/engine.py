@@ -160,14 +160,16 @@ class FgnnEngine:
     MM_ORDER = True               # ragged engines: longest-job-first order of the whole-matrix per-channel products
     PAIR_BWD = os.environ.get('FGNN_PAIR_BWD', '1') != '0'      # mlp1 + mlp2 backward of a block as one launch (fgnn_mlp_bwd_pair)
     # step(): scoring + loss + their backward as ONE launch (fgnn_score_ce_step, bit-identical to the two).  Off by default: measured in
-    # the replayed cfg2 step at 13.7 us against 5.8 + 7.0 us for the two launches it replaces (profiles/r05_c_graph_timeline.txt) --
+    # the replayed cfg2 step at 13.7 us against 5.8 + 7.0 us for the two launches it replaces (profiles/archive/r05_c_graph_timeline.txt) --
     # every workgroup of a pair repeats the score matrix and the row log-sum-exps, and inside a graph a launch boundary costs nothing
     SCORE_STEP = os.environ.get('FGNN_SCORE_STEP', '0') != '0'
     # the step's operand packing as extra workgroups of the structured block 1's first launch (FGNN_PACK_IN_STRUCT=0: its own launch)
     PACK_IN_STRUCT = os.environ.get('FGNN_PACK_IN_STRUCT', '1') != '0'
     # round 6: the MLP kernels on 16-pixel tiles / v_mfma_f32_16x16x4_f32 (csrc/*_t16.hip) where they are built; FGNN_T16=0: the
-    # 32-pixel kernels everywhere.  A comma list selects single kernels for A/B runs: 'pair', 'bwd', 'fwd'
-    T16 = os.environ.get('FGNN_T16', 'pair,bwd,fwd')
+    # 32-pixel kernels everywhere.  A comma list selects single kernels for A/B runs: 'pair', 'bwd', 'fwd3' (mlp3 forward), 'fwd12' (mlp1 +
+    # mlp2 forward: measured 0.3 us SLOWER per launch than the 32-pixel kernel, and its consumer -- the per-channel product that finalizes
+    # the statistics in its prologue -- 1.9 us slower on twice the records; off by default)
+    T16 = os.environ.get('FGNN_T16', 'pair,bwd,fwd3')
 
     # default contraction of the MLP kernels (FGNN_MFMA=x3 selects the split-bf16 kernels where they are built)
     MFMA = os.environ.get('FGNN_MFMA', 'f32')
@@ -212,8 +214,9 @@ class FgnnEngine:
         self.z = {(k, j): act() for k in range(1, K + 1) for j in (1, 2, 3)}
         self.mult = {k: act() for k in range(1, K + 1)}
         self.nrm = {(k, j): torch.empty(G * 32 * 4, **f32) for k in range(1, K + 1) for j in (1, 2, 3)}
-        self.part = [torch.empty(G * self.tpg * 32 * 2, **f32) for _ in range(2)]
-        self.cnt = torch.empty(G * self.tpg, **f32)
+        # tile statistics of the forward MLP kernels: one record per 32-pixel tile, or per 16-pixel half with fgnn_mlp_fwd_t16
+        self.part = [torch.empty(G * 2 * self.tpg * 32 * 2, **f32) for _ in range(2)]
+        self.cnt = torch.empty(G * 2 * self.tpg, **f32)
         self.E = torch.empty(G, 32, N, **f32)
         self.idx = torch.empty(G, 32, N, dtype=torch.int32, device=device)
         self.B = G // 2
@@ -254,6 +257,10 @@ class FgnnEngine:
             b12 = 3 if (self.x3 and not self.x3_pair) else 1
             if self._t16_pair(cin):
                 b12 = 5
+            if self._t16_fwd(2):
+                f12 = 4
+            if self._t16_fwd(1):
+                f3 = 4
             self._packs[('f', k, 12)] = (f12, cin, 0, 2, torch.empty(fl(f12, cin, 0, layout.depth, 2), **f32))
             self._packs[('f', k, 3)] = (f3, 32, cin, 1, torch.empty(fl(f3, 32, cin, layout.depth, 1), **f32))
             for j in (1, 2):
@@ -269,6 +276,14 @@ class FgnnEngine:
     def _t16_pair(self, cin):
         """mlp1 + mlp2 backward of a block on the 16-pixel-tile kernel (fgnn_mlp_bwd_pair_t16): dense 32-channel input slab, depth 3"""
         return (self._t16('pair') and self.PAIR_BWD and not self.x3_pair and self.layout.depth == 3 and cin == 32 and self.N <= 256)
+
+    def _t16_fwd(self, nmlp):
+        """a forward MLP launch (nmlp = 2: mlp1 + mlp2, 1: mlp3) on the 16-pixel-tile kernel (fgnn_mlp_fwd_t16: statistics per 16-pixel half)"""
+        return self._t16('fwd3' if nmlp == 1 else 'fwd12') and not self.x3 and self.layout.depth == 3 and self.N <= 256
+
+    def _recs(self, nmlp):
+        """statistics records per graph of the forward launch with nmlp MLPs"""
+        return 2 * self.tpg if self._t16_fwd(nmlp) else self.tpg
 
     def _t16_bwd3(self, cin):
         """mlp3 backward of a block on the 16-pixel-tile kernel (fgnn_mlp_bwd_t16): depth 3, input [mult ; 32 or 2 channels]"""
@@ -351,11 +366,27 @@ class FgnnEngine:
             args.ranges = self.ranges.data_ptr()
         args.cu_share = self.cu_share
         st = _lib.stream_ptr()
-        _lib.call('fgnn_mlp_fwd_x3' if (self.x3_fwd and len(js) == 2) else 'fgnn_mlp_fwd', C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        entry = 'fgnn_mlp_fwd_x3' if (self.x3_fwd and len(js) == 2) else 'fgnn_mlp_fwd'
+        recs = self._recs(len(js))
+        if self._t16_fwd(len(js)):
+            entry = 'fgnn_mlp_fwd_t16'
+        _lib.call(entry, C.byref(args), st, tag='mlp_fwd[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
         if self.decisions is not None:
             # test-only (export_decisions): the decision-exporting twin of the launch above -- same tile code, same outputs written
             # once more -- leaves one bit per hidden pre-activation of these MLPs
             bufs = [torch.zeros(self.G * (L.depth - 1) * 32 * self.tpg, dtype=torch.int32, device=self.device) for _ in js]
+            if entry == 'fgnn_mlp_fwd_t16':
+                # the twin is the 32-pixel kernel: same inputs, same records, the same chain of fused multiply-adds -> the same decisions.
+                # Its outputs go to scratch (its statistics records have another granularity), its image it builds itself (kind 0)
+                scr = [torch.empty_like(self.z[(k, j)]) for j in js]
+                spart = [torch.empty(self.G * self.tpg * 32 * 2, dtype=torch.float32, device=self.device) for _ in js]
+                scnt = torch.empty(self.G * self.tpg, dtype=torch.float32, device=self.device)
+                for m in range(len(js)):
+                    args.z[m] = scr[m].data_ptr()
+                    args.part[m] = spart[m].data_ptr()
+                args.cnt = scnt.data_ptr()
+                args.packed = None
+                self._dbg_keep = (scr, spart, scnt)
             _lib.call('fgnn_debug_mlp_fwd_x3_masks' if (self.x3_fwd and len(js) == 2) else 'fgnn_debug_mlp_fwd_masks', C.byref(args),
                       _lib.ptr(bufs[0]), _lib.ptr(bufs[1]) if len(js) == 2 else None, st)
             for j, buf in zip(js, bufs):
@@ -364,13 +395,13 @@ class FgnnEngine:
             return
         if len(js) == 2:
             r0, r1 = L.mlp[(k, js[0])], L.mlp[(k, js[1])]
-            _lib.call('fgnn_gn_finalize2', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
+            _lib.call('fgnn_gn_finalize2_r', _lib.ptr(self.part[0]), _lib.ptr(self.part[1]), _lib.ptr(self.cnt),
                       C.c_void_p(self._w(params, r0['gn_w'])), C.c_void_p(self._w(params, r1['gn_w'])), self._nv(),
-                      self.G, 32, self.N, EPS, _lib.ptr(self.nrm[(k, js[0])]), _lib.ptr(self.nrm[(k, js[1])]), st)
+                      self.G, 32, self.N, recs, EPS, _lib.ptr(self.nrm[(k, js[0])]), _lib.ptr(self.nrm[(k, js[1])]), st)
         else:
             rec = L.mlp[(k, js[0])]
-            _lib.call('fgnn_gn_finalize', _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
-                      C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, EPS,
+            _lib.call('fgnn_gn_finalize_r', _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, rec['gn_w'])), self._nv(), self.G, 32, self.N, recs, EPS,
                       _lib.ptr(self.nrm[(k, js[0])]), st)
 
     def _packed_input(self, args, k):
@@ -439,9 +470,9 @@ class FgnnEngine:
             ya, yb = self._slab_z(k, 1, params), self._slab_z(k, 2, params)
             if fin:     # the matmul finalizes the GraphNorm records of mlp1 / mlp2 itself (one launch less)
                 r1, r2 = L.mlp[(k, 1)], L.mlp[(k, 2)]
-                _lib.call('fgnn_chan_matmul_fwd_fin_ord', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
+                _lib.call('fgnn_chan_matmul_fwd_fin_ord_r', C.byref(ya), C.byref(yb), _lib.ptr(self.part[0]), _lib.ptr(self.part[1]),
                           _lib.ptr(self.cnt), C.c_void_p(self._w(params, r1['gn_w'])), C.c_void_p(self._w(params, r2['gn_w'])),
-                          EPS, self._nv(), self.G, self.N, _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp,
+                          EPS, self._nv(), self.G, self.N, self._recs(2), _lib.ptr(self.mult[k]), 32 * self.ldp, self.ldp,
                           _lib.ptr(self.mm_order) if self.mm_order is not None else None, self._fill(), st, tag='fgnn_chan_matmul_fwd')
             else:
                 _lib.call('fgnn_chan_matmul_fwd_ord', C.byref(ya), C.byref(yb), self._nv(), self.G, self.N,
@@ -453,8 +484,8 @@ class FgnnEngine:
         out = self._slab_z(L.num_blocks, 3, params)
         if pool_fin:
             rec = L.mlp[(L.num_blocks, 3)]
-            _lib.call('fgnn_colmax_fwd_fin', C.byref(out), _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
-                      C.c_void_p(self._w(params, rec['gn_w'])), EPS, self._nv(), self.G, self.N, _lib.ptr(self.E),
+            _lib.call('fgnn_colmax_fwd_fin_r', C.byref(out), _lib.ptr(self.part[0]), _lib.ptr(self.cnt),
+                      C.c_void_p(self._w(params, rec['gn_w'])), EPS, self._nv(), self.G, self.N, self._recs(1), _lib.ptr(self.E),
                       _lib.ptr(self.idx), st, tag='fgnn_colmax_fwd')
         else:
             _lib.call('fgnn_colmax_fwd', C.byref(out), self._nv(), self.G, self.N, _lib.ptr(self.E), _lib.ptr(self.idx), st)
@@ -587,11 +618,10 @@ class FgnnEngine:
         respect to the model input, a (G, c0, N, N) tensor)."""
         args = self._mlp_bwd_args(params, k, j, a, b, dy, coef, dxa, dxb, acc_a, acc_b, emit, dx_strides)
         entry = 'fgnn_mlp_bwd_x3' if (self.x3 and j != 3) else 'fgnn_mlp_bwd'
-        if j == 3 and b is not None and self._t16_bwd3(b.C):
-            if _lib.load().fgnn_mlp_bwd_t16_supported(C.byref(args)):
-                entry = 'fgnn_mlp_bwd_t16'
-            else:
-                args.packed = None          # (the image of this MLP was packed for the 16-pixel kernel: the 32-pixel one builds its own)
+        if j == 3 and b is not None and self._t16_bwd3(b.C) and _lib.load().fgnn_mlp_bwd_t16_supported(C.byref(args)):
+            entry = 'fgnn_mlp_bwd_t16'
+        elif self._packs[('b', k, j)][0] == 5:
+            args.packed = None              # (the image of this MLP was packed for a 16-pixel kernel: the 32-pixel one builds its own)
         _lib.call(entry, C.byref(args), _lib.stream_ptr(),
                   tag='mlp_bwd[cin=%d,dx=%d]' % (a.C + (b.C if b is not None else 0),
                                                 (a.C if dxa is not None else 0) + (b.C if (b is not None and dxb is not None) else 0)))

@@ -53,7 +53,7 @@ class Siamese_Node_Exp(nn.Module):
     MODULE_STEPS_MAX = 8        # captured module steps kept per model (fused_step through the module surface), LRU
 
     # MaskedTensor batches run padded to a multiple of this (batches whose largest graphs fall in the same granule replay ONE graph; cfg5
-    # through fused_step: 0.861 ms at 8, 0.876 at 16, engine on the exact size 0.846 -- profiles/r05_cfg5_surface.txt)
+    # through fused_step: 0.861 ms at 8, 0.876 at 16, engine on the exact size 0.846 -- profiles/archive/r05_cfg5_surface.txt)
     RAGGED_GRANULE = int(__import__('os').environ.get('FGNN_RAGGED_GRANULE', '8'))
     INPUT_CHECK_EVERY = 128     # input_form='tensor_representation': the device verdict is read back on every k-th fused_step (0: never)
 

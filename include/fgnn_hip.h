@@ -108,6 +108,15 @@ typedef struct {
                                                always runs FGNN_RANGE_WG workgroups */
 } fgnn_mlp_fwd_args;
 int fgnn_mlp_fwd(const fgnn_mlp_fwd_args *args, void *stream);
+/* Round 6: the same launch on 16-pixel tiles / v_mfma_f32_16x16x4_f32 (csrc/mlp_fwd_t16.hip, csrc/fgnn_t16.h).  z is BIT-IDENTICAL to
+ * fgnn_mlp_fwd's (the conv chain runs through the same sequence of fused multiply-adds).  Differences: `packed` is mandatory and of
+ * kind 4; the unit of work and of the tile statistics is a 16-pixel half tile -- part[m] is (G, R, 32, 2) and cnt (G, R) with R =
+ * fgnn_mlp_fwd_t16_records(N) = 2 * fgnn_tiles_per_graph(N) -- so the statistics go to the *_r consumers below (fgnn_gn_finalize_r,
+ * fgnn_gn_finalize2_r, fgnn_chan_matmul_fwd_fin_ord_r, fgnn_colmax_fwd_fin_r), which take the record count as an argument.
+ * Built (fgnn_mlp_fwd_t16_supported) for depth 3, N <= 256, inputs of 32 or 2 channels (nmlp = 2) and 32 + 32 / 32 + 2 (nmlp = 1). */
+int fgnn_mlp_fwd_t16_records(int N);
+int fgnn_mlp_fwd_t16_supported(const fgnn_mlp_fwd_args *args);
+int fgnn_mlp_fwd_t16(const fgnn_mlp_fwd_args *args, void *stream);
 
 /* ---- the same two MLP entry points on the bf16 matrix cores ("x3": csrc/fgnn_x3.h) ------------------------------
  * replaces the same reference lines as fgnn_mlp_fwd / fgnn_mlp_bwd (models/layers.py:126-131 and its autograd).  Tensors,
@@ -130,6 +139,11 @@ int fgnn_mlp_fwd_x3(const fgnn_mlp_fwd_args *args, void *stream);
 int fgnn_gn_finalize(const float *part, const float *cnt, const float *gn_weight /* (C) or NULL=1 */,
                      const int *nvalid, int G, int C, int N, float eps, float *nrm, void *stream);
 /* two MLPs (sharing cnt, e.g. mlp1 / mlp2 of one fgnn_mlp_fwd call) in one launch */
+/* the same two with `recs` statistics records per graph instead of fgnn_tiles_per_graph(N) (the output of fgnn_mlp_fwd_t16) */
+int fgnn_gn_finalize_r(const float *part, const float *cnt, const float *gn_weight, const int *nvalid, int G, int C, int N, int recs,
+                       float eps, float *nrm, void *stream);
+int fgnn_gn_finalize2_r(const float *part0, const float *part1, const float *cnt, const float *gn_weight0, const float *gn_weight1,
+                        const int *nvalid, int G, int C, int N, int recs, float eps, float *nrm0, float *nrm1, void *stream);
 int fgnn_gn_finalize2(const float *part0, const float *part1, const float *cnt, const float *gn_weight0,
                       const float *gn_weight1, const int *nvalid, int G, int C, int N, float eps,
                       float *nrm0, float *nrm1, void *stream);
@@ -242,6 +256,11 @@ int fgnn_chan_matmul_fwd_fin_ord(const fgnn_slab *ya, const fgnn_slab *yb, const
                                  const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
                                  const int *nvalid, int G, int N, float *out, long long ogstride, long long ldo,
                                  const int *order /* as fgnn_chan_matmul_fwd_ord; used for 64 < N <= 256 */, int fill, void *stream);
+/* ... with `recs` statistics records per graph (the output of fgnn_mlp_fwd_t16) */
+int fgnn_chan_matmul_fwd_fin_ord_r(const fgnn_slab *ya, const fgnn_slab *yb, const float *part_a, const float *part_b,
+                                   const float *cnt, const float *gn_weight_a, const float *gn_weight_b, float eps,
+                                   const int *nvalid, int G, int N, int recs, float *out, long long ogstride, long long ldo,
+                                   const int *order, int fill, void *stream);
 
 /* ---- ColumnMaxPooling.forward (models/layers.py:202-203; masked: maskedtensor.py:213-228)
  * e[g,c,i] = max_j y[g,c,i,j] (first index on ties), idx int32; rows i >= nvalid -> 0.   */
@@ -252,6 +271,9 @@ int fgnn_colmax_fwd(const fgnn_slab *y, const int *nvalid, int G, int N, float *
 int fgnn_colmax_fwd_fin_supported(int N);
 int fgnn_colmax_fwd_fin(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
                         const int *nvalid, int G, int N, float *e, int *idx, void *stream);
+int fgnn_colmax_fwd_fin_r(const fgnn_slab *y, const float *part, const float *cnt, const float *gn_weight, float eps,
+                          const int *nvalid, int G, int N, int recs /* statistics records per graph (fgnn_mlp_fwd_t16) */, float *e, int *idx,
+                          void *stream);
 
 /* ---- Siamese scoring + triplet_loss (models/trainers.py:67, toolbox/losses.py:20-34) ---
  * e1,e2: (B, C, N).  scores[b] = e1[b]^T e2[b] (B,N,N); lse (B,N) row log-sum-exp;

@@ -1,7 +1,7 @@
 """profiles/<tag>_pmc_per_kernel.txt -> profiles/pmc_traffic.json (HBM bytes per launch of the main kernels,
 read by bench.py for roofline.traffic).
-usage: python profiles/make_pmc_traffic.py profiles/r02_cfg2_x_pmc_per_kernel.txt [profiles/r02_cfg4_x_pmc_per_kernel.txt
-                                            [profiles/r03_cfg5_x_pmc_per_kernel.txt]]
+usage: python profiles/make_pmc_traffic.py profiles/archive/r02_cfg2_x_pmc_per_kernel.txt [profiles/archive/r02_cfg4_x_pmc_per_kernel.txt
+                                            [profiles/archive/r03_cfg5_x_pmc_per_kernel.txt]]
 The second file is the bf16 N=200 workload (bench.py --config cfg4); its kernels are stored under 'cfg4:<tag>'.  The third is
 the ragged fp32 workload (--config cfg5, 8 pairs, the batch of bench.py's seed); its kernels are stored under 'cfg5:<tag>'."""
 import json, os, re, sys

@@ -14,7 +14,7 @@ The yard-stick is the reference ITSELF under the same comparison (tests/golden/p
 its own fp32 gradients against fp64 on its own branch are 3.4e-6 ... 5.4e-6 from fp64 on the median tensor and 2.4e-5 ... 4.3e-5
 on its worst tensor (max-norm relative; 8 threads and 1 thread) -- pure fp32 rounding of sums over 10^5 ... 10^6 pixels; 1e-5 on
 EVERY tensor is below what fp32 arithmetic of this op sequence delivers in any evaluation order.  Gates (measured values:
-profiles/r05_pinned_table.txt):
+profiles/archive/r05_pinned_table.txt):
   median over the gradient tensors  <= 1e-5 (north_star's figure; measured 3.2e-6 ... 5.0e-6; x3 modes <= 2e-5, measured <= 1.1e-5)
   every tensor                      <= the reference's own WORST tensor on that batch (the larger of its two runs; measured 0.35 ...
                                        0.76 of it); x3 modes <= 2 x that (measured 0.5 ... 1.9)

@@ -65,7 +65,7 @@ def test_structured_block1_equals_the_generic_kernels(B, N, family, p):
         t = flat(g64)
         ours, theirs = ((flat(b[5]) - t).norm() / t.norm()).item(), ((flat(g32) - t).norm() / t.norm()).item()
         # 2 x 32 x B N^2 pre-activations of mlp3: on the large case one of them within rounding of zero is likely, and whether THIS
-        # evaluation takes the fp64 branch there is a coin (tests/gradgate.py; profiles/r04_fuzz_struct.txt shows the signature)
+        # evaluation takes the fp64 branch there is a coin (tests/gradgate.py; profiles/archive/r04_fuzz_struct.txt shows the signature)
         big = B * N * N >= 200000 or 2 * B >= 256        # (256+ graphs: 1.2e-5 against 3.6e-7 measured on the (128, 20) case, one such event)
         if big:
             # ... so there the comparison takes the decisions out (tests/test_gpu_grad_pinned.py): fp64 arithmetic on the branch THIS

@@ -5,7 +5,7 @@
   differ from the fp32-MFMA kernels' by the reassociation noise of an fp32 sum (~1e-7 per GEMM), so the discrete decisions
   of the model (ReLU masks, pooling arg-max) fall differently on inputs that sit within rounding distance of a tie (a flip
   moves a pair's gradient error from ~1e-5 to ~1e-3).  Its gradients are gated by the SAME distribution gate as the fp32-MFMA
-  engine's (tests/test_gpu_grad_gate.py, 148 reference-generated single-pair cases; profiles/r04_gradgate_table.txt shows that
+  engine's (tests/test_gpu_grad_gate.py, 148 reference-generated single-pair cases; profiles/archive/r04_gradgate_table.txt shows that
   the old single-seed gates fail 14 / 12 / 8 of 142 cases for f32 / x3 / the reference's own 1-thread run).  Here: forward
   tensors against fp64, determinism, recompute consistency, and the pair backward against the launches it replaces.
 * `FgnnEngineDual`: two half-batch chains on two streams.  Same kernels, same per-pair arithmetic: scores bit-identical to the

@@ -54,7 +54,9 @@ for var in variants[1:]:
     b = res[var]
     print('== %s vs 32-pixel kernels' % var)
     print('  scores equal', torch.equal(a['sc'], b['sc']), ' loss', a['loss'].item(), b['loss'].item())
-    print('  forward z bit-identical:', all(torch.equal(u, v) for u, v in zip(a['z'], b['z'])), ' nrm:', all(torch.equal(u, v) for u, v in zip(a['nrm'], b['nrm'])))
+    print('  forward z bit-identical:', [bool(torch.equal(u, v)) for u, v in zip(a['z'], b['z'])].count(True), 'of', len(a['z']), ' max rel L2 %.2e' % max(rel(v, u)[0] for u, v in zip(a['z'], b['z'])),
+          ' nrm bit-identical:', [bool(torch.equal(u, v)) for u, v in zip(a['nrm'], b['nrm'])].count(True), 'of', len(a['nrm']), ' max rel %.2e' % max(rel(v, u)[0] for u, v in zip(a['nrm'], b['nrm'])))
+    print('  scores rel L2 / max: %.3e %.3e' % rel(b['sc'], a['sc']))
     print('  d_in slabs rel L2 / max: %.3e %.3e | %.3e %.3e' % (rel(b['dy0'], a['dy0']) + rel(b['dy1'], a['dy1'])))
     print('  s12part rel L2 / max: %.3e %.3e' % rel(b['s12part'], a['s12part']))
     print('  grads rel L2 / max: %.3e %.3e   finite: %s' % (rel(b['g'], a['g']) + (bool(torch.isfinite(b['g']).all()),)))
