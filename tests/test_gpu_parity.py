@@ -669,7 +669,7 @@ def test_pair_backward_equals_the_two_launches_it_replaces(B, N, bits, t16, monk
         assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
     else:
         assert ((a[3] - b[3]).norm() / a[3].norm()).item() < 2e-6 and ((a[4] - b[4]).norm() / a[4].norm()).item() < 2e-6
-    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
+    assert ((a[2] - b[2]).norm() / a[2].norm()).item() < (1e-6 if t16 == '0' else 2e-6)     # (another pixel order in the weight-gradient sums)
 
 
 @pytest.mark.parametrize('t16', ['0', 'pair'])
@@ -711,4 +711,4 @@ def test_pair_backward_on_ragged_batches(t16, monkeypatch):
             assert all(torch.equal(u, v) for u, v in zip(a[3], b[3])), skip
         else:
             assert all(((u - v).norm() / u.norm()).item() < 2e-6 for u, v in zip(a[3], b[3])), skip
-        assert ((a[2] - b[2]).norm() / a[2].norm()).item() < 1e-6
+        assert ((a[2] - b[2]).norm() / a[2].norm()).item() < (1e-6 if t16 == '0' else 2e-6)
