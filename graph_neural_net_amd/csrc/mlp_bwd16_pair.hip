@@ -236,6 +236,11 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
     const int ld2 = va.ld2;
     auto roff = [&](int r) { return ((r & 3) + 8 * (r >> 2)) * ld2; };
 
+#ifndef FGNN_PRIO16
+#define FGNN_PRIO16 1
+#endif
+    // static priority for the mlp2 waves (the younger half of the workgroup AND the longer half of the pair): see mlp_bwd_pair_t16.hip
+    if (FGNN_PRIO16 > 0 && role == 1) __builtin_amdgcn_s_setprio(FGNN_PRIO16);
     int tnext = 0;
     for (int tile = first; tile < T1; tile = tnext) {
         tnext = tile + NP;

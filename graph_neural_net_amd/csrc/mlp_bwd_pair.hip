@@ -224,6 +224,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_kernel(const PairArgs
     if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = -1;
     __syncthreads();
 
+#ifndef FGNN_PRIO32
+#define FGNN_PRIO32 1
+#endif
+    // static priority for the mlp2 waves (the younger half of the workgroup AND the longer half of the pair): see mlp_bwd_pair_t16.hip
+    if (FGNN_PRIO32 > 0 && role == 1) __builtin_amdgcn_s_setprio(FGNN_PRIO32);
     int tnext = 0, prev_tile = -1;
     for (int tile = first; tile < T1; tile = tnext) {
         tnext = tile + NP;

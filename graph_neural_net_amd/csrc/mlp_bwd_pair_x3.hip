@@ -226,6 +226,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_x3_kernel(const PairA
     const F16 negI = make_neg_identity(lane);
     PH(9)
     int tnext = 0, prev_tile = -1;
+    if (role == 1) __builtin_amdgcn_s_setprio(1);      // static priority for the mlp2 waves: see mlp_bwd_pair_t16.hip
     for (int tile = first; tile < T1; tile = tnext) {
         tnext = tile + NP;
         const TileCtx c = decode_tile(tile, true, tpg, A.N, P2, j);
