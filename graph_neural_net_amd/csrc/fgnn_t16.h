@@ -83,18 +83,35 @@ DEVI void load_bias(f32x4 (&acc)[2], const float *tail, int layer, int q) {
     acc[1][0] = v1.x; acc[1][1] = v1.y; acc[1][2] = v1.z; acc[1][3] = v1.w;
 }
 
-// ---- LDS tiles [channel][pixel] ------------------------------------------------------------------------------------------
-// lane_base = chan_q(q) * TLD + px (floats); register s goes to row chan(s, q): a compile-time offset on top
+// ---- LDS tiles [row][pixel] --------------------------------------------------------------------------------------------------
+// Register s of lane (px, q) goes to ROW 16 (s >> 2) + (s & 3) + 4 q, i.e. row m of 16-row block b holds channel row_chan(16 b + m) =
+// chan(4 b + (m & 3), m >> 2) -- the row permutation of the weight images.  The four rows one ds_write touches (q = 0..3) are 4 apart:
+// 80 floats = 16 banks, so the 64 lanes cover all 64 banks (rows in channel order: q = 1 and q = 2 overlapped on 12 banks; PMC:
+// SQ_LDS_BANK_CONFLICT 1.17 M per launch of the pair backward).  The weight-gradient GEMMs read whole 16-row blocks, so their result
+// fragments are simply indexed by row_chan(); nothing else reads a tile by channel.
+// lane_base = tile_lane_base(px, q) (floats); the register part is a compile-time offset
+#ifndef FGNN_ROWMAP
+#define FGNN_ROWMAP 1       // measurement switch: 0 = rows in channel order (the first version; 2-way conflicts on 12 banks per write)
+#endif
+#if FGNN_ROWMAP
+DEVI int tile_lane_base(int px, int q) { return 4 * q * TLD + px; }
+DEVI constexpr int tile_row_s(int s) { return 16 * (s >> 2) + (s & 3); }
+DEVI int row_chan(int row) { return chan(4 * (row >> 4) + (row & 3), (row & 15) >> 2); }
+#else
+DEVI int tile_lane_base(int px, int q) { return chan_q(q) * TLD + px; }
+DEVI constexpr int tile_row_s(int s) { return chan_s(s); }
+DEVI int row_chan(int row) { return row; }
+#endif
 DEVI void stage8(float *T, int lane_base, const float (&v)[8]) {
 #if FGNN_ABL & 8           // no staging writes
     if (v[0] != 1.2345e-30f) return;
 #endif
 #pragma unroll
-    for (int s = 0; s < 8; ++s) T[lane_base + chan_s(s) * TLD] = v[s];
+    for (int s = 0; s < 8; ++s) T[lane_base + tile_row_s(s) * TLD] = v[s];
 }
 
-// dW[2 mb + nb] += Dt (rows = out channel 16 mb ..) x In (rows = in channel 16 nb ..), contraction over the 16 pixels;
-// db[mb] from the same reads (lane (i, q) holds pixels 4 q .. 4 q + 3 of channel 16 mb + i)
+// dW[2 mb + nb] += Dt (rows 16 mb ..) x In (rows 16 nb ..), contraction over the 16 pixels: register r of lane (n, q) is
+// dW[row_chan(16 mb + 4 q + r)][row_chan(16 nb + n)]; db[mb] from the same reads (lane (i, q) holds pixels 4 q .. 4 q + 3 of row 16 mb + i)
 DEVI void wgrad16(f32x4 (&dW)[4], float (&db)[2], const float *Dt, const float *In, int lane) {
 #if FGNN_ABL & 16           // no weight gradients
     return;

@@ -32,6 +32,10 @@ __device__ unsigned long long *g_phase16_buf = nullptr;
 #define PH_FLUSH
 #endif
 
+#ifndef FGNN_PRIO
+#define FGNN_PRIO 1         // static priority of the mlp2 waves (0: none)
+#endif
+
 namespace {
 
 using namespace t16;
@@ -106,12 +110,13 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     const View vdx = make_view(P.m[1].dxa, P.m[1].dxa_gstride, P.m[1].dxa_ld, P.m[1].G);
 
     PH_DECL
+    if (FGNN_PRIO > 0 && role == 1) __builtin_amdgcn_s_setprio(FGNN_PRIO);
     float *wl = smem + role * L::WEIGHT_F;              // this wave's MLP image
     float *my = smem + L::TILE_OFF + wv * (L::NSLOT * TILE_F);
     float *XA = my, *S0 = my + TILE_F, *S1 = my + 2 * TILE_F, *S2 = my + 3 * TILE_F;
     float *XCH = smem + L::XCH_OFF + pair * 1024;
     int *flags = reinterpret_cast<int *>(smem + L::FLAG_OFF) + 4 * pair;     // [0] = fragments handed over, [1] = fragments consumed
-    const int lane_base = chan_q(q) * TLD + px;
+    const int lane_base = tile_lane_base(px, q);
 
     f32x4 dW0[4], dW1[4], dW2[4];
     float db0[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f};
@@ -216,13 +221,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #ifdef FGNN_STAGGER         // measurement switch: the mlp2 waves start late by FGNN_STAGGER x 64 cycles
     if (role == 1) __builtin_amdgcn_s_sleep(FGNN_STAGGER);
 #endif
-#ifndef FGNN_PRIO
-#define FGNN_PRIO 1
-#endif
     // Static priority for the mlp2 waves: they are the younger half of the workgroup (waves 4..7) -- the loser of every arbitration for the
     // SIMD's matrix / vector issue -- AND carry the longer half (hand-over wait, dgrad at the very end, store, sums), so they set the
     // kernel's duration while the mlp1 waves idle ~ 15 % at the hand-over slots.  One s_setprio before the loop: 62.7 -> 59.3 us.
-    if (FGNN_PRIO > 0 && role == 1) __builtin_amdgcn_s_setprio(FGNN_PRIO);
+    // (set at the top of the kernel: the prologue is arbitrated the same way)
     int hk = 0;                                      // fragments this pair has handed over so far (two slots: the mlp1 wave may run a half ahead)
     // role 1: S1 / S2 of the input slab's producer, accumulated PER LANE (pixel column, 8 channels) over the pair's consecutive tiles of
     // a graph and reduced over the pixels once, at the pair's last tile of the graph -- the consumers (fgnn_gn_bwd_coef_tiles, the
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #pragma unroll
                 for (int s = 0; s < 8; ++s) es1[s] = es2[s] = 0.f;
             }
-            if (lane < 32) reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)g * tpg + tt) * FGNN_H + lane] = make_float2(t1, t2);
+            if (lane < 32) reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)g * tpg + tt) * FGNN_H + row_chan(lane)] = make_float2(t1, t2);
         }
         tile = ntile;
         hf = nhf;
@@ -449,10 +451,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[off + (16 * mb + 4 * q + r) * 32 + 16 * nb + px] = dW[2 * mb + nb][r];
+                    for (int r = 0; r < 4; ++r) red[off + row_chan(16 * mb + 4 * q + r) * 32 + row_chan(16 * nb + px)] = dW[2 * mb + nb][r];
             if (q == 0) {
-                red[off + 1024 + px] = db[0];
-                red[off + 1024 + 16 + px] = db[1];
+                red[off + 1024 + row_chan(px)] = db[0];
+                red[off + 1024 + row_chan(16 + px)] = db[1];
             }
         };
         put(0, dW0, db0);

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
     float *wl = smem;
     float *my = smem + L::TILE_OFF + wv * (L::NSLOT * TILE_F);
     float *XA = my, *XB = my + TILE_F, *S0 = my + 2 * TILE_F, *S1 = my + 3 * TILE_F, *S2 = my + 4 * TILE_F;
-    const int lane_base = chan_q(q) * TLD + px;
+    const int lane_base = tile_lane_base(px, q);
 
     f32x4 dW0a[4], dW0b[4], dW1[4], dW2[4];
     float db0[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f}, db2[2] = {0.f, 0.f}, dbx[2] = {0.f, 0.f};
@@ -241,13 +241,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
         fetch_records(g, cur_nv);
         cached_g = g;
     }
-    if constexpr (CB == 2) {                         // the slab-b tile holds two rows; rows 2..15 of its first block are read as zeros
-        for (int e = lane; e < 14 * TLD; e += 64) XB[2 * TLD + e] = 0.f;
+    if constexpr (CB == 2) {                         // the slab-b tile holds two rows (channels 0, 1 = rows 0, 8); the rest of its first block is read as zeros
+        for (int e = lane; e < 16 * TLD; e += 64) XB[e] = 0.f;          // (rows 0 and 8 are rewritten per half)
     }
     __syncthreads();
     load_dyz(h);                                     // (after the barrier, which drains every load: see mlp_bwd_pair_t16.hip)
     if (cached_g >= 0) read_records();
 
+#ifdef FGNN_PRIOB          // measurement switch: static priority for the younger waves (1) / the older waves (2)
+    if ((FGNN_PRIOB == 1) == (wv >= 4)) __builtin_amdgcn_s_setprio(1);
+#endif
     while (h < H1) {
         const int hn = next_half(h + NW);
         const int g = __builtin_amdgcn_readfirstlane(h / hpg), hh = h - g * hpg;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
             if constexpr (CB == 32) {
                 stage8(XB, lane_base, yb);
             } else {                                   // rows 0, 1 of the slab-b tile; rows 2..15 of its first block were zeroed once
-                if (q < 2) XB[q * TLD + px] = yb[0];
+                if (q < 2) XB[(FGNN_ROWMAP ? 8 : 1) * q * TLD + px] = yb[0];     // channel q = chan(0, 2 q): row 4 * (2 q)
             }
             f32x4 acc[2];
             load_bias(acc, wl + L::BIAS_F, 0, q);
@@ -393,19 +396,20 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int o = 16 * mb + 4 * q + r, c = 16 * nb + px;
+                    const int o = row_chan(16 * mb + 4 * q + r), c = row_chan(16 * nb + px);
                     red[o * CIN + c] = dW0a[2 * mb + nb][r];
                     if (c < CB) red[o * CIN + 32 + c] = dW0b[2 * mb + nb][r];
                     red[32 * CIN + 32 + o * 32 + c] = dW1[2 * mb + nb][r];
                     red[32 * CIN + 32 + 1056 + o * 32 + c] = dW2[2 * mb + nb][r];
                 }
         if (q == 0) {
-            red[32 * CIN + px] = db0[0];
-            red[32 * CIN + 16 + px] = db0[1];
-            red[32 * CIN + 32 + 1024 + px] = db1[0];
-            red[32 * CIN + 32 + 1024 + 16 + px] = db1[1];
-            red[32 * CIN + 32 + 1056 + 1024 + px] = db2[0];
-            red[32 * CIN + 32 + 1056 + 1024 + 16 + px] = db2[1];
+            const int c0 = row_chan(px), c1 = row_chan(16 + px);
+            red[32 * CIN + c0] = db0[0];
+            red[32 * CIN + c1] = db0[1];
+            red[32 * CIN + 32 + 1024 + c0] = db1[0];
+            red[32 * CIN + 32 + 1024 + c1] = db1[1];
+            red[32 * CIN + 32 + 1056 + 1024 + c0] = db2[0];
+            red[32 * CIN + 32 + 1056 + 1024 + c1] = db2[1];
         }
     }
     __syncthreads();

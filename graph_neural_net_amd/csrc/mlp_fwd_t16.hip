@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (FWD_WAVES + 3) / 4) void mlp_fwd_t
     float *wl = smem;
     float *tl = smem + L::TILE_OFF + wv * TILE_F;
     float4 *rec = reinterpret_cast<float4 *>(smem + L::REC_OFF) + wv * 64;
-    const int lane_base = chan_q(q) * TLD + px;
+    const int lane_base = tile_lane_base(px, q);
 
     int T0, T1;
     {
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES, (FWD_WAVES + 3) / 4) void mlp_fwd_t
                 m2 = ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
             }
             m2 += __shfl_xor(m2, 32);
-            if (lane < 32) reinterpret_cast<float2 *>(A.part[m])[((long long)g * hpg + hh) * FGNN_H + lane] = make_float2(mean, m2);
+            if (lane < 32) reinterpret_cast<float2 *>(A.part[m])[((long long)g * hpg + hh) * FGNN_H + row_chan(lane)] = make_float2(mean, m2);
         }
         if (lane == 0) A.cnt[(long long)g * hpg + hh] = cnt;
         h = hn;
