@@ -458,7 +458,7 @@ def module_surface_leg(args, config, rank, world, dev, engine_ms):
     leg['engine_ms_per_step'] = engine_ms
     leg['vs_engine'] = leg['ms_per_step'] / engine_ms
     leg['what'] = ("Siamese_Node_Exp(input_form='tensor_representation').fused_step({'input': x1}, {'input': x2}) on the dense loader "
-                   'batch: two pack launches (fgnn_pack_adjacency_ld, with the device verdict) + ONE replayed HIP graph per step')
+                   'batch: ONE pack launch for both sides (fgnn_pack_adjacency_pair, with the device verdict) + ONE replayed HIP graph per step')
     return leg
 
 
@@ -758,7 +758,7 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                 roofline['traffic_source'] = tr.get('_source')
         except (OSError, ValueError):
             pass
-        roofline.update({'kernel': dom, 'avg_launch_ms': dur * 1e3, 'eager_launch_ms': eager_ms,
+        roofline.update({'kernel': dom, 'avg_launch_ms': dur * 1e3, 'in_graph_launch_ms': (dur * 1e3 if ingraph else None), 'eager_launch_ms': eager_ms,
                          'timing': ('%d back-to-back launches per replay of a HIP graph (x %d replays), cycling %d operand sets of %d engines'
                                     % (ingraph['launches'], ingraph['replays'], ingraph['sets'], ingraph['engines'])) if ingraph else
                                    'eager launches, events around each',
@@ -828,7 +828,9 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                        'mlp_contraction': ('v_mfma_f32_32x32x16_bf16' if bf16 else
                                            ('mlp1 / mlp2 (forward, and the pair backward fgnn_mlp_bwd_pair_x3): 3 x bf16 split operands (8 / 6 partial '
                                             'products, fp32 accumulation) on v_mfma_f32_32x32x16_bf16; mlp3: v_mfma_f32_32x32x2_f32' if getattr(eng, 'x3', False)
-                                            else 'v_mfma_f32_32x32x2_f32')),
+                                            else ('forward: v_mfma_f32_32x32x2_f32; backward (mlp1 + mlp2 pair, mlp3): v_mfma_f32_16x16x4_f32 on 16-pixel tiles (csrc/*_t16.hip; FGNN_T16=%s)'
+                                                  % getattr(eng, 'T16', '?') if getattr(eng, 'T16', '0') not in ('0', '') else 'v_mfma_f32_32x32x2_f32'))),
+                       'env_switches': {k: v for k, v in os.environ.items() if k.startswith('FGNN_') and k not in ('FGNN_BENCH_CHILD',)},
                        'grad_allreduce': ('%s sum of %d fp32 per step' % (torch.distributed.get_backend(), layout.total)) if world > 1 else 'none'},
             'ranks_seen': dp.world_size(), 'backend': torch.distributed.get_backend() if world > 1 else None, 'allreduce_ms': allreduce_ms,
             'roofline': roofline, 'step_trace_ms': step_trace,

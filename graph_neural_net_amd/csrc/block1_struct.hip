@@ -151,6 +151,8 @@ static WsLayout sb_ws_layout(int G, int N) {
 // y SB_CW ..: it transposes ONLY those columns (a workgroup that transposed the whole matrix spent 4.6 of its 9.5 us there at
 // N = 200), writes the vertex records of the vertices in the band and, thread <-> row, the band's codes of every row.
 constexpr int SB_CW = 16;                // columns per workgroup of the per-graph kernel
+// (the kernel-argument segment is limited to 4 KB: the pack jobs travel by value next to the table arguments and ~ 20 scalars / pointers)
+static_assert(sizeof(PackJobs) + sizeof(TabArgs) + 256 <= 4096, "sb_graph_kernel: kernel arguments exceed 4 KB -- pass the pack jobs through a device buffer");
 template <int NWD>
 __global__ __launch_bounds__(256) void sb_graph_kernel(const unsigned *bits, const int *nvalid, const int N, const int cp, unsigned *code,
                                                        float4 *vinfo, float *gones, float *xdeg, void *x16, const long long ldp16,

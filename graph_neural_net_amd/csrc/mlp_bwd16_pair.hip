@@ -236,6 +236,9 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
     const int ld2 = va.ld2;
     auto roff = [&](int r) { return ((r & 3) + 8 * (r >> 2)) * ld2; };
 
+#ifndef FGNN_XEARLY
+#define FGNN_XEARLY 0     // measurement switch: x of the next tile requested in the middle of the tile (10 spilled registers: 75 -> 87 us)
+#endif
 #ifndef FGNN_PRIO16
 #define FGNN_PRIO16 1
 #endif
@@ -265,12 +268,14 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
         float *xbuf = xch + (((tile - first) / NP) & 1) * (2 * 1024);          // this tile's hand-over buffer
         const bool rmw_b = (CB >= 32) && A.dxb != nullptr && A.accumulate_b;
         if constexpr (CA >= 32) {
-            if (rmw_a) {
-                const int vo = lo4 + c.g * vdxa.gs2;
+            if (has_dx) {     // (issued on every path -- out of range when nothing is accumulated: no traffic -- so that the compiler can count
+                              // what is in flight behind the x prefetch below and its s_waitcnt for x does not drain these)
+                const int vo = (rmw_a ? lo4 : OOB_OFF) + c.g * vdxa.gs2;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) olda[r] = buf_load_u32(vdxa, vo, roff(r));
             }
         }
+        const Tile16 cn = decode16(tnext, tnext < T1, tpg, A.ldr, PP, j);       // the wave's next tile
         if constexpr (CB >= 32) {
             if (rmw_b) {
                 const int vo = lo4 + c.g * vdxb.gs2;
@@ -332,6 +337,10 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
                 yTb = transposed_input(yb, ident, false, 1.f, 0.f);
             }
 
+#if FGNN_XEARLY
+            // the next tile's x into the registers both groups have consumed by now: a tile's time instead of its last instants to arrive
+            if constexpr (GRP == 1 && CB == 0) load_slab16<CA>(xa, va, cn, h);
+#endif
             // ---- forward recompute: h_0 .. h_{d-2} ----
             F16 hs[DEPTH - 1];
             {
@@ -503,12 +512,9 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_pair_kernel(const
             es2 += __shfl_xor(es2, 32);
             if (h == 0) reinterpret_cast<float2 *>(P.m[1].s12part)[((long long)c.g * FGNN_H + j) * tpg + c.tt] = make_float2(es1, es2);
         }
-        // the wave's next tile
-        {
-            const int tn = tnext;
-            const Tile16 cn = decode16(tn, tn < T1, tpg, A.ldr, PP, j);
-            load_slab16<CA>(xa, va, cn, h);
-        }
+#if !FGNN_XEARLY
+        load_slab16<CA>(xa, va, cn, h);     // the wave's next tile
+#endif
     }
 
     if constexpr (SKIP) {       // padding-only tiles of this wave's share: empty S1/S2 / trace-term records

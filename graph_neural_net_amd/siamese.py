@@ -201,16 +201,18 @@ class Siamese_Node_Exp(nn.Module):
                 if not torch.equal(x1.nvalid, x2.nvalid):
                     raise RuntimeError('fused_step: the two sides of a MaskedTensor batch must share the per-pair vertex counts; use '
                                        'the module path `loss = model.loss(model(x1, x2)); loss.backward()`')
+            # Between those checks side 2 runs with side 1's counts (as FgnnTrainer does): a batch whose sides differ then still has the
+            # reference's target / normaliser semantics for side 1 instead of silently mixing two sets of counts
             if not tr:
                 st['nv'][:B].copy_(x1.nvalid)
-                st['nv'][B:].copy_(x2.nvalid)
+                st['nv'][B:].copy_(x1.nvalid)
         if tr:
             # ONE launch straight from the loader's tensors, both sides: rows of ballots -> (2 B, N, ceil(N/32)) words of the engine's padded
             # size, with the verdict (channel 0 in {0, 1}, channel 1 = diag(row sums), counts within the padded size) OR-ed into a flag;
             # ragged batches: the same launch copies the vertex counts into the engine's buffer and leaves 1 / sum(n) in st['inv']
             nv1 = nv2 = None
             if ragged:
-                nv1, nv2 = x1.nvalid, x2.nvalid
+                nv1, nv2 = x1.nvalid, x1.nvalid            # (side 2 with side 1's counts, see above)
                 if nv1.dtype != torch.int32 or not nv1.is_cuda or not nv1.is_contiguous() or nv2.dtype != torch.int32 \
                         or not nv2.is_cuda or not nv2.is_contiguous():
                     nv1, nv2 = nv1.to(device=dev, dtype=torch.int32).contiguous(), nv2.to(device=dev, dtype=torch.int32).contiguous()

@@ -237,7 +237,14 @@ class FgnnTrainer:
                 try:
                     g_model, scores = capture_model()
                     failed = 0.0
-                except Exception:            # noqa: BLE001 -- any capture failure takes the fallback
+                except RuntimeError as e:    # a capture failure takes the fallback; anything else (argument errors, OOM, ...) is a real error
+                    msg = str(e).lower()
+                    if not any(w in msg for w in ('captur', 'graph', 'nccl', 'rccl')):
+                        raise
+                    import warnings
+                    warnings.warn('FgnnTrainer: the gradient all-reduce could not be recorded into the step graph on rank %d (%s); every '
+                                  'rank falls back to model graph | eager all-reduce | optimizer graph' % (torch.distributed.get_rank() if torch.distributed.is_initialized() else 0, e))
+                    self.capture_fallback_reason = str(e)
                     torch.cuda.synchronize()
                     g_model, failed = None, 1.0
                 flag = torch.tensor([failed], dtype=torch.float32, device=self.params.device)
