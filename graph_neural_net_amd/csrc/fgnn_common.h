@@ -146,6 +146,17 @@ DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *n
     return next_live_tile_p(t, t_end, step, tpg, FGNN_TILE, N, nvalid);
 }
 
+// Static priority for the younger half of a workgroup's waves (the loser of every arbitration for a SIMD's issue slots, MI355X_MICROARCH.md
+// "two waves per SIMD"): measurement switch FGNN_YP (bit mask per kernel family, see the call sites); 0 = off
+#ifndef FGNN_YP
+#define FGNN_YP 0
+#endif
+DEVI void young_prio(int bit, int wv, int nw) {
+    if ((FGNN_YP >> bit) & 1) {
+        if (wv >= nw / 2) __builtin_amdgcn_s_setprio(1);
+    }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: what has been raised is remembered per
 // (launcher, device), so a process that drives a second GPU raises it there as well.
 struct LdsAttrCache {

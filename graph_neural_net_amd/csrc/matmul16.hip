@@ -599,6 +599,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_fwd16_kernel(const fgn
     __shared__ float fin_red[MM_NW][4];
     constexpr bool STRIP = MMCfg<NT, NCOL>::STRIP;
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
+    young_prio(5, tid >> 6, MM_NW);
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
     Src16 A, B;
     u32x4 pre_a[4], pre_b[4];
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(MM_THREADS) void chan_matmul_bwd16_kernel(const fgn
     const int C = ya.C, gc = blockIdx.x, g = gc / C, c = gc - g * C, tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int nv = nvalid_of(nvalid, g, N), ntv = (nv + 31) / 32;
+    young_prio(4, wv, MM_NW);
     const Src16 A = mm_src(ya, G, g, c), B = mm_src(yb, G, g, c);
     const Src16 D = mm_src_plain(dm, dmg, ldm, G, g, c);
     const View16 vOA = make_view16(da, ogstride, ldo, G), vOB = make_view16(db, ogstride, ldo, G);

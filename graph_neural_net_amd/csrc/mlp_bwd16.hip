@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64 * NWB, NWB / 4) void mlp_bwd16_kernel(const fgnn
     constexpr int CIN = CA + CB, SA = pk16_steps(CA), SB = pk16_steps(CB);
     constexpr int XA = CA >= 32 ? 16 : 2, XB = CB >= 32 ? 16 : 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    young_prio(0, wv, blockDim.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int PP = A.N * A.ldr;
     const View16 va = make_view16(A.a.ptr, A.a.gstride, A.a.ldp, A.G);

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
     using L = Layout16<CB>;
     constexpr bool NB = CB == 32;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    young_prio(3, wv, NW);
     const int px = lane & 15, q = lane >> 4;
     const int P2 = A.N * A.N, hpg = 2 * tpg;
     const View va = make_view(A.a.ptr, A.a.gstride, A.a.ldp, A.G);

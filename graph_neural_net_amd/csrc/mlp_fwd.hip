@@ -169,6 +169,7 @@ DEVI void mlp_fwd_body(const fgnn_mlp_fwd_args A, const int tpg, const int total
 #endif
     constexpr int SA = CA / 2, SB = CB / 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    young_prio(2, wv, blockDim.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int P = A.N * A.N;
     float *wl = smem;

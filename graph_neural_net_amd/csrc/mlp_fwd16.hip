@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
     constexpr int SA = pk16_steps(CA), SB = pk16_steps(CB);
     constexpr int XA = CA >= 32 ? 16 : 2, XB = CB >= 32 ? 16 : 2;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    young_prio(1, wv, blockDim.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int PP = A.N * A.ldr;
     float *wl = smem;
