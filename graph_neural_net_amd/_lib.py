@@ -221,6 +221,7 @@ _SIGNATURES = {
     'fgnn_pack16_floats': [_I, _I, _I, _I, _I],
     'fgnn_pack16_operands': [_VP, _I, _VP],
     'fgnn_mlp_fwd16': [C.POINTER(MlpFwd16Args), _VP],
+    'fgnn_debug_mlp_fwd16_masks': [C.POINTER(MlpFwd16Args), _VP, _VP, _VP],
     'fgnn_gn_finalize_tpg': [_VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP],
     'fgnn_gn_finalize2_tpg': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP],
     'fgnn_gn_bwd_coef_tiles_tpg': [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP],

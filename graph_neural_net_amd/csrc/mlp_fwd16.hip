@@ -71,9 +71,11 @@ DEVI void operands2(i32x4 &e, i32x4 &o, const unsigned (&x)[2]) {
 // SKIP (ragged batches with A.ranges): work-balanced tile range from fgnn_ragged_tile_ranges16, the waves step over tiles
 // without a valid element; those only get empty statistics records (their z elements are not written: consumers step over
 // the same tiles or read the valid corner only).
-template <int CA, int CB, int NMLP, int DEPTH, bool SKIP = false>
-__global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_fwd16_args A, const int tpg,
-                                                                 const int total_tiles) {
+// DBG (fgnn_debug_mlp_fwd16_masks, test-only): the same tile code also exports the ReLU decisions it takes -- one bit per hidden
+// pre-activation: dbg[m][((((g * (DEPTH-1) + layer) * 32 + channel) * tpg + tile) * 2 + parity], bit j = element 64 * tile + 2 j + parity
+// of the (ldr-pitched) plane.
+template <int CA, int CB, int NMLP, int DEPTH, bool SKIP, bool DBG>
+DEVI void mlp_fwd16_body(const fgnn_mlp_fwd16_args A, const int tpg, const int total_tiles, unsigned *const dbg0, unsigned *const dbg1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = Fwd16Layout<CA, CB, NMLP, DEPTH>;
     constexpr Pk16 PK = L::PK;
@@ -188,6 +190,19 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
             static_assert(DEPTH >= 2, "the swapped last layer takes a hidden fragment");
 #pragma unroll
             for (int l = 1; l < DEPTH; ++l) {
+                if constexpr (DBG) {      // the decision the packed ReLU takes: the sign of the fp32 pre-activation
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned long long mkE = __ballot(aE[r] > 0.f), mkO = __ballot(aO[r] > 0.f);
+                        if (lane == 0) {
+                            unsigned *o = (m == 0 ? dbg0 : dbg1) + ((((long long)c.g * (DEPTH - 1) + (l - 1)) * 32 + ch_of(r, 0)) * tpg + c.tt) * 2;
+                            o[0] = (unsigned)mkE;
+                            o[1] = (unsigned)mkO;
+                            o[8ll * tpg] = (unsigned)(mkE >> 32);          // channel ch_of(r, 1) = ch_of(r, 0) + 4
+                            o[8ll * tpg + 1] = (unsigned)(mkO >> 32);
+                        }
+                    }
+                }
                 pack_acc_relu(hE, aE);
                 pack_acc_relu(hO, aO);
                 load_bias16(aE, tail, l, h);
@@ -282,6 +297,28 @@ __global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_f
     }
 }
 
+template <int CA, int CB, int NMLP, int DEPTH, bool SKIP = false>
+__global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_kernel(const fgnn_mlp_fwd16_args A, const int tpg, const int total_tiles) {
+    mlp_fwd16_body<CA, CB, NMLP, DEPTH, SKIP, false>(A, tpg, total_tiles, nullptr, nullptr);
+}
+template <int CA, int CB, int NMLP, int DEPTH>
+__global__ __launch_bounds__(64 * NWF, 2) void mlp_fwd16_dbg_kernel(const fgnn_mlp_fwd16_args A, const int tpg, const int total_tiles,
+                                                                     unsigned *d0, unsigned *d1) {
+    mlp_fwd16_body<CA, CB, NMLP, DEPTH, false, true>(A, tpg, total_tiles, d0, d1);
+}
+template <int CA, int CB, int NMLP, int DEPTH>
+int launch_fwd16_dbg(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t st, unsigned *d0, unsigned *d1) {
+    using L = Fwd16Layout<CA, CB, NMLP, DEPTH>;
+    constexpr int LDS = L::LDS_F * 4;
+    static LdsAttrCache attr_cache;
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp_fwd16_dbg_kernel<CA, CB, NMLP, DEPTH>, LDS);
+    int grid = (total + NWF - 1) / NWF;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((mlp_fwd16_dbg_kernel<CA, CB, NMLP, DEPTH>), dim3(grid), dim3(64 * NWF), LDS, st, *a, tpg, total, d0, d1);
+    FGNN_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int CA, int CB, int NMLP, int DEPTH, bool SKIP>
 int launch_fwd16_impl(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t st) {
     using L = Fwd16Layout<CA, CB, NMLP, DEPTH>;
@@ -306,7 +343,7 @@ int launch_fwd16(const fgnn_mlp_fwd16_args *a, int tpg, int total, hipStream_t s
 
 extern "C" int fgnn_tiles_per_graph16(int N, int ldr) { return (N * ldr + 63) / 64; }
 
-extern "C" int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *a, void *stream) {
+static int mlp_fwd16_entry(const fgnn_mlp_fwd16_args *a, void *stream, unsigned *const *dbg) {
     FGNN_CHECK(a != nullptr, "fgnn_mlp_fwd16: null args");
     FGNN_CHECK(a->G > 0 && a->N > 0 && a->ldr >= a->N && a->ldr % 8 == 0, "fgnn_mlp_fwd16: bad G=%d N=%d ldr=%d (ldr: multiple of 8, >= N)",
                a->G, a->N, a->ldr);
@@ -329,6 +366,15 @@ extern "C" int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *a, void *stream) {
     FGNN_CHECK(total < (1ll << 30), "fgnn_mlp_fwd16: too many tiles");
     hipStream_t st = (hipStream_t)stream;
     const int ca = a->a.C, cb = a->b.C;
+    if (dbg) {          // decision-exporting twins: the fused engine's constant-size shapes
+        FGNN_CHECK(!a->ranges && dbg[0] && (a->nmlp == 1 || dbg[1]), "fgnn_debug_mlp_fwd16_masks: no ranges, one mask buffer per MLP");
+        if (a->nmlp == 2 && ca == 2 && cb == 0) return launch_fwd16_dbg<2, 0, 2, 3>(a, tpg, (int)total, st, dbg[0], dbg[1]);
+        if (a->nmlp == 2 && ca == 32 && cb == 0) return launch_fwd16_dbg<32, 0, 2, 3>(a, tpg, (int)total, st, dbg[0], dbg[1]);
+        if (a->nmlp == 1 && ca == 32 && cb == 2) return launch_fwd16_dbg<32, 2, 1, 3>(a, tpg, (int)total, st, dbg[0], nullptr);
+        if (a->nmlp == 1 && ca == 32 && cb == 32) return launch_fwd16_dbg<32, 32, 1, 3>(a, tpg, (int)total, st, dbg[0], nullptr);
+        fgnn_set_error("fgnn_debug_mlp_fwd16_masks: built for the fused engine's shapes (2 / 32 inputs with nmlp = 2; 32 + 2 / 32 + 32 with nmlp = 1)");
+        return 1;
+    }
     if (a->nmlp == 2 && ca == 2 && cb == 0) return launch_fwd16<2, 0, 2, 3>(a, tpg, (int)total, st);
     if (a->nmlp == 2 && ca == 32 && cb == 0) return launch_fwd16<32, 0, 2, 3>(a, tpg, (int)total, st);
     if (a->nmlp == 1 && ca == 32 && cb == 0) return launch_fwd16<32, 0, 1, 3>(a, tpg, (int)total, st);
@@ -338,4 +384,14 @@ extern "C" int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *a, void *stream) {
     fgnn_set_error("fgnn_mlp_fwd16: unsupported input channels (%d + %d) for nmlp=%d; built for 2, 32 and, with nmlp=1, 32+2, 32+32",
                    ca, cb, a->nmlp);
     return 1;
+}
+
+extern "C" int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *a, void *stream) { return mlp_fwd16_entry(a, stream, nullptr); }
+
+// Test-only (tests/test_gpu_grad_pinned.py, bf16 case): fgnn_mlp_fwd16 once more -- same tile code, same outputs -- that also writes the
+// ReLU decisions of the two hidden layers: masks[m] is (G, 2, 32, tiles per graph, 2) words, bit j of word (g, layer, channel, t, parity)
+// = hidden pre-activation of element 64 t + 2 j + parity of the ldr-pitched plane > 0.  Constant-size batches.
+extern "C" int fgnn_debug_mlp_fwd16_masks(const fgnn_mlp_fwd16_args *a, unsigned *masks0, unsigned *masks1, void *stream) {
+    unsigned *const dbg[2] = {masks0, masks1};
+    return mlp_fwd16_entry(a, stream, dbg);
 }

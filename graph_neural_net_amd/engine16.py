@@ -143,6 +143,13 @@ class FgnnEngineBF16:
         st = _lib.stream_ptr()
         _lib.call('fgnn_mlp_fwd16', C.byref(args), st,
                   tag='mlp_fwd16[cin=%d,nmlp=%d]' % (a.C + (b.C if b is not None else 0), len(js)))
+        if getattr(self, 'decisions', None) is not None:
+            # test-only (export_decisions): the decision-exporting twin of the launch above -- same tile code, same outputs written once
+            # more -- leaves one bit per hidden pre-activation of these MLPs
+            bufs = [torch.zeros(self.G * (L.depth - 1) * 32 * self.tpg * 2, dtype=torch.int32, device=self.device) for _ in js]
+            _lib.call('fgnn_debug_mlp_fwd16_masks', C.byref(args), _lib.ptr(bufs[0]), _lib.ptr(bufs[1]) if len(js) == 2 else None, st)
+            for j, buf in zip(js, bufs):
+                self.decisions[(k, j)] = buf
         if not finalize:
             return
         if len(js) == 2:
@@ -441,6 +448,26 @@ class FgnnEngineBF16:
                 jobs[i].dgn_b = grads.data_ptr() + 4 * rec['gn_b']
             _lib.call('fgnn_grad_finalize', jobs, len(chunk), W['nwg'], self.G, 32, st)
         return grads
+
+    def export_decisions(self, on=True):
+        """Test-only (tests/test_gpu_grad_pinned.py): from the next forward on, every fgnn_mlp_fwd16 launch is followed by its
+        decision-exporting twin (fgnn_debug_mlp_fwd16_masks); relu_decisions() + self.idx are then all the discrete ReLU / arg-max
+        decisions of a step (constant-size batches, generic block 1)."""
+        self.decisions = {} if on else None
+
+    def relu_decisions(self):
+        """{(block, mlp, hidden layer): bool (G, 32, N, N)}: [pre-activation > 0] as the kernels' ReLU saw it."""
+        L, G, N = self.layout, self.G, self.N
+        out = {}
+        bit = torch.arange(32, device=self.device, dtype=torch.int32)
+        for (k, j), buf in self.decisions.items():
+            w = buf.view(G, L.depth - 1, 32, self.tpg, 2)                                   # [..., parity], bit jp = element 64 t + 2 jp + parity
+            m = ((w.unsqueeze(-1) >> bit) & 1)                                              # (G, d-1, 32, tpg, 2, 32)
+            m = m.permute(0, 1, 2, 3, 5, 4).reshape(G, L.depth - 1, 32, self.tpg * 64)      # element order within the ldr-pitched plane
+            m = m[..., :N * self.ldr].reshape(G, L.depth - 1, 32, N, self.ldr)[..., :N]
+            for l in range(L.depth - 1):
+                out[(k, j, l)] = m[:, l].bool()
+        return out
 
     def step(self, params, grads, x, nvalid=None, total_nodes=None, loss_out=None, bits=None):
         scores, loss = self.forward(params, x, nvalid, total_nodes, defer_loss=True, loss_out=loss_out, bits=bits)

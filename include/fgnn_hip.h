@@ -605,6 +605,10 @@ typedef struct {
     const int *ranges;                      /* optional (ragged): tile bounds from fgnn_ragged_tile_ranges16, see fgnn_mlp_fwd_args.ranges */
 } fgnn_mlp_fwd16_args;
 int fgnn_mlp_fwd16(const fgnn_mlp_fwd16_args *args, void *stream);
+/* Test-only: the same launch that also writes its ReLU decisions (the bf16 twin of fgnn_debug_mlp_fwd_masks): masks[m] is
+ * (G, 2, 32, fgnn_tiles_per_graph16(N, ldr), 2) words, bit j of word (g, layer, channel, t, parity) = [hidden pre-activation of element
+ * 64 t + 2 j + parity of the ldr-pitched plane > 0].  Constant-size batches, the fused engine's shapes. */
+int fgnn_debug_mlp_fwd16_masks(const fgnn_mlp_fwd16_args *args, unsigned *masks0, unsigned *masks1, void *stream);
 
 /* GraphNorm finalize / backward-coefficient helpers of the bf16 kernels: explicit tile count per graph (the fp32 entry
  * points derive it from FGNN_TILE) and partials in the bf16 kernels' layout (G, C, tpg, 2) -- tile index fastest -- instead

@@ -33,8 +33,8 @@ EPS = O.EPS
 
 
 def rbf(t):
-    """round to bf16 (RNE) and back to fp32"""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """round to bf16 (RNE) and back to the tensor's own dtype (fp32; fp64 in the decision-pinned evaluation)"""
+    return t.to(torch.bfloat16).to(t.dtype)
 
 
 def _ident(t):
@@ -52,15 +52,20 @@ class _Mlp:
         self.gn_w = gn_w.reshape(-1)
         self.gn_b = gn_b.reshape(-1)
 
-    def forward(self, y_in):
-        """y_in: (G, Cin, N, N) operand values (already rounded).  Returns z (fp32) and the record."""
+    def forward(self, y_in, masks=None):
+        """y_in: (G, Cin, N, N) operand values (already rounded).  Returns z (fp32) and the record.
+        masks (decision-pinned evaluation, tests/test_gpu_grad_pinned.py): the ReLU decisions [pre > 0] of the hidden layers as SOME
+        evaluation took them -- relu(pre) becomes where(mask, pre, 0) here and in the backward (oracle/fgnn_oracle_pinned.py)."""
         R = self.R
         self.y_in = y_in
         self.hs = []
+        self.masks = []
         h = y_in
         for l in range(len(self.wr) - 1):
             pre = torch.einsum('oc,gcij->goij', self.wr[l], h) + self.bs[l].view(1, -1, 1, 1)
-            h = R(torch.relu(pre))
+            mk = (pre > 0) if masks is None else masks[l]
+            h = R(torch.where(mk, pre, torch.zeros((), dtype=pre.dtype, device=pre.device)))
+            self.masks.append(mk)
             self.hs.append(h)
         z = torch.einsum('oc,gcij->goij', self.wr[-1], h) + self.bs[-1].view(1, -1, 1, 1)
         n = z.shape[-1]
@@ -98,19 +103,24 @@ class _Mlp:
             if l > 0 or need_dx:
                 dh = torch.einsum('oc,goij->gcij', self.wr[l], dpre)
             if l > 0:
-                dpre = R(dh * (hin > 0).to(dh.dtype))
+                dpre = R(dh * self.masks[l - 1].to(dh.dtype))
         self.grads = {'w': gw, 'b': gb,
                       'gn_w': (self.q * s2).sum(dim=0).reshape(-1), 'gn_b': s1.sum(dim=0).reshape(-1)}
         return dh if need_dx else None
 
 
-def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
-    """One step's model work in the bf16 scheme.  Returns (scores, loss, grads{name: tensor}) in fp32."""
+def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None, decisions=None, dtype=torch.float32, device=None):
+    """One step's model work in the bf16 scheme.  Returns (scores, loss, grads{name: tensor}) in `dtype`.
+    decisions = (masks {(blk, mlp, layer): bool (G, C, N, N)}, idx (G, C, N) int64): the decision-pinned form -- the ReLU masks and the
+    pooling's arg-max are INPUTS (oracle/fgnn_oracle_pinned.py); with dtype=torch.float64 every sum is exact to 1e-16 and every R(.)
+    still rounds to the bf16 grid: the same-point evaluation of the branch an engine took."""
     R = rbf if rounding else _ident
-    sd = {k: v.detach().to(torch.float32) for k, v in O._strip(sd).items()}
+    sd = {k: v.detach().to(device=device, dtype=dtype) for k, v in O._strip(sd).items()}
     K = O.num_blocks_of(sd)
     B, N = x1.shape[0], x1.shape[-1]
-    x = R(torch.cat([x1, x2]).to(torch.float32))
+    x = R(torch.cat([x1, x2]).to(device=device, dtype=dtype))
+    pin_masks, pin_idx = decisions if decisions is not None else (None, None)
+    mk = lambda k, j: None if pin_masks is None else [pin_masks[(k, j, l)] for l in range(len(O.mlp_params(sd, k, j)[0]) - 1)]
     mlps = {}
     y_in = x
     prev = None
@@ -118,18 +128,22 @@ def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
         for j in (1, 2, 3):
             mlps[(k, j)] = _Mlp(*O.mlp_params(sd, k, j), R)
         m1, m2, m3 = mlps[(k, 1)], mlps[(k, 2)], mlps[(k, 3)]
-        m1.forward(y_in)
-        m2.forward(y_in)
+        m1.forward(y_in, mk(k, 1))
+        m2.forward(y_in, mk(k, 2))
         y1, y2 = m1.normalized(), m2.normalized()
         mult = R(torch.matmul(y1, y2))
-        m3.forward(torch.cat([mult, y_in], dim=1))
+        m3.forward(torch.cat([mult, y_in], dim=1), mk(k, 3))
         m3.y1, m3.y2, m3.mult = y1, y2, mult
         if keep is not None:
             keep[(k, 'z1')], keep[(k, 'z2')], keep[(k, 'mult')], keep[(k, 'z3')] = m1.z_bf, m2.z_bf, mult, m3.z_bf
         prev = m3
         y_in = m3.normalized()
     out = prev.normalized(rounded=False)            # the pooling reads fp32-normalised values
-    E, idx = torch.max(out, -1)
+    if pin_idx is None:
+        E, idx = torch.max(out, -1)
+    else:
+        idx = pin_idx
+        E = torch.gather(out, -1, idx.unsqueeze(-1)).squeeze(-1)
     e1, e2 = E[:B], E[B:]
     scores = torch.matmul(e1.transpose(1, 2), e2)
     if total_nodes is None:
@@ -137,7 +151,7 @@ def step_fwd_bwd(x1, x2, sd, rounding=True, total_nodes=None, keep=None):
     lse = torch.logsumexp(scores, dim=-1)
     loss = (lse - torch.diagonal(scores, dim1=1, dim2=2)).sum() / total_nodes
     # ---- backward ----
-    ds = (torch.softmax(scores, dim=-1) - torch.eye(N).unsqueeze(0)) / total_nodes
+    ds = (torch.softmax(scores, dim=-1) - torch.eye(N, dtype=scores.dtype, device=scores.device).unsqueeze(0)) / total_nodes
     de1 = torch.matmul(e2, ds.transpose(1, 2))
     de2 = torch.matmul(e1, ds)
     dE = R(torch.cat([de1, de2]))

@@ -124,3 +124,55 @@ def test_gradients_on_the_engines_own_branch(case, mode):
     assert med <= PINNED_MEDIAN[kind], (case, mode, 'median', med)
     bad = {k: v for k, v in errs.items() if not v <= PINNED_WORST[kind] * ref_worst}
     assert not bad, (case, mode, 'beyond %g x the reference\'s own worst tensor %.2e' % (PINNED_WORST[kind], ref_worst), bad)
+
+
+def test_bf16_gradients_on_the_engines_own_branch():
+    """The decision-pinned statement for the 16-bit engine (BASELINE config 4: N = 200 dense ER pairs, batch 8).  FgnnEngineBF16 exports
+    its ReLU decisions (fgnn_debug_mlp_fwd16_masks: the forward tile code once more, same outputs bit for bit) and its arg-max indices;
+    oracle/fgnn_oracle_bf16.py is evaluated in fp64 ON THAT BRANCH with every rounding point of the kernels still rounding to the bf16
+    grid (the same-point evaluation: what is left between the two is fp32 accumulation against fp64, i.e. the occasional value that lands
+    on the neighbouring bf16 number).  Yard-stick: the reference's OWN bf16 run against fp64 on the N = 200 fixture
+    (cfg4_er_n200_b1_4blk.npz, grad_refbf16 / grad64): every gradient tensor of the engine must lie closer to its pinned evaluation than
+    the reference's worst tensor lies to the truth (gate: a fifth of it), the median tensor within a fiftieth of the reference's median."""
+    from graph_neural_net_amd.engine16 import FgnnEngineBF16
+    from oracle import fgnn_oracle_bf16 as OB
+    from util import rel
+    sd = sub(load_golden('cfg2_reg_n50_b2_4blk.npz'), 'sd/')
+    x1, x2 = synthetic.make_batch(4000, 8, 200, 'ErdosRenyi', 0.5, 0.1)
+    B, N = x1.shape[0], x1.shape[-1]
+    lay = ParamLayout(2, 4, 32, 32, 3)
+    params = lay.flatten(sd, DEV)
+    eng = FgnnEngineBF16(lay, 2 * B, N, DEV, block1='generic')
+    x = torch.cat([x1, x2]).contiguous().to(DEV)
+    g0 = torch.zeros_like(params)
+    s0, l0 = eng.step(params, g0, x)
+    torch.cuda.synchronize()
+    s0, l0 = s0.clone(), l0.clone()
+    eng.export_decisions(True)
+    grads = torch.zeros_like(params)
+    scores, loss = eng.step(params, grads, x)
+    torch.cuda.synchronize()
+    assert torch.equal(grads, g0) and torch.equal(scores, s0) and torch.equal(loss, l0)      # the export does not change a bit
+    masks = eng.relu_decisions()
+    assert len(masks) == 4 * 3 * 2
+    idx = eng.idx.to(torch.int64)
+    s64, l64, g64 = OB.step_fwd_bwd(x1, x2, sd, decisions=(masks, idx), dtype=torch.float64, device=DEV)
+    got = lay.unflatten(grads)
+    errs = {}
+    for name, g in g64.items():
+        a = got[name].double()
+        if is_zero_grad(name):
+            continue
+        errs[name] = ((a - g.reshape(a.shape)).abs().max() / g.abs().max()).item()
+    d = load_golden('cfg4_er_n200_b1_4blk.npz')
+    yard = {k: rel(d['grad_refbf16/' + k], d['grad64/' + k]) for k in sub(d, 'grad/') if not is_zero_grad(k)}
+    worst = max(errs, key=errs.get)
+    med, ymed, ymax = float(np.median(list(errs.values()))), float(np.median(list(yard.values()))), max(yard.values())
+    ndec = sum(int(m.numel()) for m in masks.values()) + idx.numel()
+    print('cfg4 bf16: %d decisions pinned; scores %.2e; worst tensor %s %.2e; median %.2e; loss %.1e | reference bf16 vs fp64: worst %.2e median %.2e'
+          % (ndec, ((scores.double() - s64).abs().max() / s64.abs().max()).item(), worst, errs[worst], med,
+             abs(loss.item() - l64.item()) / abs(l64.item()), ymax, ymed))
+    assert abs(loss.item() - l64.item()) <= 2e-3 * abs(l64.item())
+    # measured (round 6): worst tensor 7.8e-2 = 0.05 x the reference's worst (1.47), median 2.9e-3 = 0.0065 x its median (0.44)
+    assert errs[worst] <= 0.2 * ymax, (worst, errs[worst], ymax)
+    assert med <= 0.02 * ymed, (med, ymed)
