@@ -57,6 +57,15 @@ class ChainArgs(C.Structure):
                 ('layer', ChainLayer * 3), ('o_ld', C.c_longlong), ('nvalid', C.c_void_p), ('G', C.c_int), ('N', C.c_int)]
 
 
+class Mlp64Args(C.Structure):          # fgnn_mlp64_args (csrc/mlp64.hip)
+    _fields_ = [('x', C.c_void_p), ('x_gstride', C.c_longlong), ('x_ld', C.c_longlong), ('cin', C.c_int),
+                ('packed', C.c_void_p), ('nvalid', C.c_void_p), ('G', C.c_int), ('N', C.c_int),
+                ('out', C.c_void_p), ('o_gstride', C.c_longlong), ('o_ld', C.c_longlong),
+                ('dz', C.c_void_p), ('dz_gstride', C.c_longlong), ('dz_ld', C.c_longlong),
+                ('dx', C.c_void_p), ('dx_gstride', C.c_longlong), ('dx_ld', C.c_longlong),
+                ('wpart', C.c_void_p)]
+
+
 class MlpBwdArgs(C.Structure):
     _fields_ = [('G', C.c_int), ('N', C.c_int), ('depth', C.c_int),
                 ('nvalid', C.c_void_p),
@@ -150,6 +159,13 @@ _SIGNATURES = {
     'fgnn_conv1x1_dw_multi': [C.POINTER(DwJob), _I, _VP, _I, _I, _VP, _VP],
     'fgnn_conv_chain_supported': [_I, _I, C.POINTER(C.c_int)],
     'fgnn_conv_chain': [C.POINTER(ChainArgs), _VP],
+    'fgnn_mlp64_supported': [_I, _I, _I],
+    'fgnn_mlp64_num_workgroups': [],
+    'fgnn_mlp64_param_count': [_I],
+    'fgnn_mlp64_packed_floats': [_I],
+    'fgnn_mlp64_pack': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP],
+    'fgnn_mlp64_fwd': [C.POINTER(Mlp64Args), _VP],
+    'fgnn_mlp64_bwd': [C.POINTER(Mlp64Args), _VP],
     'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],
     'fgnn_conv1x1_dw_chunks': [_I, _I],
     'fgnn_conv1x1_dw': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _I, _I, _I, _VP, _VP],

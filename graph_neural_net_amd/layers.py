@@ -13,6 +13,7 @@ padding.
 """
 import ctypes as C
 import math
+import os
 from collections import namedtuple
 
 import torch
@@ -338,6 +339,83 @@ class _ConvChainFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+def _mlp64_supported(cin, widths):
+    return (os.environ.get('FGNN_MLP64', '1') != '0' and len(widths) == 3 and all(m == 64 for m in widths)
+            and bool(_lib.load().fgnn_mlp64_supported(cin, 3, 64)))
+
+
+class _Mlp64Fn(torch.autograd.Function):
+    """The conv stack of a 64-wide MlpBlock_Real (models/layers.py:125-131 with depth 3, 64 hidden / output channels; input 1..32,
+    64 or 128 channels: the three MLPs of a 64-feature block) as ONE launch per direction (csrc/mlp64.hip, 16-pixel tiles on
+    v_mfma_f32_16x16x4_f32).  Only x is kept for the backward: the hidden activations are recomputed there with the forward's
+    fma sequence, the weight gradients are accumulated in the waves' registers (no d(pre-activation) tensors, no second pass)."""
+
+    @staticmethod
+    def _args(x, nvalid, packed):
+        G, K0, N, _ = x.shape
+        P = N * N
+        a = _lib.Mlp64Args()
+        a.x, a.x_gstride, a.x_ld, a.cin = x.data_ptr(), K0 * P, P, K0
+        a.packed = packed.data_ptr()
+        a.nvalid = nvalid.data_ptr() if nvalid is not None else None
+        a.G, a.N = G, N
+        return a
+
+    @staticmethod
+    def forward(ctx, x, nvalid, *wb):
+        _check(x, 'MlpBlock_Real')
+        x = x.contiguous()
+        G, K0, N, _ = x.shape
+        P = N * N
+        ws = [wb[2 * l].contiguous() for l in range(3)]
+        bs = [wb[2 * l + 1].contiguous() if wb[2 * l + 1] is not None else None for l in range(3)]
+        if ws[0].shape[1] != K0:
+            raise RuntimeError('MlpBlock_Real: conv 0 expects %d input channels, gets %d' % (ws[0].shape[1], K0))
+        st = _lib.stream_ptr()
+        f32 = dict(dtype=torch.float32, device=x.device)
+        packed = torch.empty(_lib.load().fgnn_mlp64_packed_floats(K0), **f32)      # operand record of both directions
+        _lib.call('fgnn_mlp64_pack', _lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(ws[2]), *[_lib.ptr(b) if b is not None else None for b in bs],
+                  K0, _lib.ptr(packed), st)
+        out = torch.empty(G, 64, N, N, **f32)
+        a = _Mlp64Fn._args(x, nvalid, packed)
+        a.out, a.o_gstride, a.o_ld = out.data_ptr(), 64 * P, P
+        _lib.call('fgnn_mlp64_fwd', C.byref(a), st)
+        ctx.save_for_backward(x, nvalid, packed)
+        ctx.has_bias = [b is not None for b in bs]
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, nvalid, packed = ctx.saved_tensors
+        dz = dz.contiguous()
+        G, K0, N, _ = x.shape
+        P = N * N
+        f32 = dict(dtype=torch.float32, device=x.device)
+        st = _lib.stream_ptr()
+        a = _Mlp64Fn._args(x, nvalid, packed)
+        a.dz, a.dz_gstride, a.dz_ld = dz.data_ptr(), 64 * P, P
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(G, K0, N, N, **f32)
+            a.dx, a.dx_gstride, a.dx_ld = dx.data_ptr(), K0 * P, P
+        nwg = _lib.load().fgnn_mlp64_num_workgroups()
+        cnt = _lib.load().fgnn_mlp64_param_count(K0)
+        wpart = torch.empty(nwg * cnt, **f32)
+        flat = torch.empty(cnt, **f32)
+        a.wpart = wpart.data_ptr()
+        _lib.call('fgnn_mlp64_bwd', C.byref(a), st)
+        _lib.call('fgnn_reduce_partials', _lib.ptr(wpart), nwg, cnt, _lib.ptr(flat), st)
+        k0p = (K0 + 31) // 32 * 32
+        o1 = 64 * k0p + 64
+        o2 = o1 + 64 * 64 + 64
+        dw0 = flat[:64 * k0p].view(64, k0p)[:, :K0]
+        grads = [dw0.reshape(64, K0, 1, 1),
+                 flat[64 * k0p:o1] if ctx.has_bias[0] else None,
+                 flat[o1:o1 + 4096].view(64, 64, 1, 1), flat[o1 + 4096:o2] if ctx.has_bias[1] else None,
+                 flat[o2:o2 + 4096].view(64, 64, 1, 1), flat[o2 + 4096:o2 + 4160] if ctx.has_bias[2] else None]
+        return (dx, None, *grads)
+
+
 # --------------------------------------------------------------------------------------
 # GraphNorm / normalize on an arbitrary (G, C, N, N) tensor
 # --------------------------------------------------------------------------------------
@@ -460,7 +538,12 @@ class MlpBlock_Real(nn.Module):
                 wb += [conv.weight, conv.bias]
             y = _MlpGnFn.apply(x, nvalid, self.gn.eps, self.gn.weight, self.gn.bias, *wb)
         else:       # any other widths (csrc/conv.hip), then GraphNorm on the (G, C, N, N) tensor
-            if _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
+            if _mlp64_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
+                wb = []
+                for conv in self.convs:
+                    wb += [conv.weight, conv.bias]
+                y = _Mlp64Fn.apply(x, nvalid, *wb)             # 64-wide stacks: fused, hidden activations recomputed in the backward
+            elif _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
                 wb = []
                 for conv in self.convs:
                     wb += [conv.weight, conv.bias]

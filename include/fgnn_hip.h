@@ -231,6 +231,40 @@ typedef struct {
 int fgnn_conv_chain_supported(int depth, int K0, const int *M /* depth widths */);
 int fgnn_conv_chain(const fgnn_chain_args *args, void *stream);
 
+/* ---- the conv stack of a 64-wide MlpBlock_Real, fused (csrc/mlp64.hip; models/layers.py:113-131 with out_features = 64, depth_of_mlp = 3:
+ * the three MLPs of a 64-feature block, models/blocks_emb.py:16-36) -------------------------------------------------------------------
+ *   forward   out = W2 relu(W1 relu(W0 x + b0) + b1) + b2  (zeros outside the valid corner); nothing else is written;
+ *   backward  recomputes the hidden activations from x, then dx (optional) and one row of parameter-gradient partials per workgroup:
+ *             wpart[wg][fgnn_mlp64_param_count(cin)] = [dW0 (64 x K0P, K0P = cin rounded up to 32: columns >= cin are zero) | db0 (64) |
+ *             dW1 (64 x 64) | db1 | dW2 | db2]; fgnn_reduce_partials(wpart, fgnn_mlp64_num_workgroups(), count, ...) sums the rows.
+ * fgnn_mlp64_pack turns the nn.Conv2d parameters (W0 (64, cin), W1, W2 (64, 64) row-major; biases (64) or NULL) into the operand record
+ * both directions read (MFMA operand order, forward and transposed images; one small launch per forward call).  16-pixel tiles on
+ * v_mfma_f32_16x16x4_f32; the backward keeps a wave's whole parameter-gradient set in its (AGPR) registers, one wave per SIMD.
+ * fgnn_mlp64_supported: depth 3, width 64, cin in 1..128; N <= 256. */
+typedef struct {
+    const float *x;                          /* (G, cin, N*N) */
+    long long x_gstride, x_ld;
+    int cin;
+    const float *packed;                     /* fgnn_mlp64_packed_floats(cin) floats written by fgnn_mlp64_pack */
+    const int *nvalid;                       /* (G) or NULL */
+    int G, N;
+    float *out;                              /* forward: (G, 64, N*N) */
+    long long o_gstride, o_ld;
+    const float *dz;                         /* backward: gradient of out */
+    long long dz_gstride, dz_ld;
+    float *dx;                               /* backward: (G, cin, N*N) or NULL */
+    long long dx_gstride, dx_ld;
+    float *wpart;                            /* backward: (fgnn_mlp64_num_workgroups(), fgnn_mlp64_param_count(cin)) */
+} fgnn_mlp64_args;
+int fgnn_mlp64_supported(int cin, int depth, int width);
+int fgnn_mlp64_num_workgroups(void);
+int fgnn_mlp64_param_count(int cin);
+int fgnn_mlp64_packed_floats(int cin);
+int fgnn_mlp64_pack(const float *W0, const float *W1, const float *W2, const float *b0, const float *b1, const float *b2, int cin,
+                    float *packed, void *stream);
+int fgnn_mlp64_fwd(const fgnn_mlp64_args *args, void *stream);
+int fgnn_mlp64_bwd(const fgnn_mlp64_args *args, void *stream);
+
 /* ---- Matmul.forward: per (g,c) N x N product (models/layers.py:161-162) --------------
  * out[g,c] = Ya[g,c] @ Yb[g,c], Y = normalised slab (or the raw slab when nrm == NULL). */
 int fgnn_chan_matmul_fwd(const fgnn_slab *ya, const fgnn_slab *yb, const int *nvalid, int G, int N,

@@ -587,3 +587,59 @@ def test_conv_chain_equals_the_per_layer_kernels(cin, widths, ragged):
         assert rel(a, t) < 2e-5, (rel(a, t), rel(b_, t))
         assert rel(a, b_) < 2e-5
     assert (got[0].double() * (1 - mask)).abs().max() == 0 and (got[1].double() * (1 - mask)).abs().max() == 0
+
+
+@pytest.mark.parametrize('cin', [2, 19, 32, 64, 128])
+@pytest.mark.parametrize('shape', [(3, 13, False), (3, 13, True), (5, 50, False), (4, 37, True)])
+@pytest.mark.parametrize('need_dx', [True, False])
+def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
+    """_Mlp64Fn (csrc/mlp64.hip: the conv stack of a 64-wide MlpBlock_Real fused, one launch per direction, hidden activations
+    recomputed in the backward, weight gradients accumulated in the waves' registers) against the conv chain it replaces and the
+    fp64 ATen definition with the MaskedTensor semantics (models/layers.py:125-131): output, input gradient, every parameter
+    gradient; exact zeros in the padding of ragged graphs."""
+    from graph_neural_net_amd.layers import _ConvChainFn, _Mlp64Fn, _mlp64_supported
+    assert _mlp64_supported(cin, [64, 64, 64])
+    G, N, ragged = shape
+    g = torch.Generator().manual_seed(cin * 11 + N)
+    nv = torch.tensor([N, max(N // 2, 1), N - 1, 3, N][:G], dtype=torch.int32) if ragged else None
+    mask = _valid_mask(G, N, nv)
+    x = (torch.randn(G, cin, N, N, generator=g).double() * mask).float()
+    ws, bs, k = [], [], cin
+    for m in (64, 64, 64):
+        ws.append(torch.randn(m, k, 1, 1, generator=g) / k ** 0.5)
+        bs.append(0.3 * torch.randn(m, generator=g))
+        k = m
+    dy = (torch.randn(G, 64, N, N, generator=g).double() * mask).float()
+    nvd = nv.to(DEV) if ragged else None
+
+    def run(fn):
+        xd = x.to(DEV).requires_grad_(need_dx)
+        wd = [w.to(DEV).requires_grad_(True) for w in ws]
+        bd = [b.to(DEV).requires_grad_(True) for b in bs]
+        wb = []
+        for w, b in zip(wd, bd):
+            wb += [w, b]
+        y = fn.apply(xd, nvd, *wb)
+        y.backward(dy.to(DEV))
+        return [y.detach().cpu()] + ([xd.grad.cpu()] if need_dx else []) + [w.grad.cpu() for w in wd] + [b.grad.cpu() for b in bd]
+
+    got, ref = run(_Mlp64Fn), run(_ConvChainFn)
+    xr = x.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    br = [b.double().requires_grad_(True) for b in bs]
+    yr = xr
+    for l, (w, b) in enumerate(zip(wr, br)):
+        yr = F.conv2d(yr, w, b)
+        if l < 2:
+            yr = F.relu(yr)
+        yr = yr * mask
+    yr.backward(dy.double())
+    truth = [yr.detach()] + ([xr.grad] if need_dx else []) + [w.grad for w in wr] + [b.grad for b in br]
+    assert len(got) == len(truth)
+    for a, b_, t in zip(got, ref, truth):
+        assert a.shape == t.shape
+        assert rel(a, t) < 2e-5, (rel(a, t), rel(b_, t))
+        assert rel(a, b_) < 2e-5
+    assert (got[0].double() * (1 - mask)).abs().max() == 0
+    if need_dx:
+        assert (got[1].double() * (1 - mask)).abs().max() == 0
