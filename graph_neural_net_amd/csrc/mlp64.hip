@@ -126,24 +126,38 @@ DEVI void mfma_set(f32x4 (&acc)[2], const Set4 &W, const float (&bop)[8]) {
     }
 }
 
+// Across helpers the chain continues: each takes the operands of its FIRST set already loaded (`first`) and calls `next()` before the
+// MFMAs of its LAST set -- the caller loads the following helper's first operands there.
+struct NoNext {
+    DEVI void operator()() const {}
+};
+struct FwdFirst {
+    Set4 w;
+    f32x4 bias[OG][2];
+};
+DEVI FwdFirst load_fwd_first(const float *img, const float *tail, int lane, int q) {
+    FwdFirst o;
+    o.w = load_set(img, lane);
+#pragma unroll
+    for (int og = 0; og < OG; ++og) load_bias(o.bias[og], tail + og * 32, 0, q);
+    return o;
+}
 // out[og] = act(bias + sum_ig W(og, ig) in[ig]); img = [OG][KGI] sets
-template <int KGI, bool RELU>
-DEVI void layer_fwd(float (&out)[OG][8], const float *img, const float *tail, const float (&in)[KGI][8], int lane, int q) {
+template <int KGI, bool RELU, class Next>
+DEVI void layer_fwd(float (&out)[OG][8], const float *img, const FwdFirst &first, const float (&in)[KGI][8], int lane, Next next) {
     constexpr int NS = OG * KGI;
     Set4 W[2];
-    W[0] = load_set(img, lane);
-    f32x4 bias[OG][2];
-#pragma unroll
-    for (int og = 0; og < OG; ++og) load_bias(bias[og], tail + og * 32, 0, q);
+    W[0] = first.w;
     f32x4 acc[2];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int og = i / KGI, ig = i % KGI;
         if (i + 1 < NS) W[(i + 1) & 1] = load_set(img + (i + 1) * SUB, lane);
+        else next();
         __builtin_amdgcn_sched_barrier(0);           // (left alone the scheduler sinks the reads back to their first use)
         if (ig == 0) {
-            acc[0] = bias[og][0];
-            acc[1] = bias[og][1];
+            acc[0] = first.bias[og][0];
+            acc[1] = first.bias[og][1];
         }
         mfma_set(acc, W[i & 1], in[ig]);
         if (ig == KGI - 1) {
@@ -153,16 +167,17 @@ DEVI void layer_fwd(float (&out)[OG][8], const float *img, const float *tail, co
     }
 }
 // din[rg] = sum_kg W^T(rg, kg) d[kg]; img = [RG][OG] sets
-template <int RG>
-DEVI void layer_bwd(float (&out)[RG][8], const float *img, const float (&d)[OG][8], int lane) {
+template <int RG, class Next>
+DEVI void layer_bwd(float (&out)[RG][8], const float *img, const Set4 &first, const float (&d)[OG][8], int lane, Next next) {
     constexpr int NS = RG * OG;
     Set4 W[2];
-    W[0] = load_set(img, lane);
+    W[0] = first;
     f32x4 acc[2];
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int rg = i / OG, kg = i % OG;
         if (i + 1 < NS) W[(i + 1) & 1] = load_set(img + (i + 1) * SUB, lane);
+        else next();
         __builtin_amdgcn_sched_barrier(0);
         if (kg == 0) acc[0] = acc[1] = zero4();
         mfma_set(acc, W[i & 1], d[kg]);
@@ -186,6 +201,15 @@ DEVI Pair4 load_rows(const float *T, int lane) {
     o.hi = *reinterpret_cast<const float4 *>(T + (16 + i) * TLD + 4 * q);
     return o;
 }
+struct WgFirst {
+    Pair4 a, b;
+};
+DEVI WgFirst load_wg_first(const float *TD, const float *TI, int lane) {
+    WgFirst o;
+    o.a = load_rows(TD, lane);
+    o.b = load_rows(TI, lane);
+    return o;
+}
 DEVI void wgrad_mfma(f32x4 (&dW)[4], const Pair4 &a, const Pair4 &b) {
 #define FGNN_M64_KS(e)                              \
     dW[0] = mfma16(a.lo.e, b.lo.e, dW[0]);          \
@@ -198,12 +222,13 @@ DEVI void wgrad_mfma(f32x4 (&dW)[4], const Pair4 &a, const Pair4 &b) {
     FGNN_M64_KS(w)
 #undef FGNN_M64_KS
 }
-template <int KGT, int NI, bool BIAS>
-DEVI void layer_wgrad(f32x4 (&dW)[OG][KGT][4], float (&db)[OG][2], const float *TD, const float *TI, int i0, int lane) {
+template <int KGT, int NI, bool BIAS, class Next>
+DEVI void layer_wgrad(f32x4 (&dW)[OG][KGT][4], float (&db)[OG][2], const float *TD, const float *TI, int i0, const WgFirst &first, int lane,
+                      Next next) {
     constexpr int NS = OG * NI;
     Pair4 A[2], B[2];
-    A[0] = load_rows(TD, lane);
-    B[0] = load_rows(TI, lane);
+    A[0] = first.a;
+    B[0] = first.b;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int og = i / NI, ii = i % NI;
@@ -211,6 +236,8 @@ DEVI void layer_wgrad(f32x4 (&dW)[OG][KGT][4], float (&db)[OG][2], const float *
             const int ogn = (i + 1) / NI, iin = (i + 1) % NI;
             if (iin == 0) A[ogn & 1] = load_rows(TD + ogn * TILE_F, lane);
             B[(i + 1) & 1] = load_rows(TI + iin * TILE_F, lane);
+        } else {
+            next();
         }
         __builtin_amdgcn_sched_barrier(0);
         if (BIAS && ii == 0) {
@@ -305,14 +332,16 @@ __global__ __launch_bounds__(64 * NWF) void mlp64_fwd_kernel(const fgnn_mlp64_ar
     }
     __syncthreads();
 
+    FwdFirst f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q);
     while (t < total) {
         const Tile64 cn = tile64(t + step, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
         float h1[OG][8], h2[OG][8], z[OG][8];
         asm volatile("" ::: "memory");                     // the operand reads are loop invariant: keep them from being hoisted into registers
-        layer_fwd<KG, true>(h1, smem + L::F0, smem + L::BIAS, x, lane, q);
+        FwdFirst f1, f2;
+        layer_fwd<KG, true>(h1, smem + L::F0, f0, x, lane, [&] { f1 = load_fwd_first(smem + L::F1, smem + L::BIAS + 64, lane, q); });
         load_in<KG>(x, vx, cn, q, A.cin);                  // the next tile into the registers just consumed
-        layer_fwd<OG, true>(h2, smem + L::F1, smem + L::BIAS + 64, h1, lane, q);
-        layer_fwd<OG, false>(z, smem + L::F2, smem + L::BIAS + 128, h2, lane, q);
+        layer_fwd<OG, true>(h2, smem + L::F1, f1, h1, lane, [&] { f2 = load_fwd_first(smem + L::F2, smem + L::BIAS + 128, lane, q); });
+        layer_fwd<OG, false>(z, smem + L::F2, f2, h2, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
         const int voff = lane_voff(vo, q, c.p, c.inb);
 #pragma unroll
         for (int og = 0; og < OG; ++og) {
@@ -378,13 +407,17 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
     load_in<KG>(x, vx, c, q, A.cin);
     load_in<OG>(dz, vdz, c, q, 64);
 
-    {
+#ifndef M64_ABL
+#define M64_ABL 0           // measurement switch (tools/build_variant.sh): 1 no operand copy, 2 no parameter-gradient epilogue
+#endif
+    if (!(M64_ABL & 1)) {
         constexpr Packed64 PL{KG};
         copy4(smem + L::F0, A.packed + PL.f0(), ((HAS_DX ? PL.f2() : PL.b0()) - PL.f0()) / 4, threadIdx.x, 64 * NWB);   // F0, F1, B2, B1 (, B0)
         copy4(smem + L::BIAS, A.packed + PL.bias(), 2 * 64 / 4, threadIdx.x, 64 * NWB);
     }
     __syncthreads();
 
+    FwdFirst f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q);
     while (t < total) {
         const Tile64 cn = tile64(t + step, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
         float xn[KG][8], dzn[OG][8];
@@ -393,18 +426,22 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
 
         // ---- recompute (the forward's fma sequence) ----
         float h1[OG][8], h2[OG][8];
-        layer_fwd<KG, true>(h1, smem + L::F0, smem + L::BIAS, x, lane, q);
-        layer_fwd<OG, true>(h2, smem + L::F1, smem + L::BIAS + 64, h1, lane, q);
+        FwdFirst f1;
+        Set4 wB2, wB1, wB0;
+        WgFirst g;
+        layer_fwd<KG, true>(h1, smem + L::F0, f0, x, lane, [&] { f1 = load_fwd_first(smem + L::F1, smem + L::BIAS + 64, lane, q); });
+        layer_fwd<OG, true>(h2, smem + L::F1, f1, h1, lane, [&] { wB2 = load_set(smem + L::B2, lane); });
 
-        // ---- layer 2: d2 = dz (zero outside the valid corner: those lanes loaded nothing) ----
+        // ---- layer 2: d2 = dz (zero outside the valid corner: those lanes loaded nothing).  The input-gradient GEMM runs first: the
+        //      weight-gradient GEMM's tile reads are then requested under its last MFMAs ----
         float d[OG][8];
 #pragma unroll
         for (int og = 0; og < OG; ++og) {
             stage8(TD + og * TILE_F, lane_base, dz[og]);
             stage8(TI + og * TILE_F, lane_base, h2[og]);
         }
-        layer_wgrad<OG, OG, true>(dW2, db2, TD, TI, 0, lane);
-        layer_bwd<OG>(d, smem + L::B2, dz, lane);
+        layer_bwd<OG>(d, smem + L::B2, wB2, dz, lane, [&] { g = load_wg_first(TD, TI, lane); });
+        layer_wgrad<OG, OG, true>(dW2, db2, TD, TI, 0, g, lane, [&] { wB1 = load_set(smem + L::B1, lane); });
 #pragma unroll
         for (int og = 0; og < OG; ++og)
 #pragma unroll
@@ -416,9 +453,11 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
             stage8(TD + og * TILE_F, lane_base, d[og]);
             stage8(TI + og * TILE_F, lane_base, h1[og]);
         }
-        layer_wgrad<OG, OG, true>(dW1, db1, TD, TI, 0, lane);
         float d0[OG][8];
-        layer_bwd<OG>(d0, smem + L::B1, d, lane);
+        layer_bwd<OG>(d0, smem + L::B1, wB1, d, lane, [&] { g = load_wg_first(TD, TI, lane); });
+        layer_wgrad<OG, OG, true>(dW1, db1, TD, TI, 0, g, lane, [&] {
+            if constexpr (HAS_DX) wB0 = load_set(smem + L::B0, lane);
+        });
 #pragma unroll
         for (int og = 0; og < OG; ++og)
 #pragma unroll
@@ -429,16 +468,21 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
         for (int og = 0; og < OG; ++og) stage8(TD + og * TILE_F, lane_base, d0[og]);
 #pragma unroll
         for (int ii = 0; ii < IH; ++ii) stage8(TI + ii * TILE_F, lane_base, x[ii]);
-        layer_wgrad<KG, IH, true>(dW0, db0, TD, TI, 0, lane);
-        if constexpr (KG > IH) {                            // input groups 2, 3 through the same two tiles
-#pragma unroll
-            for (int ii = 0; ii < KG - IH; ++ii) stage8(TI + ii * TILE_F, lane_base, x[IH + ii]);
-            layer_wgrad<KG, KG - IH, false>(dW0, db0, TD, TI, IH, lane);
-        }
         if constexpr (HAS_DX) {
             float dx[KG][8];
-            layer_bwd<KG>(dx, smem + L::B0, d0, lane);
+            layer_bwd<KG>(dx, smem + L::B0, wB0, d0, lane, [&] { g = load_wg_first(TD, TI, lane); });
             store_in<KG>(dx, vdx, c, q, A.cin);
+        } else {
+            g = load_wg_first(TD, TI, lane);
+        }
+        if constexpr (KG > IH) {                            // input groups 2, 3 through the same two tiles
+            layer_wgrad<KG, IH, true>(dW0, db0, TD, TI, 0, g, lane, NoNext{});
+#pragma unroll
+            for (int ii = 0; ii < KG - IH; ++ii) stage8(TI + ii * TILE_F, lane_base, x[IH + ii]);
+            g = load_wg_first(TD, TI, lane);
+            layer_wgrad<KG, KG - IH, false>(dW0, db0, TD, TI, IH, g, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
+        } else {
+            layer_wgrad<KG, IH, true>(dW0, db0, TD, TI, 0, g, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
         }
 #pragma unroll
         for (int ig = 0; ig < KG; ++ig)
@@ -508,6 +552,7 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
             o4[e] = v;
         }
     };
+    if (M64_ABL & 2) return;
     reduce_layer(dW0, db0, std::integral_constant<int, KG>{}, 0);
     reduce_layer(dW1, db1, std::integral_constant<int, OG>{}, 64 * K0P + 64);
     reduce_layer(dW2, db2, std::integral_constant<int, OG>{}, 64 * K0P + 64 + 64 * 64 + 64);

@@ -488,6 +488,80 @@ def main_widths():
     print(json.dumps({k: v for k, v in meta['cases'].items() if k.startswith('widths')}, indent=1, sort_keys=True))
 
 
+def main_wide64():
+    """The 64-feature model (original_features_num = 2, in_features = out_features = 64, depth_of_mlp = 3, 4 blocks: the widths of
+    csrc/mlp64.hip -- convs 2->64, 66->64, 64->64, 128->64): a constant-size batch of regular-graph pairs at N = 50 (fp32 + fp64
+    reference runs, intermediates of block 1 / block 4) and a ragged batch run graph by graph through the dense reference model."""
+    import_reference()
+    sys.path.insert(0, ROOT)
+    from oracle import fgnn_oracle as O
+    from graph_neural_net_amd import synthetic
+    from models.trainers import Siamese_Node_Exp
+    torch.set_num_threads(8)
+    with open(os.path.join(OUT, 'golden_meta.json')) as f:
+        meta = json.load(f)
+    torch.manual_seed(21)
+    ne = dict(NODE_EMB, num_blocks=4, in_features=64, out_features=64, depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne)
+    perturb_(model, 600)
+    x1, x2 = synthetic.make_batch(601, 2, 50, 'Regular', 0.2, 0.1)
+    worst = check_oracle_bit_equal(model, x1, x2, 'wide64')
+    s, l, gr = ref_step(model, x1, x2)
+    s64, l64, gr64 = ref_step(f64(model), x1.double(), x2.double())
+    inter = model.node_embedder({'input': x1})
+    d = {'x1': x1.numpy(), 'x2': x2.numpy(), 'scores': s.numpy(), 'loss': l.numpy(), 'scores64': s64.numpy(),
+         'loss64': l64.numpy(), 'config': np.array([2, 4, 64, 64, 3])}
+    for k, v in model.state_dict().items():
+        d['sd/' + k[len('node_embedder.'):]] = v.numpy()
+    for k, v in gr.items():
+        d['grad/' + k] = v.numpy()
+    for k, v in gr64.items():
+        d['grad64/' + k] = v.numpy().astype(np.float32)        # (the fp64 run rounded once: 2^-24 against a yard-stick of 1e-6)
+    inter64 = f64(model).node_embedder({'input': x1.double()})
+    for k in ('ne/bm/block1/mlp1', 'ne/bm/block1/mlp3', 'ne/suffix'):
+        d['inter/' + k] = inter[k].detach().numpy()[:1]
+        d['inter64/' + k] = inter64[k].detach().numpy()[:1].astype(np.float32)
+    g = torch.Generator().manual_seed(602)
+    xs = [torch.randn(2, n, n, generator=g) for n in (20, 33, 27)]
+    ys = [torch.randn(2, n, n, generator=g) for n in (20, 33, 27)]
+
+    def ref_ragged(m, cast):
+        m.zero_grad()
+        e1 = [m.node_embedder({'input': cast(x).unsqueeze(0)})['ne/suffix'].squeeze(0) for x in xs]
+        e2 = [m.node_embedder({'input': cast(y).unsqueeze(0)})['ne/suffix'].squeeze(0) for y in ys]
+        scores = [a.t() @ b for a, b in zip(e1, e2)]
+        loss, tot = 0, 0
+        for sc in scores:   # triplet_loss('mean') on a list (toolbox/losses.py:27-34)
+            loss = loss + torch.nn.functional.cross_entropy(sc, torch.arange(sc.shape[0]), reduction='sum')
+            tot += sc.shape[0]
+        loss = loss / tot
+        loss.backward()
+        return ([sc.detach() for sc in scores], loss.detach(),
+                {n[len('node_embedder.'):]: p.grad.detach().clone() for n, p in m.named_parameters()})
+
+    sr, lr_, grr = ref_ragged(model, lambda t: t)
+    sr64, lr64, grr64 = ref_ragged(f64(model), lambda t: t.double())
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    s_or, l_or, _ = O.step_fwd_bwd_ragged(xs, ys, sd)
+    for a, b in zip(s_or, sr):
+        assert torch.equal(a, b), 'wide64 ragged: oracle scores differ'
+    assert torch.equal(l_or, lr_)
+    d['ragged/ns'] = np.array([x.shape[-1] for x in xs])
+    d['ragged/loss'], d['ragged/loss64'] = lr_.numpy(), lr64.numpy()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        d['ragged/x1/%d' % i], d['ragged/x2/%d' % i] = x.numpy(), y.numpy()
+        d['ragged/scores/%d' % i], d['ragged/scores64/%d' % i] = sr[i].numpy(), sr64[i].numpy()
+    for k, v in grr.items():
+        d['ragged/grad/' + k] = v.numpy()
+    for k, v in grr64.items():
+        d['ragged/grad64/' + k] = v.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'wide64_c2_64_64_d3_4blk.npz'), **d)
+    meta['cases']['wide64_c2_64_64_d3_4blk'] = {'oracle_bit_equal_forward': True, 'oracle_worst_grad_relerr': worst}
+    with open(os.path.join(OUT, 'golden_meta.json'), 'w') as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print(json.dumps({k: v for k, v in meta['cases'].items() if k.startswith('wide64')}, indent=1, sort_keys=True))
+
+
 def main_round3():
     """Round-3 fixtures: ONE block, where 16-bit arithmetic is not yet chaotic -- the reference run in bf16 (ref_step_bf16:
     the Network.half recipe of models/utils.py:71-74), fp32 and fp64 on N = 50 regular pairs (B = 2) and one N = 200 dense
@@ -885,5 +959,7 @@ if __name__ == '__main__':
         main_round2()
     elif len(sys.argv) > 1 and sys.argv[1] == 'widths':
         main_widths()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'wide64':
+        main_wide64()
     else:
         main()

@@ -589,7 +589,7 @@ def test_conv_chain_equals_the_per_layer_kernels(cin, widths, ragged):
     assert (got[0].double() * (1 - mask)).abs().max() == 0 and (got[1].double() * (1 - mask)).abs().max() == 0
 
 
-@pytest.mark.parametrize('cin', [2, 19, 32, 64, 128])
+@pytest.mark.parametrize('cin', [2, 19, 32, 64, 66, 100, 128])
 @pytest.mark.parametrize('shape', [(3, 13, False), (3, 13, True), (5, 50, False), (4, 37, True)])
 @pytest.mark.parametrize('need_dx', [True, False])
 def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
@@ -643,3 +643,103 @@ def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
     assert (got[0].double() * (1 - mask)).abs().max() == 0
     if need_dx:
         assert (got[1].double() * (1 - mask)).abs().max() == 0
+
+
+NE64 = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=4, in_features=64, out_features=64,
+            depth_of_mlp=3)
+
+
+def _load_model64(d, **kw):
+    model = Siamese_Node_Exp(2, dict(NE64, **kw)).to(DEV)
+    model.load_state_dict({'node_embedder.' + k: v for k, v in sub(d, 'sd/').items()})
+    return model
+
+
+def _count_mlp64(fn):
+    """run fn() with the C entry points counted: {name: calls}"""
+    seen = {}
+    orig = _lib.call
+
+    def counting(name, *a, **k):
+        seen[name] = seen.get(name, 0) + 1
+        return orig(name, *a, **k)
+    _lib.call = counting
+    try:
+        out = fn()
+    finally:
+        _lib.call = orig
+    return out, seen
+
+
+def test_siamese_64_wide_against_reference_golden():
+    """original_features_num 2, in_features = out_features = 64, depth 3, 4 blocks (convs 2->64, 66->64, 64->64, 128->64) on regular-graph
+    pairs at N = 50: every conv stack runs on the fused 64-wide kernels (csrc/mlp64.hip: 12 forward + 12 backward launches per side pair),
+    scores, loss, intermediates and every gradient against the reference's own fp32 / fp64 runs (tests/golden/make_golden.py wide64)."""
+    d = load_golden('wide64_c2_64_64_d3_4blk.npz')
+    model = _load_model64(d)
+    assert model.node_embedder._standard_layout() is None          # not the 32-wide engine: the per-layer modules
+    out = model.node_embedder({'input': d['x1'].to(DEV)})
+    for k, v in sub(d, 'inter/').items():              # yard-stick: the reference's own fp32 run against its fp64 run at the same node
+        v64 = d['inter64/' + k]
+        assert rel(out[k].detach().cpu()[:1], v64) < max(2 * rel(v, v64), 1e-5), k
+
+    def step():
+        scores = model({'input': d['x1'].to(DEV)}, {'input': d['x2'].to(DEV)})
+        loss = model.loss(scores)
+        loss.backward()
+        return scores, loss
+    (scores, loss), seen = _count_mlp64(step)
+    assert seen.get('fgnn_mlp64_fwd') == 12 and seen.get('fgnn_mlp64_bwd') == 12 and 'fgnn_conv_chain' not in seen and 'fgnn_conv1x1' not in seen
+    yard = rel(d['scores'], d['scores64'])
+    assert rel(scores.detach().cpu(), d['scores64']) < max(2 * yard, 1e-5)
+    assert abs(loss.item() - d['loss64'].item()) < 1e-5 * d['loss64'].item()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        k = n[len('node_embedder.'):]
+        if is_zero_grad(k, 3):
+            assert p.grad.abs().max() < 1e-4
+        else:
+            yard = rel(d['grad/' + k], d['grad64/' + k])
+            e = rel(p.grad.cpu(), d['grad64/' + k])
+            worst = max(worst, e / (yard + 1e-12))
+            assert e < 4 * yard + 1e-5, k
+    print('64-wide golden: worst gradient error / the reference\'s own fp32-vs-fp64 error = %.2f' % worst)
+
+
+def test_siamese_64_wide_ragged_against_reference_golden():
+    d = load_golden('wide64_c2_64_64_d3_4blk.npz')
+    model = _load_model64(d, constant_n_vertices=False)
+    n = len(d['ragged/ns'])
+    m1 = from_list([d['ragged/x1/%d' % i].to(DEV) for i in range(n)], dims=(1, 2), base_name='N')
+    m2 = from_list([d['ragged/x2/%d' % i].to(DEV) for i in range(n)], dims=(1, 2), base_name='M')
+
+    def step():
+        scores = model(m1, m2)
+        loss = model.loss(scores)
+        loss.backward()
+        return scores, loss
+    (scores, loss), seen = _count_mlp64(step)
+    assert seen.get('fgnn_mlp64_fwd') == 12 and seen.get('fgnn_mlp64_bwd') == 12
+    for i, a in enumerate(list(scores)):
+        ref64 = d['ragged/scores64/%d' % i]
+        assert a.shape == ref64.shape
+        assert rel(a.detach().cpu(), ref64) < max(2 * rel(d['ragged/scores/%d' % i], ref64), 1e-5)
+    assert abs(loss.item() - d['ragged/loss64'].item()) < 1e-5 * d['ragged/loss64'].item()
+    for name, p in model.named_parameters():
+        k = name[len('node_embedder.'):]
+        if not is_zero_grad(k, 3):
+            yard = rel(d['ragged/grad/' + k], d['ragged/grad64/' + k])
+            assert rel(p.grad.cpu(), d['ragged/grad64/' + k]) < 4 * yard + 1e-5, k
+
+
+def test_mlp64_rejects_bad_arguments():
+    a = _lib.Mlp64Args()
+    x = torch.zeros(1, 64, 5, 5, device=DEV)
+    a.x, a.x_gstride, a.x_ld, a.cin, a.G, a.N = x.data_ptr(), 64 * 25, 25, 64, 1, 5
+    with pytest.raises(RuntimeError, match='packed'):
+        _lib.call('fgnn_mlp64_fwd', C.byref(a), _lib.stream_ptr())
+    a.cin = 200
+    with pytest.raises(RuntimeError, match='input channels'):
+        _lib.call('fgnn_mlp64_fwd', C.byref(a), _lib.stream_ptr())
+    assert not _lib.load().fgnn_mlp64_supported(64, 2, 64) and not _lib.load().fgnn_mlp64_supported(64, 3, 48)
+    assert _lib.load().fgnn_mlp64_supported(66, 3, 64)

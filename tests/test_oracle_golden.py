@@ -57,6 +57,31 @@ def test_widths_golden():
             assert rel(grads[k], v) < GRAD_TOL, k
 
 
+def test_wide64_golden():
+    """the 64-feature model (2 -> 64 -> 64, depth 3, 4 blocks: the widths of csrc/mlp64.hip): constant-size regular pairs at N = 50 and a
+    ragged batch, reference fp32 runs"""
+    d = load_golden('wide64_c2_64_64_d3_4blk.npz')
+    sd = sub(d, 'sd/')
+    scores, loss, grads = O.step_fwd_bwd(d['x1'], d['x2'], sd)
+    assert rel(scores, d['scores']) < FWD_TOL
+    assert abs(loss.item() - d['loss'].item()) < 1e-6 * abs(d['loss'].item()) + 1e-7
+    for k, v in sub(d, 'grad/').items():
+        if is_zero_grad(k, 3):
+            assert grads[k].abs().max() < 1e-4
+        else:
+            assert rel(grads[k], v) < GRAD_TOL, k
+    n = len(d['ragged/ns'])
+    xs = [d['ragged/x1/%d' % i] for i in range(n)]
+    ys = [d['ragged/x2/%d' % i] for i in range(n)]
+    scores, loss, grads = O.step_fwd_bwd_ragged(xs, ys, sd)
+    for i in range(n):
+        assert rel(scores[i], d['ragged/scores/%d' % i]) < FWD_TOL
+    assert abs(loss.item() - d['ragged/loss'].item()) < 1e-6
+    for k, v in sub(d, 'ragged/grad/').items():
+        if not is_zero_grad(k, 3):
+            assert rel(grads[k], v) < GRAD_TOL, k
+
+
 def test_narrow_widths_golden():
     """3 -> 16 -> 24, depth 2, 3 blocks (the widths the fused engine runs zero-padded)"""
     d = load_golden('widths_c3_16_24_d2_3blk.npz')
