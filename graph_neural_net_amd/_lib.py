@@ -59,10 +59,12 @@ class ChainArgs(C.Structure):
 
 class Mlp64Args(C.Structure):          # fgnn_mlp64_args (csrc/mlp64.hip)
     _fields_ = [('x', C.c_void_p), ('x_gstride', C.c_longlong), ('x_ld', C.c_longlong), ('cin', C.c_int),
+                ('xb', C.c_void_p), ('xb_gstride', C.c_longlong), ('xb_ld', C.c_longlong), ('cb', C.c_int),
                 ('packed', C.c_void_p), ('nvalid', C.c_void_p), ('G', C.c_int), ('N', C.c_int),
                 ('out', C.c_void_p), ('o_gstride', C.c_longlong), ('o_ld', C.c_longlong),
                 ('dz', C.c_void_p), ('dz_gstride', C.c_longlong), ('dz_ld', C.c_longlong),
                 ('dx', C.c_void_p), ('dx_gstride', C.c_longlong), ('dx_ld', C.c_longlong),
+                ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
                 ('wpart', C.c_void_p)]
 
 

@@ -19,7 +19,10 @@ using namespace t16;
 
 constexpr int OG = 2;                  // 32-channel groups of a 64-wide activation
 constexpr int SUB = 1024;              // floats per 32 x 32 operand set
-constexpr int NWF = 8, NWB = 4;        // waves per workgroup: forward (2 per SIMD), backward (1 per SIMD)
+#ifndef M64_NWF
+#define M64_NWF 8
+#endif
+constexpr int NWF = M64_NWF, NWB = 4;  // waves per workgroup: forward (2 per SIMD), backward (1 per SIMD)
 constexpr int WG64 = 256;              // persistent workgroups = rows of wpart
 
 DEVI int graph_nv(const rsrc_t &rnv, bool ragged, int g, int N) {
@@ -270,32 +273,54 @@ DEVI Tile64 tile64(int t, int total, int hpg, int P2, int N, float rcpN, const r
     }
     return c;
 }
+// The input of the MLP: one slab, or two stacked along the channels (a block's mlp3 reads [mult ; in], models/blocks_emb.py:33-36, without
+// the concatenated copy): groups 0 .. kga-1 are slab a's (a whole number of 32-channel groups when there is a slab b), the rest slab b's.
+struct In2 {
+    View a, b;
+    int cin;            // channels of both
+};
+DEVI In2 make_in2(const float *pa, long long gsa, long long lda, int ca, const float *pb, long long gsb, long long ldb, int cb, int G) {
+    In2 o;
+    o.a = make_view(pa, gsa, lda, G);
+    o.b = make_view(pb ? pb : pa, pb ? gsb : gsa, pb ? ldb : lda, G);
+    o.cin = ca + (pb ? cb : 0);
+    return o;
+}
+DEVI In2 make_in1(const float *p, long long gs, long long ld, int ch, int G) { return make_in2(p, gs, ld, ch, nullptr, 0, 0, 0, G); }
 // 8 KG registers of the input; the channels >= cin of a partial last group are not touched (read as zeros)
-template <int KG>
-DEVI void load_in(float (&x)[KG][8], const View &v, const Tile64 &c, int q, int cin) {
-    const int voff = lane_voff(v, q, c.p, c.valid);
+template <int KG, int KGA = KG>        // KGA: 32-channel groups of slab a
+DEVI void load_in(float (&x)[KG][8], const In2 &in, const Tile64 &c, int q) {
 #pragma unroll
     for (int ig = 0; ig < KG; ++ig) {
-        if (ig == KG - 1 && cin < 32 * KG) {
+        const bool ina = ig < KGA;
+        const rsrc_t r = ina ? in.a.r : in.b.r;
+        const int ld4 = ina ? in.a.ld4 : in.b.ld4, gs4 = ina ? in.a.gs4 : in.b.gs4, lg = ina ? ig : ig - KGA;
+        const int voff = c.valid ? chan_q(q) * ld4 + 4 * c.p : OOB_OFF;
+        const int s0 = c.g * gs4 + lg * 32 * ld4;
+        if (ig == KG - 1 && in.cin < 32 * KG) {
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                x[ig][s] = buf_load(v, 32 * ig + chan_s(s) + chan_q(q) < cin ? voff : OOB_OFF, c.g * v.gs4 + (ig * 32 + chan_s(s)) * v.ld4);
+                x[ig][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, 32 * ig + chan_s(s) + chan_q(q) < in.cin ? voff : OOB_OFF,
+                                                                                          s0 + chan_s(s) * ld4, 0));
         } else {
-            load8(x[ig], v, voff, c.g * v.gs4 + ig * 32 * v.ld4);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) x[ig][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, s0 + chan_s(s) * ld4, 0));
         }
     }
 }
-template <int KG>
-DEVI void store_in(const float (&x)[KG][8], const View &v, const Tile64 &c, int q, int cin) {
-    const int voff = lane_voff(v, q, c.p, c.inb);
+template <int KG, int KGA = KG>
+DEVI void store_in(const float (&x)[KG][8], const In2 &in, const Tile64 &c, int q) {
 #pragma unroll
     for (int ig = 0; ig < KG; ++ig) {
-        if (ig == KG - 1 && cin < 32 * KG) {
+        const bool ina = ig < KGA;
+        const rsrc_t r = ina ? in.a.r : in.b.r;
+        const int ld4 = ina ? in.a.ld4 : in.b.ld4, gs4 = ina ? in.a.gs4 : in.b.gs4, lg = ina ? ig : ig - KGA;
+        const int voff = c.inb ? chan_q(q) * ld4 + 4 * c.p : OOB_OFF;
+        const int s0 = c.g * gs4 + lg * 32 * ld4;
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                buf_store(x[ig][s], v, 32 * ig + chan_s(s) + chan_q(q) < cin ? voff : OOB_OFF, c.g * v.gs4 + (ig * 32 + chan_s(s)) * v.ld4);
-        } else {
-            store8(x[ig], v, voff, c.g * v.gs4 + ig * 32 * v.ld4);
+        for (int s = 0; s < 8; ++s) {
+            const bool ok = !(ig == KG - 1 && in.cin < 32 * KG) || 32 * ig + chan_s(s) + chan_q(q) < in.cin;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[ig][s]), r, ok ? voff : OOB_OFF, s0 + chan_s(s) * ld4, FGNN_STORE_AUX);
         }
     }
 }
@@ -306,14 +331,14 @@ struct FwdLayout {
     static constexpr int LDS_F = BIAS + 3 * 64;
 };
 
-template <int KG>
+template <int KG, int KGA>
 __global__ __launch_bounds__(64 * NWF) void mlp64_fwd_kernel(const fgnn_mlp64_args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = FwdLayout<KG>;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int px = lane & 15, q = lane >> 4;
     const int P2 = A.N * A.N, hpg = (P2 + 15) / 16, total = A.G * hpg;
-    const View vx = make_view(A.x, A.x_gstride, A.x_ld, A.G);
+    const In2 vx = make_in2(A.x, A.x_gstride, A.x_ld, A.cin, A.xb, A.xb_gstride, A.xb_ld, A.cb, A.G);
     const View vo = make_view(A.out, A.o_gstride, A.o_ld, A.G);
     const bool ragged = A.nvalid != nullptr;
     const rsrc_t rnv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.nvalid), 0, ragged ? A.G * 4 : 0, 0x00020000);
@@ -323,7 +348,7 @@ __global__ __launch_bounds__(64 * NWF) void mlp64_fwd_kernel(const fgnn_mlp64_ar
     int t = blockIdx.x * NWF + wv;
     float x[KG][8];
     Tile64 c = tile64(t, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
-    load_in<KG>(x, vx, c, q, A.cin);                       // in flight under the image construction
+    load_in<KG, KGA>(x, vx, c, q);                         // in flight under the operand copy
 
     {
         constexpr Packed64 PL{KG};
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(64 * NWF) void mlp64_fwd_kernel(const fgnn_mlp64_ar
         asm volatile("" ::: "memory");                     // the operand reads are loop invariant: keep them from being hoisted into registers
         FwdFirst f1, f2;
         layer_fwd<KG, true>(h1, smem + L::F0, f0, x, lane, [&] { f1 = load_fwd_first(smem + L::F1, smem + L::BIAS + 64, lane, q); });
-        load_in<KG>(x, vx, cn, q, A.cin);                  // the next tile into the registers just consumed
+        load_in<KG, KGA>(x, vx, cn, q);                    // the next tile into the registers just consumed
         layer_fwd<OG, true>(h2, smem + L::F1, f1, h1, lane, [&] { f2 = load_fwd_first(smem + L::F2, smem + L::BIAS + 128, lane, q); });
         layer_fwd<OG, false>(z, smem + L::F2, f2, h2, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
         const int voff = lane_voff(vo, q, c.p, c.inb);
@@ -368,7 +393,7 @@ struct BwdLayout {
     static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
 };
 
-template <int KG, bool HAS_DX>
+template <int KG, int KGA, bool HAS_DX>
 __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_args A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using L = BwdLayout<KG, HAS_DX>;
@@ -376,9 +401,9 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int px = lane & 15, q = lane >> 4;
     const int P2 = A.N * A.N, hpg = (P2 + 15) / 16, total = A.G * hpg;
-    const View vx = make_view(A.x, A.x_gstride, A.x_ld, A.G);
-    const View vdz = make_view(A.dz, A.dz_gstride, A.dz_ld, A.G);
-    const View vdx = make_view(A.dx, A.dx_gstride, A.dx_ld, A.G);
+    const In2 vx = make_in2(A.x, A.x_gstride, A.x_ld, A.cin, A.xb, A.xb_gstride, A.xb_ld, A.cb, A.G);
+    const In2 vdz = make_in1(A.dz, A.dz_gstride, A.dz_ld, 64, A.G);
+    const In2 vdx = make_in2(A.dx, A.dx_gstride, A.dx_ld, A.cin, A.xb ? A.dxb : nullptr, A.dxb_gstride, A.dxb_ld, A.cb, A.G);
     const bool ragged = A.nvalid != nullptr;
     const rsrc_t rnv = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(A.nvalid), 0, ragged ? A.G * 4 : 0, 0x00020000);
     const float rcpN = 1.f / (float)A.N;
@@ -404,8 +429,8 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
     int t = blockIdx.x * NWB + wv;
     float x[KG][8], dz[OG][8];
     Tile64 c = tile64(t, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
-    load_in<KG>(x, vx, c, q, A.cin);
-    load_in<OG>(dz, vdz, c, q, 64);
+    load_in<KG, KGA>(x, vx, c, q);
+    load_in<OG>(dz, vdz, c, q);
 
 #ifndef M64_ABL
 #define M64_ABL 0           // measurement switch (tools/build_variant.sh): 1 no operand copy, 2 no parameter-gradient epilogue
@@ -421,8 +446,8 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
     while (t < total) {
         const Tile64 cn = tile64(t + step, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
         float xn[KG][8], dzn[OG][8];
-        load_in<KG>(xn, vx, cn, q, A.cin);                 // the next tile's operands fly during this tile
-        load_in<OG>(dzn, vdz, cn, q, 64);
+        load_in<KG, KGA>(xn, vx, cn, q);                   // the next tile's operands fly during this tile
+        load_in<OG>(dzn, vdz, cn, q);
 
         // ---- recompute (the forward's fma sequence) ----
         float h1[OG][8], h2[OG][8];
@@ -471,7 +496,7 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
         if constexpr (HAS_DX) {
             float dx[KG][8];
             layer_bwd<KG>(dx, smem + L::B0, wB0, d0, lane, [&] { g = load_wg_first(TD, TI, lane); });
-            store_in<KG>(dx, vdx, c, q, A.cin);
+            store_in<KG, KGA>(dx, vdx, c, q);
         } else {
             g = load_wg_first(TD, TI, lane);
         }
@@ -558,31 +583,33 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
     reduce_layer(dW2, db2, std::integral_constant<int, OG>{}, 64 * K0P + 64 + 64 * 64 + 64);
 }
 
-template <int KG>
+template <int KG, int KGA = KG>
 int launch_fwd(const fgnn_mlp64_args *a, hipStream_t st) {
     constexpr int LDS = FwdLayout<KG>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp64_fwd_kernel<KG>, LDS);
-    hipLaunchKernelGGL((mlp64_fwd_kernel<KG>), dim3(WG64), dim3(64 * NWF), LDS, st, *a);
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp64_fwd_kernel<KG, KGA>, LDS);
+    hipLaunchKernelGGL((mlp64_fwd_kernel<KG, KGA>), dim3(WG64), dim3(64 * NWF), LDS, st, *a);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
-template <int KG, bool HAS_DX>
+template <int KG, int KGA, bool HAS_DX>
 int launch_bwd(const fgnn_mlp64_args *a, hipStream_t st) {
     constexpr int LDS = BwdLayout<KG, HAS_DX>::LDS_F * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
-    (void)fgnn_raise_lds(attr_cache, (const void *)mlp64_bwd_kernel<KG, HAS_DX>, LDS);
-    hipLaunchKernelGGL((mlp64_bwd_kernel<KG, HAS_DX>), dim3(WG64), dim3(64 * NWB), LDS, st, *a);
+    (void)fgnn_raise_lds(attr_cache, (const void *)mlp64_bwd_kernel<KG, KGA, HAS_DX>, LDS);
+    hipLaunchKernelGGL((mlp64_bwd_kernel<KG, KGA, HAS_DX>), dim3(WG64), dim3(64 * NWB), LDS, st, *a);
     FGNN_LAUNCH_CHECK();
     return 0;
 }
 
 int check_common(const fgnn_mlp64_args *a, const char *who) {
     FGNN_CHECK(a != nullptr, "%s: null args", who);
-    FGNN_CHECK(fgnn_mlp64_supported(a->cin, 3, 64), "%s: built for depth 3, 64 hidden / output channels and 1..128 input channels (got %d)", who,
-               a->cin);
+    const int cin = a->cin + (a->xb ? a->cb : 0);
+    FGNN_CHECK(fgnn_mlp64_supported(cin, 3, 64), "%s: built for depth 3, 64 hidden / output channels and 1..128 input channels (got %d)", who, cin);
+    FGNN_CHECK(!a->xb || (a->cin == 64 && a->cb > 0), "%s: a second slab is built for a 64-channel first slab (got %d)", who, a->cin);
+    FGNN_CHECK(!a->xb || (long long)a->G * a->xb_gstride < 0x7fffffffll / 4, "%s: xb exceeds 2 GiB (32-bit buffer addressing); split the batch", who);
     FGNN_CHECK(a->G > 0 && a->N > 0 && a->N <= 256 && a->x, "%s: bad G / N (<= 256) / x", who);
     FGNN_CHECK(a->packed != nullptr, "%s: missing packed operand record (fgnn_mlp64_pack)", who);
     const long long lim = 0x7fffffffll / 4, G = a->G;
@@ -621,9 +648,11 @@ extern "C" int fgnn_mlp64_fwd(const fgnn_mlp64_args *a, void *stream) {
     FGNN_CHECK(a->out != nullptr, "fgnn_mlp64_fwd: missing out");
     FGNN_CHECK((long long)a->G * a->o_gstride < 0x7fffffffll / 4, "fgnn_mlp64_fwd: out exceeds 2 GiB (32-bit buffer addressing); split the batch");
     hipStream_t st = (hipStream_t)stream;
-    if (a->cin <= 32) return launch_fwd<1>(a, st);
-    if (a->cin <= 64) return launch_fwd<2>(a, st);
-    if (a->cin <= 96) return launch_fwd<3>(a, st);
+    const int cin = a->cin + (a->xb ? a->cb : 0);
+    if (a->xb) return cin <= 96 ? launch_fwd<3, 2>(a, st) : launch_fwd<4, 2>(a, st);
+    if (cin <= 32) return launch_fwd<1>(a, st);
+    if (cin <= 64) return launch_fwd<2>(a, st);
+    if (cin <= 96) return launch_fwd<3>(a, st);
     return launch_fwd<4>(a, st);
 }
 
@@ -634,8 +663,14 @@ extern "C" int fgnn_mlp64_bwd(const fgnn_mlp64_args *a, void *stream) {
     FGNN_CHECK(G * a->dz_gstride < lim && (!a->dx || G * a->dx_gstride < lim), "fgnn_mlp64_bwd: a tensor exceeds 2 GiB (32-bit buffer addressing); split the batch");
     hipStream_t st = (hipStream_t)stream;
     const bool dx = a->dx != nullptr;
-    if (a->cin <= 32) return dx ? launch_bwd<1, true>(a, st) : launch_bwd<1, false>(a, st);
-    if (a->cin <= 64) return dx ? launch_bwd<2, true>(a, st) : launch_bwd<2, false>(a, st);
-    if (a->cin <= 96) return dx ? launch_bwd<3, true>(a, st) : launch_bwd<3, false>(a, st);
-    return dx ? launch_bwd<4, true>(a, st) : launch_bwd<4, false>(a, st);
+    FGNN_CHECK(!dx || !a->xb || (a->dxb && G * a->dxb_gstride < lim), "fgnn_mlp64_bwd: dx of a two-slab input needs dxb (< 2 GiB)");
+    const int cin = a->cin + (a->xb ? a->cb : 0);
+    if (a->xb) {
+        if (cin <= 96) return dx ? launch_bwd<3, 2, true>(a, st) : launch_bwd<3, 2, false>(a, st);
+        return dx ? launch_bwd<4, 2, true>(a, st) : launch_bwd<4, 2, false>(a, st);
+    }
+    if (cin <= 32) return dx ? launch_bwd<1, 1, true>(a, st) : launch_bwd<1, 1, false>(a, st);
+    if (cin <= 64) return dx ? launch_bwd<2, 2, true>(a, st) : launch_bwd<2, 2, false>(a, st);
+    if (cin <= 96) return dx ? launch_bwd<3, 3, true>(a, st) : launch_bwd<3, 3, false>(a, st);
+    return dx ? launch_bwd<4, 4, true>(a, st) : launch_bwd<4, 4, false>(a, st);
 }

@@ -351,22 +351,31 @@ class _Mlp64Fn(torch.autograd.Function):
     fma sequence, the weight gradients are accumulated in the waves' registers (no d(pre-activation) tensors, no second pass)."""
 
     @staticmethod
-    def _args(x, nvalid, packed):
+    def _args(x, xb, nvalid, packed):
         G, K0, N, _ = x.shape
         P = N * N
         a = _lib.Mlp64Args()
         a.x, a.x_gstride, a.x_ld, a.cin = x.data_ptr(), K0 * P, P, K0
+        if xb is not None:
+            a.xb, a.xb_gstride, a.xb_ld, a.cb = xb.data_ptr(), xb.shape[1] * P, P, xb.shape[1]
         a.packed = packed.data_ptr()
         a.nvalid = nvalid.data_ptr() if nvalid is not None else None
         a.G, a.N = G, N
         return a
 
     @staticmethod
-    def forward(ctx, x, nvalid, *wb):
+    def forward(ctx, x, xb, nvalid, *wb):
+        """xb: None, or a second tensor stacked after x along the channels (Concat's parts: the block's [mult ; in] without the copy)."""
         _check(x, 'MlpBlock_Real')
         x = x.contiguous()
-        G, K0, N, _ = x.shape
+        G, Ka, N, _ = x.shape
         P = N * N
+        if xb is not None:
+            _check(xb, 'MlpBlock_Real')
+            xb = xb.contiguous()
+            if xb.shape[0] != G or xb.shape[2:] != x.shape[2:]:
+                raise RuntimeError('MlpBlock_Real: stacked inputs of different shapes %s / %s' % (tuple(x.shape), tuple(xb.shape)))
+        K0 = Ka + (xb.shape[1] if xb is not None else 0)
         ws = [wb[2 * l].contiguous() for l in range(3)]
         bs = [wb[2 * l + 1].contiguous() if wb[2 * l + 1] is not None else None for l in range(3)]
         if ws[0].shape[1] != K0:
@@ -377,27 +386,32 @@ class _Mlp64Fn(torch.autograd.Function):
         _lib.call('fgnn_mlp64_pack', _lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(ws[2]), *[_lib.ptr(b) if b is not None else None for b in bs],
                   K0, _lib.ptr(packed), st)
         out = torch.empty(G, 64, N, N, **f32)
-        a = _Mlp64Fn._args(x, nvalid, packed)
+        a = _Mlp64Fn._args(x, xb, nvalid, packed)
         a.out, a.o_gstride, a.o_ld = out.data_ptr(), 64 * P, P
         _lib.call('fgnn_mlp64_fwd', C.byref(a), st)
-        ctx.save_for_backward(x, nvalid, packed)
+        ctx.save_for_backward(x, xb, nvalid, packed)
         ctx.has_bias = [b is not None for b in bs]
         return out
 
     @staticmethod
     def backward(ctx, dz):
-        x, nvalid, packed = ctx.saved_tensors
+        x, xb, nvalid, packed = ctx.saved_tensors
         dz = dz.contiguous()
-        G, K0, N, _ = x.shape
+        G, Ka, N, _ = x.shape
+        Kb = xb.shape[1] if xb is not None else 0
+        K0 = Ka + Kb
         P = N * N
         f32 = dict(dtype=torch.float32, device=x.device)
         st = _lib.stream_ptr()
-        a = _Mlp64Fn._args(x, nvalid, packed)
+        a = _Mlp64Fn._args(x, xb, nvalid, packed)
         a.dz, a.dz_gstride, a.dz_ld = dz.data_ptr(), 64 * P, P
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(G, K0, N, N, **f32)
-            a.dx, a.dx_gstride, a.dx_ld = dx.data_ptr(), K0 * P, P
+        dx = dxb = None
+        if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
+            dx = torch.empty(G, Ka, N, N, **f32)
+            a.dx, a.dx_gstride, a.dx_ld = dx.data_ptr(), Ka * P, P
+            if xb is not None:
+                dxb = torch.empty(G, Kb, N, N, **f32)
+                a.dxb, a.dxb_gstride, a.dxb_ld = dxb.data_ptr(), Kb * P, P
         nwg = _lib.load().fgnn_mlp64_num_workgroups()
         cnt = _lib.load().fgnn_mlp64_param_count(K0)
         wpart = torch.empty(nwg * cnt, **f32)
@@ -413,7 +427,22 @@ class _Mlp64Fn(torch.autograd.Function):
                  flat[64 * k0p:o1] if ctx.has_bias[0] else None,
                  flat[o1:o1 + 4096].view(64, 64, 1, 1), flat[o1 + 4096:o2] if ctx.has_bias[1] else None,
                  flat[o2:o2 + 4096].view(64, 64, 1, 1), flat[o2 + 4096:o2 + 4160] if ctx.has_bias[2] else None]
-        return (dx, None, *grads)
+        return (dx if ctx.needs_input_grad[0] else None, dxb if (xb is not None and ctx.needs_input_grad[1]) else None, None, *grads)
+
+
+class LazyCat:
+    """Concat's output before anyone needs it as ONE tensor: the parts (tensors or MaskedTensors).  The dict-graph executor
+    (network.Network.forward) hands it to an MlpBlock_Real whose fused kernels read the parts in place (csrc/mlp64.hip, two slabs);
+    every other reader gets torch.cat through materialize()."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+        self._cat = None
+
+    def materialize(self):
+        if self._cat is None:
+            self._cat = _wrap(torch.cat([_split(x)[0] for x in self.parts], dim=1), self.parts[0])
+        return self._cat
 
 
 # --------------------------------------------------------------------------------------
@@ -530,7 +559,26 @@ class MlpBlock_Real(nn.Module):
                 and self.convs[0].in_channels in FUSED_INPUT_WIDTHS and 1 <= len(self.convs) <= _lib.FGNN_MAX_DEPTH
                 and self.gn.features[1] == FGNN_H)
 
+    def takes_parts(self, parts):
+        """True when forward() reads Concat's parts in place (two stacked slabs of the fused 64-wide kernels: 64 channels, then <= 64)."""
+        if self.fused() or len(parts) != 2:
+            return False
+        ta, tb = _split(parts[0])[0], _split(parts[1])[0]
+        return (_mlp64_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]) and ta.dim() == 4 and tb.dim() == 4
+                and ta.shape[1] == 64 and 1 <= tb.shape[1] <= 64 and ta.shape[1] + tb.shape[1] == self.convs[0].in_channels
+                and ta.is_cuda and tb.is_cuda and ta.dtype == torch.float32 and tb.dtype == torch.float32)
+
     def forward(self, inputs):
+        if isinstance(inputs, LazyCat):
+            if not self.takes_parts(inputs.parts):
+                return self.forward(inputs.materialize())
+            (xa, nvalid), (xb, _) = _split(inputs.parts[0]), _split(inputs.parts[1])
+            wb = []
+            for conv in self.convs:
+                wb += [conv.weight, conv.bias]
+            y = _Mlp64Fn.apply(xa, xb, nvalid, *wb)
+            y = _GraphNormFn.apply(y, nvalid, self.gn.eps, self.gn.weight, self.gn.bias)
+            return _wrap(y, inputs.parts[0])
         x, nvalid = _split(inputs)
         if self.fused():
             wb = []
@@ -542,7 +590,7 @@ class MlpBlock_Real(nn.Module):
                 wb = []
                 for conv in self.convs:
                     wb += [conv.weight, conv.bias]
-                y = _Mlp64Fn.apply(x, nvalid, *wb)             # 64-wide stacks: fused, hidden activations recomputed in the backward
+                y = _Mlp64Fn.apply(x, None, nvalid, *wb)       # 64-wide stacks: fused, hidden activations recomputed in the backward
             elif _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
                 wb = []
                 for conv in self.convs:

@@ -88,6 +88,30 @@ def _embed_backward(ctx, dE, target, want_dx):
     return dx
 
 
+class _Outputs(dict):
+    """Network.forward's result: every node output by path.  A Concat output that only fused MLP kernels read is kept as its parts
+    (layers.LazyCat) and becomes the concatenated tensor when somebody looks at it."""
+
+    def raw(self, key):
+        return dict.__getitem__(self, key)
+
+    def _out(self, key):
+        v = dict.__getitem__(self, key)
+        return v.materialize() if hasattr(v, 'materialize') else v
+
+    def __getitem__(self, key):
+        return self._out(key)
+
+    def get(self, key, default=None):
+        return self._out(key) if key in self else default
+
+    def items(self):
+        return [(k, self._out(k)) for k in self.keys()]
+
+    def values(self):
+        return [self._out(k) for k in self.keys()]
+
+
 class _EmbedFn(torch.autograd.Function):
     """Whole node-embedder forward/backward through FgnnEngine (one autograd node) -- the fast mode.
 
@@ -158,6 +182,7 @@ class Network(nn.Module):
         for path, (node, _) in self.graph.items():
             setattr(self, path.replace(SEP, '_'), node)
         self._layout = None
+        self._lazy = None         # Concat nodes read by fused MLP kernels only (_lazy_cat_nodes)
         self._pad = None          # widths below 32 embedded in the 32-wide engine by zero padding (_padded_layout)
         self._engines = EngineCache(self.ENGINE_CACHE_BYTES)
         self._flat = None
@@ -168,11 +193,33 @@ class Network(nn.Module):
     def nodes(self):
         return (node for node, _ in self.graph.values())
 
+    def _lazy_cat_nodes(self):
+        """Concat nodes whose every reader is an MlpBlock_Real: their output stays a LazyCat (the parts) unless someone asks for the
+        tensor -- the block's mlp3 reads [mult ; in] in place (csrc/mlp64.hip) instead of a concatenated copy."""
+        if self._lazy is None:
+            from .layers import Concat, MlpBlock_Real
+            readers = {}
+            for path, (node, ins) in self.graph.items():
+                for name in ins:
+                    readers.setdefault(name, []).append(node)
+            self._lazy = {path for path, (node, _) in self.graph.items()
+                          if isinstance(node, Concat) and readers.get(path) and all(isinstance(r, MlpBlock_Real) for r in readers[path])}
+        return self._lazy
+
     def forward(self, inputs):
-        outputs = dict(inputs)
+        from .layers import LazyCat
+        lazy = self._lazy_cat_nodes()
+        outputs = _Outputs(inputs)
         for path, (node, ins) in self.graph.items():
             if path not in outputs:
-                outputs[path] = node(*[outputs[name] for name in ins])
+                args = [outputs.raw(name) for name in ins]
+                if path in lazy:
+                    outputs[path] = LazyCat(args)
+                else:
+                    from .layers import MlpBlock_Real
+                    if not isinstance(node, MlpBlock_Real):
+                        args = [a.materialize() if isinstance(a, LazyCat) else a for a in args]
+                    outputs[path] = node(*args)
         return outputs
 
     # ------------------------------------------------------------------ fused fast path

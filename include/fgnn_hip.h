@@ -245,6 +245,9 @@ typedef struct {
     const float *x;                          /* (G, cin, N*N) */
     long long x_gstride, x_ld;
     int cin;
+    const float *xb;                         /* optional second slab (G, cb, N*N) stacked after x along the channels (mlp3 of a block reads  */
+    long long xb_gstride, xb_ld;             /* [mult ; in] without the concatenated copy): cin == 64 then, cb <= 64, W0 is                   */
+    int cb;                                  /* (64, cin + cb); NULL: one slab                                                               */
     const float *packed;                     /* fgnn_mlp64_packed_floats(cin) floats written by fgnn_mlp64_pack */
     const int *nvalid;                       /* (G) or NULL */
     int G, N;
@@ -254,6 +257,8 @@ typedef struct {
     long long dz_gstride, dz_ld;
     float *dx;                               /* backward: (G, cin, N*N) or NULL */
     long long dx_gstride, dx_ld;
+    float *dxb;                              /* backward, two slabs: (G, cb, N*N), required when dx is given */
+    long long dxb_gstride, dxb_ld;
     float *wpart;                            /* backward: (fgnn_mlp64_num_workgroups(), fgnn_mlp64_param_count(cin)) */
 } fgnn_mlp64_args;
 int fgnn_mlp64_supported(int cin, int depth, int width);

@@ -619,7 +619,7 @@ def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
         wb = []
         for w, b in zip(wd, bd):
             wb += [w, b]
-        y = fn.apply(xd, nvd, *wb)
+        y = fn.apply(xd, None, nvd, *wb) if fn is _Mlp64Fn else fn.apply(xd, nvd, *wb)
         y.backward(dy.to(DEV))
         return [y.detach().cpu()] + ([xd.grad.cpu()] if need_dx else []) + [w.grad.cpu() for w in wd] + [b.grad.cpu() for b in bd]
 
@@ -743,3 +743,55 @@ def test_mlp64_rejects_bad_arguments():
         _lib.call('fgnn_mlp64_fwd', C.byref(a), _lib.stream_ptr())
     assert not _lib.load().fgnn_mlp64_supported(64, 2, 64) and not _lib.load().fgnn_mlp64_supported(64, 3, 48)
     assert _lib.load().fgnn_mlp64_supported(66, 3, 64)
+
+
+@pytest.mark.parametrize('cb', [2, 30, 64])
+@pytest.mark.parametrize('ragged', [False, True])
+def test_mlp64_two_slabs_equal_the_concatenated_input(cb, ragged):
+    """_Mlp64Fn on the two parts of a Concat ([mult ; in] of a block, models/blocks_emb.py:33-36) against the same function on the
+    concatenated tensor: output, both input gradients, every parameter gradient -- bit for bit (the same kernel arithmetic, only the
+    addresses differ)."""
+    from graph_neural_net_amd.layers import _Mlp64Fn
+    G, N = 4, 21
+    g = torch.Generator().manual_seed(900 + cb)
+    nv = torch.tensor([N, 9, N - 2, 1], dtype=torch.int32) if ragged else None
+    mask = _valid_mask(G, N, nv)
+    xa = (torch.randn(G, 64, N, N, generator=g).double() * mask).float()
+    xb = (torch.randn(G, cb, N, N, generator=g).double() * mask).float()
+    ws, bs, k = [], [], 64 + cb
+    for m in (64, 64, 64):
+        ws.append(torch.randn(m, k, 1, 1, generator=g) / k ** 0.5)
+        bs.append(0.3 * torch.randn(m, generator=g))
+        k = m
+    dy = (torch.randn(G, 64, N, N, generator=g).double() * mask).float()
+    nvd = nv.to(DEV) if ragged else None
+
+    def run(two):
+        a, b = xa.to(DEV).requires_grad_(True), xb.to(DEV).requires_grad_(True)
+        wd = [w.to(DEV).requires_grad_(True) for w in ws]
+        bd = [b_.to(DEV).requires_grad_(True) for b_ in bs]
+        wb = []
+        for w, b_ in zip(wd, bd):
+            wb += [w, b_]
+        y = _Mlp64Fn.apply(a, b, nvd, *wb) if two else _Mlp64Fn.apply(torch.cat([a, b], 1), None, nvd, *wb)
+        y.backward(dy.to(DEV))
+        return [y.detach(), a.grad, b.grad] + [w.grad for w in wd] + [b_.grad for b_ in bd]
+
+    for u, v in zip(run(True), run(False)):
+        assert torch.equal(u, v)
+
+
+def test_network_keeps_concat_lazy_for_the_fused_64_wide_mlp():
+    """Network.forward: a Concat node read only by MlpBlock_Real stays a LazyCat (no concatenated copy) and still reads as the tensor
+    through the returned dict (models/utils.py:60-69 returns every node output)."""
+    from graph_neural_net_amd.layers import LazyCat
+    d = load_golden('wide64_c2_64_64_d3_4blk.npz')
+    model = _load_model64(d)
+    out = model.node_embedder({'input': d['x1'].to(DEV)})
+    for b in (1, 2, 3, 4):
+        raw = out.raw('ne/bm/block%d/cat' % b)
+        assert isinstance(raw, LazyCat) and raw._cat is None
+    cat = out['ne/bm/block2/cat']
+    assert torch.is_tensor(cat) and cat.shape[1] == 128
+    assert torch.equal(cat[:, :64], out['ne/bm/block2/mult']) and torch.equal(cat[:, 64:], out['ne/bm/block1/mlp3'])
+    assert dict(out.items())['ne/bm/block3/cat'].shape[1] == 128

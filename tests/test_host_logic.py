@@ -265,7 +265,7 @@ def test_committed_bench_lines_follow_the_contract():
     driver contract, a consistent value / ms_per_step pair and the roofline / cpu_baseline objects."""
     import glob, json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, 'profiles', 'r02_*_bench*.json')))
+    files = sorted(glob.glob(os.path.join(root, 'profiles', 'archive', 'r02_*_bench*.json')) + glob.glob(os.path.join(root, 'profiles', 'r06_*bench*.json')))
     assert files
     for f in files:
         d = json.loads(open(f).read().strip().split('\n')[-1])
