@@ -68,6 +68,10 @@ class Mlp64Args(C.Structure):          # fgnn_mlp64_args (csrc/mlp64.hip)
                 ('wpart', C.c_void_p)]
 
 
+class Mlp64PackJob(C.Structure):       # fgnn_mlp64_pack_job
+    _fields_ = [('W', C.c_void_p * 3), ('bias', C.c_void_p * 3), ('cin', C.c_int), ('packed', C.c_void_p)]
+
+
 class MlpBwdArgs(C.Structure):
     _fields_ = [('G', C.c_int), ('N', C.c_int), ('depth', C.c_int),
                 ('nvalid', C.c_void_p),
@@ -166,6 +170,7 @@ _SIGNATURES = {
     'fgnn_mlp64_param_count': [_I],
     'fgnn_mlp64_packed_floats': [_I],
     'fgnn_mlp64_pack': [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP],
+    'fgnn_mlp64_pack_multi': [C.POINTER(Mlp64PackJob), _I, _VP],
     'fgnn_mlp64_fwd': [C.POINTER(Mlp64Args), _VP],
     'fgnn_mlp64_bwd': [C.POINTER(Mlp64Args), _VP],
     'fgnn_conv1x1': [_VP, _LL, _LL, _VP, _VP, _LL, _LL, _VP, _I, _VP, _I, _I, _I, _I, _VP, _LL, _LL, _VP],

@@ -60,16 +60,26 @@ struct Packed64 {
 };
 constexpr int packed_floats(int kg) { return (OG * kg + 3 * OG * OG + kg * OG + OG * OG) * SUB + 3 * 64; }
 
-__global__ __launch_bounds__(256) void mlp64_pack_kernel(const float *W0, const float *W1, const float *W2, const float *b0, const float *b1,
-                                                         const float *b2, int cin, int kg, float *out) {
+constexpr int PACK_MAX_JOBS = 16;
+struct PackJobs {
+    const float *W0[PACK_MAX_JOBS], *W1[PACK_MAX_JOBS], *W2[PACK_MAX_JOBS], *b0[PACK_MAX_JOBS], *b1[PACK_MAX_JOBS], *b2[PACK_MAX_JOBS];
+    float *out[PACK_MAX_JOBS];
+    int cin[PACK_MAX_JOBS];
+};
+// blockIdx.y = the MLP
+__global__ __launch_bounds__(256) void mlp64_pack_kernel(const PackJobs J) {
+    const int j = blockIdx.y;
+    const float *W0 = J.W0[j], *W1 = J.W1[j], *W2 = J.W2[j], *b0 = J.b0[j], *b1 = J.b1[j], *b2 = J.b2[j];
+    float *out = J.out[j];
+    const int cin = J.cin[j], kg = (cin + 31) / 32;
     const Packed64 L{kg};
     const int total = L.floats();
     for (int f = blockIdx.x * 256 + threadIdx.x; f < total; f += gridDim.x * 256) {
         float v;
         if (f >= L.bias()) {
-            const int r = f - L.bias(), l = r >> 6, og = (r >> 5) & 1, q = (r >> 3) & 3, j = r & 7;
+            const int r = f - L.bias(), l = r >> 6, og = (r >> 5) & 1, q = (r >> 3) & 3, jj = r & 7;
             const float *bp = l == 0 ? b0 : (l == 1 ? b1 : b2);
-            v = bp ? bp[32 * og + chan(j, q)] : 0.f;
+            v = bp ? bp[32 * og + chan(jj, q)] : 0.f;
         } else {
             // which image, forward or transposed, its weights and widths
             const float *W;
@@ -632,15 +642,30 @@ extern "C" int fgnn_mlp64_param_count(int cin) {
 
 extern "C" int fgnn_mlp64_packed_floats(int cin) { return packed_floats((cin + 31) / 32); }
 
-// the operand record of one MLP from its nn.Conv2d parameters: W0 (64, cin), W1, W2 (64, 64) row-major, biases (64) or NULL
-extern "C" int fgnn_mlp64_pack(const float *W0, const float *W1, const float *W2, const float *b0, const float *b1, const float *b2, int cin,
-                               float *packed, void *stream) {
-    FGNN_CHECK(fgnn_mlp64_supported(cin, 3, 64), "fgnn_mlp64_pack: 1..128 input channels (got %d)", cin);
-    FGNN_CHECK(W0 && W1 && W2 && packed, "fgnn_mlp64_pack: missing weights / output");
-    const int kg = (cin + 31) / 32, total = packed_floats(kg);
-    hipLaunchKernelGGL(mlp64_pack_kernel, dim3((total + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, W0, W1, W2, b0, b1, b2, cin, kg, packed);
+// the operand records of up to 16 MLPs from their nn.Conv2d parameters (W0 (64, cin), W1, W2 (64, 64) row-major, biases (64) or NULL) in ONE launch
+extern "C" int fgnn_mlp64_pack_multi(const fgnn_mlp64_pack_job *jobs, int njobs, void *stream) {
+    FGNN_CHECK(jobs && njobs >= 1 && njobs <= PACK_MAX_JOBS, "fgnn_mlp64_pack_multi: 1..%d jobs", PACK_MAX_JOBS);
+    PackJobs J = {};
+    int most = 0;
+    for (int j = 0; j < njobs; ++j) {
+        const fgnn_mlp64_pack_job &b = jobs[j];
+        FGNN_CHECK(fgnn_mlp64_supported(b.cin, 3, 64), "fgnn_mlp64_pack_multi: job %d: 1..128 input channels (got %d)", j, b.cin);
+        FGNN_CHECK(b.W[0] && b.W[1] && b.W[2] && b.packed, "fgnn_mlp64_pack_multi: job %d: missing weights / output", j);
+        J.W0[j] = b.W[0]; J.W1[j] = b.W[1]; J.W2[j] = b.W[2];
+        J.b0[j] = b.bias[0]; J.b1[j] = b.bias[1]; J.b2[j] = b.bias[2];
+        J.out[j] = b.packed;
+        J.cin[j] = b.cin;
+        const int total = packed_floats((b.cin + 31) / 32);
+        most = total > most ? total : most;
+    }
+    hipLaunchKernelGGL(mlp64_pack_kernel, dim3((most + 1023) / 1024, njobs), dim3(256), 0, (hipStream_t)stream, J);
     FGNN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int fgnn_mlp64_pack(const float *W0, const float *W1, const float *W2, const float *b0, const float *b1, const float *b2, int cin,
+                               float *packed, void *stream) {
+    const fgnn_mlp64_pack_job job = {{W0, W1, W2}, {b0, b1, b2}, cin, packed};
+    return fgnn_mlp64_pack_multi(&job, 1, stream);
 }
 
 extern "C" int fgnn_mlp64_fwd(const fgnn_mlp64_args *a, void *stream) {

@@ -364,8 +364,9 @@ class _Mlp64Fn(torch.autograd.Function):
         return a
 
     @staticmethod
-    def forward(ctx, x, xb, nvalid, *wb):
-        """xb: None, or a second tensor stacked after x along the channels (Concat's parts: the block's [mult ; in] without the copy)."""
+    def forward(ctx, x, xb, nvalid, packed, *wb):
+        """xb: None, or a second tensor stacked after x along the channels (Concat's parts: the block's [mult ; in] without the copy).
+        packed: None, or the operand record of these parameters (prepack64: one launch for every MLP of a model)."""
         _check(x, 'MlpBlock_Real')
         x = x.contiguous()
         G, Ka, N, _ = x.shape
@@ -382,9 +383,12 @@ class _Mlp64Fn(torch.autograd.Function):
             raise RuntimeError('MlpBlock_Real: conv 0 expects %d input channels, gets %d' % (ws[0].shape[1], K0))
         st = _lib.stream_ptr()
         f32 = dict(dtype=torch.float32, device=x.device)
-        packed = torch.empty(_lib.load().fgnn_mlp64_packed_floats(K0), **f32)      # operand record of both directions
-        _lib.call('fgnn_mlp64_pack', _lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(ws[2]), *[_lib.ptr(b) if b is not None else None for b in bs],
-                  K0, _lib.ptr(packed), st)
+        if packed is None:
+            packed = torch.empty(_lib.load().fgnn_mlp64_packed_floats(K0), **f32)      # operand record of both directions
+            _lib.call('fgnn_mlp64_pack', _lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(ws[2]), *[_lib.ptr(b) if b is not None else None for b in bs],
+                      K0, _lib.ptr(packed), st)
+        elif packed.numel() != _lib.load().fgnn_mlp64_packed_floats(K0):
+            raise RuntimeError('MlpBlock_Real: operand record of %d floats for %d input channels' % (packed.numel(), K0))
         out = torch.empty(G, 64, N, N, **f32)
         a = _Mlp64Fn._args(x, xb, nvalid, packed)
         a.out, a.o_gstride, a.o_ld = out.data_ptr(), 64 * P, P
@@ -427,7 +431,34 @@ class _Mlp64Fn(torch.autograd.Function):
                  flat[64 * k0p:o1] if ctx.has_bias[0] else None,
                  flat[o1:o1 + 4096].view(64, 64, 1, 1), flat[o1 + 4096:o2] if ctx.has_bias[1] else None,
                  flat[o2:o2 + 4096].view(64, 64, 1, 1), flat[o2 + 4096:o2 + 4160] if ctx.has_bias[2] else None]
-        return (dx if ctx.needs_input_grad[0] else None, dxb if (xb is not None and ctx.needs_input_grad[1]) else None, None, *grads)
+        return (dx if ctx.needs_input_grad[0] else None, dxb if (xb is not None and ctx.needs_input_grad[1]) else None, None, None, *grads)
+
+
+def prepack64(blocks):
+    """Operand records (fgnn_mlp64_pack_multi) of every 64-wide MlpBlock_Real in `blocks` in ONE launch per 16 of them; each block's next
+    forward call uses its record instead of packing by itself (network.Network.forward calls this at the top of a pass)."""
+    todo = [m for m in blocks if not m.fused() and m.convs[0].weight.is_cuda
+            and _mlp64_supported(m.convs[0].in_channels, [c.out_channels for c in m.convs])]
+    if not todo:
+        return
+    lib = _lib.load()
+    sizes = [lib.fgnn_mlp64_packed_floats(m.convs[0].in_channels) for m in todo]
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=todo[0].convs[0].weight.device)
+    off, keep = 0, []
+    for i0 in range(0, len(todo), 16):
+        chunk = todo[i0:i0 + 16]
+        jobs = (_lib.Mlp64PackJob * len(chunk))()
+        for jb, m, n in zip(jobs, chunk, sizes[i0:i0 + 16]):
+            for l, conv in enumerate(m.convs):
+                w = conv.weight if conv.weight.is_contiguous() else conv.weight.contiguous()
+                keep.append(w)
+                jb.W[l] = w.data_ptr()
+                jb.bias[l] = conv.bias.data_ptr() if conv.bias is not None else None
+            jb.cin = m.convs[0].in_channels
+            m._packed64 = buf[off:off + n]
+            jb.packed = m._packed64.data_ptr()
+            off += n
+        _lib.call('fgnn_mlp64_pack_multi', jobs, len(chunk), _lib.stream_ptr())
 
 
 class LazyCat:
@@ -559,6 +590,11 @@ class MlpBlock_Real(nn.Module):
                 and self.convs[0].in_channels in FUSED_INPUT_WIDTHS and 1 <= len(self.convs) <= _lib.FGNN_MAX_DEPTH
                 and self.gn.features[1] == FGNN_H)
 
+    def _take_packed64(self):
+        """the operand record prepack64 left for this forward call (used once), or None"""
+        p, self._packed64 = getattr(self, '_packed64', None), None
+        return p
+
     def takes_parts(self, parts):
         """True when forward() reads Concat's parts in place (two stacked slabs of the fused 64-wide kernels: 64 channels, then <= 64)."""
         if self.fused() or len(parts) != 2:
@@ -576,7 +612,7 @@ class MlpBlock_Real(nn.Module):
             wb = []
             for conv in self.convs:
                 wb += [conv.weight, conv.bias]
-            y = _Mlp64Fn.apply(xa, xb, nvalid, *wb)
+            y = _Mlp64Fn.apply(xa, xb, nvalid, self._take_packed64(), *wb)
             y = _GraphNormFn.apply(y, nvalid, self.gn.eps, self.gn.weight, self.gn.bias)
             return _wrap(y, inputs.parts[0])
         x, nvalid = _split(inputs)
@@ -590,7 +626,7 @@ class MlpBlock_Real(nn.Module):
                 wb = []
                 for conv in self.convs:
                     wb += [conv.weight, conv.bias]
-                y = _Mlp64Fn.apply(x, None, nvalid, *wb)       # 64-wide stacks: fused, hidden activations recomputed in the backward
+                y = _Mlp64Fn.apply(x, None, nvalid, self._take_packed64(), *wb)       # 64-wide stacks: fused, hidden activations recomputed in the backward
             elif _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
                 wb = []
                 for conv in self.convs:

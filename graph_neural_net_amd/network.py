@@ -207,8 +207,9 @@ class Network(nn.Module):
         return self._lazy
 
     def forward(self, inputs):
-        from .layers import LazyCat
+        from .layers import LazyCat, MlpBlock_Real, prepack64
         lazy = self._lazy_cat_nodes()
+        prepack64([node for node, _ in self.graph.values() if isinstance(node, MlpBlock_Real)])
         outputs = _Outputs(inputs)
         for path, (node, ins) in self.graph.items():
             if path not in outputs:
@@ -216,7 +217,6 @@ class Network(nn.Module):
                 if path in lazy:
                     outputs[path] = LazyCat(args)
                 else:
-                    from .layers import MlpBlock_Real
                     if not isinstance(node, MlpBlock_Real):
                         args = [a.materialize() if isinstance(a, LazyCat) else a for a in args]
                     outputs[path] = node(*args)

@@ -267,6 +267,14 @@ int fgnn_mlp64_param_count(int cin);
 int fgnn_mlp64_packed_floats(int cin);
 int fgnn_mlp64_pack(const float *W0, const float *W1, const float *W2, const float *b0, const float *b1, const float *b2, int cin,
                     float *packed, void *stream);
+typedef struct {
+    const float *W[3];                       /* W0 (64, cin), W1, W2 (64, 64) */
+    const float *bias[3];                    /* (64) or NULL */
+    int cin;
+    float *packed;                           /* fgnn_mlp64_packed_floats(cin) floats */
+} fgnn_mlp64_pack_job;
+/* ... for up to 16 MLPs in one launch (every MLP of a model at the top of its forward pass) */
+int fgnn_mlp64_pack_multi(const fgnn_mlp64_pack_job *jobs, int njobs, void *stream);
 int fgnn_mlp64_fwd(const fgnn_mlp64_args *args, void *stream);
 int fgnn_mlp64_bwd(const fgnn_mlp64_args *args, void *stream);
 

@@ -619,7 +619,7 @@ def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
         wb = []
         for w, b in zip(wd, bd):
             wb += [w, b]
-        y = fn.apply(xd, None, nvd, *wb) if fn is _Mlp64Fn else fn.apply(xd, nvd, *wb)
+        y = fn.apply(xd, None, nvd, None, *wb) if fn is _Mlp64Fn else fn.apply(xd, nvd, *wb)
         y.backward(dy.to(DEV))
         return [y.detach().cpu()] + ([xd.grad.cpu()] if need_dx else []) + [w.grad.cpu() for w in wd] + [b.grad.cpu() for b in bd]
 
@@ -773,7 +773,7 @@ def test_mlp64_two_slabs_equal_the_concatenated_input(cb, ragged):
         wb = []
         for w, b_ in zip(wd, bd):
             wb += [w, b_]
-        y = _Mlp64Fn.apply(a, b, nvd, *wb) if two else _Mlp64Fn.apply(torch.cat([a, b], 1), None, nvd, *wb)
+        y = _Mlp64Fn.apply(a, b, nvd, None, *wb) if two else _Mlp64Fn.apply(torch.cat([a, b], 1), None, nvd, None, *wb)
         y.backward(dy.to(DEV))
         return [y.detach(), a.grad, b.grad] + [w.grad for w in wd] + [b_.grad for b_ in bd]
 

@@ -9,16 +9,19 @@ pat = sys.argv[2]
 start = [i for i, l in enumerate(lines) if l.startswith('_Z') and pat in l and l.split(';')[0].rstrip().endswith(':')][0]
 end = [i for i in range(start, len(lines)) if 's_endpgm' in lines[i]][0]
 body = lines[start:end + 1]
+import re
+labs = {}
+for i, l in enumerate(body):
+    m = re.match(r'^(\.LBB\d+_\d+):', l)
+    if m:
+        labs[m.group(1)] = i
 best = None
-for hi, l in enumerate(body):
-    if 'Loop Header: Depth=' not in l:
-        continue
-    lab = l.split(':')[0]
-    back = [i for i, b in enumerate(body) if ('s_cbranch' in b or 's_branch' in b) and b.split()[-1] == lab and i > hi]
-    if back:
-        n = sum(1 for b in body[hi:back[-1] + 1] if b.strip().startswith('v_mfma'))
-        if best is None or n > best[2]:
-            best = (hi, back[-1], n)
+for i, l in enumerate(body):                      # back edges: a branch to a label above it
+    t = l.strip().split()
+    if t and (t[0].startswith('s_cbranch') or t[0] == 's_branch') and t[-1] in labs and labs[t[-1]] < i:
+        n = sum(1 for b in body[labs[t[-1]]:i + 1] if b.strip().startswith('v_mfma'))
+        if best is None or (n, i - labs[t[-1]]) > (best[2], best[1] - best[0]):
+            best = (labs[t[-1]], i, n)
 out = []
 for l in body[best[0]:best[1] + 1]:
     t = l.strip().split()
