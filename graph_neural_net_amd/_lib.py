@@ -65,6 +65,7 @@ class Mlp64Args(C.Structure):          # fgnn_mlp64_args (csrc/mlp64.hip)
                 ('dz', C.c_void_p), ('dz_gstride', C.c_longlong), ('dz_ld', C.c_longlong),
                 ('dx', C.c_void_p), ('dx_gstride', C.c_longlong), ('dx_ld', C.c_longlong),
                 ('dxb', C.c_void_p), ('dxb_gstride', C.c_longlong), ('dxb_ld', C.c_longlong),
+                ('accumulate_dx', C.c_int), ('accumulate_dxb', C.c_int),
                 ('wpart', C.c_void_p)]
 
 

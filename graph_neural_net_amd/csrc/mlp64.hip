@@ -318,8 +318,10 @@ DEVI void load_in(float (&x)[KG][8], const In2 &in, const Tile64 &c, int q) {
         }
     }
 }
+// acc_a / acc_b: add to what the slab holds (one buffer_atomic_add_f32 per element: every element is touched by exactly one lane of
+// one launch, so the sum old + new has one order) instead of storing
 template <int KG, int KGA = KG>
-DEVI void store_in(const float (&x)[KG][8], const In2 &in, const Tile64 &c, int q) {
+DEVI void store_in(const float (&x)[KG][8], const In2 &in, const Tile64 &c, int q, bool acc_a, bool acc_b) {
 #pragma unroll
     for (int ig = 0; ig < KG; ++ig) {
         const bool ina = ig < KGA;
@@ -327,10 +329,18 @@ DEVI void store_in(const float (&x)[KG][8], const In2 &in, const Tile64 &c, int 
         const int ld4 = ina ? in.a.ld4 : in.b.ld4, gs4 = ina ? in.a.gs4 : in.b.gs4, lg = ina ? ig : ig - KGA;
         const int voff = c.inb ? chan_q(q) * ld4 + 4 * c.p : OOB_OFF;
         const int s0 = c.g * gs4 + lg * 32 * ld4;
+        if (ina ? acc_a : acc_b) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const bool ok = !(ig == KG - 1 && in.cin < 32 * KG) || 32 * ig + chan_s(s) + chan_q(q) < in.cin;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[ig][s]), r, ok ? voff : OOB_OFF, s0 + chan_s(s) * ld4, FGNN_STORE_AUX);
+            for (int s = 0; s < 8; ++s) {
+                const bool ok = !(ig == KG - 1 && in.cin < 32 * KG) || 32 * ig + chan_s(s) + chan_q(q) < in.cin;
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(x[ig][s], r, ok ? voff : OOB_OFF, s0 + chan_s(s) * ld4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const bool ok = !(ig == KG - 1 && in.cin < 32 * KG) || 32 * ig + chan_s(s) + chan_q(q) < in.cin;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x[ig][s]), r, ok ? voff : OOB_OFF, s0 + chan_s(s) * ld4, FGNN_STORE_AUX);
+            }
         }
     }
 }
@@ -505,8 +515,30 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
         for (int ii = 0; ii < IH; ++ii) stage8(TI + ii * TILE_F, lane_base, x[ii]);
         if constexpr (HAS_DX) {
             float dx[KG][8];
+            // accumulating launches (the input also feeds other MLPs): up to two groups -- mlp1 / mlp2 of a block -- read what the buffer
+            // holds while the GEMM runs and store the sum; wider inputs (no registers left) add with buffer atomics
+            constexpr bool RMW = KG <= 2 && KGA == KG;
+            float old[RMW ? KG : 1][8];
+            const bool acc_a = A.accumulate_dx != 0;
+            if constexpr (RMW) {
+                if (acc_a) {
+                    Tile64 cs = c;
+                    cs.valid = c.inb;
+                    load_in<KG, KGA>(old, vdx, cs, q);
+                }
+            }
             layer_bwd<KG>(dx, smem + L::B0, wB0, d0, lane, [&] { g = load_wg_first(TD, TI, lane); });
-            store_in<KG, KGA>(dx, vdx, c, q);
+            if constexpr (RMW) {
+                if (acc_a) {
+#pragma unroll
+                    for (int ig = 0; ig < KG; ++ig)
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) dx[ig][s] += old[ig][s];
+                }
+                store_in<KG, KGA>(dx, vdx, c, q, false, false);
+            } else {
+                store_in<KG, KGA>(dx, vdx, c, q, acc_a, A.accumulate_dxb != 0);
+            }
         } else {
             g = load_wg_first(TD, TI, lane);
         }

@@ -364,9 +364,12 @@ class _Mlp64Fn(torch.autograd.Function):
         return a
 
     @staticmethod
-    def forward(ctx, x, xb, nvalid, packed, *wb):
+    def forward(ctx, x, xb, nvalid, packed, sink_a, sink_b, *wb):
         """xb: None, or a second tensor stacked after x along the channels (Concat's parts: the block's [mult ; in] without the copy).
-        packed: None, or the operand record of these parameters (prepack64: one launch for every MLP of a model)."""
+        packed: None, or the operand record of these parameters (prepack64: one launch for every MLP of a model).
+        sink_a / sink_b: None, or the GradSink of x / xb (fan_out): the backward then ADDS its input gradient to the sink's buffer inside
+        the kernel and returns nothing for that input -- the readers of one tensor share one gradient buffer, no add kernels."""
+        ctx.sinks = (sink_a, sink_b)
         _check(x, 'MlpBlock_Real')
         x = x.contiguous()
         G, Ka, N, _ = x.shape
@@ -410,11 +413,23 @@ class _Mlp64Fn(torch.autograd.Function):
         a = _Mlp64Fn._args(x, xb, nvalid, packed)
         a.dz, a.dz_gstride, a.dz_ld = dz.data_ptr(), 64 * P, P
         dx = dxb = None
+        ret_a = ret_b = None
         if ctx.needs_input_grad[0] or (xb is not None and ctx.needs_input_grad[1]):
-            dx = torch.empty(G, Ka, N, N, **f32)
+            sink_a, sink_b = ctx.sinks
+
+            def target(sink, ch, wanted):
+                """(buffer, accumulate?, what autograd gets): the sink's shared buffer, or a fresh tensor"""
+                if sink is None or not wanted:
+                    t = torch.empty(G, ch, N, N, **f32)
+                    return t, 0, (t if wanted else None)
+                first = sink.buf is None
+                if first:
+                    sink.buf = torch.empty(G, ch, N, N, **f32)
+                return sink.buf, int(not first), None
+            dx, a.accumulate_dx, ret_a = target(sink_a, Ka, ctx.needs_input_grad[0])
             a.dx, a.dx_gstride, a.dx_ld = dx.data_ptr(), Ka * P, P
             if xb is not None:
-                dxb = torch.empty(G, Kb, N, N, **f32)
+                dxb, a.accumulate_dxb, ret_b = target(sink_b, Kb, ctx.needs_input_grad[1])
                 a.dxb, a.dxb_gstride, a.dxb_ld = dxb.data_ptr(), Kb * P, P
         nwg = _lib.load().fgnn_mlp64_num_workgroups()
         cnt = _lib.load().fgnn_mlp64_param_count(K0)
@@ -431,7 +446,7 @@ class _Mlp64Fn(torch.autograd.Function):
                  flat[64 * k0p:o1] if ctx.has_bias[0] else None,
                  flat[o1:o1 + 4096].view(64, 64, 1, 1), flat[o1 + 4096:o2] if ctx.has_bias[1] else None,
                  flat[o2:o2 + 4096].view(64, 64, 1, 1), flat[o2 + 4096:o2 + 4160] if ctx.has_bias[2] else None]
-        return (dx if ctx.needs_input_grad[0] else None, dxb if (xb is not None and ctx.needs_input_grad[1]) else None, None, None, *grads)
+        return (ret_a, ret_b, None, None, None, None, *grads)
 
 
 def prepack64(blocks):
@@ -459,6 +474,42 @@ def prepack64(blocks):
             jb.packed = m._packed64.data_ptr()
             off += n
         _lib.call('fgnn_mlp64_pack_multi', jobs, len(chunk), _lib.stream_ptr())
+
+
+class GradSink:
+    """One gradient buffer for a tensor that several fused MLPs read (a block's input feeds mlp1, mlp2 and, through Concat, mlp3:
+    models/blocks_emb.py:29-36).  fan_out(x) returns x behind an autograd node that owns the sink; every _Mlp64Fn reading it adds
+    its input gradient to sink.buf inside its kernel (the first one stores) and hands autograd nothing; the node's backward returns the
+    buffer (plus whatever other readers sent the ordinary way)."""
+
+    def __init__(self):
+        self.buf = None
+
+
+class _FanOutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, sink):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        buf, ctx.sink.buf = ctx.sink.buf, None
+        if buf is None:
+            return g, None
+        return (buf if g is None else buf + g), None
+
+
+def fan_out(x):
+    """x (tensor or MaskedTensor) with a GradSink attached for the fused MLPs that read it (only when it takes part in autograd)."""
+    t, _ = _split(x)
+    if not (torch.is_tensor(t) and t.requires_grad and torch.is_grad_enabled() and t.is_cuda and t.dtype == torch.float32):
+        return x
+    sink = GradSink()
+    tf = _FanOutFn.apply(t, sink)
+    tf._fgnn_sink = sink
+    return _wrap(tf, x)
 
 
 class LazyCat:
@@ -612,7 +663,7 @@ class MlpBlock_Real(nn.Module):
             wb = []
             for conv in self.convs:
                 wb += [conv.weight, conv.bias]
-            y = _Mlp64Fn.apply(xa, xb, nvalid, self._take_packed64(), *wb)
+            y = _Mlp64Fn.apply(xa, xb, nvalid, self._take_packed64(), getattr(xa, '_fgnn_sink', None), getattr(xb, '_fgnn_sink', None), *wb)
             y = _GraphNormFn.apply(y, nvalid, self.gn.eps, self.gn.weight, self.gn.bias)
             return _wrap(y, inputs.parts[0])
         x, nvalid = _split(inputs)
@@ -626,7 +677,8 @@ class MlpBlock_Real(nn.Module):
                 wb = []
                 for conv in self.convs:
                     wb += [conv.weight, conv.bias]
-                y = _Mlp64Fn.apply(x, None, nvalid, self._take_packed64(), *wb)       # 64-wide stacks: fused, hidden activations recomputed in the backward
+                # 64-wide stacks: fused, hidden activations recomputed in the backward
+                y = _Mlp64Fn.apply(x, None, nvalid, self._take_packed64(), getattr(x, '_fgnn_sink', None), None, *wb)
             elif _chain_supported(self.convs[0].in_channels, [c.out_channels for c in self.convs]):
                 wb = []
                 for conv in self.convs:

@@ -183,6 +183,7 @@ class Network(nn.Module):
             setattr(self, path.replace(SEP, '_'), node)
         self._layout = None
         self._lazy = None         # Concat nodes read by fused MLP kernels only (_lazy_cat_nodes)
+        self._fan = set()         # outputs whose readers share one gradient buffer (layers.fan_out)
         self._pad = None          # widths below 32 embedded in the 32-wide engine by zero padding (_padded_layout)
         self._engines = EngineCache(self.ENGINE_CACHE_BYTES)
         self._flat = None
@@ -204,10 +205,18 @@ class Network(nn.Module):
                     readers.setdefault(name, []).append(node)
             self._lazy = {path for path, (node, _) in self.graph.items()
                           if isinstance(node, Concat) and readers.get(path) and all(isinstance(r, MlpBlock_Real) for r in readers[path])}
+            # outputs read by two or more (fused-capable) MLPs, directly or through such a Concat: their gradient is summed inside the
+            # MLP backward kernels (layers.fan_out) instead of by autograd's add kernels
+            n64 = {}
+            for path, (node, ins) in self.graph.items():
+                if (isinstance(node, MlpBlock_Real) and not node.fused()) or path in self._lazy:
+                    for name in ins:
+                        n64[name] = n64.get(name, 0) + 1
+            self._fan = {name for name, n in n64.items() if n >= 2}
         return self._lazy
 
     def forward(self, inputs):
-        from .layers import LazyCat, MlpBlock_Real, prepack64
+        from .layers import LazyCat, MlpBlock_Real, fan_out, prepack64
         lazy = self._lazy_cat_nodes()
         prepack64([node for node, _ in self.graph.values() if isinstance(node, MlpBlock_Real)])
         outputs = _Outputs(inputs)
@@ -220,6 +229,8 @@ class Network(nn.Module):
                     if not isinstance(node, MlpBlock_Real):
                         args = [a.materialize() if isinstance(a, LazyCat) else a for a in args]
                     outputs[path] = node(*args)
+                if path in self._fan:
+                    outputs[path] = fan_out(outputs.raw(path))
         return outputs
 
     # ------------------------------------------------------------------ fused fast path

@@ -259,6 +259,7 @@ typedef struct {
     long long dx_gstride, dx_ld;
     float *dxb;                              /* backward, two slabs: (G, cb, N*N), required when dx is given */
     long long dxb_gstride, dxb_ld;
+    int accumulate_dx, accumulate_dxb;       /* != 0: dx (dxb) += instead of a store (the input also feeds other MLPs: their launches add to one buffer) */
     float *wpart;                            /* backward: (fgnn_mlp64_num_workgroups(), fgnn_mlp64_param_count(cin)) */
 } fgnn_mlp64_args;
 int fgnn_mlp64_supported(int cin, int depth, int width);

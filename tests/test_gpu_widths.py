@@ -619,7 +619,7 @@ def test_mlp64_equals_the_conv_chain(cin, shape, need_dx):
         wb = []
         for w, b in zip(wd, bd):
             wb += [w, b]
-        y = fn.apply(xd, None, nvd, None, *wb) if fn is _Mlp64Fn else fn.apply(xd, nvd, *wb)
+        y = fn.apply(xd, None, nvd, None, None, None, *wb) if fn is _Mlp64Fn else fn.apply(xd, nvd, *wb)
         y.backward(dy.to(DEV))
         return [y.detach().cpu()] + ([xd.grad.cpu()] if need_dx else []) + [w.grad.cpu() for w in wd] + [b.grad.cpu() for b in bd]
 
@@ -773,7 +773,7 @@ def test_mlp64_two_slabs_equal_the_concatenated_input(cb, ragged):
         wb = []
         for w, b_ in zip(wd, bd):
             wb += [w, b_]
-        y = _Mlp64Fn.apply(a, b, nvd, None, *wb) if two else _Mlp64Fn.apply(torch.cat([a, b], 1), None, nvd, None, *wb)
+        y = _Mlp64Fn.apply(a, b, nvd, None, None, None, *wb) if two else _Mlp64Fn.apply(torch.cat([a, b], 1), None, nvd, None, None, None, *wb)
         y.backward(dy.to(DEV))
         return [y.detach(), a.grad, b.grad] + [w.grad for w in wd] + [b_.grad for b_ in bd]
 
@@ -795,3 +795,44 @@ def test_network_keeps_concat_lazy_for_the_fused_64_wide_mlp():
     assert torch.is_tensor(cat) and cat.shape[1] == 128
     assert torch.equal(cat[:, :64], out['ne/bm/block2/mult']) and torch.equal(cat[:, 64:], out['ne/bm/block1/mlp3'])
     assert dict(out.items())['ne/bm/block3/cat'].shape[1] == 128
+
+
+def test_fan_out_sums_the_input_gradients_inside_the_mlp_kernels():
+    """layers.fan_out: three fused MLPs reading one tensor (a block's mlp1, mlp2 and -- as the second slab -- mlp3) add their input
+    gradients to ONE buffer inside their backward kernels; an ordinary reader's gradient joins through autograd.  Same result (to one
+    rounding of the three-term sum) as autograd's own accumulation, and no `add` kernel is needed for the fused readers."""
+    from graph_neural_net_amd.layers import _Mlp64Fn, fan_out
+    G, N = 3, 17
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(G, 64, N, N, generator=g)
+    m0 = torch.randn(G, 64, N, N, generator=g)
+
+    def params(k):
+        out = []
+        for kk in (k, 64, 64):
+            out += [(torch.randn(64, kk, 1, 1, generator=g) / kk ** 0.5).to(DEV).requires_grad_(True), (0.1 * torch.randn(64, generator=g)).to(DEV).requires_grad_(True)]
+        return out
+    p1, p2, p3 = params(64), params(64), params(128)
+    dys = [torch.randn(G, 64, N, N, generator=g).to(DEV) for _ in range(3)]
+
+    def run(fanned):
+        leaf = x0.to(DEV).requires_grad_(True)
+        x = leaf * 1.0                                   # a non-leaf, like a block's output
+        if fanned:
+            x = fan_out(x)
+        sink = getattr(x, '_fgnn_sink', None)
+        assert (sink is not None) == fanned
+        mult = m0.to(DEV)
+        y1 = _Mlp64Fn.apply(x, None, None, None, sink, None, *p1)
+        y2 = _Mlp64Fn.apply(x, None, None, None, sink, None, *p2)
+        y3 = _Mlp64Fn.apply(mult, x, None, None, None, sink, *p3)
+        extra = (x * x).sum()                            # an ordinary reader
+        for p in p1 + p2 + p3:
+            p.grad = None
+        torch.autograd.backward([y1, y2, y3, extra], dys + [torch.ones((), device=DEV)])
+        return [leaf.grad] + [p.grad.clone() for p in p1 + p2 + p3]
+
+    a, b = run(True), run(False)
+    assert rel(a[0].cpu(), b[0].cpu()) < 1e-6
+    for u, v in zip(a[1:], b[1:]):
+        assert torch.equal(u, v)
