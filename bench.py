@@ -372,6 +372,8 @@ def main():
         out['batch256'] = {'value': sub['value'], 'unit': sub['unit'], 'ms_per_step': sub['ms_per_step'], 'ms_per_step_min': sub['ms_per_step_min'],
                            'ms_per_step_max': sub['ms_per_step_max'], 'dtype': sub['dtype'], 'batch_per_gpu': sub['config']['batch_per_gpu'],
                            'workload': sub['config']['workload'], 'block1': sub['config'].get('block1'), 'input': sub['config'].get('input')}
+        #   wide64      -- the cfg2 workload on the 64-feature model (the reference takes any widths: models/layers.py:113-123)
+        out['wide64'] = wide64_leg(args, dev)
     if rank == 0 and world == 1 and args.path == 'engine' and not args.no_extra_configs and out['config'].get('block1', 'generic') != 'generic':
         # ... and through the module surface a user of the reference calls (dense loader batch in, fused_step)
         out['module_surface'] = module_surface_leg(args, args.config, rank, world, dev, out['ms_per_step'])
@@ -440,6 +442,40 @@ def time_in_graph(tag, engines, work, min_launches=24, replays=20):
     torch.cuda.synchronize()
     n = rounds * len(sets)
     return {'ms': e0.elapsed_time(e1) / (replays * n), 'launches': n, 'replays': replays, 'sets': len(sets), 'engines': len(engines)}
+
+
+def wide64_leg(args, dev):
+    """The cfg2 workload (N = 50 regular pairs, 32 pairs) on the 64-FEATURE model (original_features_num 2, in_features = out_features = 64,
+    depth 3, 4 blocks; models/layers.py:113-123 takes any widths) through the module surface: Siamese_Node_Exp.fused_step = forward +
+    loss + backward of the per-module path captured into ONE replayed HIP graph.  Its conv stacks run on the fused 64-wide kernels of
+    csrc/mlp64.hip; GraphNorm, per-channel products and loss are per-module launches.  Same K / W protocol."""
+    from graph_neural_net_amd.siamese import Siamese_Node_Exp
+    B, N = 32, 50
+    x1, x2 = synthetic.make_batch(2000, B, N, 'Regular', 0.2, 0.1)
+    x1, x2 = x1.to(dev), x2.to(dev)
+    torch.manual_seed(64)
+    ne = dict(type='node_embedding', block_init='block_emb', block_inside='block', num_blocks=args.blocks, in_features=64, out_features=64,
+              depth_of_mlp=3)
+    model = Siamese_Node_Exp(2, ne, metric='max').to(dev)
+
+    def step():
+        model.fused_step({'input': x1}, {'input': x2})
+    for _ in range(3 + args.warmup):
+        step()
+    torch.cuda.synchronize()
+    window_s = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        window_s.append(time.perf_counter() - t0)
+    ms = sorted(window_s)[1] / args.steps * 1e3
+    return {'value': B / (ms * 1e-3), 'unit': 'pairs/s', 'ms_per_step': ms, 'ms_per_step_min': min(window_s) / args.steps * 1e3,
+            'ms_per_step_max': max(window_s) / args.steps * 1e3, 'dtype': 'f32', 'batch_per_gpu': B, 'features': 64,
+            'workload': 'N=50 regular-graph pairs, batch=%d, %d blocks, 2 -> 64 -> 64 features, depth 3' % (B, args.blocks),
+            'path': 'Siamese_Node_Exp.fused_step: the per-module path in one replayed HIP graph; conv stacks on csrc/mlp64.hip'}
 
 
 def module_surface_leg(args, config, rank, world, dev, engine_ms):

@@ -17,6 +17,9 @@ TAGS = {
     'sb_fwd_kernel<1>': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel<1>': 'fgnn_block1_struct_bwd',
     'chan_matmul_bwd1_kernel': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd1_kernel': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_w_kernel<7, true>': 'fgnn_chan_matmul_fwd',
 }
+# round 6: the 16-pixel-tile kernels (full template lists as rocprofv3 prints them)
+TAGS.update({'mlp_bwd_pair_t16_kernel<false, true>': 'mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_t16_kernel<32, false, false, true>': 'mlp_bwd[cin=64,dx=64]',
+             'mlp_bwd_t16_kernel<2, true, false, false>': 'mlp_bwd[cin=34,dx=32]', 'mlp_bwd_t16_kernel<2, false, false, false>': 'mlp_bwd[cin=34,dx=32]'})
 TAGS16 = {
     'mlp_bwd16_pair_kernel<32>': 'mlp_bwd16_pair[cin=32,dx=32]', 'mlp_bwd16_pair_kernel<2>': 'mlp_bwd16_pair[cin=2,dx=0]',
     'mlp_bwd16_kernel<32, 0, 3>': 'mlp_bwd16[cin=32,dx=32]', 'mlp_bwd16_kernel<32, 32, 3>': 'mlp_bwd16[cin=64,dx=64]',
@@ -30,6 +33,8 @@ TAGS16 = {
 TAGS5 = {k.replace('>', ', true>') if k.startswith(('mlp_', )) else k: v for k, v in TAGS.items()}
 TAGS5.update({'chan_matmul_bwd_big_kernel<4>': 'fgnn_chan_matmul_bwd', 'chan_matmul_fwd_big_kernel<4>': 'fgnn_chan_matmul_fwd', 'chan_matmul_fwd_big_kernel<4, true>': 'fgnn_chan_matmul_fwd',
               'sb_fwd_kernel<2>': 'fgnn_block1_struct_fwd', 'sb_bwd_reduce_kernel<2>': 'fgnn_block1_struct_bwd'})
+TAGS5.update({'mlp_bwd_pair_t16_kernel<true, true>': 'mlp_bwd_pair[cin=32,dx=32]', 'mlp_bwd_t16_kernel<32, false, true, true>': 'mlp_bwd[cin=64,dx=64]',
+              'mlp_bwd_t16_kernel<2, true, true, false>': 'mlp_bwd[cin=34,dx=32]'})
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rel = lambda f: os.path.relpath(f, root)
 out = {'_note': 'HBM traffic per launch from rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs, '
@@ -45,7 +50,8 @@ def collect(src, tags, prefix):
     for line in open(src):
         m = re.match(r'^(\S.*?)\s+\(avg', line)
         if m:
-            cur = tags.get(m.group(1).strip().replace(', false', ''))       # (PK / SKIP template flags of the dense kernels)
+            name = m.group(1).strip()
+            cur = tags.get(name) or tags.get(name.replace(', false', ''))   # (PK / SKIP template flags of the dense kernels)
             if cur:
                 cur = prefix + cur
                 out[cur] = {}
