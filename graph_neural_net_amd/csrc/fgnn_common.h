@@ -141,6 +141,61 @@ DEVI int next_live_tile_p(int t, int t_end, int step, int tpg, int T, int pitch,
     }
     return t;
 }
+// Round-robin over the LIVE tiles of a range: the next tile at or after `t` (below t_end, else t_end) whose index among the range's
+// live tiles is == who (mod nwho); `cnt` = live tiles seen so far, carried between calls (start: t = the range's first tile, cnt = 0).
+// Dealing raw tile indices round-robin and skipping the dead ones leaves the owners of a ragged batch with up to 40 % different
+// shares (runs of live tiles alternate with runs of padding in every row); this keeps them within one tile of each other at the
+// price of every owner looking at every tile of the range.  All operands wave-uniform.
+DEVI int next_owned_live_tile_p(int t, int t_end, int &cnt, int who, int nwho, int tpg, int T, int pitch, const int *nvalid) {
+    while (t < t_end) {
+        const int g = t / tpg, tt = t - g * tpg;
+        const int nv = nvalid[g];
+        if (tile_live_p(tt, T, pitch, nv)) {
+            const bool mine = cnt % nwho == who;
+            ++cnt;
+            if (mine) break;
+            ++t;
+        } else if (tt * T / pitch >= nv) {
+            t = (g + 1) * tpg;             // rows >= nv are padding up to the end of the graph
+        } else {
+            ++t;
+        }
+    }
+    return t < t_end ? t : t_end;
+}
+// The same dealing without every owner scanning the range: the workgroup's live tiles of [t0, t1), in order, as a list in LDS (built
+// by all `nthreads` threads: one tile per thread and pass, two barriers per pass; the last one also publishes the list).  Returns the
+// number of live tiles (uniform); entries beyond `cap` are not stored -- the caller falls back to next_owned_live_tile_p then.
+// scratch: nthreads / 64 ints.
+constexpr int LIVE_LIST_CAP = 2040;
+DEVI int build_live_list(int *list, int *scratch, int t0, int t1, int tpg, int T, int pitch, const int *nvalid, int tid, int nthreads) {
+    int base = 0;
+    const int wv = tid >> 6, lane = tid & 63, nw = nthreads >> 6;
+    for (int c0 = t0; c0 < t1; c0 += nthreads) {
+        const int t = c0 + tid;
+        bool live = false;
+        if (t < t1) {
+            const int g = t / tpg, tt = t - g * tpg;
+            live = tile_live_p(tt, T, pitch, nvalid[g]);
+        }
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) scratch[wv] = __popcll(m);
+        __syncthreads();
+        int off = base, tot = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int c = scratch[w];
+            off += w < wv ? c : 0;
+            tot += c;
+        }
+        if (live) {
+            const int idx = off + __popcll(m & ((1ull << lane) - 1ull));
+            if (idx < LIVE_LIST_CAP) list[idx] = t;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
 DEVI bool tile_live(int tt, int N, int nv) { return tile_live_p(tt, FGNN_TILE, N, nv); }
 DEVI int next_live_tile(int t, int t_end, int step, int tpg, int N, const int *nvalid) {
     return next_live_tile_p(t, t_end, step, tpg, FGNN_TILE, N, nvalid);

@@ -79,7 +79,8 @@ struct PairLayout16 {
     static constexpr int XCH_OFF = TILE_OFF + NW * NSLOT * TILE_F;        // per pair: the handed-over dx fragment [s][lane]
     static constexpr int FLAG_OFF = XCH_OFF + NP * 1024;                  // (two slots per pair); per pair: ready, consumed counters (+ padding)
     static constexpr int REC_OFF = FLAG_OFF + 4 * NP;                     // per wave: {coef[32], nrm[32]} float4 (graph changes only)
-    static constexpr int MAIN_F = REC_OFF + NW * 256;
+    static constexpr int LIVE_OFF = REC_OFF + NW * 256;                   // SKIP: the range's live tiles (build_live_list) + NW counters
+    static constexpr int MAIN_F = LIVE_OFF + LIVE_LIST_CAP + NW;
     static constexpr int RED_F = NW * PCOUNT;
     static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
 };
@@ -186,7 +187,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     for (int s = 0; s < 8; ++s) oldr[s] = 0.f;
     int cached_g = -1, cur_nv = A.N;
     int tile = T0 + pair;
-    if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_live_tile(tile, T1, NP, tpg, A.N, A.nvalid));
+    int live_cnt = 0;                                // SKIP: the pairs take the range's LIVE tiles in turn (fgnn_common.h)
+    if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_owned_live_tile_p(T0, T1, live_cnt, pair, NP, tpg, FGNN_TILE, A.N, A.nvalid));
     int hf = 0;
     {
         const bool act = tile < T1;
@@ -203,6 +205,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     PH(12)              // prologue a: kernel arguments, descriptors, every load of the prologue issued
     if (threadIdx.x < 4 * NP) reinterpret_cast<int *>(smem + L::FLAG_OFF)[threadIdx.x] = 0;
     PH(13)              // prologue b: images (and everything requested before them) arrived, written to LDS
+    // SKIP: the pairs' later tiles come from the list of the range's live tiles (the first one was found by scanning)
+    int *live_list = reinterpret_cast<int *>(smem + L::LIVE_OFF);
+    int nlive = 0, li = pair;
+    if constexpr (SKIP) nlive = build_live_list(live_list, live_list + LIVE_LIST_CAP, T0, T1, tpg, FGNN_TILE, A.N, A.nvalid, threadIdx.x, 64 * NW);
+    const bool use_list = SKIP && nlive <= LIVE_LIST_CAP;
     __syncthreads();
     // The first half's dy / z / old d_in are requested only now: the barrier above drains every outstanding load, and at a kernel's start
     // all CUs fetch at once (~ 10 B per cycle and CU) -- the first MFMA should wait for the images and x (57 KB per CU), not for these 48 KB
@@ -235,7 +242,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_pair_t16_kernel(const Pair
     while (tile < T1) {
         int tnext = tile + NP;
         if constexpr (SKIP) {
-            if (hf == 1) tnext = __builtin_amdgcn_readfirstlane(next_live_tile(tnext, T1, NP, tpg, A.N, A.nvalid));
+            if (hf == 1) {
+                if (use_list) {
+                    li += NP;
+                    tnext = __builtin_amdgcn_readfirstlane(li < nlive ? live_list[li] : T1);
+                } else {
+                    tnext = __builtin_amdgcn_readfirstlane(next_owned_live_tile_p(tile + 1, T1, live_cnt, pair, NP, tpg, FGNN_TILE, A.N, A.nvalid));
+                }
+            }
         }
         const int g = __builtin_amdgcn_readfirstlane(tile / tpg), tt = tile - g * tpg;
         const int p = tt * 32 + 16 * hf + px;

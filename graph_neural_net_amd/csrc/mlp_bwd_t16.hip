@@ -53,7 +53,8 @@ struct Layout16 {
     static constexpr int TILE_OFF = WEIGHT_F;
     static constexpr int REC_OFF = TILE_OFF + NW * NSLOT * TILE_F;        // per wave: {coef[32], nrm_b[32]} float4 (graph changes only)
     static constexpr int WGK_OFF = REC_OFF + NW * 256;                    // workgroup cache of dz coefficient records (s12tiles)
-    static constexpr int MAIN_F = WGK_OFF + FGNN_BWD_COEF_GRAPHS * 128;
+    static constexpr int LIVE_OFF = WGK_OFF + FGNN_BWD_COEF_GRAPHS * 128;  // SKIP: the range's live tiles (build_live_list) + NW counters
+    static constexpr int MAIN_F = LIVE_OFF + LIVE_LIST_CAP + NW;
     static constexpr int RED_F = NW * PCOUNT;
     static constexpr int LDS_F = MAIN_F > RED_F ? MAIN_F : RED_F;
 };
@@ -105,16 +106,55 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
     const int g0 = T0 / tpg;
     float4 *wgK = reinterpret_cast<float4 *>(smem + L::WGK_OFF);
 
-    // first live half at or after h (h, H1, the step: wave-uniform)
+    // the wave's next half at or after h (h, H1: wave-uniform).  Dense batches: every NW-th half.  SKIP: the waves take the LIVE halves of
+    // the range in turn (live_cnt = live halves seen so far; next_owned_live_tile_p in fgnn_common.h says why), so every wave scans the
+    // whole range and counts
+    int live_cnt = 0;
+    int *live_list = reinterpret_cast<int *>(smem + L::LIVE_OFF);
+    int nlive = 0, lk = wv - NW;                    // (SKIP) live tiles of the range; this wave's index among their halves
+    bool use_list = false;
+    if constexpr (SKIP) {                            // (before anything is in flight: its barriers would drain it)
+        nlive = build_live_list(live_list, live_list + LIVE_LIST_CAP, T0, T1, tpg, FGNN_TILE, A.N, A.nvalid, threadIdx.x, 64 * NW);
+        use_list = nlive <= LIVE_LIST_CAP;
+    }
     auto next_half = [&](int h) {
-        while (h < H1) {
-            const int g = h / hpg, hh = h - g * hpg;
-            bool live = hh * 16 < P2;
-            if constexpr (SKIP) live = live && tile_live(hh >> 1, A.N, A.nvalid[g]);
-            if (live) break;
-            h += NW;
+        if constexpr (SKIP) {
+            if (use_list) {                         // entry k = half (k & 1) of live tile k >> 1; halves past the plane's end are nobody's
+                int r = H1;
+                while (true) {
+                    lk += NW;
+                    if ((lk >> 1) >= nlive) break;
+                    const int t = live_list[lk >> 1], g = t / tpg, hh = 2 * (t - g * tpg) + (lk & 1);
+                    if (hh * 16 < P2) {
+                        r = 2 * t + (lk & 1);
+                        break;
+                    }
+                }
+                return __builtin_amdgcn_readfirstlane(r);
+            }
+            while (h < H1) {
+                const int g = h / hpg, hh = h - g * hpg;
+                const int nv = A.nvalid[g];
+                if (hh * 16 < P2 && tile_live(hh >> 1, A.N, nv)) {
+                    const bool mine = live_cnt % NW == wv;
+                    ++live_cnt;
+                    if (mine) break;
+                    ++h;
+                } else if ((hh >> 1) * FGNN_TILE / A.N >= nv) {
+                    h = (g + 1) * hpg;             // rows >= nv are padding up to the end of the graph
+                } else {
+                    ++h;
+                }
+            }
+            return __builtin_amdgcn_readfirstlane(h < H1 ? h : H1);
+        } else {
+            while (h < H1) {
+                const int g = h / hpg, hh = h - g * hpg;
+                if (hh * 16 < P2) break;
+                h += NW;
+            }
+            return __builtin_amdgcn_readfirstlane(h);
         }
-        return __builtin_amdgcn_readfirstlane(h);
     };
 
     // ---- prologue: the operand image (straight into LDS), the first half's x ----
@@ -191,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
         load8(zr, vz, lane_voff(vz, q, p, inb), g * vz.gs4);
     };
 
-    int h = next_half(H0 + wv);
+    int h = next_half(SKIP ? H0 : H0 + wv);
     load_x(h);
     int cached_g = -1, cur_nv = A.N;
 
@@ -253,7 +293,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_bwd_t16_kernel(const fgnn_mlp_
     if ((FGNN_PRIOB == 1) == (wv >= 4)) __builtin_amdgcn_s_setprio(1);
 #endif
     while (h < H1) {
-        const int hn = next_half(h + NW);
+        const int hn = next_half(SKIP ? h + 1 : h + NW);
         const int g = __builtin_amdgcn_readfirstlane(h / hpg), hh = h - g * hpg;
         const int p = hh * 16 + px;
         const bool inb = p < P2;
