@@ -197,11 +197,31 @@ DEVI void mlp_fwd_body(const fgnn_mlp_fwd_args A, const int tpg, const int total
     // is copied, so the three dependent round trips of the prologue overlap into one.
     const bool normA = A.a.nrm != nullptr, normB = (CB > 0) && A.b.nrm != nullptr;
     // the operand image is requested first (into registers): its round trip overlaps the first tile's
+    // SKIP: the waves take the range's LIVE tiles in turn (fgnn_common.h build_live_list: dealing raw indices and skipping the dead ones
+    // left most of the 16 waves of a ragged batch's workgroup with 0 or 2 tiles); the list sits behind the layout's LDS, built before
+    // anything is in flight
+    int *live_list = reinterpret_cast<int *>(smem + L::LDS_F);
+    int nlive = 0, li = wv, live_cnt = 0;
+    bool use_list = false;
+    if constexpr (SKIP) {
+        nlive = build_live_list(live_list, live_list + LIVE_LIST_CAP, T0, T1, tpg, FGNN_TILE, A.N, A.nvalid, threadIdx.x, 64 * NW);
+        use_list = nlive <= LIVE_LIST_CAP;
+    }
+    auto next_tile = [&](int cur, bool first) {        // the wave's tile after `cur` (first: its first one)
+        if constexpr (SKIP) {
+            if (use_list) {
+                if (!first) li += NW;
+                return __builtin_amdgcn_readfirstlane(li < nlive ? live_list[li] : T1);
+            }
+            return __builtin_amdgcn_readfirstlane(next_owned_live_tile_p(first ? T0 : cur + 1, T1, live_cnt, wv, NW, tpg, FGNN_TILE, A.N, A.nvalid));
+        } else {
+            return first ? T0 + wv : cur + NW;
+        }
+    };
     PkRegs<L::WEIGHT_F / 4, 64 * NW> img;
     if (A.packed) pk_load_regs(img, A.packed);
     __builtin_amdgcn_sched_barrier(0);      // keep these loads first (the scheduler would sink them to their use)
-    int tile = T0 + wv;
-    if constexpr (SKIP) tile = __builtin_amdgcn_readfirstlane(next_live_tile(tile, T1, NW, tpg, A.N, A.nvalid));
+    int tile = next_tile(0, true);
     float xa[SA > 0 ? SA : 1], xb[SB > 0 ? SB : 1];
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
     int cached_g = -1, cur_nv = A.N;
@@ -275,8 +295,7 @@ DEVI void mlp_fwd_body(const fgnn_mlp_fwd_args A, const int tpg, const int total
         }
         const bool c_valid = tile_valid(c, cur_nv);
         // prefetch this wave's next tile (static strided assignment)
-        int next = tile + NW;
-        if constexpr (SKIP) next = __builtin_amdgcn_readfirstlane(next_live_tile(next, T1, NW, tpg, A.N, A.nvalid));
+        const int next = next_tile(tile, false);
         float na[SA > 0 ? SA : 1], nb[SB > 0 ? SB : 1];
         {
             const TileCtx cn = decode_tile(next, next < T1, tpg, A.N, P, j);
@@ -423,7 +442,7 @@ template <int CA, int CB, int NMLP, int DEPTH, bool PK = false, bool SKIP = fals
 int launch_fwd_impl(const fgnn_mlp_fwd_args *a, int tpg, int total, hipStream_t st, const DbgOut &d) {
     using L = FwdLayout<CA, CB, NMLP, DEPTH>;
     constexpr int NW = L::NW;
-    constexpr int LDS = L::LDS_F * 4;
+    constexpr int LDS = (L::LDS_F + (SKIP ? LIVE_LIST_CAP + NW : 0)) * 4;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static LdsAttrCache attr_cache;
     int grid = (total + NW - 1) / NW;
