@@ -444,6 +444,63 @@ def time_in_graph(tag, engines, work, min_launches=24, replays=20):
     return {'ms': e0.elapsed_time(e1) / (replays * n), 'launches': n, 'replays': replays, 'sets': len(sets), 'engines': len(engines)}
 
 
+def time_in_step(tag, eng, work, replays=40, rounds=5):
+    """What the launches tagged `tag` cost INSIDE the step: the step's own launch sequence (every C call of one engine step, recorded and
+    re-issued in order) is captured twice -- as it is, and with every launch of `tag` issued twice in a row -- and both graphs are
+    replayed alternately; (t_doubled - t_plain) / launches is the kernel's duration in its real surroundings (the cache state the
+    preceding kernel leaves, the clock the whole step runs at), which a burst of back-to-back launches of the step's most power-hungry
+    kernel does not reproduce (time_in_graph: 60.4 - 62.5 us on boxes where the kernel trace of the replayed step shows 59.2).
+    The second launch of a pair re-reads what the first one read and accumulates into the same d_in: same traffic, same arithmetic."""
+    work(eng)
+    torch.cuda.synchronize()
+    _lib.PROFILE = []
+    work(eng)
+    torch.cuda.synchronize()
+    rec, _lib.PROFILE = _lib.PROFILE, None
+    launches = [(name, a, t == tag) for t, _, _, name, a in rec]
+    ndom = sum(1 for _, _, d in launches if d)
+    if not ndom:
+        raise RuntimeError('no launch tagged %s' % tag)
+
+    def run(double):
+        for name, a, dom in launches:
+            _lib.relaunch(name, a)
+            if double and dom:
+                _lib.relaunch(name, a)
+    graphs = []
+    for double in (False, True):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run(double)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run(double)
+        graphs.append(g)
+    for g in graphs:
+        for _ in range(5):
+            g.replay()
+    torch.cuda.synchronize()
+    diffs, plain = [], []
+    for _ in range(rounds):
+        ms = []
+        for g in graphs:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(replays):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / replays)
+        plain.append(ms[0])
+        diffs.append((ms[1] - ms[0]) / ndom)
+    diffs.sort()
+    return {'ms': diffs[len(diffs) // 2], 'ms_min': diffs[0], 'ms_max': diffs[-1], 'launches_per_step': ndom, 'replays': replays, 'rounds': rounds,
+            'step_ms_relaunched': sorted(plain)[len(plain) // 2]}
+
+
 def wide64_leg(args, dev):
     """The cfg2 workload (N = 50 regular pairs, 32 pairs) on the 64-FEATURE model (original_features_num 2, in_features = out_features = 64,
     depth 3, 4 blocks; models/layers.py:113-123 takes any widths) through the module surface: Siamese_Node_Exp.fused_step = forward +
@@ -769,7 +826,14 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
             except Exception as exc:          # noqa: BLE001 -- the eager figure stands
                 print('bench.py: in-graph timing of %s failed (%s); roofline from eager events' % (dom, exc), file=sys.stderr)
                 torch.cuda.synchronize()
-        dur = (ingraph['ms'] if ingraph else eager_ms) * 1e-3
+        instep = None
+        if path == 'engine' and ingraph is not None:
+            try:
+                instep = time_in_step(dom, eng, engine_work)
+            except Exception as exc:          # noqa: BLE001 -- the back-to-back figure stands
+                print('bench.py: in-step timing of %s failed (%s); roofline from the back-to-back launches' % (dom, exc), file=sys.stderr)
+                torch.cuda.synchronize()
+        dur = (instep['ms'] if instep else (ingraph['ms'] if ingraph else eager_ms)) * 1e-3
         mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
         if fl / (mfma_peak * 1e12) >= by / (HBM_PEAK_GBS * 1e9):
             ach = fl / dur / 1e12
@@ -794,10 +858,16 @@ def run_config(args, config, rank, world, dev, cpu_leg, windows=None, block1=Non
                 roofline['traffic_source'] = tr.get('_source')
         except (OSError, ValueError):
             pass
-        roofline.update({'kernel': dom, 'avg_launch_ms': dur * 1e3, 'in_graph_launch_ms': (dur * 1e3 if ingraph else None), 'eager_launch_ms': eager_ms,
-                         'timing': ('%d back-to-back launches per replay of a HIP graph (x %d replays), cycling %d operand sets of %d engines'
-                                    % (ingraph['launches'], ingraph['replays'], ingraph['sets'], ingraph['engines'])) if ingraph else
-                                   'eager launches, events around each',
+        roofline.update({'kernel': dom, 'avg_launch_ms': dur * 1e3, 'in_graph_launch_ms': (dur * 1e3 if (ingraph or instep) else None), 'eager_launch_ms': eager_ms,
+                         'in_step_launch_ms': instep['ms'] if instep else None,
+                         'in_step_spread_ms': [instep['ms_min'], instep['ms_max']] if instep else None,
+                         'back_to_back_launch_ms': ingraph['ms'] if ingraph else None,
+                         'timing': (('the replayed step with every launch of this kernel issued twice minus the replayed step, per launch (%d launches per '
+                                     'step, %d x %d replays of each graph, median); back_to_back_launch_ms: ' % (instep['launches_per_step'], instep['rounds'],
+                                                                                                               instep['replays'])) if instep else '') +
+                                   (('%d back-to-back launches per replay of a HIP graph (x %d replays), cycling %d operand sets of %d engines'
+                                     % (ingraph['launches'], ingraph['replays'], ingraph['sets'], ingraph['engines'])) if ingraph else
+                                    'eager launches, events around each'),
                          'outliers_dropped': dropped,
                          'algorithmic_bytes_per_launch': by, 'algorithmic_flops_per_launch': fl,
                          'alt_hbm_gbs': by / dur / 1e9, 'alt_mfma_tflops': fl / dur / 1e12})
