@@ -11,7 +11,7 @@
 //           file: the accumulators live in the AGPR half.  Per-workgroup partials, summed by fgnn_reduce_partials (fixed order).
 // The operand images come packed (fgnn_mlp64_pack: one small launch per forward call; the module path hands over nn.Conv2d parameters).
 #include <type_traits>
-#include "fgnn_t16.h"
+#include "fgnn_t16_pipe.h"
 
 namespace {
 
@@ -119,26 +119,6 @@ DEVI void copy4(float *dst, const float *src, int n4, int tid, int nthr) {
 // The kernels run one (backward) or two (forward) waves per SIMD, so nothing hides an LDS read's latency but the wave's own MFMAs:
 // every GEMM helper below requests the operands of set i + 1 BEFORE issuing the 16 MFMAs of set i (LDS returns in order, the
 // compiler's s_waitcnt lgkmcnt(n) then waits for set i only).
-struct Set4 {
-    float4 w[4];
-};
-DEVI Set4 load_set(const float *img, int lane) {
-    const float4 *p = reinterpret_cast<const float4 *>(img) + lane;
-    Set4 o;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) o.w[u] = p[u * 64];
-    return o;
-}
-DEVI void mfma_set(f32x4 (&acc)[2], const Set4 &W, const float (&bop)[8]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        acc[0] = mfma16(W.w[u].x, bop[2 * u], acc[0]);
-        acc[1] = mfma16(W.w[u].y, bop[2 * u], acc[1]);
-        acc[0] = mfma16(W.w[u].z, bop[2 * u + 1], acc[0]);
-        acc[1] = mfma16(W.w[u].w, bop[2 * u + 1], acc[1]);
-    }
-}
-
 // Across helpers the chain continues: each takes the operands of its FIRST set already loaded (`first`) and calls `next()` before the
 // MFMAs of its LAST set -- the caller loads the following helper's first operands there.
 struct NoNext {
@@ -204,16 +184,6 @@ DEVI void layer_bwd(float (&out)[RG][8], const float *img, const Set4 &first, co
 // Weight gradients of one layer from the staged tiles: dW[og][ig][2 mb + nb] += Dt_og (rows 16 mb ..) x In_ig (rows 16 nb ..) over the
 // 16 pixels (fgnn_t16.h wgrad16), db[og][mb] += pixel sums of Dt_og's rows (lane (i, q): pixels 4 q .. 4 q + 3 of row 16 mb + i).
 // NI input tiles at TI, the accumulators of input group i0 + ii.
-struct Pair4 {
-    float4 lo, hi;
-};
-DEVI Pair4 load_rows(const float *T, int lane) {
-    const int i = lane & 15, q = lane >> 4;
-    Pair4 o;
-    o.lo = *reinterpret_cast<const float4 *>(T + i * TLD + 4 * q);
-    o.hi = *reinterpret_cast<const float4 *>(T + (16 + i) * TLD + 4 * q);
-    return o;
-}
 struct WgFirst {
     Pair4 a, b;
 };
@@ -222,18 +192,6 @@ DEVI WgFirst load_wg_first(const float *TD, const float *TI, int lane) {
     o.a = load_rows(TD, lane);
     o.b = load_rows(TI, lane);
     return o;
-}
-DEVI void wgrad_mfma(f32x4 (&dW)[4], const Pair4 &a, const Pair4 &b) {
-#define FGNN_M64_KS(e)                              \
-    dW[0] = mfma16(a.lo.e, b.lo.e, dW[0]);          \
-    dW[1] = mfma16(a.lo.e, b.hi.e, dW[1]);          \
-    dW[2] = mfma16(a.hi.e, b.lo.e, dW[2]);          \
-    dW[3] = mfma16(a.hi.e, b.hi.e, dW[3]);
-    FGNN_M64_KS(x)
-    FGNN_M64_KS(y)
-    FGNN_M64_KS(z)
-    FGNN_M64_KS(w)
-#undef FGNN_M64_KS
 }
 template <int KGT, int NI, bool BIAS, class Next>
 DEVI void layer_wgrad(f32x4 (&dW)[OG][KGT][4], float (&db)[OG][2], const float *TD, const float *TI, int i0, const WgFirst &first, int lane,
