@@ -303,6 +303,25 @@ DEVI void store_in(const float (&x)[KG][8], const In2 &in, const Tile64 &c, int 
     }
 }
 
+// zeros for the existing pixels of a tile, slab by slab (do_a / do_b: the slab is being stored, not accumulated into)
+template <int KG, int KGA = KG>
+DEVI void zero_in(const In2 &in, const Tile64 &c, int q, bool do_a, bool do_b) {
+#pragma unroll
+    for (int ig = 0; ig < KG; ++ig) {
+        const bool ina = ig < KGA;
+        if (!(ina ? do_a : do_b)) continue;
+        const rsrc_t r = ina ? in.a.r : in.b.r;
+        const int ld4 = ina ? in.a.ld4 : in.b.ld4, gs4 = ina ? in.a.gs4 : in.b.gs4, lg = ina ? ig : ig - KGA;
+        const int voff = c.inb ? chan_q(q) * ld4 + 4 * c.p : OOB_OFF;
+        const int s0 = c.g * gs4 + lg * 32 * ld4;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const bool ok = !(ig == KG - 1 && in.cin < 32 * KG) || 32 * ig + chan_s(s) + chan_q(q) < in.cin;
+            __builtin_amdgcn_raw_buffer_store_b32(0u, r, ok ? voff : OOB_OFF, s0 + chan_s(s) * ld4, FGNN_STORE_AUX);
+        }
+    }
+}
+
 template <int KG>
 struct FwdLayout {
     static constexpr int F0 = 0, F1 = F0 + OG * KG * SUB, F2 = F1 + OG * OG * SUB, BIAS = F2 + OG * OG * SUB;
@@ -340,11 +359,20 @@ __global__ __launch_bounds__(64 * NWF) void mlp64_fwd_kernel(const fgnn_mlp64_ar
         const Tile64 cn = tile64(t + step, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
         float h1[OG][8], h2[OG][8], z[OG][8];
         asm volatile("" ::: "memory");                     // the operand reads are loop invariant: keep them from being hoisted into registers
-        FwdFirst f1, f2;
-        layer_fwd<KG, true>(h1, smem + L::F0, f0, x, lane, [&] { f1 = load_fwd_first(smem + L::F1, smem + L::BIAS + 64, lane, q); });
-        load_in<KG, KGA>(x, vx, cn, q);                    // the next tile into the registers just consumed
-        layer_fwd<OG, true>(h2, smem + L::F1, f1, h1, lane, [&] { f2 = load_fwd_first(smem + L::F2, smem + L::BIAS + 128, lane, q); });
-        layer_fwd<OG, false>(z, smem + L::F2, f2, h2, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
+        const bool live = !ragged || __ballot(c.valid) != 0ull;     // a tile without a valid pixel (ragged batches): zeros, no arithmetic
+        if (live) {
+            FwdFirst f1, f2;
+            layer_fwd<KG, true>(h1, smem + L::F0, f0, x, lane, [&] { f1 = load_fwd_first(smem + L::F1, smem + L::BIAS + 64, lane, q); });
+            load_in<KG, KGA>(x, vx, cn, q);                // the next tile into the registers just consumed
+            layer_fwd<OG, true>(h2, smem + L::F1, f1, h1, lane, [&] { f2 = load_fwd_first(smem + L::F2, smem + L::BIAS + 128, lane, q); });
+            layer_fwd<OG, false>(z, smem + L::F2, f2, h2, lane, [&] { f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q); });
+        } else {
+            load_in<KG, KGA>(x, vx, cn, q);
+#pragma unroll
+            for (int og = 0; og < OG; ++og)
+#pragma unroll
+                for (int s = 0; s < 8; ++s) z[og][s] = 0.f;
+        }
         const int voff = lane_voff(vo, q, c.p, c.inb);
 #pragma unroll
         for (int og = 0; og < OG; ++og) {
@@ -404,7 +432,21 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
         db0[og][0] = db0[og][1] = db1[og][0] = db1[og][1] = db2[og][0] = db2[og][1] = 0.f;
     }
 
-    int t = blockIdx.x * NWB + wv;
+    // the wave's next tile with a valid pixel after `tcur`; the padding-only tiles in between (ragged batches) get their zero dx here -- not
+    // by a branch around the tile body: accumulators that are live across a branch cost a second register set (36 - 190 spilled registers)
+    auto advance = [&](int tcur) {
+        int tn = tcur + step;
+        if (ragged) {
+            while (tn < total) {
+                const Tile64 cc = tile64(tn, total, hpg, P2, A.N, rcpN, rnv, true, px);
+                if (__ballot(cc.valid) != 0ull) break;
+                if constexpr (HAS_DX) zero_in<KG, KGA>(vdx, cc, q, A.accumulate_dx == 0, A.accumulate_dxb == 0);
+                tn += step;
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(tn);
+    };
+    int t = advance(blockIdx.x * NWB + wv - step);
     float x[KG][8], dz[OG][8];
     Tile64 c = tile64(t, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
     load_in<KG, KGA>(x, vx, c, q);
@@ -422,7 +464,8 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
 
     FwdFirst f0 = load_fwd_first(smem + L::F0, smem + L::BIAS, lane, q);
     while (t < total) {
-        const Tile64 cn = tile64(t + step, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
+        const int tnext = advance(t);
+        const Tile64 cn = tile64(tnext, total, hpg, P2, A.N, rcpN, rnv, ragged, px);
         float xn[KG][8], dzn[OG][8];
         load_in<KG, KGA>(xn, vx, cn, q);                   // the next tile's operands fly during this tile
         load_in<OG>(dzn, vdz, cn, q);
@@ -518,7 +561,7 @@ __global__ __launch_bounds__(64 * NWB) void mlp64_bwd_kernel(const fgnn_mlp64_ar
 #pragma unroll
             for (int s = 0; s < 8; ++s) dz[og][s] = dzn[og][s];
         c = cn;
-        t += step;
+        t = tnext;
     }
 
     // ---- workgroup sum of the parameter gradients: the waves add their fragments to one LDS record in turn (fixed order) ----
