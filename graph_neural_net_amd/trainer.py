@@ -278,12 +278,25 @@ class FgnnTrainer:
     def check_input_form(self):
         """input_form='tensor_representation': read the device verdict of every train_step since the last check (one host
         synchronisation); raises if one of those batches was not a tensor representation."""
-        if self._tr_flag is not None and int(self._tr_flag.item()) != 0:
+        if self._tr_flag is None:
+            return
+        if dp.world_size() > 1 or self._force_collective:
+            # every rank reads the SUM of the flags (the check runs at the same step on all of them): the rank that saw the bad batch
+            # does not raise alone while the others wait in the next gradient all-reduce
+            dp.allreduce_sum_(self._tr_flag, force=self._force_collective)
+        if int(self._tr_flag.item()) != 0:
             self._tr_flag.zero_()
             raise RuntimeError("FgnnTrainer(input_form='tensor_representation'): a batch since the last check is NOT the tensor "
                                'representation of a 0/1 adjacency (channel 0 in {0, 1}, channel 1 = diag(row sums), '
                                'loaders/data_generator.py:118-125); the updates of those steps are invalid -- run it through the dense '
                                "path (input_form='dense')")
+
+    def save_checkpoint(self, path, **kw):
+        """checkpoint.save_checkpoint of this trainer's parameters (+ optimizer) AFTER the pending input verdicts have been read: a run
+        that ends fewer than INPUT_CHECK_EVERY steps after the last check must not persist parameters a bad batch has touched."""
+        from .checkpoint import save_checkpoint
+        self.check_input_form()
+        return save_checkpoint(path, self.layout, self.params, optimizer=self.opt, **kw)
 
     def train_step_bits(self, bits1, bits2, nvalid=None):
         """The same step with the local shard handed over as bit-packed adjacency: bits1, bits2

@@ -272,3 +272,25 @@ def test_tensor_representation_opt_in_on_a_zero_padded_model_and_on_shapes_it_is
     a = torch.rand(2, 1, 12, 12, device=DEV)
     one.fused_step(a, a.clone())
     assert not one.check_input_form()                      # no flag was ever created: nothing was packed
+
+
+def test_trainer_checkpoint_reads_the_pending_input_verdicts(tmp_path):
+    """FgnnTrainer.save_checkpoint: a bad batch since the last check (the verdict is read on every INPUT_CHECK_EVERY-th step only) is
+    reported BEFORE the parameters it touched are written; after the report the trainer saves."""
+    from graph_neural_net_amd.engine import ParamLayout
+    lay = ParamLayout(2, 1, 32, 32, 3)
+    p0 = lay.init_flat(0, torch.device(DEV))
+    tr = FgnnTrainer(lay, p0.clone(), lr=1e-3, input_form='tensor_representation')
+    tr.INPUT_CHECK_EVERY = 0
+    x1, x2 = [t.to(DEV) for t in synthetic.make_batch(9400, 3, 20, 'ErdosRenyi', 0.3, 0.1)]
+    tr.train_step(x1, x2)
+    bad = x1.clone()
+    bad[0, 0, 2, 9] = 0.25
+    tr.train_step(bad, x2)
+    path = str(tmp_path / 'ck.pt')
+    with pytest.raises(RuntimeError, match='tensor representation'):
+        tr.save_checkpoint(path)
+    import os
+    assert not os.path.exists(path)
+    tr.save_checkpoint(path)                                    # the report cleared the flag
+    assert os.path.exists(path)
