@@ -111,6 +111,12 @@ class _Outputs(dict):
     def values(self):
         return [self._out(k) for k in self.keys()]
 
+    def __iter__(self):                     # (also keeps dict(outputs) / {**outputs} off the C fast path that copies the raw values)
+        return iter(list(dict.keys(self)))
+
+    def copy(self):
+        return dict(self.items())
+
 
 class _EmbedFn(torch.autograd.Function):
     """Whole node-embedder forward/backward through FgnnEngine (one autograd node) -- the fast mode.
@@ -218,19 +224,24 @@ class Network(nn.Module):
     def forward(self, inputs):
         from .layers import LazyCat, MlpBlock_Real, fan_out, prepack64
         lazy = self._lazy_cat_nodes()
-        prepack64([node for node, _ in self.graph.values() if isinstance(node, MlpBlock_Real)])
+        mlps = [node for node, _ in self.graph.values() if isinstance(node, MlpBlock_Real)]
+        prepack64(mlps)
         outputs = _Outputs(inputs)
-        for path, (node, ins) in self.graph.items():
-            if path not in outputs:
-                args = [outputs.raw(name) for name in ins]
-                if path in lazy:
-                    outputs[path] = LazyCat(args)
-                else:
-                    if not isinstance(node, MlpBlock_Real):
-                        args = [a.materialize() if isinstance(a, LazyCat) else a for a in args]
-                    outputs[path] = node(*args)
-                if path in self._fan:
-                    outputs[path] = fan_out(outputs.raw(path))
+        try:
+            for path, (node, ins) in self.graph.items():
+                if path not in outputs:
+                    args = [outputs.raw(name) for name in ins]
+                    if path in lazy:
+                        outputs[path] = LazyCat(args)
+                    else:
+                        if not isinstance(node, MlpBlock_Real):
+                            args = [a.materialize() if isinstance(a, LazyCat) else a for a in args]
+                        outputs[path] = node(*args)
+                    if path in self._fan:
+                        outputs[path] = fan_out(outputs.raw(path))
+        finally:
+            for m in mlps:                  # an operand record is good for THIS pass only (a node that did not run must not keep one)
+                m._packed64 = None
         return outputs
 
     # ------------------------------------------------------------------ fused fast path

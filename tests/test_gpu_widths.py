@@ -795,6 +795,9 @@ def test_network_keeps_concat_lazy_for_the_fused_64_wide_mlp():
     assert torch.is_tensor(cat) and cat.shape[1] == 128
     assert torch.equal(cat[:, :64], out['ne/bm/block2/mult']) and torch.equal(cat[:, 64:], out['ne/bm/block1/mlp3'])
     assert dict(out.items())['ne/bm/block3/cat'].shape[1] == 128
+    assert torch.is_tensor(dict(out)['ne/bm/block4/cat']) and torch.is_tensor({**out}['ne/bm/block4/cat']) and torch.is_tensor(out.copy()['ne/bm/block1/cat'])
+    # the operand records prepack64 hands the MLPs are good for one pass only
+    assert all(getattr(m, '_packed64', None) is None for m in model.node_embedder.modules())
 
 
 def test_fan_out_sums_the_input_gradients_inside_the_mlp_kernels():
