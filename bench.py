@@ -429,7 +429,7 @@ def time_in_graph(tag, engines, work, min_launches=24, replays=20):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode='thread_local'):      # (a process group's watchdog thread may query events meanwhile)
         burst()
     for _ in range(3):
         g.replay()
@@ -476,7 +476,7 @@ def time_in_step(tag, eng, work, replays=40, rounds=5):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             run(double)
         graphs.append(g)
     for g in graphs:
