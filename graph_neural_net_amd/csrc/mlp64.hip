@@ -11,6 +11,8 @@
 //           file: the accumulators live in the AGPR half.  Per-workgroup partials, summed by fgnn_reduce_partials (fixed order).
 // The operand images come packed (fgnn_mlp64_pack: one small launch per forward call; the module path hands over nn.Conv2d parameters).
 #include <type_traits>
+#define FGNN_STORE_AUX 0    // plain stores: z and dx are the NEXT launch's inputs (GraphNorm plane kernels); `nt` (the engine kernels' choice for
+                            // their d_in) costs the 64-feature step 0.8 % (2.999 -> 2.975 ms, tools/ab_width64.sh)
 #include "fgnn_t16_pipe.h"
 
 namespace {
